@@ -1,0 +1,144 @@
+"""Pin the CPU oracle (oracle/) to the golden vectors produced from the reference import
+(tests/golden/make_fixtures.py).  CPU only."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import nets, joint
+from oracle.fbank_tables import mel_matrix
+
+TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+def _load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name), allow_pickle=False).items()}
+
+
+def _sub(fx, prefix, grad=False):
+    out = {}
+    for k, v in fx.items():
+        if k.startswith(prefix):
+            t = torch.from_numpy(v)
+            if grad and t.dtype.is_floating_point and 'running_' not in k:
+                t = t.clone().requires_grad_(True)
+            out[k[len(prefix):]] = t
+    return out
+
+
+def test_mel_matrix_matches_reference_table(golden_dir):
+    fx = _load(golden_dir, 'fbank_tiny.npz')
+    W = mel_matrix()
+    assert W.shape == fx['W'].shape
+    assert np.abs(W - fx['W']).max() < 2e-5       # reference literals carry 5-6 digits
+    assert ((W != 0) == (fx['W'] != 0)).all()
+
+
+def test_enhance(golden_dir):
+    fx = _load(golden_dir, 'enhance_tiny.npz')
+    p = _sub(fx, 'p.', grad=True)
+    mix, mix_log = torch.from_numpy(fx['mix']), torch.from_numpy(fx['mix_log'])
+    lens = fx['lens'].tolist()
+    out = nets.enhance_forward(p, mix, mix_log, lens, 2)
+    np.testing.assert_allclose(out.detach().numpy(), fx['enhance_out'], **TOL)
+    # padded rows exactly zero (Appendix A.2)
+    for b, l in enumerate(lens):
+        assert (out[b, l:] == 0).all()
+    loss, out2 = nets.enhance_forward(p, mix, mix_log, lens, 2, torch.from_numpy(fx['clean']),
+                                      torch.from_numpy(fx['cos']))
+    np.testing.assert_allclose(loss.detach().numpy(), fx['l1_loss'], rtol=1e-5)
+    (loss + (out2 * torch.linspace(0.5, 1.5, 257)).mean()).backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx['g.' + k], rtol=2e-3, atol=2e-6, err_msg=k)
+
+
+def test_fbank_and_cmvn(golden_dir):
+    fx = _load(golden_dir, 'fbank_tiny.npz')
+    x = torch.from_numpy(fx['x']).requires_grad_(True)
+    W, cm = torch.from_numpy(fx['W']), torch.from_numpy(fx['cmvn'])
+    y0 = nets.fbank_forward(x, W)
+    y1 = nets.fbank_forward(x, W, cm)
+    np.testing.assert_allclose(y0.detach().numpy(), fx['y_nocmvn'], **TOL)
+    np.testing.assert_allclose(y1.detach().numpy(), fx['y_cmvn'], **TOL)
+    assert np.allclose(y0.detach().numpy()[0, -1], np.log(1e-7)) or fx['lens'][0] == x.shape[1]
+    (y1 * torch.linspace(-1, 1, 80)).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), fx['dx'], rtol=1e-4, atol=1e-6)
+    acc = nets.CmvnAccumulator(80, 3)
+    lens = fx['lens']
+    assert acc.update(y0.detach(), lens) is None
+    est = acc.update(y0.detach(), lens)
+    np.testing.assert_allclose(est, fx['cmvn_est'], rtol=1e-4, atol=1e-5)
+
+
+def test_e2e(golden_dir):
+    fx = _load(golden_dir, 'e2e_tiny.npz')
+    p = _sub(fx, 'p.', grad=True)
+    feat = torch.from_numpy(fx['feat']).requires_grad_(True)
+    lc, la, acc, hpad, hl = nets.e2e_forward(p, feat, torch.from_numpy(fx['targets']),
+                                              fx['lens'].tolist(), fx['tlens'].tolist(), 2)
+    np.testing.assert_allclose(hpad.detach().numpy(), fx['hpad'], **TOL)
+    assert list(hl) == fx['hlens'].tolist()
+    np.testing.assert_allclose(lc.detach().numpy(), fx['loss_ctc'], rtol=1e-4)
+    np.testing.assert_allclose(la.detach().numpy(), fx['loss_att'], rtol=1e-4)
+    assert abs(acc - float(fx['acc'])) < 1e-9
+    (0.5 * lc + 0.5 * la).backward()
+    np.testing.assert_allclose(feat.grad.numpy(), fx['dfeat'], rtol=2e-3, atol=1e-6)
+    for k, v in p.items():
+        if k.startswith('dec.att.'):
+            continue       # shared module registered twice (e2e_model.py:137); grads live on att.*
+        np.testing.assert_allclose(v.grad.numpy(), fx['g.' + k], rtol=5e-3, atol=2e-6, err_msg=k)
+
+
+def test_gan(golden_dir):
+    fx = _load(golden_dir, 'gan_tiny.npz')
+    full = _sub(fx, 'p.')
+    p = {k: v.clone().requires_grad_(True) for k, v in full.items() if v.dtype.is_floating_point and 'running' not in k}
+    buf = {k: v.clone() for k, v in full.items() if 'running' in k or 'num_batches' in k}
+    x = torch.from_numpy(fx['x']).requires_grad_(True)
+    d = nets.discriminator_forward(p, buf, x)
+    np.testing.assert_allclose(d.detach().numpy(), fx['d_out'], **TOL)
+    lr = nets.gan_loss(d, True)
+    lf = nets.gan_loss(nets.discriminator_forward(p, buf, x * 0.9 + 0.1), False)
+    np.testing.assert_allclose(lr.detach().numpy(), fx['l_real'], rtol=1e-4)
+    np.testing.assert_allclose(lf.detach().numpy(), fx['l_fake'], rtol=1e-4)
+    ((lr + lf) * 0.5).backward()
+    np.testing.assert_allclose(x.grad.numpy(), fx['dx'], rtol=2e-3, atol=1e-7)
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx['g.' + k], rtol=5e-3, atol=1e-6, err_msg=k)
+    for k, v in buf.items():     # BN running stats after two train-mode forwards (Appendix A.12)
+        np.testing.assert_allclose(v.numpy(), fx['after.' + k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def joint_cfg():
+    return dict(enhance_layers=2, elayers=2, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=0.5,
+                gan_loss_lambda=1.0, grad_clip=5.0, eps=1e-8, isGAN=True, enhance_loss_type='L2')
+
+
+def test_joint_step(golden_dir):
+    fx = _load(golden_dir, 'joint_tiny.npz')
+    st = joint.JointState(_sub(fx, 'enh.'), _sub(fx, 'asr.'), _sub(fx, 'gan.'),
+                          torch.from_numpy(_load(golden_dir, 'fbank_tiny.npz')['W']), joint_cfg())
+    batch = (torch.from_numpy(fx['clean']), torch.from_numpy(fx['mix']), torch.from_numpy(fx['mix_log']),
+             torch.from_numpy(fx['targets']), fx['lens'].tolist(), fx['tlens'].tolist())
+    out = joint.joint_step(st, batch, torch.from_numpy(fx['cmvn']))
+    np.testing.assert_allclose(out['enhance_out'].numpy(), fx['enhance_out'], **TOL)
+    for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'gan_loss', 'loss_D'):
+        np.testing.assert_allclose(out[k].numpy().reshape(-1), fx[k], rtol=3e-4, err_msg=k)
+    assert abs(out['acc'] - float(fx['acc'])) < 1e-9
+    assert abs(out['grad_norm_asr'] - float(fx['grad_norm_asr'])) < 2e-3 * float(fx['grad_norm_asr'])
+    assert abs(out['grad_norm_gan'] - float(fx['grad_norm_gan'])) < 2e-3 * float(fx['grad_norm_gan'])
+    # gradients are compared relative to each tensor's scale (att.gvec.bias has a true gradient
+    # of exactly 0 -- softmax shift invariance -- so only rounding noise ~1e-9 is left there)
+    for pre, gd in (('genh.', out['g_enh']), ('gasr.', out['g_asr']), ('ggan.', out['g_gan'])):
+        for k, v in gd.items():
+            ref = fx[pre + k]
+            err = np.abs(v.numpy() - ref).max()
+            assert err <= 1e-3 * np.abs(ref).max() + 1e-7, (pre + k, err, np.abs(ref).max())
+    # first Adadelta step: parameter deltas for three named tensors
+    for net, d, names in (('enh', st.enh, ['enc1.l_last.weight']), ('asr', st.asr, ['enc.enc2.bt0.weight', 'dec.output.bias']),
+                          ('gan', st.gan, ['model.0.weight'])):
+        for n in names:
+            np.testing.assert_allclose(d[n].detach().numpy(), fx['%s_after.%s' % (net, n)], rtol=1e-3, atol=2e-5,
+                                       err_msg=n)
+    for k, v in st.gan_buf.items():
+        np.testing.assert_allclose(v.numpy(), fx['gan_after.' + k], rtol=1e-4, atol=1e-6, err_msg=k)
