@@ -1,0 +1,233 @@
+/* re2e.h -- C ABI of libre2e_hip.so: MI355X (gfx950) kernels for the joint_train hot path of
+ * bliunlpr/Robust_e2e_gan.
+ *
+ * The reference has NO native interface on this path (all arithmetic is stock PyTorch-0.4 ATen
+ * ops plus warp-ctc, model/e2e_ctc.py:63), so each entry point cites the reference CALL SITE
+ * whose ATen/warp-ctc op it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (fp32 unless named *_i32 / *_u8);
+ *     the library never allocates, frees or retains device memory; scratch is caller-provided;
+ *     `lens_host` arguments (where present) are HOST int32 arrays read during the call only;
+ *   - asynchronous: work is enqueued on `stream`; no device synchronisation, no host read-back;
+ *   - returns RE2E_OK (0) or a negative RE2E_E* code; never throws/exits; the message for the
+ *     last failure on the calling thread is re2e_last_error();
+ *   - reductions feeding parity-checked outputs are fixed-tree (bitwise reproducible run to run);
+ *   - activations: NHWC for the conv stacks, (T,B,F) time-major inside the recurrent stacks,
+ *     (B,T,F) batch-first at the module boundary, exactly as the reference lays them out.
+ */
+#ifndef RE2E_H
+#define RE2E_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
+
+#define RE2E_OK 0
+#define RE2E_EINVAL (-1)
+#define RE2E_EUNSUPPORTED (-2)
+#define RE2E_EHIP (-3)
+
+#define RE2E_ACT_NONE 0
+#define RE2E_ACT_TANH 1
+#define RE2E_ACT_RELU 2
+#define RE2E_ACT_LRELU 3 /* slope 0.2 (model/gan_model.py:65) */
+#define RE2E_ACT_SIGMOID 4
+#define RE2E_ACT_SIGMOID_MASK_MUL 5 /* sigmoid -> length mask -> * mix (model/enhance_model.py:156-164) */
+
+#define RE2E_LOSS_L2 0
+#define RE2E_LOSS_L1 1
+#define RE2E_LOSS_SMOOTH_L1 2
+
+int re2e_version(void);
+const char* re2e_last_error(void);
+/* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
+int re2e_device_ok(void);
+
+/* ---- K3 dense GEMM (fp32 MFMA).  C[M,N] = act(op(A) op(B) + bias + bias2) + beta*C.
+ * Row-major; transa=0: A stored [M,K], transa=1: A stored [K,M]; transb=0: B stored [K,N],
+ * transb=1: B stored [N,K].
+ *   (0,1)  x W^T     -- torch.nn.Linear forward  (e2e_encoder.py:145,173)
+ *   (0,0)  dy W      -- input gradient
+ *   (1,0)  dy^T x    -- weight gradient (split-K over rows, needs workspace)
+ *   (1,1)  unsupported (RE2E_EUNSUPPORTED)
+ * act=RE2E_ACT_SIGMOID_MASK_MUL writes mask_out=sigmoid(.)*[t<lens[b]] and C=mask_out*mul,
+ * rows being (b,t) batch-first with T frames per utterance. */
+size_t re2e_gemm_workspace_bytes(int transa, int transb, int M, int N, int K);
+int re2e_gemm(int transa, int transb, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+              float* C, long ldc, const float* bias, const float* bias2, int act, float beta, const float* mul,
+              float* mask_out, const int* lens_dev, int T, void* workspace, size_t workspace_bytes,
+              re2e_stream_t stream);
+
+/* ---- K5/K9 convolution as implicit GEMM over NHWC (nn.Conv2d: e2e_encoder.py:234-237,
+ * gan_model.py:63-90).  `wg` is the gathered weight [Cout][KH][KW][C] from
+ * re2e_conv_weight_gather.  Pixel (n,py,px) of the logical PHxPW grid reads
+ * in[n][py*SY+kh*DY+OY0][px*SX+kw*DX+OX0][:] and is written at
+ * out[n][py*osy+ooy][px*osx+oox][:] of an (NI,OHF,OWF,Cout) tensor -- forward: S=stride,D=1,
+ * O0=-pad; stride-1 data gradient: S=1,D=-1,O0=+pad with transposed weights; stride-2 data
+ * gradient: one call per output parity class. */
+int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW, int PH,
+                    int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF, int OWF, int osy,
+                    int osx, int ooy, int oox, const float* bias, int act, float beta, re2e_stream_t stream);
+size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW);
+/* dW[Cout][C][KH][KW] = beta*dW + sum_pix dout[pix][co] * in[n][py*SY+kh+OY0][px*SX+kw+OX0][ci] */
+int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, int KH, int KW, int PH,
+                    int PW, int SY, int SX, int OY0, int OX0, float* dW, float beta, void* workspace,
+                    size_t workspace_bytes, re2e_stream_t stream);
+/* dst[r][a][b][c] <- W[Cout][Cin][KH][KW] at tap (kh0+a*kstep, kw0+b*kstep); transpose=0: r=co,c=ci; 1: r=ci,c=co */
+int re2e_conv_weight_gather(const float* W, float* dst, int Cout, int Cin, int KH, int KW, int transpose, int TA,
+                            int TB, int kh0, int kw0, int kstep, re2e_stream_t stream);
+
+/* ---- elementwise / layout helpers ------------------------------------------------------- */
+/* out[d1][d0][:] = in[d0][d1][:]  (batch-first <-> time-major) */
+int re2e_transpose01(const float* in, float* out, int D0, int D1, int W, re2e_stream_t stream);
+/* dz = dy * act'(y), y = activation OUTPUT (tanh / relu / lrelu / sigmoid); dz may alias dy */
+int re2e_act_bwd(const float* dy, const float* y, float* dz, long n, int act, re2e_stream_t stream);
+/* out[n] = beta*out[n] + sum_m A[m*lda+n]; workspace >= re2e_colsum_workspace_bytes */
+size_t re2e_colsum_workspace_bytes(int M, int N);
+int re2e_colsum(const float* A, int M, int N, long lda, float* out, float beta, void* workspace,
+                size_t workspace_bytes, re2e_stream_t stream);
+/* enhancer mask epilogue backward: dlin = dout * mix * m * (1-m)   (enhance_model.py:156-164) */
+int re2e_mask_mul_bwd(const float* dout, const float* mix, const float* mask, float* dlin, long n,
+                      re2e_stream_t stream);
+/* out = a*b elementwise (clean*cos target of the mask-L1 loss, enhance_model.py:170) */
+int re2e_mul(const float* a, const float* b, float* out, long n, re2e_stream_t stream);
+/* CMVN: out[r][j] = (x[r][j] + c0[j]) * c1[j]; c0==NULL gives x*c1 (its backward)  (feat_model.py:132-134) */
+int re2e_affine_cols(const float* x, const float* c0, const float* c1, float* out, long rows, int N,
+                     re2e_stream_t stream);
+/* y = a*x + b*y elementwise (gradient accumulation) */
+int re2e_axpby(float a, const float* x, float b, float* y, long n, re2e_stream_t stream);
+/* dst[i][:] = src[idx[i]][:] (rows of width W); scatter is the inverse (dst[idx[i]][:] = src[i][:]) */
+int re2e_gather_rows(const float* src, const int* idx_dev, float* dst, int nrows, int W, re2e_stream_t stream);
+int re2e_scatter_rows(const float* src, const int* idx_dev, float* dst, int nrows, int W, re2e_stream_t stream);
+/* zero rows t >= lens[b] of a (B,T,W) tensor: out = in masked (mask_by_length, e2e_common.py:190-195) */
+int re2e_mask_rows(const float* in, float* out, const int* lens_dev, int B, int T, int W, re2e_stream_t stream);
+
+/* ---- K1 batch pack/pad (data/mix_data_loader.py:264-302): ragged rows -> zero padded (B,Tmax,F) */
+int re2e_pack_pad(const float* src_flat, const int* offsets_dev, const int* lens_dev, int B, int Tmax, int F,
+                  float* dst, re2e_stream_t stream);
+
+/* ---- K2 fused fbank (model/feat_model.py:118-135): y = log(max((x^2) W, 1e-7)); optional
+ * second output y_norm = (y + cmvn[0]) * cmvn[1].  W is given banded: for filter j the taps
+ * band_w[j*maxw + i] apply to bins band_off[j]+i, i<band_len[j]. */
+int re2e_fbank_fwd(const float* x, long rows, int F, int NF, const int* band_off, const int* band_len,
+                   const float* band_w, int maxw, float* y_raw, float* y_norm, const float* cmvn,
+                   re2e_stream_t stream);
+/* dx = 2x * sum_j W[f][j] * (dy_raw + dy_norm*cmvn1)[j] / P[j], zero where P<=1e-7 (clamp) */
+int re2e_fbank_bwd(const float* x, long rows, int F, int NF, const int* band_off, const int* band_len,
+                   const float* band_w, int maxw, const float* dy_raw, const float* dy_norm, const float* cmvn,
+                   float* dx, re2e_stream_t stream);
+/* per-column sum and sum of squares over valid frames of y (B,T,NF): feat_model.py:62-80 on device */
+int re2e_cmvn_stats(const float* y, const int* lens_dev, int B, int T, int NF, float* sum_out, float* sumsq_out,
+                    re2e_stream_t stream);
+
+/* ---- K10 reductions ---------------------------------------------------------------------- */
+/* out[0] = mean_i loss(a_i - b_i) (b==NULL => constant `target`): F.mse_loss / l1 / smooth_l1
+ * (joint_train.py:162-167) and GANLoss MSE-to-constant (gan_model.py:162-171) */
+size_t re2e_reduce_workspace_bytes(long n);
+int re2e_loss_fwd(const float* a, const float* b, float target, long n, int kind, float* out, void* workspace,
+                  size_t workspace_bytes, re2e_stream_t stream);
+/* da = beta*da + (*gscale_dev) * scale * dloss/da_i / n */
+int re2e_loss_bwd(const float* a, const float* b, float target, long n, int kind, const float* gscale_dev,
+                  float scale, float* da, float beta, re2e_stream_t stream);
+/* out[0] = sum x_i^2 */
+int re2e_sumsq(const float* x, long n, float* out, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+
+/* ---- K5 pooling + VGG output packing (e2e_encoder.py:259-278) ------------------------------ */
+/* 2x2/2 ceil-mode max pool over NHWC; idx_u8 stores the argmax (0..3) for the backward */
+int re2e_maxpool2_fwd(const float* in, int NI, int H, int W, int C, float* out, unsigned char* idx_u8,
+                      re2e_stream_t stream);
+int re2e_maxpool2_bwd(const float* dout, const unsigned char* idx_u8, int NI, int H, int W, int C, float* din,
+                      re2e_stream_t stream);
+/* NHWC (NI,T,Fq,C) -> time-major (T,NI,C*Fq) with rows t>=lens[n] zeroed (cut + re-pad) */
+int re2e_vgg_pack_fwd(const float* in, const int* lens_dev, int NI, int T, int Fq, int C, float* out,
+                      re2e_stream_t stream);
+int re2e_vgg_pack_bwd(const float* dout, const int* lens_dev, int NI, int T, int Fq, int C, float* din,
+                      re2e_stream_t stream);
+
+/* ---- K9 BatchNorm2d (train mode) + LeakyReLU(0.2) over NHWC rows [P][C] (gan_model.py:76-88) */
+size_t re2e_bn_workspace_bytes(long P, int C);
+int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, int train, float* y, float* save_mean,
+                      float* save_invstd, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+/* dy is the gradient w.r.t. the LeakyReLU output; dgamma/dbeta may be NULL (frozen D) */
+int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                      float gbeta, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+
+/* ---- K4 bidirectional LSTM recurrence, packed-sequence semantics (nn.LSTM call sites
+ * e2e_encoder.py:128-132,168-170).  Time-major.  xg_f/xg_r [T*B,4H] hold x W_ih^T + b_ih + b_hh
+ * (gate order i,f,g,o) on entry and the ACTIVATED gates on exit (saved for the backward);
+ * ybuf/cbuf are [(T+2)*B, 2H] with block 0 and block T+1 zero: y[t] lives in block t+1. */
+int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
+                      const int* lens_dev, int T, int B, int H, re2e_stream_t stream);
+/* g_f/g_r: activated gates in, d(pre-activation gates) out (in place).  dy [T*B,2H].
+ * whhT_*: W_hh transposed [H,4H].  dc_state [B,2H] scratch (zeroed by the call). */
+int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whhT_f, const float* whhT_r, const float* dy,
+                      const float* ybuf, const float* cbuf, float* dc_state, const int* lens_dev, int T, int B, int H,
+                      re2e_stream_t stream);
+
+/* ---- K8 LSTMCell pointwise (decoder, e2e_decoder.py:131), embedding, cross-entropy -------- */
+/* gates [B,4H] pre-activation in -> activated out; c_prev [B,H] -> c_out, h_out */
+int re2e_lstm_cell_fwd(float* gates, const float* c_prev, float* c_out, float* h_out, int B, int H,
+                       re2e_stream_t stream);
+/* gates: activated in -> dgates (pre-activation) out; dh,dc_in -> dc_prev_out */
+int re2e_lstm_cell_bwd(float* gates, const float* c_prev, const float* c_cur, const float* dh, const float* dc_in,
+                       float* dc_prev_out, int B, int H, re2e_stream_t stream);
+int re2e_embedding_fwd(const float* table, const int* ids_dev, int n, int D, float* out, long ldo,
+                       re2e_stream_t stream);
+/* dtable[v][:] = beta*dtable + sum_{i: ids[i]==v} dout[i][:] in index order (deterministic) */
+int re2e_embedding_bwd(const float* dout, long ldo, const int* ids_dev, int n, int D, int V, float* dtable,
+                       float beta, re2e_stream_t stream);
+/* F.cross_entropy(ignore_index=-1, mean) * scale and th_accuracy (e2e_decoder.py:155-161).
+ * out[0]=loss, out[1]=#correct, out[2]=#valid ; lse [R] saved for the backward */
+int re2e_ce_fwd(const float* logits, const int* targets_dev, int R, int V, float scale, float* out, float* lse,
+                void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+/* dlogits = (*gscale_dev)*scale/#valid * (softmax - onehot) on valid rows, 0 on ignored rows */
+int re2e_ce_bwd(const float* logits, const int* targets_dev, const float* lse, const float* fwd_out, int R, int V,
+                float scale, const float* gscale_dev, float* dlogits, re2e_stream_t stream);
+
+/* ---- K6 CTC (warp-ctc call site e2e_ctc.py:63): logits (T,B,V) raw activations, blank 0,
+ * loss = sum_b nll_b / B.  labels_dev: flat int32; label_off_dev/label_len_dev per utterance. */
+size_t re2e_ctc_workspace_bytes(int T, int B, int Lmax);
+int re2e_ctc_fwd(const float* logits, int T, int B, int V, const int* hlens_dev, const int* labels_dev,
+                 const int* label_off_dev, const int* label_len_dev, int Lmax, float* loss_out, float* nll_per_utt,
+                 void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+/* dlogits = (*gscale_dev)/B * (softmax - occupancy) for t<hlens[b], 0 otherwise; uses the workspace of fwd */
+int re2e_ctc_bwd(const float* logits, int T, int B, int V, const int* hlens_dev, const int* labels_dev,
+                 const int* label_off_dev, const int* label_len_dev, int Lmax, const float* nll_per_utt,
+                 const float* gscale_dev, float* dlogits, const void* workspace, re2e_stream_t stream);
+
+/* ---- K7 fused location-aware attention step (model/e2e_attention.py:258-297) --------------- */
+/* per utterance b: w = softmax_t(2*(gvec . tanh(W_att conv(att_prev) + pre[b,t] + W_dec z[b]) + gb)),
+ * c[b] = sum_t w[t]*enc[b,t].  att_prev==NULL => uniform 1/hlen over valid frames. */
+int re2e_attloc_fwd(const float* pre, const float* enc, const float* z, const float* att_prev, const int* hlens_dev,
+                    const float* w_dec, const float* w_att, const float* w_conv, const float* gvec, const float* gvec_b,
+                    int B, int T, int eprojs, int dunits, int adim, int chans, int filts, float* w_out, float* c_out,
+                    long ldc_out, re2e_stream_t stream);
+size_t re2e_attloc_partial_floats(int adim, int chans, int filts);
+/* backward of one step; accumulates d_pre/d_enc (+=), writes d_att_prev (may be NULL for step 0),
+ * d_decproj [B,adim] (for the mlp_dec GEMMs) and per-utterance weight-grad partials (+=) laid out
+ * [B][gvec(adim) | gvec_b(1) | w_att(adim*chans) | w_conv(chans*(2*filts+1))] */
+int re2e_attloc_bwd(const float* pre, const float* enc, const float* z, const float* att_prev, const float* w_cur,
+                    const int* hlens_dev, const float* w_dec, const float* w_att, const float* w_conv,
+                    const float* gvec, const float* dc, long ld_dc, const float* dw_in, int B, int T, int eprojs,
+                    int dunits, int adim, int chans, int filts, float* d_pre, float* d_enc, float* d_att_prev,
+                    float* d_decproj, float* partials, re2e_stream_t stream);
+
+/* ---- K11 optimizer (joint_train.py:131-140,188-193; Appendix A.16) ------------------------ */
+/* stats[0]=||g||_2, stats[1]=clip coefficient (<=1), stats[2]=1 if finite else 0; from sumsq[0];
+ * stats[3..5] = the same with coefficient 1 (NaN gate only).  stats_dev holds 6 floats. */
+int re2e_clip_coef(const float* sumsq_dev, float max_norm, float* stats_dev, re2e_stream_t stream);
+/* g <- coef*g applied on the fly; skipped entirely when stats[2]==0 (NaN guard, no host sync) */
+int re2e_adadelta_step(float* p, const float* g, float* sq_avg, float* acc_delta, long n, float rho, float eps,
+                       float lr, const float* stats_dev, re2e_stream_t stream);
+int re2e_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                   float eps, int step, const float* stats_dev, re2e_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RE2E_H */

@@ -1,0 +1,78 @@
+// Shared device/host helpers for the re2e HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/re2e.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RE2E_WAVE 64
+
+void re2e_set_error(const char* fmt, ...);
+
+#define RE2E_CHECK_ARG(cond, msg)                     \
+  do {                                                \
+    if (!(cond)) {                                    \
+      re2e_set_error("%s: %s", __func__, msg);        \
+      return RE2E_EINVAL;                             \
+    }                                                 \
+  } while (0)
+
+#define RE2E_LAUNCH_CHECK()                                                        \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      re2e_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__));   \
+      return RE2E_EHIP;                                                            \
+    }                                                                              \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh via exp; accurate to ~1e-7 relative for |x|<10, saturates cleanly
+__device__ __forceinline__ float tanhf_(float x) {
+  float ax = fabsf(x);
+  float e = __expf(-2.0f * ax);
+  float t = (1.0f - e) / (1.0f + e);
+  return copysignf(t, x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (fixed tree => deterministic).  `red` >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  int nw = (blockDim.x + 63) >> 6;
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  int nw = (blockDim.x + 63) >> 6;
+  float r = -3.0e38f;
+  for (int i = 0; i < nw; ++i) r = fmaxf(r, red[i]);
+  return r;
+}

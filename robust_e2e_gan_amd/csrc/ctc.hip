@@ -1,0 +1,226 @@
+// K6: CTC loss (replaces the warp-ctc call at model/e2e_ctc.py:63; warp-ctc is a third-party
+// dependency that is not vendored in the reference -- restated here as the textbook CTC negative
+// log-likelihood: softmax inside, blank = 0, loss = sum_b nll_b / B).
+//
+//   ctc_lse_gather : one wavefront per (t,b) row of the (T,B,V) logits -- max / log-sum-exp over V
+//                    with wavefront shuffles, then gathers log p at the 2L+1 extended-label states
+//   ctc_alpha_beta : one workgroup per utterance, alpha/beta recursions with the previous column
+//                    staged in LDS; log domain
+//   ctc_grad       : one wavefront per row, dlogits = scale * (softmax - occupancy)
+// HBM traffic: logits are read twice (lse, grad) and dlogits written once.
+#include "common.h"
+
+namespace {
+constexpr float NEG = -1.0e30f;
+
+__device__ __forceinline__ float lse2(float a, float b) {
+  float m = fmaxf(a, b);
+  if (m <= 0.5f * NEG) return NEG;
+  return m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  float m = fmaxf(a, fmaxf(b, c));
+  if (m <= 0.5f * NEG) return NEG;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// workspace layout (floats): lse[T*B] | lp[T*B*S] | alpha[T*B*S] | beta[T*B*S],  S = 2*Lmax+1
+__global__ __launch_bounds__(256) void ctc_lse_gather(const float* __restrict__ logits, int T, int B, int V,
+                                                      const int* __restrict__ hlens, const int* __restrict__ labels,
+                                                      const int* __restrict__ loff, const int* __restrict__ llen, int S,
+                                                      float* __restrict__ lse, float* __restrict__ lp) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= T * B) return;
+  int t = row / B, b = row % B;
+  if (t >= hlens[b]) return;
+  const float* x = logits + (long)row * V;
+  float m = -3.0e38f;
+  for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int v = lane; v < V; v += 64) s += expf(x[v] - m);
+  s = wave_sum(s);
+  float l = m + logf(s);
+  if (lane == 0) lse[row] = l;
+  int Sb = 2 * llen[b] + 1;
+  const int* lab = labels + loff[b];
+  for (int sidx = lane; sidx < Sb; sidx += 64) {
+    int v = (sidx & 1) ? lab[sidx >> 1] : 0;
+    lp[(long)row * S + sidx] = x[v] - l;
+  }
+}
+
+__global__ void ctc_alpha_beta(int T, int B, const int* __restrict__ hlens, const int* __restrict__ labels,
+                               const int* __restrict__ loff, const int* __restrict__ llen, int S,
+                               const float* __restrict__ lp, float* __restrict__ alpha, float* __restrict__ beta,
+                               float* __restrict__ nll) {
+  extern __shared__ float sm[];      // prev[2][S+2]
+  int b = blockIdx.x;
+  int s = threadIdx.x;
+  int L = llen[b], Sb = 2 * L + 1, Tb = hlens[b];
+  const int* lab = labels + loff[b];
+  float* p0 = sm;
+  float* p1 = sm + (S + 2);
+  // skip transition allowed into state s from s-2 ?
+  bool skip_in = false, skip_out = false;
+  if (s < Sb && (s & 1)) {
+    if (s >= 3) skip_in = lab[s >> 1] != lab[(s >> 1) - 1];
+    if (s + 2 < Sb) skip_out = lab[s >> 1] != lab[(s >> 1) + 1];
+  }
+  // ---- alpha ----
+  float a = NEG;
+  if (s < Sb && Tb > 0) {
+    if (s == 0) a = lp[((long)0 * B + b) * S + 0];
+    else if (s == 1 && Sb > 1) a = lp[((long)0 * B + b) * S + 1];
+    alpha[((long)0 * B + b) * S + s] = a;
+  }
+  for (int t = 1; t < Tb; ++t) {
+    float* cur = (t & 1) ? p0 : p1;
+    if (s < Sb) cur[s + 2] = a;
+    if (s < 2) cur[s] = NEG;
+    __syncthreads();
+    if (s < Sb) {
+      float v = skip_in ? lse3(cur[s + 2], cur[s + 1], cur[s]) : lse2(cur[s + 2], cur[s + 1]);
+      a = v + lp[((long)t * B + b) * S + s];
+      if (v <= 0.5f * NEG) a = NEG;
+      alpha[((long)t * B + b) * S + s] = a;
+    }
+  }
+  __syncthreads();
+  if (Tb > 0) {
+    float* cur = p0;
+    if (s < Sb) cur[s] = a;
+    __syncthreads();
+    if (s == 0) nll[b] = -(Sb > 1 ? lse2(cur[Sb - 1], cur[Sb - 2]) : cur[Sb - 1]);
+  } else if (s == 0) nll[b] = 0.f;
+  __syncthreads();
+  // ---- beta (includes lp at its own frame) ----
+  float be = NEG;
+  if (s < Sb && Tb > 0) {
+    if (s == Sb - 1 || s == Sb - 2) be = lp[((long)(Tb - 1) * B + b) * S + s];
+    beta[((long)(Tb - 1) * B + b) * S + s] = be;
+  }
+  for (int t = Tb - 2; t >= 0; --t) {
+    float* cur = (t & 1) ? p0 : p1;
+    if (s < Sb) cur[s] = be;
+    if (s < 2) cur[Sb + s] = NEG;
+    __syncthreads();
+    if (s < Sb) {
+      float v = skip_out ? lse3(cur[s], cur[s + 1], cur[s + 2]) : lse2(cur[s], cur[s + 1]);
+      be = v + lp[((long)t * B + b) * S + s];
+      if (v <= 0.5f * NEG) be = NEG;
+      beta[((long)t * B + b) * S + s] = be;
+    }
+  }
+}
+
+__global__ void ctc_loss_final(const float* __restrict__ nll, int B, float* loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += nll[b];
+    loss[0] = s / (float)B;
+  }
+}
+
+__global__ __launch_bounds__(256) void ctc_grad(const float* __restrict__ logits, int T, int B, int V,
+                                                const int* __restrict__ hlens, const int* __restrict__ labels,
+                                                const int* __restrict__ loff, const int* __restrict__ llen, int S,
+                                                const float* __restrict__ lse, const float* __restrict__ lp,
+                                                const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                const float* __restrict__ nll, const float* __restrict__ gscale,
+                                                float* __restrict__ dlogits) {
+  extern __shared__ float occ[];     // [4][S]
+  int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + wv;
+  bool live = row < T * B;
+  int t = live ? row / B : 0, b = live ? row % B : 0;
+  bool active = live && t < hlens[b];
+  float scale = (gscale ? gscale[0] : 1.f) / (float)B;
+  float* o = occ + wv * S;
+  int Sb = active ? 2 * llen[b] + 1 : 0;
+  const int* lab = labels + (live ? loff[b] : 0);
+  float blank = 0.f;
+  if (active) {
+    float nl = nll[b];
+    for (int s = lane; s < Sb; s += 64) {
+      long i = (long)row * S + s;
+      float a = alpha[i], be = beta[i];
+      float v = (a <= 0.5f * NEG || be <= 0.5f * NEG) ? 0.f : expf(a + be - lp[i] + nl);
+      o[s] = v;
+      if (!(s & 1)) blank += v;
+    }
+    blank = wave_sum(blank);
+  }
+  float* dst = dlogits + (long)row * V;
+  if (live) {
+    if (!active) {
+      for (int v = lane; v < V; v += 64) dst[v] = 0.f;
+    } else {
+      const float* x = logits + (long)row * V;
+      float l = lse[row];
+      for (int v = lane; v < V; v += 64) {
+        float y = expf(x[v] - l);
+        if (v == 0) y -= blank;
+        dst[v] = scale * y;
+      }
+    }
+  }
+  __syncthreads();     // block-wide visibility of the row just written (and of occ[])
+  if (active) {
+    for (int s = 1 + 2 * lane; s < Sb; s += 128) {     // odd states: one label each
+      int l = lab[s >> 1];
+      bool first = true;
+      for (int s2 = 1; s2 < s; s2 += 2) if (lab[s2 >> 1] == l) { first = false; break; }
+      if (first) {
+        float tot = 0.f;
+        for (int s2 = s; s2 < Sb; s2 += 2) if (lab[s2 >> 1] == l) tot += o[s2];
+        dst[l] -= scale * tot;
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" size_t re2e_ctc_workspace_bytes(int T, int B, int Lmax) {
+  size_t S = 2 * (size_t)Lmax + 1;
+  return ((size_t)T * B * (1 + 3 * S)) * sizeof(float);
+}
+
+extern "C" int re2e_ctc_fwd(const float* logits, int T, int B, int V, const int* hlens, const int* labels, const int* loff,
+                            const int* llen, int Lmax, float* loss_out, float* nll_per_utt, void* workspace,
+                            size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(logits && hlens && labels && loff && llen && loss_out && nll_per_utt && workspace, "null arg");
+  RE2E_CHECK_ARG(T > 0 && B > 0 && V > 1 && Lmax >= 0, "bad shape");
+  int S = 2 * Lmax + 1;
+  RE2E_CHECK_ARG(S <= 1024, "label sequence too long (2L+1 must be <= 1024)");
+  RE2E_CHECK_ARG(workspace_bytes >= re2e_ctc_workspace_bytes(T, B, Lmax), "workspace too small");
+  float* lse = (float*)workspace;
+  float* lp = lse + (size_t)T * B;
+  float* alpha = lp + (size_t)T * B * S;
+  float* beta = alpha + (size_t)T * B * S;
+  hipLaunchKernelGGL(ctc_lse_gather, dim3(cdiv((long)T * B, 4)), dim3(256), 0, stream, logits, T, B, V, hlens, labels, loff, llen,
+                     S, lse, lp);
+  int threads = ((S + 63) / 64) * 64;
+  hipLaunchKernelGGL(ctc_alpha_beta, dim3(B), dim3(threads), (size_t)2 * (S + 2) * sizeof(float), stream, T, B, hlens, labels, loff,
+                     llen, S, (const float*)lp, alpha, beta, nll_per_utt);
+  hipLaunchKernelGGL(ctc_loss_final, dim3(1), dim3(64), 0, stream, (const float*)nll_per_utt, B, loss_out);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+extern "C" int re2e_ctc_bwd(const float* logits, int T, int B, int V, const int* hlens, const int* labels, const int* loff,
+                            const int* llen, int Lmax, const float* nll_per_utt, const float* gscale, float* dlogits,
+                            const void* workspace, hipStream_t stream) {
+  RE2E_CHECK_ARG(logits && hlens && labels && loff && llen && nll_per_utt && dlogits && workspace, "null arg");
+  RE2E_CHECK_ARG(T > 0 && B > 0 && V > 1 && Lmax >= 0, "bad shape");
+  int S = 2 * Lmax + 1;
+  const float* lse = (const float*)workspace;
+  const float* lp = lse + (size_t)T * B;
+  const float* alpha = lp + (size_t)T * B * S;
+  const float* beta = alpha + (size_t)T * B * S;
+  hipLaunchKernelGGL(ctc_grad, dim3(cdiv((long)T * B, 4)), dim3(256), (size_t)4 * S * sizeof(float), stream, logits, T, B, V, hlens,
+                     labels, loff, llen, S, lse, lp, alpha, beta, nll_per_utt, gscale, dlogits);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}

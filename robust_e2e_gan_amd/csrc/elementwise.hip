@@ -1,0 +1,544 @@
+// HBM-bound helpers: layout transposes, activation backward, column sums, enhancer mask backward,
+// row gather/scatter, length masking, K1 batch pack/pad, K10 loss reductions, K5 pooling and VGG
+// output packing, K9 BatchNorm2d(+LeakyReLU), K11 optimizer.  All reductions are two-stage with a
+// fixed tree (bitwise reproducible).  Coalescing rule everywhere: consecutive lanes touch
+// consecutive floats of the innermost (feature / channel) axis.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+inline int grid_for(long n, int per = TPB, int cap = 8192) {
+  long g = (n + per - 1) / per;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+__global__ void transpose01_kernel(const float* __restrict__ in, float* __restrict__ out, int D0, int D1, int W) {
+  long tot = (long)D0 * D1 * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    int w = (int)(i % W); long r = i / W; int d0 = (int)(r % D0); int d1 = (int)(r / D0);   // out index (d1,d0,w)
+    out[i] = in[((long)d0 * D1 + d1) * W + w];
+  }
+}
+extern "C" int re2e_transpose01(const float* in, float* out, int D0, int D1, int W, hipStream_t stream) {
+  RE2E_CHECK_ARG(in && out && D0 > 0 && D1 > 0 && W > 0, "bad args");
+  long tot = (long)D0 * D1 * W;
+  hipLaunchKernelGGL(transpose01_kernel, dim3(grid_for(tot)), dim3(TPB), 0, stream, in, out, D0, D1, W);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+__global__ void act_bwd_kernel(const float* dy, const float* __restrict__ y, float* dz, long n, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = y[i], g = dy[i];
+    switch (act) {
+      case RE2E_ACT_TANH: g *= (1.f - v * v); break;
+      case RE2E_ACT_RELU: g = v > 0.f ? g : 0.f; break;
+      case RE2E_ACT_LRELU: g = v > 0.f ? g : 0.2f * g; break;
+      case RE2E_ACT_SIGMOID: g *= v * (1.f - v); break;
+      default: break;
+    }
+    dz[i] = g;
+  }
+}
+extern "C" int re2e_act_bwd(const float* dy, const float* y, float* dz, long n, int act, hipStream_t stream) {
+  RE2E_CHECK_ARG(dy && y && dz && n > 0, "bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, dy, y, dz, n, act);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// ---- column sums: partial[chunk][N] then fixed-order sum over chunks --------------------------
+__global__ void colsum_partial_kernel(const float* __restrict__ A, int M, int N, long lda, int rows_per_chunk,
+                                      float* __restrict__ part) {
+  __shared__ float red[4][64];
+  int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  int col = blockIdx.x * 64 + cx;
+  int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + ry; r < r1; r += 4) s += A[(long)r * lda + col];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < N) part[(long)blockIdx.y * N + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, int N, float* out, float beta) {
+  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(long)c * N + col];
+  out[col] = (beta != 0.f ? beta * out[col] : 0.f) + s;
+}
+static inline int colsum_chunks(int M) { int c = cdiv(M, 128); return c > 512 ? 512 : (c < 1 ? 1 : c); }
+extern "C" size_t re2e_colsum_workspace_bytes(int M, int N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
+extern "C" int re2e_colsum(const float* A, int M, int N, long lda, float* out, float beta, void* workspace,
+                           size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(A && out && workspace && M > 0 && N > 0, "bad args");
+  int chunks = colsum_chunks(M);
+  RE2E_CHECK_ARG(workspace_bytes >= (size_t)chunks * N * sizeof(float), "workspace too small");
+  int rpc = cdiv(M, chunks);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, stream, A, M, N, lda, rpc,
+                     (float*)workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, (const float*)workspace, chunks, N,
+                     out, beta);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+__global__ void mask_mul_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ mix,
+                                    const float* __restrict__ mask, float* __restrict__ dlin, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float m = mask[i];
+    dlin[i] = dout[i] * mix[i] * m * (1.f - m);
+  }
+}
+extern "C" int re2e_mask_mul_bwd(const float* dout, const float* mix, const float* mask, float* dlin, long n,
+                                 hipStream_t stream) {
+  RE2E_CHECK_ARG(dout && mix && mask && dlin && n > 0, "bad args");
+  hipLaunchKernelGGL(mask_mul_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, dout, mix, mask, dlin, n);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+__global__ void axpby_kernel(float a, const float* __restrict__ x, float b, float* y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
+}
+extern "C" int re2e_axpby(float a, const float* x, float b, float* y, long n, hipStream_t stream) {
+  RE2E_CHECK_ARG(x && y && n > 0, "bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, a, x, b, y, n);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+extern "C" int re2e_mul(const float* a, const float* b, float* out, long n, hipStream_t stream) {
+  RE2E_CHECK_ARG(a && b && out && n > 0, "bad args");
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, a, b, out, n);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// out[r][j] = (x[r][j] + c0[j]) * c1[j]   (c0 == NULL: x*c1 -- the backward form)
+__global__ void affine_cols_kernel(const float* __restrict__ x, const float* __restrict__ c0, const float* __restrict__ c1,
+                                   float* __restrict__ out, long rows, int N) {
+  long tot = rows * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    int j = (int)(i % N);
+    float v = x[i];
+    if (c0) v += c0[j];
+    out[i] = v * c1[j];
+  }
+}
+extern "C" int re2e_affine_cols(const float* x, const float* c0, const float* c1, float* out, long rows, int N, hipStream_t stream) {
+  RE2E_CHECK_ARG(x && c1 && out && rows > 0 && N > 0, "bad args");
+  hipLaunchKernelGGL(affine_cols_kernel, dim3(grid_for(rows * N)), dim3(TPB), 0, stream, x, c0, c1, out, rows, N);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
+                                   int nrows, int W, int scatter) {
+  long tot = (long)nrows * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    int w = (int)(i % W); int r = (int)(i / W);
+    if (scatter) dst[(long)idx[r] * W + w] = src[i];
+    else dst[i] = src[(long)idx[r] * W + w];
+  }
+}
+extern "C" int re2e_gather_rows(const float* src, const int* idx, float* dst, int nrows, int W, hipStream_t stream) {
+  RE2E_CHECK_ARG(src && idx && dst && nrows > 0 && W > 0, "bad args");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)nrows * W)), dim3(TPB), 0, stream, src, idx, dst, nrows, W, 0);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+extern "C" int re2e_scatter_rows(const float* src, const int* idx, float* dst, int nrows, int W, hipStream_t stream) {
+  RE2E_CHECK_ARG(src && idx && dst && nrows > 0 && W > 0, "bad args");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)nrows * W)), dim3(TPB), 0, stream, src, idx, dst, nrows, W, 1);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+__global__ void mask_rows_kernel(const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ lens,
+                                 int B, int T, int W) {
+  long tot = (long)B * T * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    long r = i / W; int t = (int)(r % T); int b = (int)(r / T);
+    out[i] = t < lens[b] ? in[i] : 0.f;
+  }
+}
+extern "C" int re2e_mask_rows(const float* in, float* out, const int* lens, int B, int T, int W, hipStream_t stream) {
+  RE2E_CHECK_ARG(in && out && lens && B > 0 && T > 0 && W > 0, "bad args");
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for((long)B * T * W)), dim3(TPB), 0, stream, in, out, lens, B, T, W);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+__global__ void pack_pad_kernel(const float* __restrict__ src, const int* __restrict__ off, const int* __restrict__ lens,
+                                int B, int Tmax, int F, float* __restrict__ dst) {
+  long tot = (long)B * Tmax * F;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    int f = (int)(i % F); long r = i / F; int t = (int)(r % Tmax); int b = (int)(r / Tmax);
+    dst[i] = t < lens[b] ? src[((long)off[b] + t) * F + f] : 0.f;
+  }
+}
+extern "C" int re2e_pack_pad(const float* src_flat, const int* offsets, const int* lens, int B, int Tmax, int F, float* dst,
+                             hipStream_t stream) {
+  RE2E_CHECK_ARG(src_flat && offsets && lens && dst && B > 0 && Tmax > 0 && F > 0, "bad args");
+  hipLaunchKernelGGL(pack_pad_kernel, dim3(grid_for((long)B * Tmax * F)), dim3(TPB), 0, stream, src_flat, offsets, lens, B,
+                     Tmax, F, dst);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// ---- K10 loss reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float loss_elem(float d, int kind) {
+  if (kind == RE2E_LOSS_L2) return d * d;
+  float ad = fabsf(d);
+  if (kind == RE2E_LOSS_L1) return ad;
+  return ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+}
+__device__ __forceinline__ float loss_grad(float d, int kind) {
+  if (kind == RE2E_LOSS_L2) return 2.f * d;
+  if (kind == RE2E_LOSS_L1) return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+}
+static inline int reduce_blocks(long n) { long g = (n + 4095) / 4096; return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g)); }
+extern "C" size_t re2e_reduce_workspace_bytes(long n) { return (size_t)reduce_blocks(n) * sizeof(float); }
+
+__global__ void loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float target, long n,
+                                    int kind, float* __restrict__ part) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    s += loss_elem(a[i] - (b ? b[i] : target), kind);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void sum_final_kernel(const float* __restrict__ part, int np, float scale, float* out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+extern "C" int re2e_loss_fwd(const float* a, const float* b, float target, long n, int kind, float* out, void* workspace,
+                             size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(a && out && workspace && n > 0, "bad args");
+  int nb = reduce_blocks(n);
+  RE2E_CHECK_ARG(workspace_bytes >= (size_t)nb * sizeof(float), "workspace too small");
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, stream, a, b, target, n, kind, (float*)workspace);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, nb, 1.0f / (float)n, out);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+__global__ void loss_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float target, long n, int kind,
+                                const float* __restrict__ gscale, float scale, float* da, float beta) {
+  float g = (gscale ? gscale[0] : 1.f) * scale / (float)n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = g * loss_grad(a[i] - (b ? b[i] : target), kind);
+    da[i] = (beta != 0.f ? beta * da[i] : 0.f) + v;
+  }
+}
+extern "C" int re2e_loss_bwd(const float* a, const float* b, float target, long n, int kind, const float* gscale, float scale,
+                             float* da, float beta, hipStream_t stream) {
+  RE2E_CHECK_ARG(a && da && n > 0, "bad args");
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, a, b, target, n, kind, gscale, scale, da, beta);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+__global__ void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += x[i] * x[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+extern "C" int re2e_sumsq(const float* x, long n, float* out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(x && out && workspace && n > 0, "bad args");
+  int nb = reduce_blocks(n);
+  RE2E_CHECK_ARG(workspace_bytes >= (size_t)nb * sizeof(float), "workspace too small");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, stream, x, n, (float*)workspace);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, nb, 1.0f, out);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// ---- K5 max pool 2x2 stride 2 ceil mode over NHWC -------------------------------------------
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ in, int NI, int H, int W, int C, float* __restrict__ out,
+                                    unsigned char* __restrict__ idx) {
+  int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  long tot = (long)NI * OH * OW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); long r = i / C; int ox = (int)(r % OW); r /= OW; int oy = (int)(r % OH); int n = (int)(r / OH);
+    float best = -3.0e38f; int bi = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      int iy = oy * 2 + (d >> 1), ix = ox * 2 + (d & 1);
+      if (iy < H && ix < W) {
+        float v = in[(((long)n * H + iy) * W + ix) * C + c];
+        if (v > best) { best = v; bi = d; }     // first max wins (PyTorch order: row-major scan)
+      }
+    }
+    out[i] = best; idx[i] = (unsigned char)bi;
+  }
+}
+extern "C" int re2e_maxpool2_fwd(const float* in, int NI, int H, int W, int C, float* out, unsigned char* idx,
+                                 hipStream_t stream) {
+  RE2E_CHECK_ARG(in && out && idx && NI > 0 && H > 0 && W > 0 && C > 0, "bad args");
+  long tot = (long)NI * ((H + 1) / 2) * ((W + 1) / 2) * C;
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(tot)), dim3(TPB), 0, stream, in, NI, H, W, C, out, idx);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ idx, int NI, int H,
+                                    int W, int C, float* __restrict__ din) {
+  int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  long tot = (long)NI * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); long r = i / C; int ix = (int)(r % W); r /= W; int iy = (int)(r % H); int n = (int)(r / H);
+    int oy = iy >> 1, ox = ix >> 1; int d = ((iy & 1) << 1) | (ix & 1);
+    long o = (((long)n * OH + oy) * OW + ox) * C + c;
+    din[i] = (idx[o] == d) ? dout[o] : 0.f;
+  }
+}
+extern "C" int re2e_maxpool2_bwd(const float* dout, const unsigned char* idx, int NI, int H, int W, int C, float* din,
+                                 hipStream_t stream) {
+  RE2E_CHECK_ARG(dout && idx && din && NI > 0 && H > 0 && W > 0 && C > 0, "bad args");
+  long tot = (long)NI * H * W * C;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(tot)), dim3(TPB), 0, stream, dout, idx, NI, H, W, C, din);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// NHWC (NI,T,Fq,C) -> (T,NI,C*Fq): feature index c*Fq+f (e2e_encoder.py:274-276), zero for t>=lens[n]
+__global__ void vgg_pack_kernel(const float* __restrict__ src, const int* __restrict__ lens, int NI, int T, int Fq, int C,
+                                float* __restrict__ dst, int backward) {
+  long tot = (long)T * NI * C * Fq;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    if (!backward) {       // i indexes dst (t, n, c, f): coalesced writes
+      int f = (int)(i % Fq); long r = i / Fq; int c = (int)(r % C); r /= C; int n = (int)(r % NI); int t = (int)(r / NI);
+      dst[i] = t < lens[n] ? src[(((long)n * T + t) * Fq + f) * C + c] : 0.f;
+    } else {               // i indexes din (n, t, f, c): coalesced writes
+      int c = (int)(i % C); long r = i / C; int f = (int)(r % Fq); r /= Fq; int t = (int)(r % T); int n = (int)(r / T);
+      dst[i] = t < lens[n] ? src[(((long)t * NI + n) * C + c) * Fq + f] : 0.f;
+    }
+  }
+}
+extern "C" int re2e_vgg_pack_fwd(const float* in, const int* lens, int NI, int T, int Fq, int C, float* out, hipStream_t stream) {
+  RE2E_CHECK_ARG(in && lens && out && NI > 0 && T > 0 && Fq > 0 && C > 0, "bad args");
+  hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, in, lens, NI, T, Fq, C, out, 0);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+extern "C" int re2e_vgg_pack_bwd(const float* dout, const int* lens, int NI, int T, int Fq, int C, float* din, hipStream_t stream) {
+  RE2E_CHECK_ARG(dout && lens && din && NI > 0 && T > 0 && Fq > 0 && C > 0, "bad args");
+  hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, dout, lens, NI, T, Fq, C, din, 1);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// ---- K9 BatchNorm2d (train) + LeakyReLU(0.2) over rows [P][C] ---------------------------------
+// partial sums over row chunks: mode 0: sum(x - center) ; mode 1: sum((x-center)^2)
+// mode 2 (backward): s0 = sum dz, s1 = sum dz*xhat with dz = dy * lrelu'(bn(x))
+static inline int bn_chunks(long P) { long c = (P + 255) / 256; return (int)(c > 512 ? 512 : (c < 1 ? 1 : c)); }
+extern "C" size_t re2e_bn_workspace_bytes(long P, int C) { return (size_t)bn_chunks(P) * 2 * C * sizeof(float) + 4 * C * sizeof(float); }
+
+__global__ void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, long P, int C, long rows_per_chunk,
+                                  int mode, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ part) {
+  __shared__ float r0[4][64], r1[4][64];
+  int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  int c = blockIdx.x * 64 + cx;
+  long p0 = (long)blockIdx.y * rows_per_chunk, p1 = p0 + rows_per_chunk; if (p1 > P) p1 = P;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    float mu = mean ? mean[c] : 0.f;
+    float is = invstd ? invstd[c] : 1.f, ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    for (long p = p0 + ry; p < p1; p += 4) {
+      float v = x[p * C + c] - mu;
+      if (mode == 0) s0 += v;
+      else if (mode == 1) s0 += v * v;
+      else {
+        float xh = v * is; float y = xh * ga + be; float dz = dy[p * C + c]; dz = y > 0.f ? dz : 0.2f * dz;
+        s0 += dz; s1 += dz * xh;
+      }
+    }
+  }
+  r0[ry][cx] = s0; r1[ry][cx] = s1;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    part[((long)blockIdx.y * 2 + 0) * C + c] = (r0[0][cx] + r0[1][cx]) + (r0[2][cx] + r0[3][cx]);
+    part[((long)blockIdx.y * 2 + 1) * C + c] = (r1[0][cx] + r1[1][cx]) + (r1[2][cx] + r1[3][cx]);
+  }
+}
+// stats[0..C) = result of slot 0 summed over chunks * scale0 ; stats[C..2C) = slot 1 * scale1
+__global__ void bn_combine_kernel(const float* __restrict__ part, int chunks, int C, float scale0, float scale1, float* out0, float* out1) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = 0; k < chunks; ++k) { s0 += part[((long)k * 2 + 0) * C + c]; s1 += part[((long)k * 2 + 1) * C + c]; }
+  if (out0) out0[c] = s0 * scale0;
+  if (out1) out1[c] = s1 * scale1;
+}
+__global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ var_b, long P, int C, float momentum,
+                                   float eps, float* running_mean, float* running_var, float* save_mean, float* save_invstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float m = mean[c], v = var_b[c];
+  save_mean[c] = m; save_invstd[c] = rsqrtf(v + eps);
+  float unb = P > 1 ? v * ((float)P / (float)(P - 1)) : v;
+  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+  running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+}
+__global__ void bn_eval_stats_kernel(const float* rm, const float* rv, int C, float eps, float* save_mean, float* save_invstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  save_mean[c] = rm[c]; save_invstd[c] = rsqrtf(rv[c] + eps);
+}
+__global__ void bn_apply_kernel(const float* __restrict__ x, long P, int C, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                float* __restrict__ y) {
+  long tot = P * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    float v = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    y[i] = v > 0.f ? v : 0.2f * v;
+  }
+}
+extern "C" int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float momentum, float eps, int train, float* y, float* save_mean,
+                                 float* save_invstd, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && save_mean && save_invstd && workspace, "null arg");
+  RE2E_CHECK_ARG(P > 0 && C > 0, "bad shape");
+  RE2E_CHECK_ARG(workspace_bytes >= re2e_bn_workspace_bytes(P, C), "workspace too small");
+  int chunks = bn_chunks(P);
+  long rpc = (P + chunks - 1) / chunks;
+  float* part = (float*)workspace;
+  float* tmp = part + (size_t)chunks * 2 * C;    // [mean | var]
+  dim3 g(cdiv(C, 64), chunks);
+  if (train) {
+    hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 0, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
+                       0.f, tmp, (float*)nullptr);
+    hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 1, (const float*)tmp,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
+                       0.f, tmp + C, (float*)nullptr);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)tmp, (const float*)(tmp + C), P, C,
+                       momentum, eps, running_mean, running_var, save_mean, save_invstd);
+  } else {
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)running_mean,
+                       (const float*)running_var, C, eps, save_mean, save_invstd);
+  }
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, x, P, C, (const float*)save_mean,
+                     (const float*)save_invstd, gamma, beta, y);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, long P, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ sdz, const float* __restrict__ sdzx,
+                                    float* __restrict__ dx) {
+  long tot = P * C;
+  float invP = 1.0f / (float)P;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    float xh = (x[i] - mean[c]) * invstd[c];
+    float yv = xh * gamma[c] + beta[c];
+    float dz = dy[i]; dz = yv > 0.f ? dz : 0.2f * dz;
+    dx[i] = gamma[c] * invstd[c] * (dz - sdz[c] * invP - xh * sdzx[c] * invP);
+  }
+}
+__global__ void bn_param_grad_kernel(const float* sdz, const float* sdzx, int C, float* dgamma, float* dbeta, float gbeta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dgamma[c] = (gbeta != 0.f ? gbeta * dgamma[c] : 0.f) + sdzx[c];
+  dbeta[c] = (gbeta != 0.f ? gbeta * dbeta[c] : 0.f) + sdz[c];
+}
+extern "C" int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                                 float gbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dx && workspace, "null arg");
+  RE2E_CHECK_ARG(workspace_bytes >= re2e_bn_workspace_bytes(P, C), "workspace too small");
+  int chunks = bn_chunks(P);
+  long rpc = (P + chunks - 1) / chunks;
+  float* part = (float*)workspace;
+  float* tmp = part + (size_t)chunks * 2 * C;
+  dim3 g(cdiv(C, 64), chunks);
+  hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part);
+  hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)part, chunks, C, 1.0f, 1.0f, tmp, tmp + C);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, dy, x, P, C, save_mean, save_invstd, gamma,
+                     beta, (const float*)tmp, (const float*)(tmp + C), dx);
+  if (dgamma && dbeta)
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)tmp, (const float*)(tmp + C), C,
+                       dgamma, dbeta, gbeta);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// ---- K11 optimizer ------------------------------------------------------------------------
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* stats) {
+  float n = sqrtf(sumsq[0]);
+  float c = max_norm / (n + 1e-6f);
+  stats[0] = n;
+  stats[1] = c < 1.f ? c : 1.f;
+  stats[2] = (n == n && fabsf(n) < 3.0e38f) ? 1.f : 0.f;     // torch only tests isnan; inf norm => coef 0 anyway
+  if (!(n == n)) stats[2] = 0.f;
+  // second triple: "gate only" view (coefficient 1) for optimizers that share the NaN guard but
+  // are not clipped (enhancer in joint_train.py:188-193)
+  stats[3] = n; stats[4] = 1.f; stats[5] = stats[2];
+}
+extern "C" int re2e_clip_coef(const float* sumsq, float max_norm, float* stats, hipStream_t stream) {
+  RE2E_CHECK_ARG(sumsq && stats, "null arg");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sumsq, max_norm, stats);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+__global__ void adadelta_kernel(float* p, const float* __restrict__ g, float* sq, float* acc, long n, float rho, float eps, float lr,
+                                const float* __restrict__ stats) {
+  float coef = 1.f;
+  if (stats) { if (stats[2] == 0.f) return; coef = stats[1]; }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gr = g[i] * coef;
+    float v = sq[i] * rho + gr * gr * (1.f - rho);
+    float u = acc[i];
+    float delta = sqrtf(u + eps) / sqrtf(v + eps) * gr;
+    sq[i] = v;
+    acc[i] = u * rho + delta * delta * (1.f - rho);
+    p[i] -= lr * delta;
+  }
+}
+extern "C" int re2e_adadelta_step(float* p, const float* g, float* sq_avg, float* acc_delta, long n, float rho, float eps, float lr,
+                                  const float* stats, hipStream_t stream) {
+  RE2E_CHECK_ARG(p && g && sq_avg && acc_delta && n > 0, "bad args");
+  hipLaunchKernelGGL(adadelta_kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, p, g, sq_avg, acc_delta, n, rho, eps, lr, stats);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+__global__ void adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2, const float* __restrict__ stats) {
+  float coef = 1.f;
+  if (stats) { if (stats[2] == 0.f) return; coef = stats[1]; }
+  float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gr = g[i] * coef;
+    float mi = m[i] * b1 + (1.f - b1) * gr;
+    float vi = v[i] * b2 + (1.f - b2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= step_size * mi / denom;
+  }
+}
+extern "C" int re2e_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                              int step, const float* stats, hipStream_t stream) {
+  RE2E_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "bad args");
+  float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2, stats);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}

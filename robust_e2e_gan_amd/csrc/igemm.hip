@@ -1,0 +1,545 @@
+// K3 / K5 / K9: fp32 MFMA (v_mfma_f32_32x32x2_f32) tiled GEMM engine for gfx950.
+//
+// One mainloop serves the dense Linear GEMMs (NT / NN / TN), the implicit-GEMM convolution
+// forward + data-gradient (im2col gather as the A operand, NHWC activations) and the
+// convolution weight-gradient (im2col gather as the A operand over the pixel (=K) axis,
+// split-K partial slabs + deterministic reduce).  Wave = 64 lanes computes TMxTN tiles of 32x32;
+// the k index inside a group of 8 is assigned k = 8q + 4*(lane>>5) + j so that a lane fetches
+// its 4 k-values for 4 consecutive MFMAs with ONE ds_read_b128 (LDS rows padded to 36 floats:
+// conflict-free for the b128 lane groups).
+//
+// Replaces (reference, stock ATen ops): torch.nn.Linear / torch.mm call sites in
+// model/e2e_encoder.py:145-147,173-174, model/e2e_ctc.py:51, model/e2e_attention.py:256,
+// model/e2e_decoder.py:131,150, model/enhance_model.py:108-114 and nn.Conv2d in
+// model/e2e_encoder.py:234-237 (VGG2L) and model/gan_model.py:63-90 (discriminator).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;        // k-tile
+constexpr int LDK = BK + 4;   // padded k stride of a k-major LDS tile (floats)
+
+template <int WM_, int WN_, int TM_, int TN_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr int BM = WM_ * TM_ * 32, BN = WN_ * TN_ * 32;
+  static constexpr int THREADS = WM_ * WN_ * 64;
+};
+
+// ------------------------------------------------------------------------------------------
+// Operand loaders.  A loader describes a logical matrix X[row][k] (rows = M for the A operand,
+// N for the B operand).  KMAJ loaders fetch float4 along k (LDS tile [row][LDK]); MMAJ loaders
+// fetch float4 along rows (LDS tile [k][ROWS+4]).  `init` caches per-thread row state once.
+// ------------------------------------------------------------------------------------------
+struct DenseK {   // X[row*ld + k]
+  static constexpr bool KMAJ = true;
+  const float* p; long ld; int rows, K; bool vec;
+  struct St { const float* rp; int k; };
+  __device__ void init(St& s, int row, int kofs, int kbegin) const {
+    s.rp = row < rows ? p + (long)row * ld : nullptr; s.k = kbegin + kofs;
+  }
+  __device__ void advance(St& s) const { s.k += BK; }
+  __device__ f32x4 load(const St& s) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s.rp == nullptr) return v;
+    const int k = s.k;
+    if (vec && k + 3 < K) return *reinterpret_cast<const f32x4*>(s.rp + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = s.rp[k + j];
+    return v;
+  }
+};
+
+struct DenseM {   // X[k*ld + row]
+  static constexpr bool KMAJ = false;
+  const float* p; long ld; int rows, K; bool vec;
+  struct St { int r0; int k; };
+  __device__ void init(St& s, int row0, int kofs, int kbegin) const { s.r0 = row0; s.k = kbegin + kofs; }
+  __device__ void advance(St& s) const { s.k += BK; }
+  __device__ f32x4 load(const St& s) const {   // rows r0..r0+3 at column k
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s.k >= K || s.r0 >= rows) return v;
+    const float* q = p + (long)s.k * ld + s.r0;
+    if (vec && s.r0 + 3 < rows) return *reinterpret_cast<const f32x4*>(q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (s.r0 + j < rows) v[j] = q[j];
+    return v;
+  }
+};
+
+// im2col geometry over an NHWC tensor: logical pixel grid (NI, PH, PW) -> input coordinate
+// iy = py*SY + kh*DY + OY0, ix = px*SX + kw*DX + OX0 ; taps KH x KW ; C channels innermost.
+struct ConvGeom {
+  const float* in; int NI, H, W, C; int PH, PW; int KH, KW; int SY, SX, DY, DX, OY0, OX0;
+};
+
+struct ConvK {    // rows = pixels, k = (kh, kw, ci) with ci fastest
+  static constexpr bool KMAJ = true;
+  ConvGeom g; int rows, K; bool vec;
+  struct St { int n, iy0, ix0; int k, ci, kh, kw; };
+  __device__ void init(St& s, int row, int kofs, int kbegin) const {
+    if (row >= rows) { s.n = -1; s.iy0 = 0; s.ix0 = 0; }
+    else {
+      int px = row % g.PW; int t = row / g.PW; int py = t % g.PH; s.n = t / g.PH;
+      s.iy0 = py * g.SY + g.OY0; s.ix0 = px * g.SX + g.OX0;
+    }
+    s.k = kbegin + kofs; s.ci = s.k % g.C; int tap = s.k / g.C; s.kw = tap % g.KW; s.kh = tap / g.KW;
+  }
+  __device__ void advance(St& s) const {
+    s.k += BK; s.ci += BK;
+    while (s.ci >= g.C) { s.ci -= g.C; if (++s.kw == g.KW) { s.kw = 0; ++s.kh; } }
+  }
+  __device__ f32x4 load(const St& s) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s.n < 0 || s.k >= K) return v;
+    if (vec) {
+      int iy = s.iy0 + s.kh * g.DY, ix = s.ix0 + s.kw * g.DX;
+      if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return v;
+      return *reinterpret_cast<const f32x4*>(g.in + (((long)s.n * g.H + iy) * g.W + ix) * g.C + s.ci);
+    }
+    int ci = s.ci, kw = s.kw, kh = s.kh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (s.k + j < K) {
+        int iy = s.iy0 + kh * g.DY, ix = s.ix0 + kw * g.DX;
+        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+          v[j] = g.in[(((long)s.n * g.H + iy) * g.W + ix) * g.C + ci];
+      }
+      if (++ci == g.C) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+    }
+    return v;
+  }
+};
+
+struct ConvM {    // rows = (kh, kw, ci) (ci fastest), k = pixel  (weight-gradient A operand)
+  static constexpr bool KMAJ = false;
+  ConvGeom g; int rows, K; bool vec;
+  struct St { int r0, ci, kh, kw; int k, n, py, px; };
+  __device__ void init(St& s, int row0, int kofs, int kbegin) const {
+    s.r0 = row0;
+    int r = row0 < rows ? row0 : 0;
+    s.ci = r % g.C; int tap = r / g.C; s.kw = tap % g.KW; s.kh = tap / g.KW;
+    s.k = kbegin + kofs; s.px = s.k % g.PW; int t = s.k / g.PW; s.py = t % g.PH; s.n = t / g.PH;
+  }
+  __device__ void advance(St& s) const {
+    s.k += BK; s.px += BK;
+    while (s.px >= g.PW) { s.px -= g.PW; if (++s.py == g.PH) { s.py = 0; ++s.n; } }
+  }
+  __device__ f32x4 load(const St& s) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s.k >= K || s.r0 >= rows) return v;
+    if (vec) {
+      int iy = s.py * g.SY + s.kh * g.DY + g.OY0, ix = s.px * g.SX + s.kw * g.DX + g.OX0;
+      if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return v;
+      return *reinterpret_cast<const f32x4*>(g.in + (((long)s.n * g.H + iy) * g.W + ix) * g.C + s.ci);
+    }
+    int ci = s.ci, kw = s.kw, kh = s.kh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (s.r0 + j < rows) {
+        int iy = s.py * g.SY + kh * g.DY + g.OY0, ix = s.px * g.SX + kw * g.DX + g.OX0;
+        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+          v[j] = g.in[(((long)s.n * g.H + iy) * g.W + ix) * g.C + ci];
+      }
+      if (++ci == g.C) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+    }
+    return v;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Epilogue description
+// ------------------------------------------------------------------------------------------
+struct Epi {
+  float* C; long ldc; int M, N;
+  const float* bias; const float* bias2;   // per-column, optional
+  int act; float beta;                     // beta in {0,1}: C = act(acc + bias) + beta*C_old
+  // ACT_SIGMOID_MASK_MUL extras (enhancer fc epilogue, enhance_model.py:156-164)
+  const float* mul; float* mask_out; const int* lens; int T;
+  // output row remap for the stride-2 data-gradient parity classes: row m=(n,i,j) ->
+  // ((n*OHF + i*osy+ooy)*OWF + j*osx+oox)*ldc ; remap==0 => m*ldc
+  int remap, PH, PW, OHF, OWF, osy, osx, ooy, oox;
+  // split-K: when nsplit>1 raw accumulators go to ws[z][M][N]
+  float* ws; int nsplit;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case RE2E_ACT_TANH: return tanhf_(v);
+    case RE2E_ACT_RELU: return fmaxf(v, 0.f);
+    case RE2E_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case RE2E_ACT_SIGMOID: return sigmoidf_(v);
+    default: return v;
+  }
+}
+
+template <class LA, class LB, class CF>
+__global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep, int K) {
+  constexpr int BM = CF::BM, BN = CF::BN, TH = CF::THREADS;
+  constexpr int LDA_M = BM + 4, LDB_M = BN + 4;   // row strides of row-major (MMAJ) LDS tiles
+  constexpr int ASZ = LA::KMAJ ? BM * LDK : BK * LDA_M;
+  constexpr int BSZ = LB::KMAJ ? BN * LDK : BK * LDB_M;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][ASZ]
+  float* Bs = smem + 2 * ASZ;       // [2][BSZ]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / CF::WN, wn = wid % CF::WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // split-K range
+  const int nkt_total = (K + BK - 1) / BK;
+  const int kt_per = (nkt_total + ep.nsplit - 1) / ep.nsplit;
+  const int kt_begin = blockIdx.z * kt_per;
+  const int kt_end = min(nkt_total, kt_begin + kt_per);
+
+  // float4 items per thread per tile
+  constexpr int AIT = BM * (BK / 4) / TH, BIT = BN * (BK / 4) / TH;
+  static_assert(AIT >= 1 && BIT >= 1, "tile too small for thread count");
+  typename LA::St sa[AIT];
+  typename LB::St sb[BIT];
+  int a_lds[AIT], b_lds[BIT];
+  const int kbegin = kt_begin * BK;
+#pragma unroll
+  for (int i = 0; i < AIT; ++i) {
+    int idx = i * TH + tid;
+    if (LA::KMAJ) { int r = idx >> 3, kq = idx & 7; la.init(sa[i], m0 + r, kq * 4, kbegin); a_lds[i] = r * LDK + kq * 4; }
+    else { int kk = idx / (BM / 4), rq = idx % (BM / 4); la.init(sa[i], m0 + rq * 4, kk, kbegin); a_lds[i] = kk * LDA_M + rq * 4; }
+  }
+#pragma unroll
+  for (int i = 0; i < BIT; ++i) {
+    int idx = i * TH + tid;
+    if (LB::KMAJ) { int r = idx >> 3, kq = idx & 7; lb.init(sb[i], n0 + r, kq * 4, kbegin); b_lds[i] = r * LDK + kq * 4; }
+    else { int kk = idx / (BN / 4), rq = idx % (BN / 4); lb.init(sb[i], n0 + rq * 4, kk, kbegin); b_lds[i] = kk * LDB_M + rq * 4; }
+  }
+
+  f32x16 acc[CF::TM][CF::TN];
+#pragma unroll
+  for (int i = 0; i < CF::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < CF::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[AIT], rb[BIT];
+  if (kt_begin < kt_end) {
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) ra[i] = la.load(sa[i]);
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) rb[i] = lb.load(sb[i]);
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) *reinterpret_cast<f32x4*>(As + a_lds[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) *reinterpret_cast<f32x4*>(Bs + b_lds[i]) = rb[i];
+  }
+  __syncthreads();
+
+  const int lr = lane & 31, lh = lane >> 5;
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = (kt + 1 < kt_end);
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) { la.advance(sa[i]); ra[i] = la.load(sa[i]); }
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) { lb.advance(sb[i]); rb[i] = lb.load(sb[i]); }
+    }
+    const float* Ac = As + cur * ASZ;
+    const float* Bc = Bs + cur * BSZ;
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      f32x4 fa[CF::TM], fb[CF::TN];
+#pragma unroll
+      for (int i = 0; i < CF::TM; ++i) {
+        int r = (wm * CF::TM + i) * 32 + lr;
+        if (LA::KMAJ) fa[i] = *reinterpret_cast<const f32x4*>(Ac + r * LDK + q * 8 + lh * 4);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fa[i][j] = Ac[(q * 8 + lh * 4 + j) * LDA_M + r];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CF::TN; ++i) {
+        int r = (wn * CF::TN + i) * 32 + lr;
+        if (LB::KMAJ) fb[i] = *reinterpret_cast<const f32x4*>(Bc + r * LDK + q * 8 + lh * 4);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[i][j] = Bc[(q * 8 + lh * 4 + j) * LDB_M + r];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < CF::TM; ++a)
+#pragma unroll
+          for (int b = 0; b < CF::TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+    }
+    if (more) {
+      float* An = As + (cur ^ 1) * ASZ;
+      float* Bn = Bs + (cur ^ 1) * BSZ;
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) *reinterpret_cast<f32x4*>(An + a_lds[i]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) *reinterpret_cast<f32x4*>(Bn + b_lds[i]) = rb[i];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------------------------- epilogue ----------------------------------
+  if (ep.nsplit > 1) {
+    float* W = ep.ws + (long)blockIdx.z * ep.M * ep.N;
+#pragma unroll
+    for (int a = 0; a < CF::TM; ++a)
+#pragma unroll
+      for (int b = 0; b < CF::TN; ++b) {
+        int col = n0 + (wn * CF::TN + b) * 32 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = m0 + (wm * CF::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < ep.M && col < ep.N) W[(long)row * ep.N + col] = acc[a][b][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < CF::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < CF::TN; ++b) {
+      int col = n0 + (wn * CF::TN + b) * 32 + lr;
+      float bv = 0.f;
+      if (col < ep.N) {
+        if (ep.bias) bv += ep.bias[col];
+        if (ep.bias2) bv += ep.bias2[col];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + (wm * CF::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < ep.M && col < ep.N) {
+          long off;
+          if (ep.remap) {
+            int j = row % ep.PW; int t = row / ep.PW; int i = t % ep.PH; int n = t / ep.PH;
+            off = (((long)n * ep.OHF + i * ep.osy + ep.ooy) * ep.OWF + j * ep.osx + ep.oox) * ep.ldc + col;
+          } else {
+            off = (long)row * ep.ldc + col;
+          }
+          float v = acc[a][b][r] + bv;
+          if (ep.act == RE2E_ACT_SIGMOID_MASK_MUL) {
+            int bi = row / ep.T, t = row - bi * ep.T;
+            float s = (t < ep.lens[bi]) ? sigmoidf_(v) : 0.f;
+            ep.mask_out[off] = s;
+            v = s * ep.mul[off];
+          } else {
+            v = apply_act(v, ep.act);
+          }
+          if (ep.beta != 0.f) v += ep.C[off];
+          ep.C[off] = v;
+        }
+      }
+    }
+}
+
+// Deterministic split-K reduce: C[perm(m,n)] = sum_z ws[z][m][n] (+ beta*C).  perm: plain
+// (m*ldc+n) or the conv weight layout (rows m=(kh,kw,ci), cols n=co -> W[co][ci][kh][kw]).
+__global__ void splitk_reduce_kernel(const float* ws, int nsplit, int M, int N, float* C, long ldc, float beta,
+                                     int conv_perm, int Cin, int KHW) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long tot = (long)M * N;
+  if (i >= tot) return;
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += ws[(long)z * tot + i];
+  int m = (int)(i / N), n = (int)(i % N);
+  long off;
+  if (conv_perm) { int ci = m % Cin; int tap = m / Cin; off = ((long)n * Cin + ci) * KHW + tap; }
+  else off = (long)m * ldc + n;
+  if (beta != 0.f) s += C[off];
+  C[off] = s;
+}
+
+template <class LA, class LB, class CF>
+int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
+  constexpr int ASZ = LA::KMAJ ? CF::BM * LDK : BK * (CF::BM + 4);
+  constexpr int BSZ = LB::KMAJ ? CF::BN * LDK : BK * (CF::BN + 4);
+  size_t lds = (size_t)2 * (ASZ + BSZ) * sizeof(float);
+  static bool attr_done = false;   // idempotent; racing writers set the same value
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<LA, LB, CF>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  dim3 grid(cdiv(ep.M, CF::BM), cdiv(ep.N, CF::BN), ep.nsplit);
+  hipLaunchKernelGGL((igemm_kernel<LA, LB, CF>), grid, dim3(CF::THREADS), lds, st, la, lb, ep, K);
+  return 0;
+}
+
+using C128 = Cfg<2, 2, 2, 2>;   // 128 x 128
+using C256x64 = Cfg<4, 1, 2, 2>;
+using C256x32 = Cfg<4, 1, 2, 1>;
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int pick_splits(int M, int N, int K, int bm, int bn) {
+  long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
+  int nkt = cdiv(K, BK);
+  if (tiles >= 384 || nkt < 16) return 1;
+  long want = (768 + tiles - 1) / tiles;
+  long maxs = nkt / 8;           // >= 8 k-tiles (256 k) per split
+  long s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  return (int)s;
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" size_t re2e_gemm_workspace_bytes(int transa, int transb, int M, int N, int K) {
+  if (!(transa && !transb)) return 0;     // only the A^T B (weight-gradient) form is split
+  int s = pick_splits(M, N, K, 128, 128);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const float* A, long lda, const float* B,
+                         long ldb, float* C, long ldc, const float* bias, const float* bias2, int act, float beta,
+                         const float* mul, float* mask_out, const int* lens_dev, int T, void* workspace,
+                         size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(M > 0 && N > 0 && K > 0, "M,N,K must be positive");
+  RE2E_CHECK_ARG(A && B && C, "null operand");
+  RE2E_CHECK_ARG(beta == 0.f || beta == 1.f, "beta must be 0 or 1");
+  RE2E_CHECK_ARG(act >= 0 && act <= RE2E_ACT_SIGMOID_MASK_MUL, "bad activation");
+  if (act == RE2E_ACT_SIGMOID_MASK_MUL) RE2E_CHECK_ARG(mul && mask_out && lens_dev && T > 0, "mask epilogue needs mul/mask_out/lens/T");
+  Epi ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.C = C; ep.ldc = ldc; ep.M = M; ep.N = N; ep.bias = bias; ep.bias2 = bias2; ep.act = act; ep.beta = beta;
+  ep.mul = mul; ep.mask_out = mask_out; ep.lens = lens_dev; ep.T = T; ep.nsplit = 1;
+  if (!transa && transb) {   // C = A[M,K] * B[N,K]^T   (Linear forward)
+    DenseK la{A, lda, M, K, (lda % 4 == 0) && aligned16(A)};
+    DenseK lb{B, ldb, N, K, (ldb % 4 == 0) && aligned16(B)};
+    launch_igemm<DenseK, DenseK, C128>(la, lb, ep, K, stream);
+  } else if (!transa && !transb) {   // C = A[M,K] * B[K,N]   (input gradient)
+    DenseK la{A, lda, M, K, (lda % 4 == 0) && aligned16(A)};
+    DenseM lb{B, ldb, N, K, (ldb % 4 == 0) && aligned16(B)};
+    launch_igemm<DenseK, DenseM, C128>(la, lb, ep, K, stream);
+  } else if (transa && !transb) {   // C = A[K,M]^T * B[K,N]   (weight gradient), split-K
+    DenseM la{A, lda, M, K, (lda % 4 == 0) && aligned16(A)};
+    DenseM lb{B, ldb, N, K, (ldb % 4 == 0) && aligned16(B)};
+    int s = pick_splits(M, N, K, 128, 128);
+    if (s > 1) {
+      RE2E_CHECK_ARG(workspace && workspace_bytes >= (size_t)s * M * N * sizeof(float), "workspace too small");
+      RE2E_CHECK_ARG(act == RE2E_ACT_NONE && !bias && !bias2, "split-K form has no epilogue");
+      ep.ws = (float*)workspace; ep.nsplit = s;
+    }
+    launch_igemm<DenseM, DenseM, C128>(la, lb, ep, K, stream);
+    if (s > 1) {
+      long tot = (long)M * N;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s,
+                         M, N, C, ldc, beta, 0, 0, 0);
+    }
+  } else {
+    re2e_set_error("re2e_gemm: transa && transb is not supported");
+    return RE2E_EUNSUPPORTED;
+  }
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// ---- convolution (NHWC activations, weights pre-gathered by re2e_conv_weight_gather) ----------
+static int conv_dispatch(const ConvK& la, const DenseK& lb, Epi& ep, int K, hipStream_t st) {
+  if (ep.N <= 32) return launch_igemm<ConvK, DenseK, C256x32>(la, lb, ep, K, st);
+  if (ep.N <= 64) return launch_igemm<ConvK, DenseK, C256x64>(la, lb, ep, K, st);
+  return launch_igemm<ConvK, DenseK, C128>(la, lb, ep, K, st);
+}
+
+// Forward / data-gradient implicit GEMM:
+//   out[pix(n,py,px)][co] = act( sum_{kh,kw,ci} in[n][py*SY+kh*DY+OY0][px*SX+kw*DX+OX0][ci] * w[co][kh][kw][ci] + bias[co] )
+// written at out[((n*OHF + py*osy+ooy)*OWF + px*osx+oox)*Cout + co].
+extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW,
+                               int PH, int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF,
+                               int OWF, int osy, int osx, int ooy, int oox, const float* bias, int act, float beta,
+                               hipStream_t stream) {
+  RE2E_CHECK_ARG(in && wg && out, "null operand");
+  RE2E_CHECK_ARG(NI > 0 && H > 0 && W > 0 && C > 0 && Cout > 0 && PH > 0 && PW > 0, "bad geometry");
+  RE2E_CHECK_ARG(act >= 0 && act <= RE2E_ACT_SIGMOID, "bad activation");
+  ConvGeom g{in, NI, H, W, C, PH, PW, KH, KW, SY, SX, DY, DX, OY0, OX0};
+  int M = NI * PH * PW, K = KH * KW * C;
+  ConvK la{g, M, K, (C % 4 == 0) && aligned16(in)};
+  DenseK lb{wg, (long)K, Cout, K, (K % 4 == 0) && aligned16(wg)};
+  Epi ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.C = out; ep.ldc = Cout; ep.M = M; ep.N = Cout; ep.bias = bias; ep.act = act; ep.beta = beta; ep.nsplit = 1;
+  ep.remap = 1; ep.PH = PH; ep.PW = PW; ep.OHF = OHF; ep.OWF = OWF; ep.osy = osy; ep.osx = osx; ep.ooy = ooy; ep.oox = oox;
+  if (osy == 1 && osx == 1 && ooy == 0 && oox == 0 && OHF == PH && OWF == PW) ep.remap = 0;
+  conv_dispatch(la, lb, ep, K, stream);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+static int wgrad_splits(int Mrows, int Cout, long P) {
+  int bm, bn;
+  if (Cout <= 32) { bm = 256; bn = 32; } else if (Cout <= 64) { bm = 256; bn = 64; } else { bm = 128; bn = 128; }
+  return pick_splits(Mrows, Cout, (int)P, bm, bn);
+}
+
+extern "C" size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW) {
+  int Mrows = KH * KW * C;
+  long P = (long)NI * PH * PW;
+  int s = wgrad_splits(Mrows, Cout, P);
+  return (size_t)s * Mrows * Cout * sizeof(float);   // always reduce through the workspace (layout permute)
+}
+
+// Weight gradient: dW[co][ci][kh][kw] (+)= sum_pix dout[pix][co] * in[n][py*SY+kh+OY0][px*SX+kw+OX0][ci]
+extern "C" int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, int KH, int KW,
+                               int PH, int PW, int SY, int SX, int OY0, int OX0, float* dW, float beta,
+                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(in && dout && dW && workspace, "null operand");
+  ConvGeom g{in, NI, H, W, C, PH, PW, KH, KW, SY, SX, 1, 1, OY0, OX0};
+  int Mrows = KH * KW * C;
+  long P = (long)NI * PH * PW;
+  RE2E_CHECK_ARG(P < 2147483647L, "too many pixels");
+  int s = wgrad_splits(Mrows, Cout, P);
+  RE2E_CHECK_ARG(workspace_bytes >= (size_t)s * Mrows * Cout * sizeof(float), "workspace too small");
+  ConvM la{g, Mrows, (int)P, (C % 4 == 0) && aligned16(in)};
+  DenseM lb{dout, (long)Cout, Cout, (int)P, (Cout % 4 == 0) && aligned16(dout)};
+  Epi ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.M = Mrows; ep.N = Cout; ep.nsplit = s; ep.ws = (float*)workspace;
+  if (s == 1) {   // still go through the slab so that the reduce kernel applies the layout permute
+    ep.C = (float*)workspace; ep.ldc = Cout;
+  }
+  if (Cout <= 32) launch_igemm<ConvM, DenseM, C256x32>(la, lb, ep, (int)P, stream);
+  else if (Cout <= 64) launch_igemm<ConvM, DenseM, C256x64>(la, lb, ep, (int)P, stream);
+  else launch_igemm<ConvM, DenseM, C128>(la, lb, ep, (int)P, stream);
+  long tot = (long)Mrows * Cout;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s, Mrows,
+                     Cout, dW, (long)Cout, beta, 1, C, KH * KW);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// Weight gather: dst[r][a][b][c] laid out for the implicit GEMM B operand from the PyTorch layout
+// W[Cout][Cin][KH][KW].  transpose=0: r=co, c=ci (forward) ; transpose=1: r=ci, c=co (data gradient).
+// Tap (a,b) of the destination reads source tap (kh0 + a*kstep, kw0 + b*kstep).
+__global__ void weight_gather_kernel(const float* W, float* dst, int Cout, int Cin, int KH, int KW, int transpose, int TA,
+                                     int TB, int kh0, int kw0, int kstep) {
+  int R = transpose ? Cin : Cout, Cc = transpose ? Cout : Cin;
+  long tot = (long)R * TA * TB * Cc;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tot) return;
+  int c = (int)(i % Cc); long t = i / Cc; int b = (int)(t % TB); t /= TB; int a = (int)(t % TA); int r = (int)(t / TA);
+  int co = transpose ? c : r, ci = transpose ? r : c;
+  int kh = kh0 + a * kstep, kw = kw0 + b * kstep;
+  dst[i] = W[(((long)co * Cin + ci) * KH + kh) * KW + kw];
+}
+
+extern "C" int re2e_conv_weight_gather(const float* W, float* dst, int Cout, int Cin, int KH, int KW, int transpose,
+                                       int TA, int TB, int kh0, int kw0, int kstep, hipStream_t stream) {
+  RE2E_CHECK_ARG(W && dst, "null operand");
+  RE2E_CHECK_ARG(kh0 + (TA - 1) * kstep < KH && kw0 + (TB - 1) * kstep < KW && kh0 >= 0 && kw0 >= 0, "tap out of range");
+  long tot = (long)Cout * Cin * TA * TB;
+  hipLaunchKernelGGL(weight_gather_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, W, dst, Cout, Cin, KH, KW, transpose,
+                     TA, TB, kh0, kw0, kstep);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}

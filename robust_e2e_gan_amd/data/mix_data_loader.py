@@ -1,0 +1,87 @@
+"""Batch collation for the joint trainer (mirror of data/mix_data_loader.py:264-346).
+
+``_collate_fn`` keeps the reference's host-side semantics (sort by length desc, zero padding,
+IntTensor sizes, flat LongTensor targets).  ``collate_device`` is the MI355X-first variant (K1):
+the ragged utterances are concatenated once on the host, shipped with ONE H2D copy per stream and
+zero-padded on the device by re2e_pack_pad -- 3 live tensors instead of 5 (cos_angles and
+clean_log_inputs are never read by joint_train.py)."""
+import numpy as np
+import torch
+
+from ..lib import call
+
+
+def _collate_fn(batch):
+    """sample = (utt_id, spk_id, clean, clean_log, mix, mix_log, cos_angle, target)"""
+    batch = sorted(batch, key=lambda sample: sample[2].size(0), reverse=True)
+    longest = batch[0][2]
+    F_, B, T = longest.size(1), len(batch), longest.size(0)
+    outs = [torch.zeros(B, T, F_) for _ in range(5)]
+    input_sizes = torch.IntTensor(B)
+    target_sizes = torch.IntTensor(B)
+    targets, utt_ids, spk_ids = [], [], []
+    for x, s in enumerate(batch):
+        utt_ids.append(s[0])
+        spk_ids.append(s[1])
+        n = s[2].size(0)
+        for k in range(5):
+            outs[k][x].narrow(0, 0, n).copy_(s[2 + k])
+        input_sizes[x] = n
+        target_sizes[x] = len(s[7])
+        targets.extend(s[7])
+    return (utt_ids, spk_ids, outs[0], outs[1], outs[2], outs[3], outs[4], torch.LongTensor(targets), input_sizes, target_sizes)
+
+
+def pack_pad_device(flat_dev, lens, Tmax):
+    """(sum T_i, F) device rows -> zero padded (B, Tmax, F) on the device (re2e_pack_pad)."""
+    B, F_ = len(lens), flat_dev.shape[1]
+    dev = flat_dev.device
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    out = torch.empty(B, Tmax, F_, dtype=torch.float32, device=dev)
+    call('re2e_pack_pad', flat_dev.data_ptr(), torch.from_numpy(off).to(dev).data_ptr(), torch.tensor(lens, dtype=torch.int32, device=dev).data_ptr(),
+         B, Tmax, F_, out.data_ptr())
+    return out
+
+
+def collate_device(batch, device, streams=(2, 4, 5)):
+    """Device-side collate: returns the same 10-tuple as ``_collate_fn`` with the selected streams
+    (default clean, mix, mix_log) padded on ``device``; the unused ones are None."""
+    batch = sorted(batch, key=lambda sample: sample[2].size(0), reverse=True)
+    lens = [int(s[2].size(0)) for s in batch]
+    T = lens[0]
+    outs = [None] * 5
+    for k in streams:
+        flat = torch.cat([s[k] for s in batch], 0).pin_memory() if torch.cuda.is_available() else torch.cat([s[k] for s in batch], 0)
+        outs[k - 2] = pack_pad_device(flat.to(device, non_blocking=True), lens, T)
+    targets = torch.LongTensor([t for s in batch for t in s[7]])
+    return ([s[0] for s in batch], [s[1] for s in batch], outs[0], outs[1], outs[2], outs[3], outs[4], targets, torch.IntTensor(lens),
+            torch.IntTensor([len(s[7]) for s in batch]))
+
+
+class BucketingSampler(object):
+    """data/mix_data_loader.py:314-346: batches of similarly sized utterances from length bins."""
+
+    def __init__(self, bins_to_samples, batch_size=1):
+        self.bins_to_samples = bins_to_samples
+        self.batch_size = batch_size
+        self.bins = self.build_bins()
+
+    def build_bins(self):
+        ids = []
+        for _, sample_idx in self.bins_to_samples.items():
+            sample_idx = list(sample_idx)
+            np.random.shuffle(sample_idx)
+            ids.extend(sample_idx)
+        return [ids[i:i + self.batch_size] for i in range(0, len(ids), self.batch_size)]
+
+    def __iter__(self):
+        for ids in self.bins:
+            np.random.shuffle(ids)
+            yield ids
+
+    def __len__(self):
+        return len(self.bins)
+
+    def shuffle(self, epoch):
+        self.bins = self.build_bins()
+        np.random.shuffle(self.bins)

@@ -1,0 +1,91 @@
+"""C1: data-parallel gradient exchange -- one process per GPU, RCCL all-reduce over xGMI.
+
+The reference has no collective (single device, joint_train.py:55).  Utterance minibatches shard
+across ranks; every rank holds full replicas; after (and, for the ASR net, during) the G-backward
+the flat fp32 gradient buffer of each network (optim.FlatOptimizer.grad) is averaged with ONE
+all-reduce -- 116.6 MB (ASR) + 11.3 MB (enhancer) + 11.1 MB (D) at the config-4 architecture.
+xGMI is point-to-point (7 links x ~153 GB/s), so a few large buffers beat many small buckets; the
+ASR all-reduce is launched from an autograd hook the moment d(enhance_feat) exists (all ASR
+gradients are complete by then) and overlaps with the enhancer BLSTM backward."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env():
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shard_indices(n, rank, world):
+    """Rank r takes utterances r::N of the length-sorted batch (keeps Tmax balanced)."""
+    return list(range(rank, n, world))
+
+
+def allreduce_mean_(flat, async_op=False):
+    """In-place mean over ranks of a flat gradient buffer.  No-op at world_size 1 (no RCCL needed)."""
+    if world_size() == 1:
+        return None
+    if dist.get_backend() == 'nccl':
+        return dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=async_op)
+    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=False)     # gloo (CPU tests): SUM then scale
+    flat.div_(world_size())
+    return None
+
+
+class GradSync:
+    """Overlapped gradient averaging for the joint step.
+
+        sync = GradSync()
+        sync.arm(enhance_feat, asr_opt)     # before loss.backward(): hook fires when ASR grads are complete
+        loss.backward()
+        sync.finish([enh_opt])              # remaining (small) buffers, then wait for everything
+    """
+
+    def __init__(self):
+        self.pending = []
+
+    def arm(self, boundary_tensor, early_opt):
+        if world_size() == 1 or not boundary_tensor.requires_grad:
+            self._early = None
+            return
+        self._early = early_opt
+
+        def hook(grad):
+            w = allreduce_mean_(early_opt.grad, async_op=True)
+            if w is not None:
+                self.pending.append(w)
+            self._early = None
+            return grad
+
+        boundary_tensor.register_hook(hook)
+
+    def finish(self, opts):
+        if world_size() == 1:
+            return
+        if getattr(self, '_early', None) is not None:        # hook never fired (boundary had no grad)
+            opts = [self._early] + list(opts)
+            self._early = None
+        for o in opts:
+            w = allreduce_mean_(o.grad, async_op=True)
+            if w is not None:
+                self.pending.append(w)
+        for w in self.pending:
+            w.wait()
+        self.pending = []

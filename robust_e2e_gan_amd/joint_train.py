@@ -1,0 +1,142 @@
+"""joint_train loop API (reference joint_train.py:32-50 compute_cmvn_epoch, :156-214 training step).
+
+``JointTrainer.step(data)`` is the hot path BASELINE.json names: enhancer -> fbank -> shared E2E
+(+CTC, +location-attention decoder) + discriminator, G-step then D-step, with the reference's
+order of operations (Appendix A.12-14): freeze toggling, clip on the ASR net only, NaN guard
+gating both G optimizers, D clipped separately.  Every rank runs it on its own utterance shard;
+gradients are averaged by dist.GradSync (RCCL) before clipping."""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import lib, ops
+from .dist import GradSync
+from .model.e2e_common import set_requires_grad
+from .model.gan_model import CORAL, GANLoss
+from .optim import FlatOptimizer
+
+_LOSS_KIND = {'L2': lib.LOSS_L2, 'L1': lib.LOSS_L1, 'smooth_L1': lib.LOSS_SMOOTH_L1}
+
+
+def compute_cmvn_epoch(opt, train_loader, enhance_model, feat_model):
+    """joint_train.py:32-50 (quirk kept: the accumulators are never reset between calls)."""
+    enhance_model.eval()
+    feat_model.eval()
+    enhance_cmvn = None
+    with torch.no_grad():
+        for data in train_loader:
+            mix_inputs, mix_log_inputs, input_sizes = data[4], data[5], data[8]
+            enhance_out = enhance_model(mix_inputs, mix_log_inputs, input_sizes)
+            enhance_cmvn = feat_model.compute_cmvn(enhance_out, input_sizes)
+            if enhance_cmvn is not None:
+                if getattr(opt, 'exp_path', None):
+                    os.makedirs(opt.exp_path, exist_ok=True)
+                    np.save(os.path.join(opt.exp_path, 'enhance_cmvn.npy'), enhance_cmvn)
+                break
+    enhance_model.train()
+    feat_model.train()
+    if enhance_cmvn is None:
+        raise RuntimeError('train_loader exhausted before cmvn_num utterances were accumulated')
+    return torch.FloatTensor(enhance_cmvn)
+
+
+def build_optimizers(opt, enhance_model, asr_model, gan_model=None):
+    """joint_train.py:127-140 on flat buffers (fbank params are in no optimizer, Appendix A.16)."""
+    def mk(m):
+        ps = [p for p in m.parameters() if p.requires_grad]
+        if opt.opt_type == 'adadelta':
+            return FlatOptimizer(ps, 'adadelta', rho=0.95, eps=opt.eps)
+        return FlatOptimizer(ps, 'adam', lr=opt.lr, betas=(opt.beta1, 0.999), eps=1e-8)
+    return mk(enhance_model), mk(asr_model), (mk(gan_model) if gan_model is not None else None)
+
+
+class JointTrainer(object):
+    def __init__(self, opt, enhance_model, feat_model, asr_model, gan_model=None):
+        self.opt = opt
+        self.enhance_model, self.feat_model, self.asr_model, self.gan_model = enhance_model, feat_model, asr_model, gan_model
+        self.isGAN = bool(getattr(opt, 'isGAN', False)) and gan_model is not None
+        self.enhance_optimizer, self.asr_optimizer, self.gan_optimizer = build_optimizers(opt, enhance_model, asr_model,
+                                                                                          gan_model if self.isGAN else None)
+        self.criterionGAN = GANLoss(use_lsgan=not opt.no_lsgan) if self.isGAN else None
+        self.asr_model.dec.return_acc_tensor = True
+        self.sync_each_step = False        # True => .item() the NaN guards like the reference (one host sync)
+
+    def step(self, data, sche_samp_rate, enhance_cmvn):
+        """One training iteration (joint_train.py:157-213).  Returns a dict of DEVICE scalars (call
+        ``to_floats`` to log them: that is the only host synchronisation)."""
+        opt = self.opt
+        clean_inputs, mix_inputs, mix_log_inputs, targets, input_sizes, target_sizes = data[2], data[4], data[5], data[7], data[8], data[9]
+        enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
+        enhance_feat = self.feat_model(enhance_out)
+        with torch.no_grad():
+            clean_feat = self.feat_model(clean_inputs)
+        enhance_loss = opt.enhance_loss_lambda * ops.mean_loss(enhance_feat, clean_feat, 0.0, _LOSS_KIND[opt.enhance_loss_type])
+        loss_ctc, loss_att, acc, clean_context, mix_context = self.asr_model(clean_feat, enhance_feat, targets, input_sizes, target_sizes,
+                                                                              sche_samp_rate, enhance_cmvn)
+        coral_loss = opt.coral_loss_lambda * CORAL(clean_context, mix_context)
+        asr_loss = opt.mtlalpha * loss_ctc.view(()) + (1 - opt.mtlalpha) * loss_att
+        loss = asr_loss + enhance_loss + coral_loss
+        out = {}
+        if self.isGAN:
+            set_requires_grad([self.gan_model], False)
+            gan_loss = opt.gan_loss_lambda * self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
+            loss = loss + gan_loss
+            out['train/gan_loss'] = opt.gan_loss_lambda * gan_loss.detach()
+        self.enhance_optimizer.zero_grad()
+        self.asr_optimizer.zero_grad()
+        sync = GradSync()
+        sync.arm(enhance_feat, self.asr_optimizer)
+        loss.backward()
+        sync.finish([self.enhance_optimizer])
+        grad_norm = self.asr_optimizer.clip_grad_norm(opt.grad_clip)           # ASR params only (:188)
+        if self.sync_each_step and math.isnan(float(grad_norm)):
+            pass                                                                # the kernels skip on the device flag anyway
+        self.enhance_optimizer.step(self.asr_optimizer.gate_stats())           # unclipped, same NaN gate (:189-193)
+        self.asr_optimizer.step()
+        if self.isGAN:
+            set_requires_grad([self.gan_model], True)
+            self.gan_optimizer.zero_grad()
+            loss_D_real = self.criterionGAN(self.gan_model(clean_feat.detach(), enhance_cmvn), True)
+            loss_D_fake = self.criterionGAN(self.gan_model(enhance_feat.detach(), enhance_cmvn), False)
+            loss_D = (loss_D_real + loss_D_fake) * 0.5
+            loss_D.backward()
+            GradSync().finish([self.gan_optimizer])
+            self.gan_optimizer.clip_grad_norm(opt.grad_clip)
+            self.gan_optimizer.step()
+            out['train/loss_D'] = loss_D.detach()
+        out.update({'train/loss': loss.detach(), 'train/loss_ctc': loss_ctc.detach().view(()), 'train/acc': acc, 'train/loss_att': loss_att.detach(),
+                    'train/enhance_loss': enhance_loss.detach(), 'train/coral_loss': coral_loss.detach(), 'grad_norm': grad_norm})
+        self.last = dict(enhance_out=enhance_out, enhance_feat=enhance_feat)
+        return out
+
+    @staticmethod
+    def to_floats(errors):
+        keys = list(errors.keys())
+        vals = torch.stack([errors[k].detach().float().reshape(()) for k in keys]).cpu().tolist()
+        return dict(zip(keys, vals))
+
+    def state(self, epoch, iters, best_loss=float('inf'), best_acc=0.0):
+        """checkpoint dict with the reference's keys (joint_train.py:225-233)."""
+        st = {'asr_state_dict': self.asr_model.state_dict(), 'fbank_state_dict': self.feat_model.state_dict(),
+              'enhance_state_dict': self.enhance_model.state_dict(), 'opt': self.opt, 'epoch': epoch, 'iters': iters,
+              'eps': self.opt.eps, 'lr': self.opt.lr, 'best_loss': best_loss, 'best_acc': best_acc, 'acc_report': None, 'loss_report': None}
+        if self.isGAN:
+            st['gan_state_dict'] = self.gan_model.state_dict()
+        return st
+
+
+def config4_opt(**over):
+    """Namespace with BASELINE.json config-4 architecture."""
+    import argparse
+    V = 4233
+    d = dict(idim=257, odim=V, fbank_dim=80, char_list=[str(i) for i in range(V)], gpu_ids=[0], verbose=0, enhance_type='blstm',
+             enhance_layers=2, enhance_units=256, enhance_projs=256, dropout_rate=0.0, subsample_type='skip', subsample='1_1_1_1_1',
+             fbank_opti_type='frozen', train_dataset_len=128, num_utt_cmvn=20000, etype='vggblstmp', elayers=3, eunits=512, eprojs=512,
+             atype='location', adim=320, aconv_chans=10, aconv_filts=100, awin=5, aheads=4, dlayers=1, dunits=300, mtlalpha=0.5,
+             lsm_type='', lsm_weight=0.0, labeldist=None, fusion='', lmtype=None, rnnlm=None, ndf=64, norm_D='batch', input_nc=1,
+             n_layers_D=3, no_lsgan=False, netD_type='basic', enhance_loss_type='L2', enhance_loss_lambda=1.0, coral_loss_lambda=0.1,
+             gan_loss_lambda=1.0, grad_clip=5.0, eps=1e-8, isGAN=True, opt_type='adadelta', lr=0.005, beta1=0.5, exp_path=None)
+    d.update(over)
+    return argparse.Namespace(**d)

@@ -1,0 +1,139 @@
+"""ctypes binding of libre2e_hip.so (C ABI declared in include/re2e.h).
+
+The product path has NO fallback: if the shared library is missing or the device is not gfx950
+every op raises.  ``load()`` only dlopen()s the library and checks the exported symbols (usable
+on a CPU-only box for the build/ABI checks); the first kernel call needs a GPU.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libre2e_hip.so')
+
+ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
+LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1 = range(3)
+
+P, I, L, F, Z = c_void_p, c_int, c_long, c_float, c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol of include/re2e.h (tests/test_abi.py).
+SIGNATURES = {
+    're2e_version': (I, []),
+    're2e_last_error': (c_char_p, []),
+    're2e_device_ok': (I, []),
+    're2e_gemm_workspace_bytes': (Z, [I, I, I, I, I]),
+    're2e_gemm': (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, I, F, P, P, P, I, P, Z, P]),
+    're2e_conv_igemm': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, I, F, P]),
+    're2e_conv_wgrad_workspace_bytes': (Z, [I, I, I, I, I, I, I]),
+    're2e_conv_wgrad': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, P, F, P, Z, P]),
+    're2e_conv_weight_gather': (I, [P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    're2e_transpose01': (I, [P, P, I, I, I, P]),
+    're2e_act_bwd': (I, [P, P, P, L, I, P]),
+    're2e_colsum_workspace_bytes': (Z, [I, I]),
+    're2e_colsum': (I, [P, I, I, L, P, F, P, Z, P]),
+    're2e_mask_mul_bwd': (I, [P, P, P, P, L, P]),
+    're2e_mul': (I, [P, P, P, L, P]),
+    're2e_affine_cols': (I, [P, P, P, P, L, I, P]),
+    're2e_axpby': (I, [F, P, F, P, L, P]),
+    're2e_gather_rows': (I, [P, P, P, I, I, P]),
+    're2e_scatter_rows': (I, [P, P, P, I, I, P]),
+    're2e_mask_rows': (I, [P, P, P, I, I, I, P]),
+    're2e_pack_pad': (I, [P, P, P, I, I, I, P, P]),
+    're2e_fbank_fwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P]),
+    're2e_fbank_bwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P, P]),
+    're2e_cmvn_stats': (I, [P, P, I, I, I, P, P, P]),
+    're2e_reduce_workspace_bytes': (Z, [L]),
+    're2e_loss_fwd': (I, [P, P, F, L, I, P, P, Z, P]),
+    're2e_loss_bwd': (I, [P, P, F, L, I, P, F, P, F, P]),
+    're2e_sumsq': (I, [P, L, P, P, Z, P]),
+    're2e_maxpool2_fwd': (I, [P, I, I, I, I, P, P, P]),
+    're2e_maxpool2_bwd': (I, [P, P, I, I, I, I, P, P]),
+    're2e_vgg_pack_fwd': (I, [P, P, I, I, I, I, P, P]),
+    're2e_vgg_pack_bwd': (I, [P, P, I, I, I, I, P, P]),
+    're2e_bn_workspace_bytes': (Z, [L, I]),
+    're2e_bn_lrelu_fwd': (I, [P, L, I, P, P, P, P, F, F, I, P, P, P, P, Z, P]),
+    're2e_bn_lrelu_bwd': (I, [P, P, L, I, P, P, P, P, P, P, P, F, P, Z, P]),
+    're2e_lstm_seq_fwd': (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    're2e_lstm_seq_bwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    're2e_lstm_cell_fwd': (I, [P, P, P, P, I, I, P]),
+    're2e_lstm_cell_bwd': (I, [P, P, P, P, P, P, I, I, P]),
+    're2e_embedding_fwd': (I, [P, P, I, I, P, L, P]),
+    're2e_embedding_bwd': (I, [P, L, P, I, I, I, P, F, P]),
+    're2e_ce_fwd': (I, [P, P, I, I, F, P, P, P, Z, P]),
+    're2e_ce_bwd': (I, [P, P, P, P, I, I, F, P, P, P]),
+    're2e_ctc_workspace_bytes': (Z, [I, I, I]),
+    're2e_ctc_fwd': (I, [P, I, I, I, P, P, P, P, I, P, P, P, Z, P]),
+    're2e_ctc_bwd': (I, [P, I, I, I, P, P, P, P, I, P, P, P, P, P]),
+    're2e_attloc_fwd': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, L, P]),
+    're2e_attloc_partial_floats': (Z, [I, I, I]),
+    're2e_attloc_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, L, P, I, I, I, I, I, I, I, P, P, P, P, P, P]),
+    're2e_clip_coef': (I, [P, F, P, P]),
+    're2e_adadelta_step': (I, [P, P, P, P, L, F, F, F, P, P]),
+    're2e_adam_step': (I, [P, P, P, P, L, F, F, F, F, I, P, P]),
+}
+
+_lib = None
+
+
+class Re2eError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every symbol; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Re2eError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                        '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int32/uint8 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise Re2eError('expected a CUDA tensor, got device %s' % t.device)
+    if not t.is_contiguous():
+        raise Re2eError('expected a contiguous tensor')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke ``name`` on the current torch stream; raises Re2eError(re2e_last_error()) on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise Re2eError('%s failed (%d): %s' % (name, rc, lib.re2e_last_error().decode()))
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag='ws'):
+    """Grow-only scratch buffer per (device, tag); contents are undefined between calls."""
+    nbytes = max(int(nbytes), 16)
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf

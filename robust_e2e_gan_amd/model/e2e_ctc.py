@@ -1,0 +1,32 @@
+"""CTC head (mirror of CTC.__init__/forward, model/e2e_ctc.py:17-66)."""
+import numpy as np
+import torch
+
+from .. import ops
+from ..lib import Re2eError
+from .e2e_common import LinearParams, lens_dev, lens_list
+
+
+class CTC(torch.nn.Module):
+    def __init__(self, odim, eprojs, dropout_rate):
+        super(CTC, self).__init__()
+        if dropout_rate:
+            raise Re2eError('dropout > 0 is outside the round-1 hot path (Appendix A.8)')
+        self.dropout_rate = dropout_rate
+        self.loss = None
+        self.ctc_lo = LinearParams(eprojs, odim)
+        self.ignore_id = -1
+
+    def forward_tm(self, hs_tm, hlens, ys):
+        """hs_tm: time-major (T',B,eprojs) encoder states (unmasked, Appendix A.8)."""
+        dev = hs_tm.device
+        ylist = [[int(v) for v in y.tolist() if int(v) != self.ignore_id] for y in ys]
+        ll = [len(y) for y in ylist]
+        flat = torch.tensor(sum(ylist, []), dtype=torch.int32, device=dev)
+        off = torch.tensor(np.concatenate([[0], np.cumsum(ll)[:-1]]).astype(np.int32), dtype=torch.int32, device=dev)
+        logits = ops.linear(hs_tm, self.ctc_lo.weight, self.ctc_lo.bias)           # (T',B,V): warp-ctc's layout
+        self.loss = ops.ctc_loss(logits, lens_dev(hlens, dev), flat, off, torch.tensor(ll, dtype=torch.int32, device=dev), max(ll))
+        return self.loss
+
+    def forward(self, hs_pad, hlens, ys_pad):
+        return self.forward_tm(ops.transpose01(hs_pad), hlens, ys_pad)

@@ -1,0 +1,131 @@
+"""Encoder stacks (mirror of model/e2e_encoder.py): VGG2L :231-279, BLSTMP :101-150, BLSTM :153-177.
+
+Internal layouts are MI355X-first: NHWC through the conv stack, time-major (T,B,F) through the
+recurrent stack; module boundaries stay batch-first (B,T,F) like the reference."""
+import logging
+import math
+import sys
+
+import torch
+
+from .. import ops
+from ..lib import Re2eError
+from .e2e_common import ConvParams, LinearParams, LSTMParams, _get_vgg2l_odim, lens_dev, lens_list
+
+
+class BLSTM(torch.nn.Module):
+    """nn.LSTM(idim, cdim, elayers, bidirectional) + tanh(Linear(2*cdim, hdim))."""
+
+    def __init__(self, idim, elayers, cdim, hdim, dropout):
+        super(BLSTM, self).__init__()
+        if dropout:
+            raise Re2eError('dropout > 0 is outside the round-1 hot path (Appendix A.8)')
+        self.nblstm = LSTMParams(idim, cdim, elayers)
+        self.l_last = LinearParams(cdim * 2, hdim)
+        self.elayers = elayers
+
+    def forward_tm(self, x_tm, lens_d):
+        """time-major (T,B,I) -> (T,B,hdim)"""
+        for l in range(self.elayers):
+            x_tm = ops.bilstm(x_tm, lens_d, self.nblstm.layer_weights(l))
+        return ops.linear(x_tm, self.l_last.weight, self.l_last.bias, 'tanh')
+
+    def forward(self, xpad, ilens):
+        lens = lens_list(ilens)
+        T = max(lens)
+        x_tm = ops.transpose01(xpad)[:T]
+        y = self.forward_tm(x_tm, lens_dev(lens, xpad.device))
+        return ops.transpose01(y), lens
+
+
+class BLSTMP(torch.nn.Module):
+    def __init__(self, idim, elayers, cdim, hdim, subsample, subsample_type, dropout):
+        super(BLSTMP, self).__init__()
+        if dropout:
+            raise Re2eError('dropout > 0 is outside the round-1 hot path (Appendix A.8)')
+        for i in range(elayers):
+            setattr(self, 'bilstm%d' % i, LSTMParams(idim if i == 0 else hdim, cdim, 1))
+            setattr(self, 'bt%d' % i, LinearParams(2 * cdim, hdim))
+        self.elayers, self.cdim = elayers, cdim
+        self.subsample, self.subsample_type = subsample, subsample_type
+        if any(int(s) > 1 for s in subsample[1:elayers + 1]):
+            raise Re2eError('BLSTMP frame subsampling (e2e_encoder.py:133-143) is a "next" row (N4), not built yet')
+
+    def forward_tm(self, x_tm, lens_d):
+        for l in range(self.elayers):
+            y = ops.bilstm(x_tm, lens_d, getattr(self, 'bilstm%d' % l).layer_weights(0))
+            bt = getattr(self, 'bt%d' % l)
+            x_tm = ops.linear(y, bt.weight, bt.bias, 'tanh')      # applied to padded rows too (:145-147)
+        return x_tm
+
+    def forward(self, xpad, ilens):
+        lens = lens_list(ilens)
+        T = max(lens)
+        y = self.forward_tm(ops.transpose01(xpad)[:T], lens_dev(lens, xpad.device))
+        return ops.transpose01(y), lens
+
+
+class VGG2L(torch.nn.Module):
+    def __init__(self, in_channel=1):
+        super(VGG2L, self).__init__()
+        self.conv1_1 = ConvParams(in_channel, 64, 3, stride=1, padding=1)
+        self.conv1_2 = ConvParams(64, 64, 3, stride=1, padding=1)
+        self.conv2_1 = ConvParams(64, 128, 3, stride=1, padding=1)
+        self.conv2_2 = ConvParams(128, 128, 3, stride=1, padding=1)
+        self.in_channel = in_channel
+
+    def forward_tm(self, xs, ilens):
+        """(B,T,idim) batch-first -> time-major (T',B,128*F') with the cut + zero re-pad of :272-278."""
+        if self.in_channel != 1:
+            raise Re2eError('VGG2L with in_channel != 1 is not on the hot path')
+        B, T, Fd = xs.shape
+        h = xs.contiguous().view(B, T, Fd, 1)                                     # NCHW (B,1,T,F) == NHWC (B,T,F,1)
+        h = ops.conv2d(h, self.conv1_1.weight, self.conv1_1.bias, 1, 1, 'relu')
+        h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu')
+        h = ops.maxpool2(h)
+        h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu')
+        h = ops.conv2d(h, self.conv2_2.weight, self.conv2_2.bias, 1, 1, 'relu')
+        h = ops.maxpool2(h)
+        nl = [int(math.ceil(math.ceil(l / 2.0) / 2.0)) for l in lens_list(ilens)]
+        out = ops.vgg_pack(h, lens_dev(nl, xs.device))                             # (T'box, B, C*F')
+        return out[:max(nl)], nl
+
+    def forward(self, xs, ilens):
+        y, nl = self.forward_tm(xs, ilens)
+        return ops.transpose01(y), nl
+
+
+class Encoder(torch.nn.Module):
+    """model/e2e_encoder.py:17-98 dispatcher (blstm / blstmp / vggblstm / vggblstmp)."""
+
+    def __init__(self, etype, idim, elayers, eunits, eprojs, subsample, subsample_type, dropout, in_channel=1):
+        super(Encoder, self).__init__()
+        if etype == 'blstm':
+            self.enc1 = BLSTM(idim, elayers, eunits, eprojs, dropout)
+        elif etype == 'blstmp':
+            self.enc1 = BLSTMP(idim, elayers, eunits, eprojs, subsample, subsample_type, dropout)
+        elif etype == 'vggblstmp':
+            self.enc1 = VGG2L(in_channel)
+            self.enc2 = BLSTMP(_get_vgg2l_odim(idim, in_channel=in_channel), elayers, eunits, eprojs, subsample, subsample_type, dropout)
+        elif etype == 'vggblstm':
+            self.enc1 = VGG2L(in_channel)
+            self.enc2 = BLSTM(_get_vgg2l_odim(idim, in_channel=in_channel), elayers, eunits, eprojs, dropout)
+        elif etype in ('cnnblstmp', 'cnnblstm'):
+            raise Re2eError('etype %s (CNN2L) is out of scope for the hot path (SURVEY section 2, row 5)' % etype)
+        else:
+            logging.error('Error: need to specify an appropriate encoder archtecture')
+            sys.exit()
+        self.etype = etype
+
+    def forward_tm(self, xs, ilens):
+        """-> time-major (T',B,eprojs), lens'"""
+        if self.etype in ('blstm', 'blstmp'):
+            lens = lens_list(ilens)
+            x_tm = ops.transpose01(xs)[:max(lens)]
+            return self.enc1.forward_tm(x_tm, lens_dev(lens, xs.device)), lens
+        h_tm, nl = self.enc1.forward_tm(xs, ilens)
+        return self.enc2.forward_tm(h_tm, lens_dev(nl, xs.device)), nl
+
+    def forward(self, xs, ilens):
+        y, lens = self.forward_tm(xs, ilens)
+        return ops.transpose01(y), lens

@@ -1,0 +1,126 @@
+"""E2E (mirror of model/e2e_model.py:20-202) and ShareE2E (S1: missing upstream, contract from
+joint_train.py:97,120,170,266,280 -- build-defined)."""
+import logging
+import sys
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..lib import Re2eError
+from .e2e_attention import AttLoc
+from .e2e_common import ModelBase, lecun_normal_init_parameters, lens_dev, lens_list, set_forget_bias_to_one, to_cuda
+from .e2e_ctc import CTC
+from .e2e_decoder import Decoder
+from .e2e_encoder import Encoder
+
+
+class E2E(ModelBase):
+    def __init__(self, args):
+        super(E2E, self).__init__()
+        self.opt = args
+        idim, odim = args.fbank_dim, args.odim
+        self.etype, self.verbose = args.etype, args.verbose
+        self.char_list = args.char_list
+        self.mtlalpha = args.mtlalpha
+        self.sos = self.eos = odim - 1                                   # e2e_model.py:34-35
+        subsample = np.ones(args.elayers + 1, dtype=int)
+        if args.etype == 'blstmp':
+            ss = args.subsample.split('_')
+            for j in range(min(args.elayers + 1, len(ss))):
+                subsample[j] = int(ss[j])
+        self.subsample = subsample
+        labeldist = args.labeldist if getattr(args, 'lsm_type', '') else None
+        self.enc = Encoder(args.etype, idim, args.elayers, args.eunits, args.eprojs, self.subsample, args.subsample_type,
+                           args.dropout_rate)
+        self.ctc = CTC(odim, args.eprojs, args.dropout_rate)
+        if args.atype == 'location':
+            self.att = AttLoc(args.eprojs, args.dunits, args.adim, args.aconv_chans, args.aconv_filts, 'softmax')
+        elif args.atype in ('noatt', 'dot', 'add', 'location2d', 'location_recurrent', 'coverage', 'coverage_location', 'multi_head_dot',
+                            'multi_head_add', 'multi_head_loc', 'multi_head_multi_res_loc'):
+            raise Re2eError('atype %s is out of scope: only the default location-aware attention is on the hot path' % args.atype)
+        else:
+            logging.error('Error: need to specify an appropriate attention archtecture')
+            sys.exit()
+        if getattr(args, 'fusion', '') in ('deep_fusion', 'cold_fusion'):
+            raise Re2eError('LM fusion is decode-time only and out of scope (SURVEY section 2, row 15)')
+        self.dec = Decoder(args.eprojs, odim, args.dlayers, args.dunits, self.sos, self.eos, self.att, self.verbose, self.char_list,
+                           labeldist, args.lsm_weight)
+        self.init_like_chainer()
+
+    def init_like_chainer(self):
+        """e2e_model.py:148-166: LeCun normal, embed ~ N(0,1), decoder forget-gate bias 1."""
+        lecun_normal_init_parameters(self)
+        self.dec.embed.weight.data.normal_(0, 1)
+        for l in range(len(self.dec.decoder)):
+            set_forget_bias_to_one(self.dec.decoder[l].bias_ih)
+
+    @staticmethod
+    def _split_targets(targets, target_sizes):
+        ys, off = [], 0
+        for s in lens_list(target_sizes):
+            ys.append(targets[off:off + s])
+            off += s
+        return ys
+
+    def forward(self, inputs, targets, input_sizes, target_sizes, scheduled_sampling_rate=0.0):
+        """-> (loss_ctc, loss_att, acc)   (e2e_model.py:169-202)"""
+        xpad = to_cuda(self, inputs)
+        ilens = lens_list(input_sizes)
+        ys = self._split_targets(targets, target_sizes)
+        h_tm, hlens = self.enc.forward_tm(xpad, ilens)
+        loss_ctc = self.ctc.forward_tm(h_tm, hlens, ys) if self.mtlalpha != 0 else None
+        if self.mtlalpha == 1:
+            loss_att, acc = None, None
+        else:
+            loss_att, acc = self.dec(ops.transpose01(h_tm), hlens, ys, scheduled_sampling_rate)
+        return loss_ctc, loss_att, acc
+
+    def calculate_all_attentions(self, inputs, targets, input_sizes, target_sizes):
+        with torch.no_grad():
+            hpad, hlens = self.enc(to_cuda(self, inputs), lens_list(input_sizes))
+            return self.dec.calculate_all_attentions(hpad, hlens, self._split_targets(targets, target_sizes))
+
+    def recognize(self, *a, **k):
+        raise Re2eError('beam-search decoding (e2e_decoder.py:171-369) is a "next" row (N3), not built yet')
+
+
+class ShareE2E(E2E):
+    """S1.  forward(clean_feat, enhance_feat, targets, input_sizes, target_sizes, ss_rate, cmvn) ->
+    (loss_ctc, loss_att, acc, clean_context, mix_context): both inputs are CMVN-normalised
+    ``(x + cmvn[0]) * cmvn[1]`` (cf. joint_recog.py:148), the SHARED encoder runs on both branches as
+    one 2B batch, losses come from the enhanced branch exactly as E2E.forward, contexts are the
+    encoder states of the valid frames of each branch."""
+
+    def forward(self, clean_feat, enhance_feat, targets, input_sizes, target_sizes, scheduled_sampling_rate=0.0, cmvn=None):
+        enh = to_cuda(self, enhance_feat)
+        cln = to_cuda(self, clean_feat)
+        ilens = lens_list(input_sizes)
+        B = enh.shape[0]
+        ys = self._split_targets(targets, target_sizes)
+        if cmvn is not None:
+            x2 = ops.cmvn_pair(enh, cln, to_cuda(self, cmvn).float().contiguous())
+        else:
+            x2 = torch.cat([enh, cln], 0)
+        h_tm2, hl2 = self.enc.forward_tm(x2, ilens + ilens)               # (T', 2B, E)
+        hlens = hl2[:B]
+        hpad2 = ops.transpose01(h_tm2)                                     # (2B, T', E)
+        hpad_enh, hpad_cln = hpad2[:B], hpad2[B:]
+        Tq, E = hpad2.shape[1], hpad2.shape[2]
+        loss_ctc = self.ctc.forward(hpad_enh, hlens, ys) if self.mtlalpha != 0 else None
+        if self.mtlalpha == 1:
+            loss_att, acc = None, None
+        else:
+            loss_att, acc = self.dec(hpad_enh, hlens, ys, scheduled_sampling_rate)
+        idx = torch.tensor([b * Tq + t for b in range(B) for t in range(hlens[b])], dtype=torch.int32, device=enh.device)
+        mix_context = ops.gather_rows(hpad_enh.reshape(B * Tq, E), idx)
+        clean_context = ops.gather_rows(hpad_cln.reshape(B * Tq, E), idx)
+        return loss_ctc, loss_att, acc, clean_context, mix_context
+
+    def calculate_all_attentions(self, enhance_feat, targets, input_sizes, target_sizes, cmvn=None):
+        with torch.no_grad():
+            enh = to_cuda(self, enhance_feat)
+            if cmvn is not None:
+                enh = ops.cmvn_pair(enh, None, to_cuda(self, cmvn).float().contiguous())
+            hpad, hlens = self.enc(enh, lens_list(input_sizes))
+            return self.dec.calculate_all_attentions(hpad, hlens, self._split_targets(targets, target_sizes))

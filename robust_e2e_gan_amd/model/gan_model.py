@@ -1,0 +1,119 @@
+"""Discriminator + GAN loss (mirror of model/gan_model.py:55-171) and CORAL (S2, missing upstream)."""
+import torch
+
+from .. import lib, ops
+from ..lib import Re2eError
+from .e2e_common import ConvParams, ModelBase, to_cuda
+
+
+class BatchNormParams(torch.nn.Module):
+    """nn.BatchNorm2d's state: weight, bias, running_mean, running_var, num_batches_tracked."""
+
+    def __init__(self, c, momentum=0.1, eps=1e-5):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(c))
+        self.bias = torch.nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self.momentum, self.eps = momentum, eps
+
+
+class _Act(torch.nn.Module):
+    """placeholder that keeps nn.Sequential's numbering (LeakyReLU is fused into the conv / BN kernels)."""
+
+
+def init_NLayerDiscriminator(input_nc, ndf=64, n_layers=3):
+    """gan_model.py:55-95 with norm_layer = BatchNorm2d (use_bias False on the normalised convs)."""
+    seq = [ConvParams(input_nc, ndf, 4, stride=2, padding=1), _Act()]
+    nf_mult = 1
+    for n in range(1, n_layers):
+        nf_prev, nf_mult = nf_mult, min(2 ** n, 8)
+        seq += [ConvParams(ndf * nf_prev, ndf * nf_mult, 4, bias=False, stride=2, padding=1), BatchNormParams(ndf * nf_mult), _Act()]
+    nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
+    seq += [ConvParams(ndf * nf_prev, ndf * nf_mult, 4, bias=False, stride=1, padding=1), BatchNormParams(ndf * nf_mult), _Act()]
+    seq += [ConvParams(ndf * nf_mult, 1, 4, stride=1, padding=1)]
+    return torch.nn.Sequential(*seq)
+
+
+def init_net(net, gain=0.02):
+    """gan_model.py:18-39 ('normal'): conv weights ~ N(0, gain), biases 0, BN gamma ~ N(1, gain)."""
+    for m in net.modules():
+        if isinstance(m, ConvParams):
+            m.weight.data.normal_(0.0, gain)
+            if m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, BatchNormParams):
+            m.weight.data.normal_(1.0, gain)
+            m.bias.data.zero_()
+
+
+class GANModel(ModelBase):
+    def __init__(self, args):
+        super(GANModel, self).__init__()
+        self.opt = args
+        if args.norm_D != 'batch':
+            raise Re2eError('norm_D=%s: only BatchNorm discriminators are on the hot path' % args.norm_D)
+        if args.no_lsgan:
+            raise Re2eError('--no_lsgan (sigmoid + BCE) is outside the round-1 hot path')
+        if args.netD_type == 'basic':
+            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, n_layers=3)
+        elif args.netD_type == 'n_layers':
+            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, args.n_layers_D)
+        elif args.netD_type == 'pixel':
+            raise Re2eError('netD_type pixel is a "next" row (N4), not built yet')
+        else:
+            raise NotImplementedError('Discriminator model name [%s] is not recognized' % args.netD_type)
+        init_net(self.model, 0.02)
+
+    def forward(self, input, cmvn=None):
+        """(B,T,80) [-> CMVN, S3] -> PatchGAN logits (B,1,H',W')   (gan_model.py:141-145)"""
+        x = to_cuda(self, input)
+        if cmvn is not None:
+            x = ops.cmvn_pair(x, None, to_cuda(self, cmvn).float().contiguous())
+        if x.dim() == 3:
+            B, T, Fd = x.shape
+            h = x.contiguous().view(B, T, Fd, 1)          # NCHW (B,1,T,F) and NHWC (B,T,F,1) share memory
+        else:
+            h = x.permute(0, 2, 3, 1).contiguous()
+        mods = list(self.model)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, ConvParams):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if isinstance(nxt, _Act):
+                    h = ops.conv2d(h, m.weight, m.bias, m.stride, m.padding, 'lrelu')
+                    i += 2
+                elif isinstance(nxt, BatchNormParams):
+                    h = ops.conv2d(h, m.weight, m.bias, m.stride, m.padding, None)
+                    h = ops.bn_lrelu(h, nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var, self.training, nxt.momentum, nxt.eps)
+                    if self.training:
+                        nxt.num_batches_tracked += 1
+                    i += 3
+                else:
+                    h = ops.conv2d(h, m.weight, m.bias, m.stride, m.padding, None)
+                    i += 1
+            else:
+                i += 1
+        return h.permute(0, 3, 1, 2)                      # logical NCHW like the reference (view, Cout == 1)
+
+
+class GANLoss(torch.nn.Module):
+    """LSGAN: MSE(D(x), 1.0 or 0.0 broadcast)   (gan_model.py:152-171)"""
+
+    def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0):
+        super(GANLoss, self).__init__()
+        if not use_lsgan:
+            raise Re2eError('--no_lsgan (BCE) is outside the round-1 hot path')
+        self.register_buffer('real_label', torch.tensor(target_real_label))
+        self.register_buffer('fake_label', torch.tensor(target_fake_label))
+        self._real, self._fake = float(target_real_label), float(target_fake_label)
+
+    def __call__(self, input, target_is_real):
+        return ops.mean_loss(input, None, self._real if target_is_real else self._fake, lib.LOSS_L2)
+
+
+def CORAL(source, target):
+    """S2 (build-defined): Deep-CORAL ||Cov(src) - Cov(tgt)||_F^2 / (4 d^2) over valid-frame rows."""
+    return ops.coral(source, target)

@@ -1,0 +1,359 @@
+"""Parity of every HIP kernel family (through the C ABI + autograd wrappers) against plain
+PyTorch fp32 ops on the CPU.  GPU only.  Tolerance: 1e-3 relative to the tensor scale
+(north_star: "within 1e-3 fp32"); most kernels land at 1e-5..1e-6."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def _ops():
+    from robust_e2e_gan_amd import ops, lib
+    assert lib.query('re2e_device_ok') == 1, 'not a gfx950 device'
+    return ops, lib
+
+
+def close(name, got, ref, tol=1e-3, atol=1e-6):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert math.isfinite(err), name
+    assert err <= tol * scale + atol, '%s: max err %.3e vs scale %.3e' % (name, err, scale)
+    return err
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(77, 257, 130), (256, 128, 64), (5, 3, 7), (300, 4233, 512), (130, 64, 257)])
+def test_gemm_nt_nn(M, N, K):
+    ops, lib = _ops()
+    A, Bm, bias, C0 = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
+    a, b, bi = A.to(DEV), Bm.to(DEV), bias.to(DEV)
+    c = torch.empty(M, N, device=DEV)
+    ops.gemm(a, b, c, M, N, K, transb=True, bias=bi, act=lib.ACT_TANH)
+    close('nt+bias+tanh', c, torch.tanh(A @ Bm.t() + bias))
+    c = C0.to(DEV).clone()
+    ops.gemm(a, b, c, M, N, K, transb=True, beta=1.0)
+    close('nt beta', c, A @ Bm.t() + C0)
+    bt = Bm.t().contiguous().to(DEV)        # stored [K,N]
+    c = torch.empty(M, N, device=DEV)
+    ops.gemm(a, bt, c, M, N, K, act=lib.ACT_RELU)
+    close('nn relu', c, torch.relu(A @ Bm.t()))
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 96, 5000), (257, 130, 77), (1200, 812, 1312), (8, 4, 40000)])
+def test_gemm_tn_splitk(M, N, K):
+    ops, lib = _ops()
+    A, Bm, C0 = rnd(K, M), rnd(K, N, seed=1), rnd(M, N, seed=2)
+    c = C0.to(DEV).clone()
+    ops.gemm(A.to(DEV), Bm.to(DEV), c, M, N, K, transa=True, beta=1.0)
+    close('tn', c, A.t() @ Bm + C0, tol=2e-4)
+    c2 = C0.to(DEV).clone()
+    ops.gemm(A.to(DEV), Bm.to(DEV), c2, M, N, K, transa=True, beta=1.0)
+    assert torch.equal(c, c2), 'split-K reduction must be bitwise reproducible'
+
+
+def test_linear_autograd():
+    ops, lib = _ops()
+    x, W, b = rnd(4, 9, 37), rnd(21, 37, seed=1), rnd(21, seed=2)
+    xr, Wr, br = [t.clone().requires_grad_(True) for t in (x, W, b)]
+    yr = torch.tanh(F.linear(xr, Wr, br))
+    (yr * rnd(4, 9, 21, seed=5)).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    Wg, bg = torch.nn.Parameter(W.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    y = ops.linear(xg, Wg, bg, 'tanh')
+    (y * rnd(4, 9, 21, seed=5).to(DEV)).sum().backward()
+    close('y', y, yr)
+    close('dx', xg.grad, xr.grad)
+    close('dW', Wg.grad, Wr.grad)
+    close('db', bg.grad, br.grad)
+    # second backward accumulates into .grad (beta=1 path)
+    y = ops.linear(xg, Wg, bg, 'tanh')
+    (y * rnd(4, 9, 21, seed=5).to(DEV)).sum().backward()
+    close('dW x2', Wg.grad, 2 * Wr.grad)
+
+
+def test_mask_fc():
+    ops, lib = _ops()
+    B, T, K, N = 3, 11, 16, 257
+    lens = [11, 7, 4]
+    proj, W, mix = rnd(B, T, K), rnd(N, K, seed=1), rnd(B, T, N, seed=2).abs()
+    pr, Wr = proj.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    valid = (torch.arange(T).unsqueeze(0) < torch.tensor(lens).view(-1, 1)).unsqueeze(-1).float()
+    ref = torch.sigmoid(F.linear(pr, Wr)) * valid * mix
+    (ref * rnd(B, T, N, seed=3)).sum().backward()
+    pg = proj.to(DEV).requires_grad_(True)
+    Wg = torch.nn.Parameter(W.to(DEV))
+    out, mask = ops.mask_fc(pg, Wg, mix.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), T)
+    (out * rnd(B, T, N, seed=3).to(DEV)).sum().backward()
+    close('out', out, ref)
+    assert (out[1, 7:] == 0).all() and (out[2, 4:] == 0).all()
+    close('dproj', pg.grad, pr.grad)
+    close('dW', Wg.grad, Wr.grad)
+
+
+def test_fbank():
+    ops, lib = _ops()
+    from oracle import nets
+    from robust_e2e_gan_amd.model.feat_model import band_from_matrix, mel_matrix
+    W = torch.from_numpy(mel_matrix())
+    x = rnd(3, 13, 257, scale=20.0).abs()
+    x[1, 9:] = 0
+    cm = torch.stack([torch.linspace(10, 14, 80), torch.linspace(0.3, 0.6, 80)])
+    xr = x.clone().requires_grad_(True)
+    y0, y1 = nets.fbank_forward(xr, W), nets.fbank_forward(xr, W, cm)
+    g0, g1 = rnd(3, 13, 80, seed=1), rnd(3, 13, 80, seed=2)
+    ((y0 * g0).sum() + (y1 * g1).sum()).backward()
+    band = band_from_matrix(W, DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    raw, nrm = ops.fbank(xg, band, cm.to(DEV), True, True)
+    ((raw * g0.to(DEV)).sum() + (nrm * g1.to(DEV)).sum()).backward()
+    close('raw', raw, y0, tol=1e-5)
+    close('norm', nrm, y1, tol=1e-5)
+    assert torch.allclose(raw[1, 9:].cpu(), torch.full((4, 80), math.log(1e-7)))
+    close('dx', xg.grad, xr.grad, tol=1e-4)
+
+
+@pytest.mark.parametrize('kind', [0, 1, 2])
+def test_mean_loss(kind):
+    ops, lib = _ops()
+    a, b = rnd(5, 7, 80, scale=2.0), rnd(5, 7, 80, seed=1, scale=2.0)
+    fn = [F.mse_loss, F.l1_loss, F.smooth_l1_loss][kind]
+    ar = a.clone().requires_grad_(True)
+    lr = fn(ar, b)
+    (lr * 1.7).backward()
+    ag = a.to(DEV).requires_grad_(True)
+    l = ops.mean_loss(ag, b.to(DEV), 0.0, kind)
+    (l * 1.7).backward()
+    close('loss', l.view(1), lr.view(1), tol=1e-5)
+    close('da', ag.grad, ar.grad, tol=1e-5)
+    if kind == 0:
+        l1 = ops.mean_loss(ag, None, 1.0, 0)
+        close('lsgan', l1.view(1), ((a - 1.0) ** 2).mean().view(1), tol=1e-5)
+
+
+CONVS = [  # N, H, W, Cin, Cout, k, stride, pad, act, bias
+    (3, 37, 20, 1, 8, 3, 1, 1, 'relu', True),
+    (2, 16, 12, 64, 64, 3, 1, 1, 'relu', True),
+    (2, 9, 10, 64, 128, 3, 1, 1, None, True),
+    (3, 37, 80, 1, 8, 4, 2, 1, 'lrelu', True),
+    (3, 18, 40, 8, 16, 4, 2, 1, None, False),
+    (2, 18, 40, 64, 128, 4, 2, 1, None, False),
+    (3, 9, 9, 16, 32, 4, 1, 1, None, False),
+    (3, 8, 8, 32, 1, 4, 1, 1, None, True),
+    (2, 7, 5, 6, 10, 3, 1, 1, 'relu', True),
+]
+
+
+@pytest.mark.parametrize('cfg', CONVS)
+def test_conv2d(cfg):
+    ops, lib = _ops()
+    N, H, W, Cin, Cout, k, s, p, act, has_b = cfg
+    x, Wt = rnd(N, Cin, H, W), rnd(Cout, Cin, k, k, seed=1, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=2) if has_b else None
+    xr, Wr = x.clone().requires_grad_(True), Wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_b else None
+    yr = F.conv2d(xr, Wr, br, stride=s, padding=p)
+    yr = {'relu': F.relu, 'lrelu': lambda t: F.leaky_relu(t, 0.2), None: lambda t: t}[act](yr)
+    go = rnd(*yr.shape, seed=3)
+    (yr * go).sum().backward()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    Wg = torch.nn.Parameter(Wt.to(DEV))
+    bg = torch.nn.Parameter(b.to(DEV)) if has_b else None
+    y = ops.conv2d(xg, Wg, bg, s, p, act)
+    (y * go.permute(0, 2, 3, 1).contiguous().to(DEV)).sum().backward()
+    close('y', y.permute(0, 3, 1, 2), yr, tol=2e-4)
+    close('dx', xg.grad.permute(0, 3, 1, 2), xr.grad, tol=2e-4)
+    close('dW', Wg.grad, Wr.grad, tol=2e-4)
+    if has_b:
+        close('db', bg.grad, br.grad, tol=2e-4)
+
+
+def test_pool_and_pack():
+    ops, lib = _ops()
+    x = rnd(3, 6, 37, 21)                     # NCHW
+    xr = x.clone().requires_grad_(True)
+    pr = F.max_pool2d(xr, 2, stride=2, ceil_mode=True)
+    lens = [19, 12, 5]
+    T2 = pr.shape[2]
+    ref = pr.transpose(1, 2).contiguous().view(3, T2, -1)
+    ref = torch.stack([torch.cat([ref[i, :lens[i]], torch.zeros(T2 - lens[i], ref.shape[2])]) for i in range(3)])
+    go = rnd(3, T2, ref.shape[2], seed=4)
+    (ref * go).sum().backward()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    pg = ops.maxpool2(xg)
+    out = ops.vgg_pack(pg, torch.tensor(lens, dtype=torch.int32, device=DEV))     # (T,N,C*F)
+    (out * go.transpose(0, 1).contiguous().to(DEV)).sum().backward()
+    close('pool', pg.permute(0, 3, 1, 2), pr, tol=0, atol=0)
+    close('pack', out.transpose(0, 1), ref, tol=0, atol=0)
+    close('dx', xg.grad.permute(0, 3, 1, 2), xr.grad, tol=1e-6)
+
+
+def test_bn_lrelu():
+    ops, lib = _ops()
+    x = rnd(3, 16, 9, 5, scale=2.0) + 0.5
+    bn = torch.nn.BatchNorm2d(16)
+    bn.weight.data.normal_(1, 0.02)
+    bn.bias.data.normal_(0, 0.1)
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(bn(xr), 0.2)
+    go = rnd(3, 16, 9, 5, seed=3)
+    (yr * go).sum().backward()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    gam, bet = torch.nn.Parameter(bn.weight.data.clone().to(DEV)), torch.nn.Parameter(bn.bias.data.clone().to(DEV))
+    rm, rv = torch.zeros(16, device=DEV), torch.ones(16, device=DEV)
+    y = ops.bn_lrelu(xg, gam, bet, rm, rv, True)
+    (y * go.permute(0, 2, 3, 1).contiguous().to(DEV)).sum().backward()
+    close('y', y.permute(0, 3, 1, 2), yr, tol=1e-5)
+    close('dx', xg.grad.permute(0, 3, 1, 2), xr.grad, tol=1e-4)
+    close('dgamma', gam.grad, bn.weight.grad, tol=1e-4)
+    close('dbeta', bet.grad, bn.bias.grad, tol=1e-4)
+    close('running_mean', rm, bn.running_mean, tol=1e-5)
+    close('running_var', rv, bn.running_var, tol=1e-5)
+
+
+@pytest.mark.parametrize('B,T,I,H,lens', [(3, 11, 20, 16, [11, 7, 4]), (40, 9, 33, 64, None), (5, 6, 257, 24, [6, 6, 5, 2, 1])])
+def test_bilstm(B, T, I, H, lens):
+    ops, lib = _ops()
+    if lens is None:
+        lens = sorted([1 + (i * 7) % T for i in range(B)], reverse=True)
+        lens[0] = T
+    lstm = torch.nn.LSTM(I, H, 1, batch_first=True, bidirectional=True)
+    x = rnd(B, T, I)
+    for b, l in enumerate(lens):
+        x[b, l:] = 0
+    xr = x.clone().requires_grad_(True)
+    pk = torch.nn.utils.rnn.pack_padded_sequence(xr, torch.tensor(lens), batch_first=True)
+    yr, _ = torch.nn.utils.rnn.pad_packed_sequence(lstm(pk)[0], batch_first=True, total_length=T)
+    go = rnd(B, T, 2 * H, seed=9)
+    (yr * go).sum().backward()
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+    ws = [torch.nn.Parameter(getattr(lstm, n + sfx).data.clone().to(DEV)) for sfx in ('', '_reverse') for n in names]
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.bilstm(ops.transpose01(xg), torch.tensor(lens, dtype=torch.int32, device=DEV), ws)
+    (y * go.transpose(0, 1).contiguous().to(DEV)).sum().backward()
+    close('y', y.transpose(0, 1), yr, tol=1e-4)
+    close('dx', xg.grad, xr.grad, tol=2e-4)
+    i = 0
+    for sfx in ('', '_reverse'):
+        for n in names:
+            close(n + sfx, ws[i].grad, getattr(lstm, n + sfx).grad, tol=3e-4)
+            i += 1
+
+
+def test_ctc():
+    ops, lib = _ops()
+    T, B, V = 23, 4, 17
+    logits = rnd(T, B, V, scale=2.0)
+    hlens = [23, 20, 14, 9]
+    labels = [[3, 3, 5, 1, 1, 1, 9], [2, 4], [7, 7], [16]]
+    lr = logits.clone().requires_grad_(True)
+    ref = F.ctc_loss(lr.log_softmax(2), torch.tensor(sum(labels, [])), torch.tensor(hlens), torch.tensor([len(l) for l in labels]),
+                     blank=0, reduction='sum') / B
+    (ref * 1.3).backward()
+    lg = logits.to(DEV).requires_grad_(True)
+    flat = torch.tensor(sum(labels, []), dtype=torch.int32, device=DEV)
+    ll = [len(l) for l in labels]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(ll)[:-1]]), dtype=torch.int32, device=DEV)
+    loss = ops.ctc_loss(lg, torch.tensor(hlens, dtype=torch.int32, device=DEV), flat, off, torch.tensor(ll, dtype=torch.int32, device=DEV), max(ll))
+    (loss * 1.3).sum().backward()
+    close('loss', loss.view(1), ref.view(1), tol=1e-5)
+    close('dlogits', lg.grad, lr.grad, tol=1e-4)
+    assert (lg.grad[20:, 1] == 0).all()
+
+
+def test_decoder_loop_and_ce(golden_dir):
+    import os
+    ops, lib = _ops()
+    from oracle import nets
+    fx = dict(np.load(os.path.join(golden_dir, 'e2e_tiny.npz')))
+    p = {k[2:]: torch.from_numpy(v).clone().requires_grad_(True) for k, v in fx.items() if k.startswith('p.') and not k.startswith('p.dec.att.')}
+    hpad = torch.from_numpy(fx['hpad']).clone().requires_grad_(True)
+    hlens = fx['hlens'].tolist()
+    ys = nets.split_targets(torch.from_numpy(fx['targets']), fx['tlens'].tolist())
+    V = p['dec.output.weight'].shape[0]
+    loss_r, acc_r, att_r = nets.decoder_forward(p, hpad, hlens, ys, V - 1, return_att=True)
+    loss_r.backward()
+
+    from robust_e2e_gan_amd.model.e2e_decoder import decoder_forward_hip
+    pg = {k: torch.nn.Parameter(v.detach().clone().to(DEV)) for k, v in p.items() if k.startswith('dec.') or k.startswith('att.')}
+    hg = hpad.detach().clone().to(DEV).requires_grad_(True)
+    loss, acc, att = decoder_forward_hip(pg, hg, hlens, ys, V - 1, return_att=True)
+    loss.backward()
+    close('att_w', att, att_r, tol=1e-4)
+    close('loss_att', loss.view(1), loss_r.view(1), tol=1e-4)
+    assert abs(float(acc) - acc_r) < 1e-6
+    close('d_hpad', hg.grad, hpad.grad, tol=5e-4)
+    for k, v in pg.items():
+        ref = p[k].grad
+        close(k, v.grad, ref, tol=1e-3, atol=1e-7)
+
+
+def test_coral():
+    ops, lib = _ops()
+    from oracle import nets
+    a, b = rnd(37, 20), rnd(41, 20, seed=1) * 1.3 + 0.2
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lr = nets.coral(ar, br)
+    (lr * 2.0).backward()
+    ag, bg = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    l = ops.coral(ag, bg)
+    (l * 2.0).backward()
+    close('coral', l.view(1), lr.view(1), tol=1e-4)
+    close('da', ag.grad, ar.grad, tol=1e-3)
+    close('db', bg.grad, br.grad, tol=1e-3)
+
+
+def test_optimizers():
+    ops, lib = _ops()
+    from robust_e2e_gan_amd.optim import FlatOptimizer
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(33, 17)
+    mine = torch.nn.Linear(33, 17)
+    mine.load_state_dict(ref.state_dict())
+    mine.to(DEV)
+    for kind, kw in (('adadelta', dict(rho=0.95, eps=1e-8)), ('adam', dict(lr=0.005, betas=(0.5, 0.999)))):
+        o_ref = torch.optim.Adadelta(ref.parameters(), **kw) if kind == 'adadelta' else torch.optim.Adam(ref.parameters(), **kw)
+        o = FlatOptimizer(mine.parameters(), kind, **kw)
+        for it in range(3):
+            g = [rnd(*p.shape, seed=it) * 4 for p in ref.parameters()]
+            for p, gi in zip(ref.parameters(), g):
+                p.grad = gi.clone()
+            o.zero_grad()
+            for p, gi in zip(mine.parameters(), g):
+                p.grad.copy_(gi.to(DEV))
+            n_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 5.0)
+            n = o.clip_grad_norm(5.0)
+            o_ref.step()
+            o.step()
+            assert abs(float(n) - float(n_ref)) < 1e-3 * float(n_ref)
+        for p, q in zip(ref.parameters(), mine.parameters()):
+            close(kind, q, p, tol=1e-4)
+
+
+def test_misc_layout_kernels():
+    ops, lib = _ops()
+    x = rnd(4, 7, 13)
+    close('transpose01', ops.transpose01(x.to(DEV)), x.transpose(0, 1), tol=0, atol=0)
+    idx = torch.tensor([5, 0, 27, 13], dtype=torch.int32)
+    close('gather', ops.gather_rows(x.view(28, 13).to(DEV), idx.to(DEV)), x.view(28, 13)[idx.long()], tol=0, atol=0)
+    lens = [7, 3, 5, 1]
+    close('mask_rows', ops.mask_rows(x.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV)),
+          x * (torch.arange(7).unsqueeze(0) < torch.tensor(lens).view(-1, 1)).unsqueeze(-1), tol=0, atol=0)
+    from robust_e2e_gan_amd.data.mix_data_loader import pack_pad_device
+    flat = torch.cat([x[i, :lens[i]] for i in range(4)])
+    padded = pack_pad_device(flat.to(DEV), lens, 7)
+    ref = torch.stack([torch.cat([x[i, :lens[i]], torch.zeros(7 - lens[i], 13)]) for i in range(4)])
+    close('pack_pad', padded, ref, tol=0, atol=0)

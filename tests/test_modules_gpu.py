@@ -1,0 +1,162 @@
+"""Module-surface parity on the GPU against the golden vectors produced from the reference import
+(tests/golden/*.npz) -- EnhanceModel, FbankModel, E2E, GANModel/GANLoss and one composed
+joint_train step.  Calls go through the C ABI (libre2e_hip.so).  Tolerance 1e-3 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _fx(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _opt():
+    import __graft_entry__ as g
+    return g._tiny_opt()
+
+
+def _load(m, fx, prefix):
+    sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith(prefix)}
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    return m.to(DEV).train()
+
+
+def rel(name, got, ref, tol=1e-3, atol=1e-7):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = np.asarray(ref)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = np.abs(got - ref).max()
+    assert np.isfinite(err) and err <= tol * np.abs(ref).max() + atol, '%s: err %.3e scale %.3e' % (name, err, np.abs(ref).max())
+
+
+def test_state_dict_names_match_reference(golden_dir):
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    fx = _fx(golden_dir, 'joint_tiny.npz')
+    opt = _opt()
+    for cls, pre in ((EnhanceModel, 'enh.'), (ShareE2E, 'asr.'), (GANModel, 'gan.')):
+        want = {k[len(pre):]: v.shape for k, v in fx.items() if k.startswith(pre)}
+        have = {k: tuple(v.shape) for k, v in cls(opt).state_dict().items()}
+        assert want == have, (pre, set(want) ^ set(have))
+
+
+def test_enhance_model(golden_dir):
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    fx = _fx(golden_dir, 'enhance_tiny.npz')
+    m = _load(EnhanceModel(_opt()), fx, 'p.')
+    t = lambda k: torch.from_numpy(fx[k])
+    lens = torch.IntTensor(fx['lens'])
+    out = m(t('mix'), t('mix_log'), lens)                      # CPU inputs: the module moves them (to_cuda)
+    rel('enhance_out', out, fx['enhance_out'])
+    for b, l in enumerate(fx['lens']):
+        assert (out[b, l:] == 0).all()
+    loss, out2 = m(t('mix'), t('mix_log'), lens, t('clean'), t('cos'))
+    rel('l1_loss', loss.view(()), fx['l1_loss'])
+    (loss + (out2 * torch.linspace(0.5, 1.5, 257).to(DEV)).mean()).backward()
+    for k, p in m.named_parameters():
+        rel('g.' + k, p.grad, fx['g.' + k], tol=2e-3)
+
+
+def test_fbank_model(golden_dir):
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    import argparse
+    fx = _fx(golden_dir, 'fbank_tiny.npz')
+    opt = _opt()
+    m = FbankModel(opt)
+    m.load_state_dict({'fc': torch.from_numpy(fx['W'])})
+    m = m.to(DEV)
+    x = torch.from_numpy(fx['x']).to(DEV).requires_grad_(True)
+    cm = torch.from_numpy(fx['cmvn'])
+    rel('y_nocmvn', m(x), fx['y_nocmvn'], tol=1e-5)
+    y1 = m(x, cm)
+    rel('y_cmvn', y1, fx['y_cmvn'], tol=1e-5)
+    (y1 * torch.linspace(-1, 1, 80).to(DEV)).sum().backward()
+    rel('dx', x.grad, fx['dx'], tol=1e-4)
+    mc = FbankModel(argparse.Namespace(**{**vars(opt), 'train_dataset_len': 3}))
+    mc.load_state_dict({'fc': torch.from_numpy(fx['W'])})
+    mc = mc.to(DEV)
+    lens = torch.IntTensor(fx['lens'])
+    assert mc.compute_cmvn(x.detach(), lens) is None
+    rel('cmvn_est', mc.compute_cmvn(x.detach(), lens), fx['cmvn_est'], tol=1e-4)
+
+
+def test_e2e(golden_dir):
+    from robust_e2e_gan_amd.model.e2e_model import E2E
+    fx = _fx(golden_dir, 'e2e_tiny.npz')
+    m = _load(E2E(_opt()), fx, 'p.')
+    feat = torch.from_numpy(fx['feat']).to(DEV).requires_grad_(True)
+    lens, tl = torch.IntTensor(fx['lens']), torch.IntTensor(fx['tlens'])
+    hpad, hl = m.enc(feat, lens)
+    rel('hpad', hpad, fx['hpad'])
+    assert list(hl) == fx['hlens'].tolist()
+    lc, la, acc = m(feat, torch.from_numpy(fx['targets']), lens, tl, 0.0)
+    rel('loss_ctc', lc.view(1), fx['loss_ctc'])
+    rel('loss_att', la.view(()), fx['loss_att'])
+    assert abs(float(acc) - float(fx['acc'])) < 1e-6
+    (0.5 * lc.view(()) + 0.5 * la).backward()
+    rel('dfeat', feat.grad, fx['dfeat'], tol=3e-3)
+    for k, p in m.named_parameters():
+        rel('g.' + k, p.grad, fx['g.' + k], tol=3e-3)
+
+
+def test_gan(golden_dir):
+    from robust_e2e_gan_amd.model.gan_model import GANModel, GANLoss
+    fx = _fx(golden_dir, 'gan_tiny.npz')
+    m = _load(GANModel(_opt()), fx, 'p.')
+    crit = GANLoss(use_lsgan=True)
+    x = torch.from_numpy(fx['x']).to(DEV).requires_grad_(True)
+    d = m(x)
+    rel('d_out', d, fx['d_out'])
+    lr = crit(d, True)
+    lf = crit(m(x * 0.9 + 0.1), False)
+    rel('l_real', lr.view(()), fx['l_real'])
+    rel('l_fake', lf.view(()), fx['l_fake'])
+    ((lr + lf) * 0.5).backward()
+    rel('dx', x.grad, fx['dx'], tol=3e-3)
+    for k, p in m.named_parameters():
+        rel('g.' + k, p.grad, fx['g.' + k], tol=3e-3)
+    for k, v in m.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            rel('after.' + k, v, fx['after.' + k], tol=1e-4)
+
+
+def test_joint_step(golden_dir):
+    """One composed joint_train.py:156-212 step vs the reference-generated vectors (S1-S3 semantics)."""
+    import __graft_entry__ as g
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    fx = _fx(golden_dir, 'joint_tiny.npz')
+    W = _fx(golden_dir, 'fbank_tiny.npz')['W']
+    opt = g._tiny_opt()
+    enh, asr, gan = _load(EnhanceModel(opt), fx, 'enh.'), _load(ShareE2E(opt), fx, 'asr.'), _load(GANModel(opt), fx, 'gan.')
+    fb = FbankModel(opt)
+    fb.load_state_dict({'fc': torch.from_numpy(W)})
+    fb = fb.to(DEV).train()
+    tr = JointTrainer(opt, enh, fb, asr, gan)
+    t = lambda k: torch.from_numpy(fx[k])
+    data = (None, None, t('clean'), None, t('mix'), t('mix_log'), None, t('targets'), torch.IntTensor(fx['lens']), torch.IntTensor(fx['tlens']))
+    # capture gradients before the optimizer step overwrites nothing (grads stay in the flat buffers)
+    out = JointTrainer.to_floats(tr.step(data, 0.0, t('cmvn')))
+    rel('enhance_out', tr.last['enhance_out'], fx['enhance_out'])
+    rel('enhance_feat', tr.last['enhance_feat'], fx['enhance_feat'], tol=1e-4)
+    for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'loss_D'):
+        assert abs(out['train/' + k] - float(fx[k][0])) <= 1e-3 * max(1.0, abs(float(fx[k][0]))), (k, out['train/' + k], fx[k])
+    assert abs(out['train/gan_loss'] - float(fx['gan_loss'][0])) <= 1e-3
+    assert abs(out['train/acc'] - float(fx['acc'])) < 1e-6
+    assert abs(out['grad_norm'] - float(fx['grad_norm_asr'])) <= 2e-3 * float(fx['grad_norm_asr'])
+    for pre, m in (('genh.', enh), ('gasr.', asr), ('ggan.', gan)):
+        for k, p in m.named_parameters():
+            rel(pre + k, p.grad, fx[pre + k], tol=3e-3)
+    for pre, m in (('enh_after.', enh), ('asr_after.', asr), ('gan_after.', gan)):
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point:
+                rel(pre + k, v, fx[pre + k], tol=1e-3, atol=2e-5)
