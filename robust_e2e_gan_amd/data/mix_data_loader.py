@@ -38,8 +38,9 @@ def pack_pad_device(flat_dev, lens, Tmax):
     dev = flat_dev.device
     off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
     out = torch.empty(B, Tmax, F_, dtype=torch.float32, device=dev)
-    call('re2e_pack_pad', flat_dev.data_ptr(), torch.from_numpy(off).to(dev).data_ptr(), torch.tensor(lens, dtype=torch.int32, device=dev).data_ptr(),
-         B, Tmax, F_, out.data_ptr())
+    off_d = torch.from_numpy(off).to(dev)                 # keep both index tensors alive across the launch
+    len_d = torch.tensor(lens, dtype=torch.int32, device=dev)
+    call('re2e_pack_pad', flat_dev.data_ptr(), off_d.data_ptr(), len_d.data_ptr(), B, Tmax, F_, out.data_ptr())
     return out
 
 

@@ -104,7 +104,8 @@ class FbankModel(ModelBase):
         if self.cmvn_processed_num < self.cmvn_num:
             B, T, NF = feats.shape
             s, q = torch.empty(NF, device=feats.device), torch.empty(NF, device=feats.device)
-            call('re2e_cmvn_stats', feats.data_ptr(), lens_dev(input_sizes, feats.device).data_ptr(), B, T, NF, s.data_ptr(), q.data_ptr())
+            ld = lens_dev(input_sizes, feats.device)
+            call('re2e_cmvn_stats', feats.data_ptr(), ld.data_ptr(), B, T, NF, s.data_ptr(), q.data_ptr())
             self.sum = np.add(self.sum, s.cpu().numpy())
             self.sum_sq = np.add(self.sum_sq, q.cpu().numpy())
             ll = lens_list(input_sizes)
