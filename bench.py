@@ -105,7 +105,7 @@ def conv_roofline(dev, iters=20):
 
 
 def cpu_baseline(opt):
-    """Oracle ('port') on the host cores: one joint step on a bounded sample (B=4 of 32 utterances,
+    """Oracle ('port') on the host cores: one joint step on a bounded sample (B=16 of 32 utterances,
     same T/L/V/architecture) after a small warm-up step."""
     from oracle import joint as oj
     from robust_e2e_gan_amd.data.synthetic import make_batch
@@ -120,14 +120,14 @@ def cpu_baseline(opt):
                enhance_loss_type='L2')
     st = oj.JointState(sd[0], sd[2], sd[3], torch.from_numpy(mel_matrix()), cfg)
     cm = torch.stack([torch.full((80,), -8.0), torch.full((80,), 0.5)])
-    for B, T, L, timed in ((2, 200, 10, False), (4, 800, 40, True)):
+    for B, T, L, timed in ((2, 200, 10, False), (16, 800, 40, True)):
         clean, mix, mix_log, targets, il, tl = make_batch(B, T, L, opt.odim, seed=1234)
         t0 = time.time()
         oj.joint_step(st, (clean, mix, mix_log, targets, il.tolist(), tl.tolist()), cm)
         dt = time.time() - t0
         log('cpu_baseline: B=%d T=%d step took %.1fs' % (B, T, dt))
-    return {'value': round(4.0 / dt, 4), 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
-            'sample': 'oracle/joint.py joint_step, config-4 architecture, B=4 of 32 utterances, T=800, L=40, V=4233, 1 timed step after a '
+    return {'value': round(16.0 / dt, 4), 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle/joint.py joint_step, config-4 architecture, B=16 of 32 utterances, T=800, L=40, V=4233, 1 timed step after a '
                       'B=2,T=200 warm-up; torch CPU fp32, %d threads' % cores, 'seconds': round(dt, 2)}
 
 
