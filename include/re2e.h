@@ -161,13 +161,16 @@ int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C, const floa
  * e2e_encoder.py:128-132,168-170).  Time-major.  xg_f/xg_r [T*B,4H] hold x W_ih^T + b_ih + b_hh
  * (gate order i,f,g,o) on entry and the ACTIVATED gates on exit (saved for the backward);
  * ybuf/cbuf are [(T+2)*B, 2H] with block 0 and block T+1 zero: y[t] lives in block t+1. */
+size_t re2e_lstm_workspace_bytes(int B, int H);
 int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
-                      const int* lens_dev, int T, int B, int H, re2e_stream_t stream);
-/* g_f/g_r: activated gates in, d(pre-activation gates) out (in place).  dy [T*B,2H].
- * whhT_*: W_hh transposed [H,4H].  dc_state [B,2H] scratch (zeroed by the call). */
-int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whhT_f, const float* whhT_r, const float* dy,
-                      const float* ybuf, const float* cbuf, float* dc_state, const int* lens_dev, int T, int B, int H,
+                      const int* lens_dev, int T, int B, int H, void* workspace, size_t workspace_bytes,
                       re2e_stream_t stream);
+/* g_f/g_r: activated gates in, d(pre-activation gates) out (in place).  dy [T*B,2H].
+ * whh_*: W_hh [4H,H] as stored by nn.LSTM.  dc_state [B,2H] scratch (zeroed by the call).
+ * workspace (re2e_lstm_workspace_bytes) holds the MFMA-fragment-ordered weight / state copies. */
+int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, const float* whh_r, const float* dy,
+                      const float* ybuf, const float* cbuf, float* dc_state, const int* lens_dev, int T, int B, int H,
+                      void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 
 /* ---- K8 LSTMCell pointwise (decoder, e2e_decoder.py:131), embedding, cross-entropy -------- */
 /* gates [B,4H] pre-activation in -> activated out; c_prev [B,H] -> c_out, h_out */

@@ -16,54 +16,47 @@
 
 namespace {
 
-constexpr int BK = 32;        // k-tile
-constexpr int LDK = BK + 4;   // padded k stride of a k-major LDS tile (floats)
-
-template <int WM_, int WN_, int TM_, int TN_>
+template <int WM_, int WN_, int TM_, int TN_, int BK_>
 struct Cfg {
-  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
   static constexpr int BM = WM_ * TM_ * 32, BN = WN_ * TN_ * 32;
   static constexpr int THREADS = WM_ * WN_ * 64;
+  static constexpr int LDK = BK_ + 4;   // padded k stride of a k-major LDS tile (floats): conflict-free b128 reads
 };
 
 // ------------------------------------------------------------------------------------------
 // Operand loaders.  A loader describes a logical matrix X[row][k] (rows = M for the A operand,
-// N for the B operand).  KMAJ loaders fetch float4 along k (LDS tile [row][LDK]); MMAJ loaders
-// fetch float4 along rows (LDS tile [k][ROWS+4]).  `init` caches per-thread row state once.
+// N for the B operand) and returns the BYTE OFFSET of an element group inside its tensor, or
+// `nbytes` (= one past the end) when the group is out of range.  The kernel fetches through a raw
+// buffer descriptor (buffer_load_dwordx4 ... offen): the hardware range check returns 0 for the
+// out-of-range offset, so there is no branch and no select between a load and its LDS store --
+// a tile's loads are issued back to back and stay in flight under the MFMA block.
+// KMAJ loaders fetch along k (LDS tile [row][LDK]): per-item row state + ONE per-thread k state.
+// MMAJ loaders fetch along rows (LDS tile [k][ROWS+4]): ONE per-thread row state + per-item k state.
 // ------------------------------------------------------------------------------------------
 struct DenseK {   // X[row*ld + k]
   static constexpr bool KMAJ = true;
-  const float* p; long ld; int rows, K; bool vec;
-  struct St { const float* rp; int k; };
-  __device__ void init(St& s, int row, int kofs, int kbegin) const {
-    s.rp = row < rows ? p + (long)row * ld : nullptr; s.k = kbegin + kofs;
-  }
-  __device__ void advance(St& s) const { s.k += BK; }
-  __device__ f32x4 load(const St& s) const {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (s.rp == nullptr) return v;
-    const int k = s.k;
-    if (vec && k + 3 < K) return *reinterpret_cast<const f32x4*>(s.rp + k);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = s.rp[k + j];
-    return v;
+  const float* p; unsigned nbytes; long ld; int rows, K;
+  struct Row { unsigned base; };     // row*ld*4, or nbytes when the row is out of range
+  struct Kst { int k; };
+  __device__ void init_row(Row& r, int row) const { r.base = row < rows ? (unsigned)((long)row * ld * 4) : nbytes; }
+  __device__ void init_k(Kst& s, int k) const { s.k = k; }
+  __device__ void advance(Kst& s, int bk) const { s.k += bk; }
+  __device__ unsigned off(const Row& r, const Kst& s, int j) const {     // element k+j (j=0 for a float4 group)
+    return (r.base != nbytes && s.k + j < K) ? r.base + (unsigned)(s.k + j) * 4u : nbytes;
   }
 };
 
 struct DenseM {   // X[k*ld + row]
   static constexpr bool KMAJ = false;
-  const float* p; long ld; int rows, K; bool vec;
-  struct St { int r0; int k; };
-  __device__ void init(St& s, int row0, int kofs, int kbegin) const { s.r0 = row0; s.k = kbegin + kofs; }
-  __device__ void advance(St& s) const { s.k += BK; }
-  __device__ f32x4 load(const St& s) const {   // rows r0..r0+3 at column k
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (s.k >= K || s.r0 >= rows) return v;
-    const float* q = p + (long)s.k * ld + s.r0;
-    if (vec && s.r0 + 3 < rows) return *reinterpret_cast<const f32x4*>(q);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (s.r0 + j < rows) v[j] = q[j];
-    return v;
+  const float* p; unsigned nbytes; long ld; int rows, K;
+  struct Row { int r0; };
+  struct Kst { int k; };
+  __device__ void init_row(Row& r, int row0) const { r.r0 = row0; }
+  __device__ void init_k(Kst& s, int k) const { s.k = k; }
+  __device__ void advance(Kst& s, int bk) const { s.k += bk; }
+  __device__ unsigned off(const Row& r, const Kst& s, int j) const {
+    return (s.k < K && r.r0 + j < rows) ? (unsigned)(((long)s.k * ld + r.r0 + j) * 4) : nbytes;
   }
 };
 
@@ -75,77 +68,69 @@ struct ConvGeom {
 
 struct ConvK {    // rows = pixels, k = (kh, kw, ci) with ci fastest
   static constexpr bool KMAJ = true;
-  ConvGeom g; int rows, K; bool vec;
-  struct St { int n, iy0, ix0; int k, ci, kh, kw; };
-  __device__ void init(St& s, int row, int kofs, int kbegin) const {
-    if (row >= rows) { s.n = -1; s.iy0 = 0; s.ix0 = 0; }
+  ConvGeom g; const float* p; unsigned nbytes; int rows, K;
+  struct Row { int n, iy0, ix0; };
+  struct Kst { int k, ci, kh, kw; };
+  __device__ void init_row(Row& r, int row) const {
+    if (row >= rows) { r.n = -1; r.iy0 = 0; r.ix0 = 0; }
     else {
-      int px = row % g.PW; int t = row / g.PW; int py = t % g.PH; s.n = t / g.PH;
-      s.iy0 = py * g.SY + g.OY0; s.ix0 = px * g.SX + g.OX0;
+      int px = row % g.PW; int t = row / g.PW; int py = t % g.PH; r.n = t / g.PH;
+      r.iy0 = py * g.SY + g.OY0; r.ix0 = px * g.SX + g.OX0;
     }
-    s.k = kbegin + kofs; s.ci = s.k % g.C; int tap = s.k / g.C; s.kw = tap % g.KW; s.kh = tap / g.KW;
   }
-  __device__ void advance(St& s) const {
-    s.k += BK; s.ci += BK;
+  __device__ void init_k(Kst& s, int k) const {
+    s.k = k; s.ci = k % g.C; int tap = k / g.C; s.kw = tap % g.KW; s.kh = tap / g.KW;
+  }
+  __device__ void advance(Kst& s, int bk) const {
+    s.k += bk; s.ci += bk;
     while (s.ci >= g.C) { s.ci -= g.C; if (++s.kw == g.KW) { s.kw = 0; ++s.kh; } }
   }
-  __device__ f32x4 load(const St& s) const {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (s.n < 0 || s.k >= K) return v;
-    if (vec) {
-      int iy = s.iy0 + s.kh * g.DY, ix = s.ix0 + s.kw * g.DX;
-      if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return v;
-      return *reinterpret_cast<const f32x4*>(g.in + (((long)s.n * g.H + iy) * g.W + ix) * g.C + s.ci);
-    }
-    int ci = s.ci, kw = s.kw, kh = s.kh;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (s.k + j < K) {
-        int iy = s.iy0 + kh * g.DY, ix = s.ix0 + kw * g.DX;
-        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-          v[j] = g.in[(((long)s.n * g.H + iy) * g.W + ix) * g.C + ci];
-      }
-      if (++ci == g.C) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
-    }
-    return v;
+  __device__ unsigned off(const Row& r, const Kst& s, int j) const {
+    int ci = s.ci + j, kw = s.kw, kh = s.kh;
+    while (ci >= g.C) { ci -= g.C; if (++kw == g.KW) { kw = 0; ++kh; } }     // j>0 only on the scalar path
+    const int iy = r.iy0 + kh * g.DY, ix = r.ix0 + kw * g.DX;
+    const bool ok = (r.n >= 0) & (s.k + j < K) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+    return ok ? (unsigned)(((((long)r.n * g.H + iy) * g.W + ix) * g.C + ci) * 4) : nbytes;
   }
 };
 
 struct ConvM {    // rows = (kh, kw, ci) (ci fastest), k = pixel  (weight-gradient A operand)
   static constexpr bool KMAJ = false;
-  ConvGeom g; int rows, K; bool vec;
-  struct St { int r0, ci, kh, kw; int k, n, py, px; };
-  __device__ void init(St& s, int row0, int kofs, int kbegin) const {
-    s.r0 = row0;
-    int r = row0 < rows ? row0 : 0;
-    s.ci = r % g.C; int tap = r / g.C; s.kw = tap % g.KW; s.kh = tap / g.KW;
-    s.k = kbegin + kofs; s.px = s.k % g.PW; int t = s.k / g.PW; s.py = t % g.PH; s.n = t / g.PH;
+  ConvGeom g; const float* p; unsigned nbytes; int rows, K;
+  struct Row { int r0, ci, kh, kw; };
+  struct Kst { int k, n, py, px; };
+  __device__ void init_row(Row& r, int row0) const {
+    r.r0 = row0;
+    int rr = row0 < rows ? row0 : 0;
+    r.ci = rr % g.C; int tap = rr / g.C; r.kw = tap % g.KW; r.kh = tap / g.KW;
   }
-  __device__ void advance(St& s) const {
-    s.k += BK; s.px += BK;
+  __device__ void init_k(Kst& s, int k) const {
+    s.k = k; s.px = k % g.PW; int t = k / g.PW; s.py = t % g.PH; s.n = t / g.PH;
+  }
+  __device__ void advance(Kst& s, int bk) const {
+    s.k += bk; s.px += bk;
     while (s.px >= g.PW) { s.px -= g.PW; if (++s.py == g.PH) { s.py = 0; ++s.n; } }
   }
-  __device__ f32x4 load(const St& s) const {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (s.k >= K || s.r0 >= rows) return v;
-    if (vec) {
-      int iy = s.py * g.SY + s.kh * g.DY + g.OY0, ix = s.px * g.SX + s.kw * g.DX + g.OX0;
-      if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return v;
-      return *reinterpret_cast<const f32x4*>(g.in + (((long)s.n * g.H + iy) * g.W + ix) * g.C + s.ci);
-    }
-    int ci = s.ci, kw = s.kw, kh = s.kh;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (s.r0 + j < rows) {
-        int iy = s.py * g.SY + kh * g.DY + g.OY0, ix = s.px * g.SX + kw * g.DX + g.OX0;
-        if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-          v[j] = g.in[(((long)s.n * g.H + iy) * g.W + ix) * g.C + ci];
-      }
-      if (++ci == g.C) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
-    }
-    return v;
+  __device__ unsigned off(const Row& r, const Kst& s, int j) const {
+    int ci = r.ci + j, kw = r.kw, kh = r.kh;
+    while (ci >= g.C) { ci -= g.C; if (++kw == g.KW) { kw = 0; ++kh; } }
+    const int iy = s.py * g.SY + kh * g.DY + g.OY0, ix = s.px * g.SX + kw * g.DX + g.OX0;
+    const bool ok = (s.k < K) & (r.r0 + j < rows) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+    return ok ? (unsigned)(((((long)s.n * g.H + iy) * g.W + ix) * g.C + ci) * 4) : nbytes;
   }
 };
+
+template <bool VEC, class L>
+__device__ __forceinline__ f32x4 fetch(const L& l, __amdgpu_buffer_rsrc_t rs, const typename L::Row& r, const typename L::Kst& s) {
+  if constexpr (VEC) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l.off(r, s, 0), 0, 0));
+  } else {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, l.off(r, s, j), 0, 0));
+    return v;
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // Epilogue description
@@ -173,9 +158,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <class LA, class LB, class CF>
+template <class LA, class LB, class CF, bool VEC>
 __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep, int K) {
-  constexpr int BM = CF::BM, BN = CF::BN, TH = CF::THREADS;
+  constexpr int BM = CF::BM, BN = CF::BN, TH = CF::THREADS, BK = CF::BK, LDK = CF::LDK;
   constexpr int LDA_M = BM + 4, LDB_M = BN + 4;   // row strides of row-major (MMAJ) LDS tiles
   constexpr int ASZ = LA::KMAJ ? BM * LDK : BK * LDA_M;
   constexpr int BSZ = LB::KMAJ ? BN * LDK : BK * LDB_M;
@@ -186,30 +171,56 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / CF::WN, wn = wid % CF::WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(la.p), 0, la.nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lb.p), 0, lb.nbytes, 0x00020000);
   // split-K range
   const int nkt_total = (K + BK - 1) / BK;
   const int kt_per = (nkt_total + ep.nsplit - 1) / ep.nsplit;
   const int kt_begin = blockIdx.z * kt_per;
   const int kt_end = min(nkt_total, kt_begin + kt_per);
+  const int kbegin = kt_begin * BK;
 
   // float4 items per thread per tile
-  constexpr int AIT = BM * (BK / 4) / TH, BIT = BN * (BK / 4) / TH;
-  static_assert(AIT >= 1 && BIT >= 1, "tile too small for thread count");
-  typename LA::St sa[AIT];
-  typename LB::St sb[BIT];
+  constexpr int KQ = BK / 4;
+  constexpr int AIT = BM * KQ / TH, BIT = BN * KQ / TH;
+  static_assert(AIT >= 1 && BIT >= 1 && (BM * KQ) % TH == 0 && (BN * KQ) % TH == 0, "tile / thread-count mismatch");
+  static_assert(TH % KQ == 0 && TH % (BM / 4) == 0 && TH % (BN / 4) == 0, "per-thread k / row state must be item-invariant");
+  constexpr int NRA = LA::KMAJ ? AIT : 1, NKA = LA::KMAJ ? 1 : AIT;
+  constexpr int NRB = LB::KMAJ ? BIT : 1, NKB = LB::KMAJ ? 1 : BIT;
+  typename LA::Row ra_row[NRA];
+  typename LA::Kst ra_k[NKA];
+  typename LB::Row rb_row[NRB];
+  typename LB::Kst rb_k[NKB];
   int a_lds[AIT], b_lds[BIT];
-  const int kbegin = kt_begin * BK;
 #pragma unroll
   for (int i = 0; i < AIT; ++i) {
     int idx = i * TH + tid;
-    if (LA::KMAJ) { int r = idx >> 3, kq = idx & 7; la.init(sa[i], m0 + r, kq * 4, kbegin); a_lds[i] = r * LDK + kq * 4; }
-    else { int kk = idx / (BM / 4), rq = idx % (BM / 4); la.init(sa[i], m0 + rq * 4, kk, kbegin); a_lds[i] = kk * LDA_M + rq * 4; }
+    if (LA::KMAJ) {
+      int r = idx / KQ, kq = idx % KQ;
+      la.init_row(ra_row[LA::KMAJ ? i : 0], m0 + r);
+      if (i == 0) la.init_k(ra_k[0], kbegin + kq * 4);
+      a_lds[i] = r * LDK + kq * 4;
+    } else {
+      int kk = idx / (BM / 4), rq = idx % (BM / 4);
+      if (i == 0) la.init_row(ra_row[0], m0 + rq * 4);
+      la.init_k(ra_k[LA::KMAJ ? 0 : i], kbegin + kk);
+      a_lds[i] = kk * LDA_M + rq * 4;
+    }
   }
 #pragma unroll
   for (int i = 0; i < BIT; ++i) {
     int idx = i * TH + tid;
-    if (LB::KMAJ) { int r = idx >> 3, kq = idx & 7; lb.init(sb[i], n0 + r, kq * 4, kbegin); b_lds[i] = r * LDK + kq * 4; }
-    else { int kk = idx / (BN / 4), rq = idx % (BN / 4); lb.init(sb[i], n0 + rq * 4, kk, kbegin); b_lds[i] = kk * LDB_M + rq * 4; }
+    if (LB::KMAJ) {
+      int r = idx / KQ, kq = idx % KQ;
+      lb.init_row(rb_row[LB::KMAJ ? i : 0], n0 + r);
+      if (i == 0) lb.init_k(rb_k[0], kbegin + kq * 4);
+      b_lds[i] = r * LDK + kq * 4;
+    } else {
+      int kk = idx / (BN / 4), rq = idx % (BN / 4);
+      if (i == 0) lb.init_row(rb_row[0], n0 + rq * 4);
+      lb.init_k(rb_k[LB::KMAJ ? 0 : i], kbegin + kk);
+      b_lds[i] = kk * LDB_M + rq * 4;
+    }
   }
 
   f32x16 acc[CF::TM][CF::TN];
@@ -223,9 +234,9 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   f32x4 ra[AIT], rb[BIT];
   if (kt_begin < kt_end) {
 #pragma unroll
-    for (int i = 0; i < AIT; ++i) ra[i] = la.load(sa[i]);
+    for (int i = 0; i < AIT; ++i) ra[i] = fetch<VEC>(la, rsA, ra_row[LA::KMAJ ? i : 0], ra_k[LA::KMAJ ? 0 : i]);
 #pragma unroll
-    for (int i = 0; i < BIT; ++i) rb[i] = lb.load(sb[i]);
+    for (int i = 0; i < BIT; ++i) rb[i] = fetch<VEC>(lb, rsB, rb_row[LB::KMAJ ? i : 0], rb_k[LB::KMAJ ? 0 : i]);
 #pragma unroll
     for (int i = 0; i < AIT; ++i) *reinterpret_cast<f32x4*>(As + a_lds[i]) = ra[i];
 #pragma unroll
@@ -239,9 +250,13 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
     const bool more = (kt + 1 < kt_end);
     if (more) {
 #pragma unroll
-      for (int i = 0; i < AIT; ++i) { la.advance(sa[i]); ra[i] = la.load(sa[i]); }
+      for (int i = 0; i < NKA; ++i) la.advance(ra_k[i], BK);
 #pragma unroll
-      for (int i = 0; i < BIT; ++i) { lb.advance(sb[i]); rb[i] = lb.load(sb[i]); }
+      for (int i = 0; i < NKB; ++i) lb.advance(rb_k[i], BK);
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) ra[i] = fetch<VEC>(la, rsA, ra_row[LA::KMAJ ? i : 0], ra_k[LA::KMAJ ? 0 : i]);
+#pragma unroll
+      for (int i = 0; i < BIT; ++i) rb[i] = fetch<VEC>(lb, rsB, rb_row[LB::KMAJ ? i : 0], rb_k[LB::KMAJ ? 0 : i]);
     }
     const float* Ac = As + cur * ASZ;
     const float* Bc = Bs + cur * BSZ;
@@ -356,34 +371,35 @@ __global__ void splitk_reduce_kernel(const float* ws, int nsplit, int M, int N, 
   C[off] = s;
 }
 
-template <class LA, class LB, class CF>
+template <class LA, class LB, class CF, bool VEC>
 int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
-  constexpr int ASZ = LA::KMAJ ? CF::BM * LDK : BK * (CF::BM + 4);
-  constexpr int BSZ = LB::KMAJ ? CF::BN * LDK : BK * (CF::BN + 4);
+  constexpr int ASZ = LA::KMAJ ? CF::BM * CF::LDK : CF::BK * (CF::BM + 4);
+  constexpr int BSZ = LB::KMAJ ? CF::BN * CF::LDK : CF::BK * (CF::BN + 4);
   size_t lds = (size_t)2 * (ASZ + BSZ) * sizeof(float);
   static bool attr_done = false;   // idempotent; racing writers set the same value
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<LA, LB, CF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<LA, LB, CF, VEC>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   dim3 grid(cdiv(ep.M, CF::BM), cdiv(ep.N, CF::BN), ep.nsplit);
-  hipLaunchKernelGGL((igemm_kernel<LA, LB, CF>), grid, dim3(CF::THREADS), lds, st, la, lb, ep, K);
+  hipLaunchKernelGGL((igemm_kernel<LA, LB, CF, VEC>), grid, dim3(CF::THREADS), lds, st, la, lb, ep, K);
   return 0;
 }
 
-using C128 = Cfg<2, 2, 2, 2>;   // 128 x 128
-using C256x64 = Cfg<4, 1, 2, 2>;
-using C256x32 = Cfg<4, 1, 2, 1>;
+constexpr int BKD = 16;              // k-tile: 16 keeps LDS <= 46 KB per block => 2-3 blocks per CU
+using C128 = Cfg<2, 2, 2, 2, BKD>;    // 128 x 128
+using C256x64 = Cfg<4, 1, 2, 2, BKD>;
+using C256x32 = Cfg<4, 1, 2, 1, 32>;   // BN=32 needs BK=32 to give every thread a B item
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int pick_splits(int M, int N, int K, int bm, int bn) {
   long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
-  int nkt = cdiv(K, BK);
-  if (tiles >= 384 || nkt < 16) return 1;
+  int nkt = cdiv(K, BKD);
+  if (tiles >= 384 || nkt < 32) return 1;
   long want = (768 + tiles - 1) / tiles;
-  long maxs = nkt / 8;           // >= 8 k-tiles (256 k) per split
+  long maxs = nkt / 16;          // >= 16 k-tiles (256 k) per split
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
   if (s > 512) s = 512;
@@ -401,6 +417,28 @@ extern "C" size_t re2e_gemm_workspace_bytes(int transa, int transb, int M, int N
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
+// bytes spanned by a (outer x inner) row-major view with leading dimension ld
+static inline unsigned kbytes(long outer, long ld, long inner) { return (unsigned)(((outer - 1) * ld + inner) * 4); }
+static inline bool fits32(long outer, long ld, long inner) { return ((outer - 1) * ld + inner) * 4 < 0xFFFFFFF0L; }
+
+template <bool V>
+static void gemm_dispatch(int transa, int transb, int M, int N, int K, const float* A, long lda, const float* B, long ldb, Epi& ep,
+                          hipStream_t st) {
+  if (!transa && transb) {          // C = A[M,K] * B[N,K]^T   (Linear forward)
+    DenseK la{A, kbytes(M, lda, K), lda, M, K};
+    DenseK lb{B, kbytes(N, ldb, K), ldb, N, K};
+    launch_igemm<DenseK, DenseK, C128, V>(la, lb, ep, K, st);
+  } else if (!transa && !transb) {  // C = A[M,K] * B[K,N]     (input gradient)
+    DenseK la{A, kbytes(M, lda, K), lda, M, K};
+    DenseM lb{B, kbytes(K, ldb, N), ldb, N, K};
+    launch_igemm<DenseK, DenseM, C128, V>(la, lb, ep, K, st);
+  } else {                          // C = A[K,M]^T * B[K,N]   (weight gradient)
+    DenseM la{A, kbytes(K, lda, M), lda, M, K};
+    DenseM lb{B, kbytes(K, ldb, N), ldb, N, K};
+    launch_igemm<DenseM, DenseM, C128, V>(la, lb, ep, K, st);
+  }
+}
+
 extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const float* A, long lda, const float* B,
                          long ldb, float* C, long ldc, const float* bias, const float* bias2, int act, float beta,
                          const float* mul, float* mask_out, const int* lens_dev, int T, void* workspace,
@@ -410,46 +448,47 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
   RE2E_CHECK_ARG(beta == 0.f || beta == 1.f, "beta must be 0 or 1");
   RE2E_CHECK_ARG(act >= 0 && act <= RE2E_ACT_SIGMOID_MASK_MUL, "bad activation");
   if (act == RE2E_ACT_SIGMOID_MASK_MUL) RE2E_CHECK_ARG(mul && mask_out && lens_dev && T > 0, "mask epilogue needs mul/mask_out/lens/T");
+  if (transa && transb) {
+    re2e_set_error("re2e_gemm: transa && transb is not supported");
+    return RE2E_EUNSUPPORTED;
+  }
+  RE2E_CHECK_ARG(fits32(transa ? K : M, lda, transa ? M : K) && fits32(transb ? N : K, ldb, transb ? K : N), "operand larger than 4 GiB");
   Epi ep;
   memset(&ep, 0, sizeof(ep));
   ep.C = C; ep.ldc = ldc; ep.M = M; ep.N = N; ep.bias = bias; ep.bias2 = bias2; ep.act = act; ep.beta = beta;
   ep.mul = mul; ep.mask_out = mask_out; ep.lens = lens_dev; ep.T = T; ep.nsplit = 1;
-  if (!transa && transb) {   // C = A[M,K] * B[N,K]^T   (Linear forward)
-    DenseK la{A, lda, M, K, (lda % 4 == 0) && aligned16(A)};
-    DenseK lb{B, ldb, N, K, (ldb % 4 == 0) && aligned16(B)};
-    launch_igemm<DenseK, DenseK, C128>(la, lb, ep, K, stream);
-  } else if (!transa && !transb) {   // C = A[M,K] * B[K,N]   (input gradient)
-    DenseK la{A, lda, M, K, (lda % 4 == 0) && aligned16(A)};
-    DenseM lb{B, ldb, N, K, (ldb % 4 == 0) && aligned16(B)};
-    launch_igemm<DenseK, DenseM, C128>(la, lb, ep, K, stream);
-  } else if (transa && !transb) {   // C = A[K,M]^T * B[K,N]   (weight gradient), split-K
-    DenseM la{A, lda, M, K, (lda % 4 == 0) && aligned16(A)};
-    DenseM lb{B, ldb, N, K, (ldb % 4 == 0) && aligned16(B)};
-    int s = pick_splits(M, N, K, 128, 128);
+  int s = 1;
+  if (transa && !transb) {
+    s = pick_splits(M, N, K, 128, 128);
     if (s > 1) {
       RE2E_CHECK_ARG(workspace && workspace_bytes >= (size_t)s * M * N * sizeof(float), "workspace too small");
       RE2E_CHECK_ARG(act == RE2E_ACT_NONE && !bias && !bias2, "split-K form has no epilogue");
       ep.ws = (float*)workspace; ep.nsplit = s;
     }
-    launch_igemm<DenseM, DenseM, C128>(la, lb, ep, K, stream);
-    if (s > 1) {
-      long tot = (long)M * N;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s,
-                         M, N, C, ldc, beta, 0, 0, 0);
-    }
-  } else {
-    re2e_set_error("re2e_gemm: transa && transb is not supported");
-    return RE2E_EUNSUPPORTED;
+  }
+  // 16-byte vector loads need aligned bases, leading dimensions that are multiples of 4 and no
+  // float4 straddling a bound (k-contiguous operands: K % 4; row-contiguous operands: rows % 4)
+  bool va = aligned16(A) && lda % 4 == 0 && (transa ? M % 4 == 0 : K % 4 == 0);
+  bool vb = aligned16(B) && ldb % 4 == 0 && (transb ? K % 4 == 0 : N % 4 == 0);
+  if (va && vb) gemm_dispatch<true>(transa, transb, M, N, K, A, lda, B, ldb, ep, stream);
+  else gemm_dispatch<false>(transa, transb, M, N, K, A, lda, B, ldb, ep, stream);
+  if (s > 1) {
+    long tot = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s,
+                       M, N, C, ldc, beta, 0, 0, 0);
   }
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
 
 // ---- convolution (NHWC activations, weights pre-gathered by re2e_conv_weight_gather) ----------
-static int conv_dispatch(const ConvK& la, const DenseK& lb, Epi& ep, int K, hipStream_t st) {
-  if (ep.N <= 32) return launch_igemm<ConvK, DenseK, C256x32>(la, lb, ep, K, st);
-  if (ep.N <= 64) return launch_igemm<ConvK, DenseK, C256x64>(la, lb, ep, K, st);
-  return launch_igemm<ConvK, DenseK, C128>(la, lb, ep, K, st);
+template <bool V>
+static void conv_dispatch(const ConvGeom& g, int M, int K, const float* wg, int Cout, Epi& ep, hipStream_t st) {
+  ConvK la{g, g.in, (unsigned)((long)g.NI * g.H * g.W * g.C * 4), M, K};
+  DenseK lb{wg, kbytes(Cout, K, K), (long)K, Cout, K};
+  if (ep.N <= 32) launch_igemm<ConvK, DenseK, C256x32, V>(la, lb, ep, K, st);
+  else if (ep.N <= 64) launch_igemm<ConvK, DenseK, C256x64, V>(la, lb, ep, K, st);
+  else launch_igemm<ConvK, DenseK, C128, V>(la, lb, ep, K, st);
 }
 
 // Forward / data-gradient implicit GEMM:
@@ -462,16 +501,17 @@ extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, con
   RE2E_CHECK_ARG(in && wg && out, "null operand");
   RE2E_CHECK_ARG(NI > 0 && H > 0 && W > 0 && C > 0 && Cout > 0 && PH > 0 && PW > 0, "bad geometry");
   RE2E_CHECK_ARG(act >= 0 && act <= RE2E_ACT_SIGMOID, "bad activation");
+  RE2E_CHECK_ARG((long)NI * PH * PW < 2147483647L, "too many pixels");
+  RE2E_CHECK_ARG((long)NI * H * W * C * 4 < 0xFFFFFFF0L, "input tensor larger than 4 GiB");
   ConvGeom g{in, NI, H, W, C, PH, PW, KH, KW, SY, SX, DY, DX, OY0, OX0};
   int M = NI * PH * PW, K = KH * KW * C;
-  ConvK la{g, M, K, (C % 4 == 0) && aligned16(in)};
-  DenseK lb{wg, (long)K, Cout, K, (K % 4 == 0) && aligned16(wg)};
   Epi ep;
   memset(&ep, 0, sizeof(ep));
   ep.C = out; ep.ldc = Cout; ep.M = M; ep.N = Cout; ep.bias = bias; ep.act = act; ep.beta = beta; ep.nsplit = 1;
   ep.remap = 1; ep.PH = PH; ep.PW = PW; ep.OHF = OHF; ep.OWF = OWF; ep.osy = osy; ep.osx = osx; ep.ooy = ooy; ep.oox = oox;
   if (osy == 1 && osx == 1 && ooy == 0 && oox == 0 && OHF == PH && OWF == PW) ep.remap = 0;
-  conv_dispatch(la, lb, ep, K, stream);
+  if (C % 4 == 0 && aligned16(in) && aligned16(wg)) conv_dispatch<true>(g, M, K, wg, Cout, ep, stream);
+  else conv_dispatch<false>(g, M, K, wg, Cout, ep, stream);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
@@ -480,6 +520,15 @@ static int wgrad_splits(int Mrows, int Cout, long P) {
   int bm, bn;
   if (Cout <= 32) { bm = 256; bn = 32; } else if (Cout <= 64) { bm = 256; bn = 64; } else { bm = 128; bn = 128; }
   return pick_splits(Mrows, Cout, (int)P, bm, bn);
+}
+
+template <bool V>
+static void wgrad_dispatch(const ConvGeom& g, int Mrows, int P, const float* dout, int Cout, Epi& ep, hipStream_t st) {
+  ConvM la{g, g.in, (unsigned)((long)g.NI * g.H * g.W * g.C * 4), Mrows, P};
+  DenseM lb{dout, kbytes(P, Cout, Cout), (long)Cout, Cout, P};
+  if (Cout <= 32) launch_igemm<ConvM, DenseM, C256x32, V>(la, lb, ep, P, st);
+  else if (Cout <= 64) launch_igemm<ConvM, DenseM, C256x64, V>(la, lb, ep, P, st);
+  else launch_igemm<ConvM, DenseM, C128, V>(la, lb, ep, P, st);
 }
 
 extern "C" size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW) {
@@ -498,19 +547,17 @@ extern "C" int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, con
   int Mrows = KH * KW * C;
   long P = (long)NI * PH * PW;
   RE2E_CHECK_ARG(P < 2147483647L, "too many pixels");
+  RE2E_CHECK_ARG((long)NI * H * W * C * 4 < 0xFFFFFFF0L && P * Cout * 4 < 0xFFFFFFF0L, "tensor larger than 4 GiB");
   int s = wgrad_splits(Mrows, Cout, P);
   RE2E_CHECK_ARG(workspace_bytes >= (size_t)s * Mrows * Cout * sizeof(float), "workspace too small");
-  ConvM la{g, Mrows, (int)P, (C % 4 == 0) && aligned16(in)};
-  DenseM lb{dout, (long)Cout, Cout, (int)P, (Cout % 4 == 0) && aligned16(dout)};
   Epi ep;
   memset(&ep, 0, sizeof(ep));
   ep.M = Mrows; ep.N = Cout; ep.nsplit = s; ep.ws = (float*)workspace;
   if (s == 1) {   // still go through the slab so that the reduce kernel applies the layout permute
     ep.C = (float*)workspace; ep.ldc = Cout;
   }
-  if (Cout <= 32) launch_igemm<ConvM, DenseM, C256x32>(la, lb, ep, (int)P, stream);
-  else if (Cout <= 64) launch_igemm<ConvM, DenseM, C256x64>(la, lb, ep, (int)P, stream);
-  else launch_igemm<ConvM, DenseM, C128>(la, lb, ep, (int)P, stream);
+  if (C % 4 == 0 && Cout % 4 == 0 && aligned16(in) && aligned16(dout)) wgrad_dispatch<true>(g, Mrows, (int)P, dout, Cout, ep, stream);
+  else wgrad_dispatch<false>(g, Mrows, (int)P, dout, Cout, ep, stream);
   long tot = (long)Mrows * Cout;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s, Mrows,
                      Cout, dW, (long)Cout, beta, 1, C, KH * KW);

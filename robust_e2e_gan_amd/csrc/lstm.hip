@@ -25,115 +25,188 @@ __device__ __forceinline__ void store_acc(float* red, const f32x16& acc, int lan
   }
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void lstm_fwd_step(float* xg_f, float* xg_r, const float* __restrict__ whh_f,
-                                                            const float* __restrict__ whh_r, float* ybuf, float* cbuf,
-                                                            const int* __restrict__ lens, int T, int B, int H, int s) {
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [WAVES][32][33]
-  const int dir = blockIdx.z;
-  const int t = dir ? T - 1 - s : s;
-  float* xg = dir ? xg_r : xg_f;
-  const float* whh = dir ? whh_r : whh_f;
-  const int j0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
-  const int KC = H / WAVES, kc0 = wid * KC;
-  const int prev_blk = dir ? t + 2 : t;
-  const long H2 = 2L * H;
-  const bool bvalid = (b0 + lr) < B;
-  const float* hrow = ybuf + ((long)prev_blk * B + (bvalid ? b0 + lr : 0)) * H2 + dir * H + kc0 + lh * 4;
-  const float* wrow = whh + (long)((lr >> 3) * H + j0 + (lr & 7)) * H + kc0 + lh * 4;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int q = 0; q < KC / 8; ++q) {
-    f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-    if (bvalid) a4 = *reinterpret_cast<const f32x4*>(hrow + q * 8);
-    f32x4 b4 = *reinterpret_cast<const f32x4*>(wrow + q * 8);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc, 0, 0, 0);
+// ---- MFMA-fragment-ordered operand copies -------------------------------------------------------
+// A lane of v_mfma_f32_32x32x2_f32 owns one operand row and, with the k assignment
+// k = 8Q + 4*(lane>>5) + i, four consecutive k per group Q.  Reading those four floats straight
+// from a row-major matrix makes every lane of a load instruction touch a different 4 KB-strided
+// row (64 cache lines per instruction, L1 thrash).  Instead the step kernels read operands that
+// were stored in fragment order: [tile][Q][lane][4] for the weights (packed once per sequence) and
+// [m-tile][k/4][b%32][4] for the recurrent state (written by the previous step's epilogue), so
+// that one wave-instruction reads 1 KB (weights) / 2 x 512 B (state) of contiguous memory.
+__global__ void pack_w_fwd_kernel(const float* __restrict__ whh, float* __restrict__ wf, int H) {
+  // wf[((x*(H/8) + Q)*64 + lane)*4 + i] = whh[((n>>3)*H + 8x + (n&7))*H + 8Q + 4h + i],  n = lane&31, h = lane>>5
+  long tot = (long)4 * H * H;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e & 3); int lane = (int)((e >> 2) & 63); long r = e >> 8; int Q = (int)(r % (H / 8)); int x = (int)(r / (H / 8));
+    int n = lane & 31, h = lane >> 5;
+    wf[e] = whh[((long)((n >> 3) * H + 8 * x + (n & 7))) * H + 8 * Q + 4 * h + i];
   }
-  store_acc(red + wid * (32 * 33), acc, lane);
-  __syncthreads();
-  for (int idx = tid; idx < 256; idx += WAVES * 64) {
-    int bm = idx >> 3, jj = idx & 7;
-    int b = b0 + bm;
-    if (b >= B) continue;
-    int j = j0 + jj;
-    float pre[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v = 0.f;
-      for (int w = 0; w < WAVES; ++w) v += red[w * (32 * 33) + bm * 33 + g * 8 + jj];
-      pre[g] = v + xg[((long)t * B + b) * 4 * H + g * H + j];
-    }
-    float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), go = sigmoidf_(pre[3]);
-    float cp = cbuf[((long)prev_blk * B + b) * H2 + dir * H + j];
-    float c = gf * cp + gi * gg;
-    float h = go * tanhf_(c);
-    if (t >= lens[b]) { c = 0.f; h = 0.f; }      // packed semantics: padded outputs 0, state stays 0
-    float* go_ = xg + ((long)t * B + b) * 4 * H + j;
-    go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
-    cbuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = c;
-    ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = h;
+}
+__global__ void pack_w_bwd_kernel(const float* __restrict__ whh, float* __restrict__ wt, int H) {
+  // wt[((x*(H/2) + Q)*64 + lane)*4 + i] = whh[(8Q + 4h + i)*H + 32x + (lane&31)]   (0 beyond H)
+  int nx = (H + 31) / 32;
+  long tot = (long)nx * (H / 2) * 256;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e & 3); int lane = (int)((e >> 2) & 63); long r = e >> 8; int Q = (int)(r % (H / 2)); int x = (int)(r / (H / 2));
+    int j = 32 * x + (lane & 31), n = 8 * Q + 4 * (lane >> 5) + i;
+    wt[e] = j < H ? whh[(long)n * H + j] : 0.f;
   }
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void lstm_bwd_step(float* g_f, float* g_r, const float* __restrict__ whhT_f,
-                                                            const float* __restrict__ whhT_r, const float* __restrict__ dy,
-                                                            const float* __restrict__ cbuf, float* dc_state,
-                                                            const int* __restrict__ lens, int T, int B, int H, int s) {
+__global__ __launch_bounds__(WAVES * 64) void lstm_fwd_step(float* xg_f, float* xg_r, const float* __restrict__ wfrag, float* ybuf,
+                                                            float* cbuf, float* hfrag, const int* __restrict__ lens, int T, int B,
+                                                            int H, int s) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [WAVES][32][33]
-  const int dir = blockIdx.z;
-  const int t = dir ? s : T - 1 - s;            // reverse order of the forward pass
-  const int tnext = dir ? t - 1 : t + 1;        // step whose dgates were produced by the previous launch
-  float* G = dir ? g_r : g_f;
-  const float* whhT = dir ? whhT_r : whhT_f;
-  const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
-  const int K4 = 4 * H, KC = K4 / WAVES, kc0 = wid * KC;
+  constexpr int NTH = WAVES * 64;
+  constexpr int ITER = (256 + NTH - 1) / NTH;
+  const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y;
+  const int t = dir ? T - 1 - s : s;
+  float* xg = dir ? xg_r : xg_f;
+  const int j0 = x * 8, b0 = mt * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lh = lane >> 5;
+  const int QN = H / 8 / WAVES;                     // k-groups of 8 per wave
+  const int prev_blk = dir ? t + 2 : t;
   const long H2 = 2L * H;
+  const long hf_sz = (long)2 * MT * H * 32;          // floats per parity buffer: [dir][mt][H/4][32][4]
+  const float* hf_rd = hfrag + ((s & 1) ^ 1) * hf_sz + (long)(dir * MT + mt) * H * 32;
+  float* hf_wr = hfrag + (s & 1) * hf_sz + (long)(dir * MT + mt) * H * 32;
+  // ---- prefetch the pointwise operands (independent of the matmul) ----
+  float pre[ITER][4], cp[ITER];
+  int ln[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    int idx = tid + it * NTH;
+    int bm = idx >> 3, jj = idx & 7, b = b0 + bm, j = j0 + jj;
+    bool ok = idx < 256 && b < B;
+    const float* gp = xg + ((long)t * B + (ok ? b : 0)) * 4 * H + j;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[it][g] = ok ? gp[g * H] : 0.f;
+    cp[it] = ok ? cbuf[((long)prev_blk * B + b) * H2 + dir * H + j] : 0.f;
+    ln[it] = ok ? lens[b] : 0;
+  }
+  // ---- h_{t-1} W_hh^T for 32 utterances x (8 units x 4 gates) ----
+  const f32x4* wp = reinterpret_cast<const f32x4*>(wfrag) + ((long)(dir * (H / 8) + x) * (H / 8) + wid * QN) * 64 + lane;
+  const f32x4* hp = reinterpret_cast<const f32x4*>(hf_rd) + ((long)(2 * wid * QN + lh)) * 32 + (lane & 31);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   if (s > 0) {
-    const bool bvalid = (b0 + lr) < B, jvalid = (j0 + lr) < H;
-    const float* arow = G + ((long)tnext * B + (bvalid ? b0 + lr : 0)) * K4 + kc0 + lh * 4;
-    const float* brow = whhT + (long)(jvalid ? j0 + lr : 0) * K4 + kc0 + lh * 4;
-    for (int q = 0; q < KC / 8; ++q) {
-      f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
-      if (bvalid) a4 = *reinterpret_cast<const f32x4*>(arow + q * 8);
-      if (jvalid) b4 = *reinterpret_cast<const f32x4*>(brow + q * 8);
+    for (int q = 0; q < QN; ++q) {
+      f32x4 a4 = hp[(long)q * 64];
+      f32x4 b4 = wp[(long)q * 64];
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc, 0, 0, 0);
     }
   }
   store_acc(red + wid * (32 * 33), acc, lane);
   __syncthreads();
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    int idx = tid + it * NTH;
+    int bm = idx >> 3, jj = idx & 7, b = b0 + bm, j = j0 + jj;
+    if (idx >= 256 || b >= B) continue;
+    float v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float a = 0.f;
+      for (int w = 0; w < WAVES; ++w) a += red[w * (32 * 33) + bm * 33 + g * 8 + jj];
+      v[g] = a + pre[it][g];
+    }
+    float gi = sigmoidf_(v[0]), gf = sigmoidf_(v[1]), gg = tanhf_(v[2]), go = sigmoidf_(v[3]);
+    float c = gf * cp[it] + gi * gg;
+    float h = go * tanhf_(c);
+    if (t >= ln[it]) { c = 0.f; h = 0.f; }      // packed semantics: padded outputs 0, state stays 0
+    float* go_ = xg + ((long)t * B + b) * 4 * H + j;
+    go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
+    cbuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = c;
+    ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = h;
+    hf_wr[((long)(j >> 2) * 32 + bm) * 4 + (j & 3)] = h;
+  }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void lstm_bwd_step(float* g_f, float* g_r, const float* __restrict__ wtfrag,
+                                                            const float* __restrict__ dy, const float* __restrict__ cbuf,
+                                                            float* dc_state, float* gfrag, const int* __restrict__ lens, int T, int B,
+                                                            int H, int s) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [WAVES][32][33]
+  constexpr int NTH = WAVES * 64;
+  constexpr int ITER = 1024 / NTH;
+  const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y;
+  const int t = dir ? s : T - 1 - s;            // reverse order of the forward pass
+  float* G = dir ? g_r : g_f;
+  const int j0 = x * 32, b0 = mt * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lh = lane >> 5;
+  const int K4 = 4 * H;
+  const int QN = K4 / 8 / WAVES;
+  const long H2 = 2L * H;
   const int prev_blk = dir ? t + 2 : t;
-  for (int idx = tid; idx < 1024; idx += WAVES * 64) {
-    int bm = idx >> 5, jc = idx & 31;
-    int b = b0 + bm, j = j0 + jc;
+  const long gf_sz = (long)2 * MT * K4 * 32;          // floats per parity buffer: [dir][mt][4H/4][32][4]
+  const float* gf_rd = gfrag + ((s & 1) ^ 1) * gf_sz + (long)(dir * MT + mt) * K4 * 32;
+  float* gf_wr = gfrag + (s & 1) * gf_sz + (long)(dir * MT + mt) * K4 * 32;
+  // ---- prefetch the pointwise operands ----
+  float pdy[ITER], pg[ITER][4], pc[ITER], pcp[ITER], pdc[ITER];
+  int ln[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    int idx = tid + it * NTH;
+    int bm = idx >> 5, jc = idx & 31, b = b0 + bm, j = j0 + jc;
+    bool ok = b < B && j < H;
+    long bb = ok ? b : 0; int jj = ok ? j : 0;
+    pdy[it] = dy[((long)t * B + bb) * H2 + dir * H + jj];
+    const float* gp = G + ((long)t * B + bb) * K4 + jj;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pg[it][g] = gp[g * H];
+    pc[it] = cbuf[((long)(t + 1) * B + bb) * H2 + dir * H + jj];
+    pcp[it] = cbuf[((long)prev_blk * B + bb) * H2 + dir * H + jj];
+    pdc[it] = dc_state[bb * H2 + dir * H + jj];
+    ln[it] = lens[bb];
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (s > 0) {
+    const int nx = gridDim.x;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wtfrag) + ((long)(dir * nx + x) * (K4 / 8) + wid * QN) * 64 + lane;
+    const f32x4* gp = reinterpret_cast<const f32x4*>(gf_rd) + ((long)(2 * wid * QN + lh)) * 32 + (lane & 31);
+    for (int q = 0; q < QN; ++q) {
+      f32x4 a4 = gp[(long)q * 64];
+      f32x4 b4 = wp[(long)q * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc, 0, 0, 0);
+    }
+  }
+  store_acc(red + wid * (32 * 33), acc, lane);
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    int idx = tid + it * NTH;
+    int bm = idx >> 5, jc = idx & 31, b = b0 + bm, j = j0 + jc;
     if (b >= B || j >= H) continue;
-    float dh = dy[((long)t * B + b) * H2 + dir * H + j];
+    float dh = pdy[it];
     for (int w = 0; w < WAVES; ++w) dh += red[w * (32 * 33) + bm * 33 + jc];
-    float* gp = G + ((long)t * B + b) * K4 + j;
-    float gi = gp[0], gf = gp[H], gg = gp[2 * H], go = gp[3 * H];
-    float c = cbuf[((long)(t + 1) * B + b) * H2 + dir * H + j];
-    float cp = cbuf[((long)prev_blk * B + b) * H2 + dir * H + j];
-    float dc = dc_state[(long)b * H2 + dir * H + j];
+    float gi = pg[it][0], gf = pg[it][1], gg = pg[it][2], go = pg[it][3];
+    float dc = pdc[it];
     float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = dc;
-    if (t < lens[b]) {
-      float tc = tanhf_(c);
+    if (t < ln[it]) {
+      float tc = tanhf_(pc[it]);
       float dct = dh * go * (1.f - tc * tc) + dc;
       dout = dh * tc * go * (1.f - go);
       di = dct * gg * gi * (1.f - gi);
-      df = dct * cp * gf * (1.f - gf);
+      df = dct * pcp[it] * gf * (1.f - gf);
       dg = dct * gi * (1.f - gg * gg);
       dcp = dct * gf;
     }
+    float* gp = G + ((long)t * B + b) * K4 + j;
     gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dout;
     dc_state[(long)b * H2 + dir * H + j] = dcp;
+    float dv[4] = {di, df, dg, dout};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int n = g * H + j;
+      gf_wr[((long)(n >> 2) * 32 + bm) * 4 + (n & 3)] = dv[g];
+    }
   }
 }
 
@@ -147,62 +220,91 @@ int pick_waves(int K, int min_kc) {
   return K % 8 == 0 ? 1 : 0;
 }
 
+// workspace (floats): fwd  = wfrag[2][4H*H] | hfrag[2][2][MT][H*32]
+//                     bwd  = wtfrag[2][nx*(H/2)*256] | gfrag[2][2][MT][4H*32]
+size_t fwd_ws_floats(int B, int H) { long MT = (B + 31) / 32; return (size_t)2 * 4 * H * H + (size_t)2 * 2 * MT * H * 32; }
+size_t bwd_ws_floats(int B, int H) {
+  long MT = (B + 31) / 32, nx = (H + 31) / 32;
+  return (size_t)2 * nx * (H / 2) * 256 + (size_t)2 * 2 * MT * 4 * H * 32;
+}
+
 template <int W>
-void launch_fwd(dim3 grid, hipStream_t st, float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf,
-                float* cbuf, const int* lens, int T, int B, int H) {
+void launch_fwd(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, float* ybuf, float* cbuf, float* hfrag, const int* lens,
+                int T, int B, int H) {
   size_t lds = (size_t)W * 32 * 33 * sizeof(float);
   static bool done = false;
   if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_step<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  dim3 grid(H / 8, cdiv(B, 32), 2);
   for (int s = 0; s < T; ++s)
-    hipLaunchKernelGGL((lstm_fwd_step<W>), grid, dim3(W * 64), lds, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, lens, T, B, H, s);
+    hipLaunchKernelGGL((lstm_fwd_step<W>), grid, dim3(W * 64), lds, st, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens, T, B, H, s);
 }
 template <int W>
-void launch_bwd(dim3 grid, hipStream_t st, float* g_f, float* g_r, const float* wt_f, const float* wt_r, const float* dy,
-                const float* cbuf, float* dc, const int* lens, int T, int B, int H) {
+void launch_bwd(hipStream_t st, float* g_f, float* g_r, const float* wtfrag, const float* dy, const float* cbuf, float* dc, float* gfrag,
+                const int* lens, int T, int B, int H) {
   size_t lds = (size_t)W * 32 * 33 * sizeof(float);
   static bool done = false;
   if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_step<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  dim3 grid(cdiv(H, 32), cdiv(B, 32), 2);
   for (int s = 0; s < T; ++s)
-    hipLaunchKernelGGL((lstm_bwd_step<W>), grid, dim3(W * 64), lds, st, g_f, g_r, wt_f, wt_r, dy, cbuf, dc, lens, T, B, H, s);
+    hipLaunchKernelGGL((lstm_bwd_step<W>), grid, dim3(W * 64), lds, st, g_f, g_r, wtfrag, dy, cbuf, dc, gfrag, lens, T, B, H, s);
 }
 
 }  // namespace
 
+extern "C" size_t re2e_lstm_workspace_bytes(int B, int H) {
+  size_t a = fwd_ws_floats(B, H), b = bwd_ws_floats(B, H);
+  return (a > b ? a : b) * sizeof(float);
+}
+
 extern "C" int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
-                                 const int* lens_dev, int T, int B, int H, hipStream_t stream) {
-  RE2E_CHECK_ARG(xg_f && xg_r && whh_f && whh_r && ybuf && cbuf && lens_dev, "null arg");
+                                 const int* lens_dev, int T, int B, int H, void* workspace, size_t workspace_bytes,
+                                 hipStream_t stream) {
+  RE2E_CHECK_ARG(xg_f && xg_r && whh_f && whh_r && ybuf && cbuf && lens_dev && workspace, "null arg");
   RE2E_CHECK_ARG(T > 0 && B > 0 && H > 0, "bad shape");
   if (H % 8 != 0) { re2e_set_error("re2e_lstm_seq_fwd: hidden size must be a multiple of 8 (got %d)", H); return RE2E_EUNSUPPORTED; }
+  RE2E_CHECK_ARG(workspace_bytes >= fwd_ws_floats(B, H) * sizeof(float), "workspace too small");
+  float* wfrag = (float*)workspace;
+  float* hfrag = wfrag + (size_t)2 * 4 * H * H;
+  long wn = (long)4 * H * H, hn = (long)2 * 2 * cdiv(B, 32) * H * 32;
+  hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wfrag, H);
+  hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wfrag + wn, H);
+  hipLaunchKernelGGL(zero_kernel, dim3(cdiv(hn, 256) > 1024 ? 1024 : cdiv(hn, 256)), dim3(256), 0, stream, hfrag, hn);
   int w = pick_waves(H, 32);
-  dim3 grid(H / 8, cdiv(B, 32), 2);
   switch (w) {
-    case 16: launch_fwd<16>(grid, stream, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, lens_dev, T, B, H); break;
-    case 8: launch_fwd<8>(grid, stream, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, lens_dev, T, B, H); break;
-    case 4: launch_fwd<4>(grid, stream, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, lens_dev, T, B, H); break;
-    case 2: launch_fwd<2>(grid, stream, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, lens_dev, T, B, H); break;
-    default: launch_fwd<1>(grid, stream, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, lens_dev, T, B, H); break;
+    case 16: launch_fwd<16>(stream, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens_dev, T, B, H); break;
+    case 8: launch_fwd<8>(stream, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens_dev, T, B, H); break;
+    case 4: launch_fwd<4>(stream, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens_dev, T, B, H); break;
+    case 2: launch_fwd<2>(stream, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens_dev, T, B, H); break;
+    default: launch_fwd<1>(stream, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens_dev, T, B, H); break;
   }
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
 
-extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whhT_f, const float* whhT_r, const float* dy,
-                                 const float* ybuf, const float* cbuf, float* dc_state, const int* lens_dev, int T, int B, int H,
-                                 hipStream_t stream) {
+extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, const float* whh_r, const float* dy, const float* ybuf,
+                                 const float* cbuf, float* dc_state, const int* lens_dev, int T, int B, int H, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
   (void)ybuf;
-  RE2E_CHECK_ARG(g_f && g_r && whhT_f && whhT_r && dy && cbuf && dc_state && lens_dev, "null arg");
+  RE2E_CHECK_ARG(g_f && g_r && whh_f && whh_r && dy && cbuf && dc_state && lens_dev && workspace, "null arg");
   RE2E_CHECK_ARG(T > 0 && B > 0 && H > 0, "bad shape");
   if (H % 8 != 0) { re2e_set_error("re2e_lstm_seq_bwd: hidden size must be a multiple of 8 (got %d)", H); return RE2E_EUNSUPPORTED; }
+  RE2E_CHECK_ARG(workspace_bytes >= bwd_ws_floats(B, H) * sizeof(float), "workspace too small");
+  long nx = cdiv(H, 32);
+  long wn = nx * (H / 2) * 256, gn = (long)2 * 2 * cdiv(B, 32) * 4 * H * 32;
+  float* wtfrag = (float*)workspace;
+  float* gfrag = wtfrag + 2 * wn;
+  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wtfrag, H);
+  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wtfrag + wn, H);
+  hipLaunchKernelGGL(zero_kernel, dim3(cdiv(gn, 256) > 1024 ? 1024 : cdiv(gn, 256)), dim3(256), 0, stream, gfrag, gn);
   long nz = (long)B * 2 * H;
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(nz, 256)), dim3(256), 0, stream, dc_state, nz);
   int w = pick_waves(4 * H, 64);
-  dim3 grid(cdiv(H, 32), cdiv(B, 32), 2);
   switch (w) {
-    case 16: launch_bwd<16>(grid, stream, g_f, g_r, whhT_f, whhT_r, dy, cbuf, dc_state, lens_dev, T, B, H); break;
-    case 8: launch_bwd<8>(grid, stream, g_f, g_r, whhT_f, whhT_r, dy, cbuf, dc_state, lens_dev, T, B, H); break;
-    case 4: launch_bwd<4>(grid, stream, g_f, g_r, whhT_f, whhT_r, dy, cbuf, dc_state, lens_dev, T, B, H); break;
-    case 2: launch_bwd<2>(grid, stream, g_f, g_r, whhT_f, whhT_r, dy, cbuf, dc_state, lens_dev, T, B, H); break;
-    default: launch_bwd<1>(grid, stream, g_f, g_r, whhT_f, whhT_r, dy, cbuf, dc_state, lens_dev, T, B, H); break;
+    case 16: launch_bwd<16>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
+    case 8: launch_bwd<8>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
+    case 4: launch_bwd<4>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
+    case 2: launch_bwd<2>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
+    default: launch_bwd<1>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
   }
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;

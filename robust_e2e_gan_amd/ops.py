@@ -450,8 +450,10 @@ class BiLstmFn(torch.autograd.Function):
             gemm(x2, w[4 * d], xg[d], T * B, 4 * H, I, transb=True, bias=w[4 * d + 2], bias2=w[4 * d + 3])
         ybuf = zeros((T + 2, B, 2 * H), x)
         cbuf = zeros((T + 2, B, 2 * H), x)
+        wsb = query('re2e_lstm_workspace_bytes', B, H)
+        ws = workspace(wsb, x.device, 'lstm')
         call('re2e_lstm_seq_fwd', xg[0].data_ptr(), xg[1].data_ptr(), w[1].data_ptr(), w[5].data_ptr(), ybuf.data_ptr(), cbuf.data_ptr(),
-             lens_dev.data_ptr(), T, B, H)
+             lens_dev.data_ptr(), T, B, H, ws.data_ptr(), wsb)
         ctx.w, ctx.lens = w, lens_dev
         ctx.save_for_backward(x2, xg[0], xg[1], ybuf, cbuf)
         ctx.dims = (T, B, I, H)
@@ -464,12 +466,11 @@ class BiLstmFn(torch.autograd.Function):
         T, B, I, H = ctx.dims
         dy = _f32(dy)
         # the saved gates are overwritten with d(pre-activation gates); a second backward is not supported
-        whhT = [empty((H, 4 * H), dy), empty((H, 4 * H), dy)]
-        call('re2e_transpose01', w[1].data_ptr(), whhT[0].data_ptr(), 4 * H, H, 1)
-        call('re2e_transpose01', w[5].data_ptr(), whhT[1].data_ptr(), 4 * H, H, 1)
         dc = empty((B, 2 * H), dy)
-        call('re2e_lstm_seq_bwd', g_f.data_ptr(), g_r.data_ptr(), whhT[0].data_ptr(), whhT[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
-             cbuf.data_ptr(), dc.data_ptr(), ctx.lens.data_ptr(), T, B, H)
+        wsb = query('re2e_lstm_workspace_bytes', B, H)
+        ws = workspace(wsb, dy.device, 'lstm')
+        call('re2e_lstm_seq_bwd', g_f.data_ptr(), g_r.data_ptr(), w[1].data_ptr(), w[5].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
+             cbuf.data_ptr(), dc.data_ptr(), ctx.lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
         dG = (g_f, g_r)
         M = T * B
         dx = None
