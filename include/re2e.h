@@ -205,9 +205,10 @@ int re2e_ctc_bwd(const float* logits, int T, int B, int V, const int* hlens_dev,
 
 /* ---- K7 fused location-aware attention step (model/e2e_attention.py:258-297) --------------- */
 /* per utterance b: w = softmax_t(2*(gvec . tanh(W_att conv(att_prev) + pre[b,t] + W_dec z[b]) + gb)),
- * c[b] = sum_t w[t]*enc[b,t].  att_prev==NULL => uniform 1/hlen over valid frames. */
+ * c[b] = sum_t w[t]*enc[b,t].  att_prev==NULL => uniform 1/hlen over valid frames.
+ * w_decT is mlp_dec.weight TRANSPOSED, (dunits, adim) (coalesced reads; transpose once per utterance batch). */
 int re2e_attloc_fwd(const float* pre, const float* enc, const float* z, const float* att_prev, const int* hlens_dev,
-                    const float* w_dec, const float* w_att, const float* w_conv, const float* gvec, const float* gvec_b,
+                    const float* w_decT, const float* w_att, const float* w_conv, const float* gvec, const float* gvec_b,
                     int B, int T, int eprojs, int dunits, int adim, int chans, int filts, float* w_out, float* c_out,
                     long ldc_out, re2e_stream_t stream);
 size_t re2e_attloc_partial_floats(int adim, int chans, int filts);
@@ -215,7 +216,7 @@ size_t re2e_attloc_partial_floats(int adim, int chans, int filts);
  * d_decproj [B,adim] (for the mlp_dec GEMMs) and per-utterance weight-grad partials (+=) laid out
  * [B][gvec(adim) | gvec_b(1) | w_att(adim*chans) | w_conv(chans*(2*filts+1))] */
 int re2e_attloc_bwd(const float* pre, const float* enc, const float* z, const float* att_prev, const float* w_cur,
-                    const int* hlens_dev, const float* w_dec, const float* w_att, const float* w_conv,
+                    const int* hlens_dev, const float* w_decT, const float* w_att, const float* w_conv,
                     const float* gvec, const float* dc, long ld_dc, const float* dw_in, int B, int T, int eprojs,
                     int dunits, int adim, int chans, int filts, float* d_pre, float* d_enc, float* d_att_prev,
                     float* d_decproj, float* partials, re2e_stream_t stream);

@@ -19,7 +19,7 @@ struct Lds {
 __device__ __forceinline__ int cpad(int C) { return (C + 3) & ~3; }
 
 // common prologue: z -> LDS, att_prev (or uniform init) -> padded LDS, dec_proj, location conv
-__device__ void prologue(const Lds& L, const float* z, const float* att_prev, int hl, const float* w_dec, const float* w_conv,
+__device__ void prologue(const Lds& L, const float* z, const float* att_prev, int hl, const float* w_decT, const float* w_conv,
                          int b, int T, int D, int A, int C, int F) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -32,11 +32,20 @@ __device__ void prologue(const Lds& L, const float* z, const float* att_prev, in
     L.ap[i] = v;
   }
   __syncthreads();
-  for (int a = wid; a < A; a += NW) {
-    float s = 0.f;
-    for (int d = lane; d < D; d += 64) s += w_dec[(long)a * D + d] * L.zs[d];
-    s = wave_sum(s);
-    if (lane == 0) L.dp[a] = s;
+  // dec_proj[a] = sum_d W_dec[a][d] z[d]; w_decT is W_dec transposed (D, A): lanes run over a => coalesced,
+  // independent loads (8 in flight per lane)
+  for (int a = tid; a < A; a += NT) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int d = 0;
+    for (; d + 8 <= D; d += 8) {
+      float w0 = w_decT[(long)(d + 0) * A + a], w1 = w_decT[(long)(d + 1) * A + a], w2 = w_decT[(long)(d + 2) * A + a],
+            w3 = w_decT[(long)(d + 3) * A + a], w4 = w_decT[(long)(d + 4) * A + a], w5 = w_decT[(long)(d + 5) * A + a],
+            w6 = w_decT[(long)(d + 6) * A + a], w7 = w_decT[(long)(d + 7) * A + a];
+      s0 += w0 * L.zs[d] + w4 * L.zs[d + 4]; s1 += w1 * L.zs[d + 1] + w5 * L.zs[d + 5];
+      s2 += w2 * L.zs[d + 2] + w6 * L.zs[d + 6]; s3 += w3 * L.zs[d + 3] + w7 * L.zs[d + 7];
+    }
+    for (; d < D; ++d) s0 += w_decT[(long)d * A + a] * L.zs[d];
+    L.dp[a] = (s0 + s1) + (s2 + s3);
   }
   // conv[t][c] = sum_k w_conv[c][k] * ap[t+k]; a wavefront owns one channel group so the filter
   // taps are wave-uniform (scalar loads), lanes run over t
@@ -50,6 +59,7 @@ __device__ void prologue(const Lds& L, const float* z, const float* att_prev, in
 #pragma unroll
     for (int cc = 0; cc < CG; ++cc) acc[cc] = 0.f;
     int tt = t < T ? t : T - 1;
+#pragma unroll 8
     for (int k = 0; k < Kf; ++k) {
       float x = L.ap[tt + k];
 #pragma unroll
@@ -68,7 +78,7 @@ __device__ void prologue(const Lds& L, const float* z, const float* att_prev, in
 template <int CMAX, int AIMAX>
 __global__ __launch_bounds__(NT) void attloc_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ enc,
                                                         const float* __restrict__ z, const float* __restrict__ att_prev,
-                                                        const int* __restrict__ hlens, const float* __restrict__ w_dec,
+                                                        const int* __restrict__ hlens, const float* __restrict__ w_decT,
                                                         const float* __restrict__ w_att, const float* __restrict__ w_conv,
                                                         const float* __restrict__ gvec, const float* __restrict__ gvec_b, int B,
                                                         int T, int E, int D, int A, int C, int F, float* __restrict__ w_out,
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(NT) void attloc_fwd_kernel(const float* __restrict_
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hl = hlens[b];
-  prologue(L, z, att_prev, hl, w_dec, w_conv, b, T, D, A, C, F);
+  prologue(L, z, att_prev, hl, w_decT, w_conv, b, T, D, A, C, F);
 
   // ---- energies: one wavefront per frame, lanes over the attention dimension ----
   float wa[AIMAX][CMAX], gv[AIMAX], dpv[AIMAX];
@@ -101,24 +111,36 @@ __global__ __launch_bounds__(NT) void attloc_fwd_kernel(const float* __restrict_
     for (int c = 0; c < CMAX; ++c) wa[i][c] = (a < A && c < C) ? w_att[a * C + c] : 0.f;
   }
   const float gb = gvec_b[0];
-  for (int t = wid; t < T; t += NW) {
-    float cv[CMAX];
+  for (int tb = wid; tb < T; tb += 2 * NW) {       // two frames per iteration: 2*AIMAX independent row loads in flight
+    const int t0 = tb, t1 = tb + NW;
+    const bool h1 = t1 < T;
+    float p0[AIMAX], p1[AIMAX];
+    const float* pr0 = pre + ((long)b * T + t0) * A;
+    const float* pr1 = pre + ((long)b * T + (h1 ? t1 : t0)) * A;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) cv[c] = c < C ? L.conv[t * CP + c] : 0.f;
-    const float* pr = pre + ((long)b * T + t) * A;
-    float s = 0.f;
+    for (int i = 0; i < AIMAX; ++i) {
+      int a = lane + 64 * i;
+      p0[i] = a < A ? pr0[a] : 0.f;
+      p1[i] = a < A ? pr1[a] : 0.f;
+    }
+    float cv0[CMAX], cv1[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { cv0[c] = c < C ? L.conv[t0 * CP + c] : 0.f; cv1[c] = (c < C && h1) ? L.conv[t1 * CP + c] : 0.f; }
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < AIMAX; ++i) {
       int a = lane + 64 * i;
       if (a < A) {
-        float x = pr[a] + dpv[i];
+        float x0 = p0[i] + dpv[i], x1 = p1[i] + dpv[i];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) x += wa[i][c] * cv[c];
-        s += gv[i] * tanhf_(x);
+        for (int c = 0; c < CMAX; ++c) { x0 += wa[i][c] * cv0[c]; x1 += wa[i][c] * cv1[c]; }
+        s0 += gv[i] * tanhf_(x0);
+        s1 += gv[i] * tanhf_(x1);
       }
     }
-    s = wave_sum(s);
-    if (lane == 0) L.e[t] = s + gb;
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) { L.e[t0] = s0 + gb; if (h1) L.e[t1] = s1 + gb; }
   }
   __syncthreads();
   // ---- softmax(2e) over all T frames ----
@@ -139,10 +161,12 @@ __global__ __launch_bounds__(NT) void attloc_fwd_kernel(const float* __restrict_
     const int tg = tid / per, d4 = tid % per;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const f32x4* er = reinterpret_cast<const f32x4*>(enc + (long)b * T * E) + d4;
-    for (int t = tg; t < T; t += ntg) {
-      f32x4 v = er[(long)t * per];
-      acc += v * L.w[t];
+    int t = tg;
+    for (; t + 3 * ntg < T; t += 4 * ntg) {          // 4 independent row loads in flight
+      f32x4 v0 = er[(long)t * per], v1 = er[(long)(t + ntg) * per], v2 = er[(long)(t + 2 * ntg) * per], v3 = er[(long)(t + 3 * ntg) * per];
+      acc += v0 * L.w[t] + v1 * L.w[t + ntg] + v2 * L.w[t + 2 * ntg] + v3 * L.w[t + 3 * ntg];
     }
+    for (; t < T; t += ntg) acc += er[(long)t * per] * L.w[t];
     *reinterpret_cast<f32x4*>(L.scr + (long)tg * E + d4 * 4) = acc;
   }
   __syncthreads();
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(NT) void attloc_fwd_kernel(const float* __restrict_
 template <int CMAX, int AIMAX>
 __global__ __launch_bounds__(NT) void attloc_bwd_kernel(
     const float* __restrict__ pre, const float* __restrict__ enc, const float* __restrict__ z, const float* __restrict__ att_prev,
-    const float* __restrict__ w_cur, const int* __restrict__ hlens, const float* __restrict__ w_dec, const float* __restrict__ w_att,
+    const float* __restrict__ w_cur, const int* __restrict__ hlens, const float* __restrict__ w_decT, const float* __restrict__ w_att,
     const float* __restrict__ w_conv, const float* __restrict__ gvec, const float* __restrict__ dc, long ld_dc,
     const float* __restrict__ dw_in, int B, int T, int E, int D, int A, int C, int F, float* d_pre, float* d_enc,
     float* __restrict__ d_att_prev, float* __restrict__ d_decproj, float* partials) {
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(NT) void attloc_bwd_kernel(
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hl = hlens[b];
-  prologue(L, z, att_prev, hl, w_dec, w_conv, b, T, D, A, C, F);
+  prologue(L, z, att_prev, hl, w_decT, w_conv, b, T, D, A, C, F);
   for (int d = tid; d < E; d += NT) dcs[d] = dc[(long)b * ld_dc + d];
   for (int t = tid; t < T; t += NT) L.w[t] = w_cur[(long)b * T + t];
   for (int i = tid; i < (T + 2 * F) * CP; i += NT) dcp[i] = 0.f;
@@ -187,21 +211,29 @@ __global__ __launch_bounds__(NT) void attloc_bwd_kernel(
   // ---- 1. dw[t] = dw_in[t] + dc . enc[t] ; d_enc[t] += w[t] dc ----
   {
     const int per = E / 4;
-    for (int t = wid; t < T; t += NW) {
-      const f32x4* er = reinterpret_cast<const f32x4*>(enc + ((long)b * T + t) * E);
-      f32x4* der = reinterpret_cast<f32x4*>(d_enc + ((long)b * T + t) * E);
-      float wt = L.w[t];
-      float s = 0.f;
+    for (int tb = wid; tb < T; tb += 2 * NW) {     // two frames per iteration
+      const int t0 = tb, t1 = tb + NW;
+      const bool h1 = t1 < T;
+      const f32x4* er0 = reinterpret_cast<const f32x4*>(enc + ((long)b * T + t0) * E);
+      const f32x4* er1 = reinterpret_cast<const f32x4*>(enc + ((long)b * T + (h1 ? t1 : t0)) * E);
+      f32x4* der0 = reinterpret_cast<f32x4*>(d_enc + ((long)b * T + t0) * E);
+      f32x4* der1 = reinterpret_cast<f32x4*>(d_enc + ((long)b * T + (h1 ? t1 : t0)) * E);
+      const float wt0 = L.w[t0], wt1 = h1 ? L.w[t1] : 0.f;
+      float s0 = 0.f, s1 = 0.f;
       for (int d4 = lane; d4 < per; d4 += 64) {
-        f32x4 v = er[d4];
+        f32x4 v0 = er0[d4], v1 = er1[d4], o0 = der0[d4], o1 = der1[d4];
         f32x4 g = *reinterpret_cast<const f32x4*>(dcs + d4 * 4);
-        s += v[0] * g[0] + v[1] * g[1] + v[2] * g[2] + v[3] * g[3];
-        f32x4 o = der[d4];
-        o += g * wt;
-        der[d4] = o;
+        s0 += v0[0] * g[0] + v0[1] * g[1] + v0[2] * g[2] + v0[3] * g[3];
+        s1 += v1[0] * g[0] + v1[1] * g[1] + v1[2] * g[2] + v1[3] * g[3];
+        der0[d4] = o0 + g * wt0;
+        if (h1) der1[d4] = o1 + g * wt1;
       }
-      s = wave_sum(s);
-      if (lane == 0) L.e[t] = s + (dw_in ? dw_in[(long)b * T + t] : 0.f);
+      s0 = wave_sum(s0);
+      s1 = wave_sum(s1);
+      if (lane == 0) {
+        L.e[t0] = s0 + (dw_in ? dw_in[(long)b * T + t0] : 0.f);
+        if (h1) L.e[t1] = s1 + (dw_in ? dw_in[(long)b * T + t1] : 0.f);
+      }
     }
   }
   __syncthreads();
@@ -356,21 +388,21 @@ extern "C" size_t re2e_attloc_partial_floats(int adim, int chans, int filts) {
 }
 
 extern "C" int re2e_attloc_fwd(const float* pre, const float* enc, const float* z, const float* att_prev, const int* hlens,
-                               const float* w_dec, const float* w_att, const float* w_conv, const float* gvec, const float* gvec_b,
+                               const float* w_decT, const float* w_att, const float* w_conv, const float* gvec, const float* gvec_b,
                                int B, int T, int eprojs, int dunits, int adim, int chans, int filts, float* w_out, float* c_out,
                                long ldc_out, hipStream_t stream) {
-  RE2E_CHECK_ARG(pre && enc && hlens && w_dec && w_att && w_conv && gvec && gvec_b && w_out && c_out, "null arg");
+  RE2E_CHECK_ARG(pre && enc && hlens && w_decT && w_att && w_conv && gvec && gvec_b && w_out && c_out, "null arg");
   RE2E_CHECK_ARG(B > 0 && T > 0 && eprojs > 0 && eprojs % 4 == 0 && eprojs <= 2048 && dunits > 0 && adim > 0 && chans > 0 && filts >= 0, "bad shape");
   if (chans > 16 || adim > 512) { re2e_set_error("re2e_attloc_fwd: chans<=16 and adim<=512 supported"); return RE2E_EUNSUPPORTED; }
   size_t lds = fwd_lds_floats(T, eprojs, dunits, adim, chans, filts) * sizeof(float);
   if (lds > 160 * 1024) { re2e_set_error("re2e_attloc_fwd: T=%d needs %zu bytes of LDS (>160 KiB)", T, lds); return RE2E_EUNSUPPORTED; }
   if (chans <= 12 && adim <= 320) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_fwd_kernel<12, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attloc_fwd_kernel<12, 5>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, hlens, w_dec, w_att, w_conv,
+    hipLaunchKernelGGL((attloc_fwd_kernel<12, 5>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, hlens, w_decT, w_att, w_conv,
                        gvec, gvec_b, B, T, eprojs, dunits, adim, chans, filts, w_out, c_out, ldc_out);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_fwd_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attloc_fwd_kernel<16, 8>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, hlens, w_dec, w_att, w_conv,
+    hipLaunchKernelGGL((attloc_fwd_kernel<16, 8>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, hlens, w_decT, w_att, w_conv,
                        gvec, gvec_b, B, T, eprojs, dunits, adim, chans, filts, w_out, c_out, ldc_out);
   }
   RE2E_LAUNCH_CHECK();
@@ -378,11 +410,11 @@ extern "C" int re2e_attloc_fwd(const float* pre, const float* enc, const float* 
 }
 
 extern "C" int re2e_attloc_bwd(const float* pre, const float* enc, const float* z, const float* att_prev, const float* w_cur,
-                               const int* hlens, const float* w_dec, const float* w_att, const float* w_conv, const float* gvec,
+                               const int* hlens, const float* w_decT, const float* w_att, const float* w_conv, const float* gvec,
                                const float* dc, long ld_dc, const float* dw_in, int B, int T, int eprojs, int dunits, int adim,
                                int chans, int filts, float* d_pre, float* d_enc, float* d_att_prev, float* d_decproj,
                                float* partials, hipStream_t stream) {
-  RE2E_CHECK_ARG(pre && enc && w_cur && hlens && w_dec && w_att && w_conv && gvec && dc && d_pre && d_enc && d_decproj && partials, "null arg");
+  RE2E_CHECK_ARG(pre && enc && w_cur && hlens && w_decT && w_att && w_conv && gvec && dc && d_pre && d_enc && d_decproj && partials, "null arg");
   RE2E_CHECK_ARG(B > 0 && T > 0 && eprojs > 0 && eprojs % 4 == 0 && eprojs <= 2048 && dunits > 0 && adim > 0 && chans > 0 && filts >= 0, "bad shape");
   if (chans > 16 || adim > 512) { re2e_set_error("re2e_attloc_bwd: chans<=16 and adim<=512 supported"); return RE2E_EUNSUPPORTED; }
   bool small = chans <= 12 && adim <= 320;
@@ -390,12 +422,12 @@ extern "C" int re2e_attloc_bwd(const float* pre, const float* enc, const float* 
   if (lds > 160 * 1024) { re2e_set_error("re2e_attloc_bwd: T=%d needs %zu bytes of LDS (>160 KiB)", T, lds); return RE2E_EUNSUPPORTED; }
   if (small) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_bwd_kernel<12, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attloc_bwd_kernel<12, 5>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, w_cur, hlens, w_dec, w_att,
+    hipLaunchKernelGGL((attloc_bwd_kernel<12, 5>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, w_cur, hlens, w_decT, w_att,
                        w_conv, gvec, dc, ld_dc, dw_in, B, T, eprojs, dunits, adim, chans, filts, d_pre, d_enc, d_att_prev, d_decproj,
                        partials);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_bwd_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attloc_bwd_kernel<16, 8>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, w_cur, hlens, w_dec, w_att,
+    hipLaunchKernelGGL((attloc_bwd_kernel<16, 8>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, w_cur, hlens, w_decT, w_att,
                        w_conv, gvec, dc, ld_dc, dw_in, B, T, eprojs, dunits, adim, chans, filts, d_pre, d_enc, d_att_prev, d_decproj,
                        partials);
   }

@@ -12,6 +12,8 @@
 // model/e2e_encoder.py:145-147,173-174, model/e2e_ctc.py:51, model/e2e_attention.py:256,
 // model/e2e_decoder.py:131,150, model/enhance_model.py:108-114 and nn.Conv2d in
 // model/e2e_encoder.py:234-237 (VGG2L) and model/gan_model.py:63-90 (discriminator).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -170,7 +172,24 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / CF::WN, wn = wid % CF::WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each),
+  // so give every XCD a contiguous chunk of the tile sequence (bijective remap), and walk the
+  // sequence in groups of 8 M-tiles so that co-resident workgroups share A and B panels in L2.
+  int tile_m, tile_n;
+  {
+    const int ntm = gridDim.x, ntn = gridDim.y, nwg = ntm * ntn;
+    const int orig = blockIdx.y * ntm + blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int GROUP = 8;
+    const int per_group = GROUP * ntn;
+    const int gid = pid / per_group;
+    const int first_m = gid * GROUP;
+    const int gsz = min(ntm - first_m, GROUP);
+    tile_m = first_m + (pid % per_group) % gsz;
+    tile_n = (pid % per_group) / gsz;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(la.p), 0, la.nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lb.p), 0, lb.nbytes, 0x00020000);
   // split-K range
@@ -354,10 +373,10 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
     }
 }
 
-// Deterministic split-K reduce: C[perm(m,n)] = sum_z ws[z][m][n] (+ beta*C).  perm: plain
+// Deterministic split-K reduce: C[perm(m,n)] = act(sum_z ws[z][m][n] + bias) + beta*C.  perm: plain
 // (m*ldc+n) or the conv weight layout (rows m=(kh,kw,ci), cols n=co -> W[co][ci][kh][kw]).
 __global__ void splitk_reduce_kernel(const float* ws, int nsplit, int M, int N, float* C, long ldc, float beta,
-                                     int conv_perm, int Cin, int KHW) {
+                                     int conv_perm, int Cin, int KHW, const float* bias, const float* bias2, int act) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long tot = (long)M * N;
   if (i >= tot) return;
@@ -367,6 +386,9 @@ __global__ void splitk_reduce_kernel(const float* ws, int nsplit, int M, int N, 
   long off;
   if (conv_perm) { int ci = m % Cin; int tap = m / Cin; off = ((long)n * Cin + ci) * KHW + tap; }
   else off = (long)m * ldc + n;
+  if (bias) s += bias[n];
+  if (bias2) s += bias2[n];
+  s = apply_act(s, act);
   if (beta != 0.f) s += C[off];
   C[off] = s;
 }
@@ -391,6 +413,39 @@ constexpr int BKD = 16;              // k-tile: 16 keeps LDS <= 46 KB per block 
 using C128 = Cfg<2, 2, 2, 2, BKD>;    // 128 x 128
 using C256x64 = Cfg<4, 1, 2, 2, BKD>;
 using C256x32 = Cfg<4, 1, 2, 1, 32>;   // BN=32 needs BK=32 to give every thread a B item
+using C32x128 = Cfg<1, 4, 1, 1, 32>;   // skinny (M<=32) GEMMs of the decoder loop, always split-K
+// tuning variants (tools/bench_gemm.py, env RE2E_IGEMM_VARIANT): 1 = BK 32, 2 = 8-wave 256x128 tile
+using C128b = Cfg<2, 2, 2, 2, 32>;
+using C256x64b = Cfg<4, 1, 2, 2, 32>;
+using C256x128 = Cfg<4, 2, 2, 2, 16>;
+
+inline int igemm_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RE2E_IGEMM_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+// big-tile launch.  WIDE = the 8-wave 256x128 tile is the measured default for this operand combination
+// (tools/bench_gemm.py on MI355X: +5..35 % for Linear-forward / weight-gradient GEMMs and conv forward /
+// data-gradient with Cout >= 128; the 4-wave 128x128 tile stays better for NN and conv weight-gradient).
+// RE2E_IGEMM_VARIANT = 1 (BK 32) / 2 (force wide) / 3 (force 128x128) override for tuning.
+template <class LA, class LB, bool V, bool WIDE>
+void launch_big(const LA& la, const LB& lb, Epi& ep, int K, hipStream_t st) {
+  if constexpr (V) {
+    int v = igemm_variant();
+    if (v == 1) { launch_igemm<LA, LB, C128b, V>(la, lb, ep, K, st); return; }
+    bool wide = v == 2 ? true : (v == 3 ? false : (WIDE && ep.M >= 2048));
+    if (wide) { launch_igemm<LA, LB, C256x128, V>(la, lb, ep, K, st); return; }
+  }
+  launch_igemm<LA, LB, C128, V>(la, lb, ep, K, st);
+}
+template <class LA, class LB, bool V>
+void launch_n64(const LA& la, const LB& lb, Epi& ep, int K, hipStream_t st) {
+  if constexpr (V) {
+    if (igemm_variant() == 1) { launch_igemm<LA, LB, C256x64b, V>(la, lb, ep, K, st); return; }
+  }
+  launch_igemm<LA, LB, C256x64, V>(la, lb, ep, K, st);
+}
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -406,14 +461,34 @@ int pick_splits(int M, int N, int K, int bm, int bn) {
   return (int)s;
 }
 
+// skinny path (M <= 32): latency-bound, so spread K over many workgroups (>= 2 k-tiles of 32 each)
+int pick_splits_skinny(int N, int K) {
+  long tiles = cdiv(N, 128);
+  int nkt = cdiv(K, 32);
+  long want = (192 + tiles - 1) / tiles;
+  long maxs = nkt / 2;
+  long s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+inline bool use_skinny(int transa, int M, int N, int K) { return !transa && M <= 32 && K >= 128; }
+
+int gemm_splits(int transa, int transb, int M, int N, int K) {
+  if (use_skinny(transa, M, N, K)) return pick_splits_skinny(N, K);
+  if (transa && !transb) return pick_splits(M, N, K, M >= 2048 ? 256 : 128, 128);
+  return 1;
+}
+
 }  // namespace
 
 // ============================================================================================
 // C ABI
 // ============================================================================================
 extern "C" size_t re2e_gemm_workspace_bytes(int transa, int transb, int M, int N, int K) {
-  if (!(transa && !transb)) return 0;     // only the A^T B (weight-gradient) form is split
-  int s = pick_splits(M, N, K, 128, 128);
+  if (transa && transb) return 0;
+  int s = gemm_splits(transa, transb, M, N, K);
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
@@ -424,18 +499,21 @@ static inline bool fits32(long outer, long ld, long inner) { return ((outer - 1)
 template <bool V>
 static void gemm_dispatch(int transa, int transb, int M, int N, int K, const float* A, long lda, const float* B, long ldb, Epi& ep,
                           hipStream_t st) {
+  const bool skinny = use_skinny(transa, M, N, K);
   if (!transa && transb) {          // C = A[M,K] * B[N,K]^T   (Linear forward)
     DenseK la{A, kbytes(M, lda, K), lda, M, K};
     DenseK lb{B, kbytes(N, ldb, K), ldb, N, K};
-    launch_igemm<DenseK, DenseK, C128, V>(la, lb, ep, K, st);
+    if (skinny) launch_igemm<DenseK, DenseK, C32x128, V>(la, lb, ep, K, st);
+    else launch_big<DenseK, DenseK, V, true>(la, lb, ep, K, st);
   } else if (!transa && !transb) {  // C = A[M,K] * B[K,N]     (input gradient)
     DenseK la{A, kbytes(M, lda, K), lda, M, K};
     DenseM lb{B, kbytes(K, ldb, N), ldb, N, K};
-    launch_igemm<DenseK, DenseM, C128, V>(la, lb, ep, K, st);
+    if (skinny) launch_igemm<DenseK, DenseM, C32x128, V>(la, lb, ep, K, st);
+    else launch_big<DenseK, DenseM, V, false>(la, lb, ep, K, st);
   } else {                          // C = A[K,M]^T * B[K,N]   (weight gradient)
     DenseM la{A, kbytes(K, lda, M), lda, M, K};
     DenseM lb{B, kbytes(K, ldb, N), ldb, N, K};
-    launch_igemm<DenseM, DenseM, C128, V>(la, lb, ep, K, st);
+    launch_big<DenseM, DenseM, V, true>(la, lb, ep, K, st);
   }
 }
 
@@ -457,14 +535,11 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
   memset(&ep, 0, sizeof(ep));
   ep.C = C; ep.ldc = ldc; ep.M = M; ep.N = N; ep.bias = bias; ep.bias2 = bias2; ep.act = act; ep.beta = beta;
   ep.mul = mul; ep.mask_out = mask_out; ep.lens = lens_dev; ep.T = T; ep.nsplit = 1;
-  int s = 1;
-  if (transa && !transb) {
-    s = pick_splits(M, N, K, 128, 128);
-    if (s > 1) {
-      RE2E_CHECK_ARG(workspace && workspace_bytes >= (size_t)s * M * N * sizeof(float), "workspace too small");
-      RE2E_CHECK_ARG(act == RE2E_ACT_NONE && !bias && !bias2, "split-K form has no epilogue");
-      ep.ws = (float*)workspace; ep.nsplit = s;
-    }
+  const int s = gemm_splits(transa, transb, M, N, K);
+  if (s > 1) {
+    RE2E_CHECK_ARG(workspace && workspace_bytes >= (size_t)s * M * N * sizeof(float), "workspace too small");
+    RE2E_CHECK_ARG(act != RE2E_ACT_SIGMOID_MASK_MUL, "split-K form does not support the mask epilogue");
+    ep.ws = (float*)workspace; ep.nsplit = s;
   }
   // 16-byte vector loads need aligned bases, leading dimensions that are multiples of 4 and no
   // float4 straddling a bound (k-contiguous operands: K % 4; row-contiguous operands: rows % 4)
@@ -475,7 +550,7 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
   if (s > 1) {
     long tot = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s,
-                       M, N, C, ldc, beta, 0, 0, 0);
+                       M, N, C, ldc, beta, 0, 0, 0, bias, bias2, act);
   }
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
@@ -487,8 +562,8 @@ static void conv_dispatch(const ConvGeom& g, int M, int K, const float* wg, int 
   ConvK la{g, g.in, (unsigned)((long)g.NI * g.H * g.W * g.C * 4), M, K};
   DenseK lb{wg, kbytes(Cout, K, K), (long)K, Cout, K};
   if (ep.N <= 32) launch_igemm<ConvK, DenseK, C256x32, V>(la, lb, ep, K, st);
-  else if (ep.N <= 64) launch_igemm<ConvK, DenseK, C256x64, V>(la, lb, ep, K, st);
-  else launch_igemm<ConvK, DenseK, C128, V>(la, lb, ep, K, st);
+  else if (ep.N <= 64) launch_n64<ConvK, DenseK, V>(la, lb, ep, K, st);
+  else launch_big<ConvK, DenseK, V, true>(la, lb, ep, K, st);
 }
 
 // Forward / data-gradient implicit GEMM:
@@ -527,8 +602,8 @@ static void wgrad_dispatch(const ConvGeom& g, int Mrows, int P, const float* dou
   ConvM la{g, g.in, (unsigned)((long)g.NI * g.H * g.W * g.C * 4), Mrows, P};
   DenseM lb{dout, kbytes(P, Cout, Cout), (long)Cout, Cout, P};
   if (Cout <= 32) launch_igemm<ConvM, DenseM, C256x32, V>(la, lb, ep, P, st);
-  else if (Cout <= 64) launch_igemm<ConvM, DenseM, C256x64, V>(la, lb, ep, P, st);
-  else launch_igemm<ConvM, DenseM, C128, V>(la, lb, ep, P, st);
+  else if (Cout <= 64) launch_n64<ConvM, DenseM, V>(la, lb, ep, P, st);
+  else launch_big<ConvM, DenseM, V, false>(la, lb, ep, P, st);
 }
 
 extern "C" size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW) {
@@ -560,7 +635,7 @@ extern "C" int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, con
   else wgrad_dispatch<false>(g, Mrows, (int)P, dout, Cout, ep, stream);
   long tot = (long)Mrows * Cout;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s, Mrows,
-                     Cout, dW, (long)Cout, beta, 1, C, KH * KW);
+                     Cout, dW, (long)Cout, beta, 1, C, KH * KW, (const float*)nullptr, (const float*)nullptr, RE2E_ACT_NONE);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

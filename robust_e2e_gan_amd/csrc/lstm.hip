@@ -12,6 +12,8 @@
 // through LDS, then the same workgroup applies the cell non-linearity -- gates never leave the
 // CU between the matmul and the pointwise update.  Time-major buffers padded by one zero block at
 // each end remove every boundary special case (h_{-1}=c_{-1}=0, reverse start).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -22,6 +24,28 @@ __device__ __forceinline__ void store_acc(float* red, const f32x16& acc, int lan
   for (int r = 0; r < 16; ++r) {
     int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
     red[row * 33 + lr] = acc[r];
+  }
+}
+
+// acc += sum_q A_q B_q with ALL fragment loads of a batch of 8 k-groups issued before the first MFMA:
+// the step kernels are latency-bound, a load -> MFMA dependency per k-group costs one L2 round trip each.
+__device__ __forceinline__ void mfma_chain(const f32x4* __restrict__ ap, const f32x4* __restrict__ bp, int QN, f32x16& acc) {
+  constexpr int CH = 8;
+  for (int q0 = 0; q0 < QN; q0 += CH) {
+    f32x4 a[CH], b[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      int q = q0 + u < QN ? q0 + u : QN - 1;
+      a[u] = ap[(long)q * 64];
+      b[u] = bp[(long)q * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      if (q0 + u < QN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], b[u][j], acc, 0, 0, 0);
+      }
+    }
   }
 }
 
@@ -91,14 +115,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_step(float* xg_f, float* 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if (s > 0) {
-    for (int q = 0; q < QN; ++q) {
-      f32x4 a4 = hp[(long)q * 64];
-      f32x4 b4 = wp[(long)q * 64];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc, 0, 0, 0);
-    }
-  }
+  if (s > 0) mfma_chain(hp, wp, QN, acc);
   store_acc(red + wid * (32 * 33), acc, lane);
   __syncthreads();
 #pragma unroll
@@ -170,12 +187,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_bwd_step(float* g_f, float* g
     const int nx = gridDim.x;
     const f32x4* wp = reinterpret_cast<const f32x4*>(wtfrag) + ((long)(dir * nx + x) * (K4 / 8) + wid * QN) * 64 + lane;
     const f32x4* gp = reinterpret_cast<const f32x4*>(gf_rd) + ((long)(2 * wid * QN + lh)) * 32 + (lane & 31);
-    for (int q = 0; q < QN; ++q) {
-      f32x4 a4 = gp[(long)q * 64];
-      f32x4 b4 = wp[(long)q * 64];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc, 0, 0, 0);
-    }
+    mfma_chain(gp, wp, QN, acc);
   }
   store_acc(red + wid * (32 * 33), acc, lane);
   __syncthreads();
@@ -214,7 +226,11 @@ __global__ void zero_kernel(float* p, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
 }
 
-int pick_waves(int K, int min_kc) {
+int pick_waves(int K, int min_kc, const char* env = nullptr) {
+  if (env) {                       // tuning override (tools/bench_lstm.py): RE2E_LSTM_WAVES_{FWD,BWD}
+    const char* v = getenv(env);
+    if (v) { int w = atoi(v); if (w >= 1 && w <= 16 && (w & (w - 1)) == 0 && K % (8 * w) == 0) return w; }
+  }
   for (int w = 16; w >= 1; w >>= 1)
     if (K % (8 * w) == 0 && K / w >= min_kc) return w;
   return K % 8 == 0 ? 1 : 0;
@@ -269,7 +285,7 @@ extern "C" int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, c
   hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wfrag, H);
   hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wfrag + wn, H);
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(hn, 256) > 1024 ? 1024 : cdiv(hn, 256)), dim3(256), 0, stream, hfrag, hn);
-  int w = pick_waves(H, 32);
+  int w = pick_waves(H, 32, "RE2E_LSTM_WAVES_FWD");
   switch (w) {
     case 16: launch_fwd<16>(stream, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens_dev, T, B, H); break;
     case 8: launch_fwd<8>(stream, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens_dev, T, B, H); break;
@@ -298,7 +314,7 @@ extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, con
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(gn, 256) > 1024 ? 1024 : cdiv(gn, 256)), dim3(256), 0, stream, gfrag, gn);
   long nz = (long)B * 2 * H;
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(nz, 256)), dim3(256), 0, stream, dc_state, nz);
-  int w = pick_waves(4 * H, 64);
+  int w = pick_waves(4 * H, 64, "RE2E_LSTM_WAVES_BWD");
   switch (w) {
     case 16: launch_bwd<16>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
     case 8: launch_bwd<8>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;

@@ -61,7 +61,8 @@ class JointTrainer(object):
                                                                                           gan_model if self.isGAN else None)
         self.criterionGAN = GANLoss(use_lsgan=not opt.no_lsgan) if self.isGAN else None
         self.asr_model.dec.return_acc_tensor = True
-        self.sync_each_step = False        # True => .item() the NaN guards like the reference (one host sync)
+        self.overlap_dstep = True          # run the D-step on a side HIP stream under the enhancer backward
+        self.side_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
 
     def step(self, data, sche_samp_rate, enhance_cmvn):
         """One training iteration (joint_train.py:157-213).  Returns a dict of DEVICE scalars (call
@@ -88,28 +89,58 @@ class JointTrainer(object):
         self.asr_optimizer.zero_grad()
         sync = GradSync()
         sync.arm(enhance_feat, self.asr_optimizer)
-        loss.backward()
+        if self.isGAN and self.overlap_dstep:
+            # Phase 1: backward of everything downstream of the enhancer (ASR, D, fbank) on the main stream.
+            main = torch.cuda.current_stream()
+            ev_fwd = torch.cuda.Event()
+            ev_fwd.record(main)
+            (g_eo,) = torch.autograd.grad(loss, [enhance_out])
+            ev_bwd1 = torch.cuda.Event()
+            ev_bwd1.record(main)
+            # D-step (joint_train.py:195-212) on a side stream: it only needs the forward results, so it fills
+            # the CUs that the latency-bound enhancer BLSTM backward (1600 dependent launches) leaves idle.
+            side = self.side_stream
+            side.wait_event(ev_fwd)
+            with torch.cuda.stream(side):
+                for t_ in (enhance_feat, clean_feat, enhance_cmvn):
+                    if isinstance(t_, torch.Tensor) and t_.is_cuda:
+                        t_.record_stream(side)
+                loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, wait_before_update=ev_bwd1)
+            # Phase 2: the enhancer backward chain on the main stream.
+            enhance_out.backward(g_eo)
+        else:
+            loss.backward()
+            loss_D = None
         sync.finish([self.enhance_optimizer])
         grad_norm = self.asr_optimizer.clip_grad_norm(opt.grad_clip)           # ASR params only (:188)
-        if self.sync_each_step and math.isnan(float(grad_norm)):
-            pass                                                                # the kernels skip on the device flag anyway
         self.enhance_optimizer.step(self.asr_optimizer.gate_stats())           # unclipped, same NaN gate (:189-193)
         self.asr_optimizer.step()
         if self.isGAN:
-            set_requires_grad([self.gan_model], True)
-            self.gan_optimizer.zero_grad()
-            loss_D_real = self.criterionGAN(self.gan_model(clean_feat.detach(), enhance_cmvn), True)
-            loss_D_fake = self.criterionGAN(self.gan_model(enhance_feat.detach(), enhance_cmvn), False)
-            loss_D = (loss_D_real + loss_D_fake) * 0.5
-            loss_D.backward()
-            GradSync().finish([self.gan_optimizer])
-            self.gan_optimizer.clip_grad_norm(opt.grad_clip)
-            self.gan_optimizer.step()
+            if loss_D is None:
+                loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn)
+            else:
+                torch.cuda.current_stream().wait_stream(self.side_stream)
             out['train/loss_D'] = loss_D.detach()
         out.update({'train/loss': loss.detach(), 'train/loss_ctc': loss_ctc.detach().view(()), 'train/acc': acc, 'train/loss_att': loss_att.detach(),
                     'train/enhance_loss': enhance_loss.detach(), 'train/coral_loss': coral_loss.detach(), 'grad_norm': grad_norm})
         self.last = dict(enhance_out=enhance_out, enhance_feat=enhance_feat)
         return out
+
+    def _d_step(self, clean_feat, enhance_feat, enhance_cmvn, wait_before_update=None):
+        """Discriminator update (joint_train.py:195-212) on the CURRENT stream."""
+        opt = self.opt
+        set_requires_grad([self.gan_model], True)
+        self.gan_optimizer.zero_grad()
+        loss_D_real = self.criterionGAN(self.gan_model(clean_feat.detach(), enhance_cmvn), True)
+        loss_D_fake = self.criterionGAN(self.gan_model(enhance_feat.detach(), enhance_cmvn), False)
+        loss_D = (loss_D_real + loss_D_fake) * 0.5
+        loss_D.backward()
+        GradSync().finish([self.gan_optimizer])
+        self.gan_optimizer.clip_grad_norm(opt.grad_clip)
+        if wait_before_update is not None:     # the G-step backward still reads D's weights on the main stream
+            torch.cuda.current_stream().wait_event(wait_before_update)
+        self.gan_optimizer.step()
+        return loss_D
 
     @staticmethod
     def to_floats(errors):

@@ -130,9 +130,10 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag='ws'):
-    """Grow-only scratch buffer per (device, tag); contents are undefined between calls."""
+    """Grow-only scratch buffer per (device, stream, tag); contents are undefined between calls.
+    Keyed by the current stream so that work overlapped on a side stream never shares scratch."""
     nbytes = max(int(nbytes), 16)
-    key = (str(device), tag)
+    key = (str(device), torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)

@@ -37,14 +37,15 @@ def zeros(shape, like):
 # raw helpers
 # ---------------------------------------------------------------------------------------------
 def gemm(A, B, C, M, N, K, transa=False, transb=False, lda=None, ldb=None, ldc=None, bias=None, bias2=None,
-         act=lib.ACT_NONE, beta=0.0, mul=None, mask_out=None, lens=None, T=0):
+         act=lib.ACT_NONE, beta=0.0, mul=None, mask_out=None, lens=None, T=0, dev=None):
     """C[M,N] = act(op(A) op(B) + bias + bias2) + beta*C   (see re2e_gemm)."""
     lda = lda if lda is not None else (M if transa else K)
     ldb = ldb if ldb is not None else (K if transb else N)
     ldc = ldc if ldc is not None else N
     wsb = query('re2e_gemm_workspace_bytes', int(transa), int(transb), M, N, K)
-    ws = workspace(wsb, A.device, 'gemm') if wsb else None
-    call('re2e_gemm', int(transa), int(transb), M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc,
+    ws = workspace(wsb, dev if dev is not None else A.device, 'gemm') if wsb else None
+    _p = lambda t: t if isinstance(t, int) else t.data_ptr()       # tensors or raw device addresses (sub-matrix views)
+    call('re2e_gemm', int(transa), int(transb), M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc,
          ptr(bias), ptr(bias2), act, float(beta), ptr(mul), ptr(mask_out), ptr(lens), T, ptr(ws), wsb)
     return C
 
@@ -731,50 +732,64 @@ class DecoderLoopFn(torch.autograd.Function):
 
     ``P`` is a dict of the decoder / attention Parameters (reference names):
       embed, w_ih, w_hh, b_ih, b_hh, mlp_dec, mlp_att, loc_conv, gvec_w, gvec_b
-    """
+    Teacher forcing makes the embedding half of the LSTMCell input projection independent of the
+    recurrence, so it is ONE batched GEMM over all (L+1)*B tokens before the loop; inside the loop only
+    the context (K=eprojs) and recurrent (K=dunits) halves remain (skinny split-K GEMMs)."""
 
     @staticmethod
     def forward(ctx, hmask, pre, ids_tm, hlens_dev, L1, Pm):
         _need_gpu(hmask)
         hmask, pre = _f32(hmask), _f32(pre)
+        dev = hmask.device
         B, T, E = hmask.shape
         A = pre.shape[2]
         Dd = Pm['embed'].shape[1]
         D = Pm['w_hh'].shape[1]
         C, Kf = Pm['loc_conv'].shape[0], Pm['loc_conv'].shape[3]
         Fh = (Kf - 1) // 2
-        ey = empty((L1, B, Dd + E), hmask)
-        call('re2e_embedding_fwd', Pm['embed'].data_ptr(), ids_tm.data_ptr(), L1 * B, Dd, ey.data_ptr(), Dd + E)
+        M = L1 * B
+        w_ih = Pm['w_ih']
+        ldw = Dd + E
+        emb = empty((L1, B, Dd), hmask)
+        call('re2e_embedding_fwd', Pm['embed'].data_ptr(), ids_tm.data_ptr(), M, Dd, emb.data_ptr(), Dd)
+        gates = empty((L1, B, 4 * D), hmask)
+        gemm(emb, w_ih, gates, M, 4 * D, Dd, transb=True, ldb=ldw, bias=Pm['b_ih'], bias2=Pm['b_hh'])
+        cx = empty((L1, B, E), hmask)
         z = zeros((L1 + 1, B, D), hmask)
         c = zeros((L1 + 1, B, D), hmask)
         w = empty((L1, B, T), hmask)
-        gates = empty((L1, B, 4 * D), hmask)
+        w_ctx = w_ih.data_ptr() + 4 * Dd            # W_ih[:, Dd:]  (4D, E) view with leading dimension Dd+E
+        w_decT = empty((D, A), hmask)               # mlp_dec.weight transposed once: coalesced reads in the step kernel
+        call('re2e_transpose01', Pm['mlp_dec'].data_ptr(), w_decT.data_ptr(), A, D, 1)
         for i in range(L1):
             call('re2e_attloc_fwd', pre.data_ptr(), hmask.data_ptr(), z[i].data_ptr(), w[i - 1].data_ptr() if i > 0 else None,
-                 hlens_dev.data_ptr(), Pm['mlp_dec'].data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(),
-                 Pm['gvec_w'].data_ptr(), Pm['gvec_b'].data_ptr(), B, T, E, D, A, C, Fh, w[i].data_ptr(),
-                 ey[i].data_ptr() + 4 * Dd, Dd + E)
-            gemm(ey[i], Pm['w_ih'], gates[i], B, 4 * D, Dd + E, transb=True, bias=Pm['b_ih'], bias2=Pm['b_hh'])
+                 hlens_dev.data_ptr(), w_decT.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(),
+                 Pm['gvec_w'].data_ptr(), Pm['gvec_b'].data_ptr(), B, T, E, D, A, C, Fh, w[i].data_ptr(), cx[i].data_ptr(), E)
+            gemm(cx[i], w_ctx, gates[i], B, 4 * D, E, transb=True, ldb=ldw, beta=1.0, dev=dev)
             gemm(z[i], Pm['w_hh'], gates[i], B, 4 * D, D, transb=True, beta=1.0)
             call('re2e_lstm_cell_fwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), z[i + 1].data_ptr(), B, D)
         ctx.Pm, ctx.ids, ctx.hlens = Pm, ids_tm, hlens_dev
         ctx.dims = (B, T, E, A, Dd, D, C, Fh, L1)
-        ctx.save_for_backward(hmask, pre, ey, z, c, w, gates)
+        ctx.save_for_backward(hmask, pre, emb, cx, z, c, w, gates, w_decT)
         ctx.mark_non_differentiable(w)
         return z[1:], w
 
     @staticmethod
     def backward(ctx, dZ, _dw_unused):
-        hmask, pre, ey, z, c, w, gates = ctx.saved_tensors
+        hmask, pre, emb, cx, z, c, w, gates, w_decT = ctx.saved_tensors
         Pm = ctx.Pm
         B, T, E, A, Dd, D, C, Fh, L1 = ctx.dims
+        dev = hmask.device
         dZ = _f32(dZ)
+        w_ih = Pm['w_ih']
+        ldw = Dd + E
+        w_ctx = w_ih.data_ptr() + 4 * Dd
         d_pre = zeros((B, T, A), hmask)
         d_enc = zeros((B, T, E), hmask)
         npart = query('re2e_attloc_partial_floats', A, C, Fh)
         partials = zeros((B, npart), hmask)
         ddp = empty((L1, B, A), hmask)
-        d_ey = empty((L1, B, Dd + E), hmask)
+        d_cx = empty((B, E), hmask)
         dz_carry = zeros((B, D), hmask)
         dc_a, dc_b = zeros((B, D), hmask), empty((B, D), hmask)
         dw_a, dw_b = empty((B, T), hmask), empty((B, T), hmask)
@@ -784,20 +799,21 @@ class DecoderLoopFn(torch.autograd.Function):
             call('re2e_lstm_cell_bwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), dz_carry.data_ptr(), dc_a.data_ptr(),
                  dc_b.data_ptr(), B, D)
             dc_a, dc_b = dc_b, dc_a
-            gemm(gates[i], Pm['w_ih'], d_ey[i], B, Dd + E, 4 * D)
-            gemm(gates[i], Pm['w_hh'], dz_carry, B, D, 4 * D)
+            gemm(gates[i], w_ctx, d_cx, B, E, 4 * D, ldb=ldw, dev=dev)                     # d ctx = dgates W_ih[:, Dd:]
+            gemm(gates[i], Pm['w_hh'], dz_carry, B, D, 4 * D)                                # d z_{i-1} (recurrent path)
             call('re2e_attloc_bwd', pre.data_ptr(), hmask.data_ptr(), z[i].data_ptr(), w[i - 1].data_ptr() if i > 0 else None,
-                 w[i].data_ptr(), ctx.hlens.data_ptr(), Pm['mlp_dec'].data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(),
-                 Pm['gvec_w'].data_ptr(), d_ey[i].data_ptr() + 4 * Dd, Dd + E, dw_a.data_ptr() if have_dw else None, B, T, E, D, A, C, Fh,
+                 w[i].data_ptr(), ctx.hlens.data_ptr(), w_decT.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(),
+                 Pm['gvec_w'].data_ptr(), d_cx.data_ptr(), E, dw_a.data_ptr() if have_dw else None, B, T, E, D, A, C, Fh,
                  d_pre.data_ptr(), d_enc.data_ptr(), dw_b.data_ptr() if i > 0 else None, ddp[i].data_ptr(), partials.data_ptr())
             dw_a, dw_b = dw_b, dw_a
             have_dw = True
             gemm(ddp[i], Pm['mlp_dec'], dz_carry, B, D, A, beta=1.0)
         M = L1 * B
-        G2, ey2, zp2 = gates.view(M, 4 * D), ey.view(M, Dd + E), z[:L1].reshape(M, D)
-        if Pm['w_ih'].requires_grad:
-            gw, beta = grad_target(Pm['w_ih'])
-            gemm(G2, ey2, gw, 4 * D, Dd + E, M, transa=True, beta=beta)
+        G2, zp2 = gates.view(M, 4 * D), z[:L1].reshape(M, D)
+        if w_ih.requires_grad:
+            gw, beta = grad_target(w_ih)
+            gemm(G2, emb.view(M, Dd), gw, 4 * D, Dd, M, transa=True, ldc=ldw, beta=beta)                       # dW_ih[:, :Dd]
+            gemm(G2, cx.view(M, E), gw.data_ptr() + 4 * Dd, 4 * D, E, M, transa=True, ldc=ldw, beta=beta)      # dW_ih[:, Dd:]
             gw, beta = grad_target(Pm['w_hh'])
             gemm(G2, zp2, gw, 4 * D, D, M, transa=True, beta=beta)
             for k in ('b_ih', 'b_hh'):
@@ -805,9 +821,11 @@ class DecoderLoopFn(torch.autograd.Function):
                 colsum_into(G2, M, 4 * D, gb, beta)
             gw, beta = grad_target(Pm['mlp_dec'])
             gemm(ddp.view(M, A), zp2, gw, A, D, M, transa=True, beta=beta)
+            d_emb = empty((M, Dd), hmask)
+            gemm(G2, w_ih, d_emb, M, Dd, 4 * D, ldb=ldw)                                                        # dgates W_ih[:, :Dd]
             gw, beta = grad_target(Pm['embed'])
             V = Pm['embed'].shape[0]
-            call('re2e_embedding_bwd', d_ey.data_ptr(), Dd + E, ctx.ids.data_ptr(), M, Dd, V, gw.data_ptr(), beta)
+            call('re2e_embedding_bwd', d_emb.data_ptr(), Dd, ctx.ids.data_ptr(), M, Dd, V, gw.data_ptr(), beta)
             tot = empty((npart,), hmask)
             colsum_into(partials, B, npart, tot, 0.0)
             off = 0
