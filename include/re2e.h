@@ -203,23 +203,31 @@ int re2e_ctc_bwd(const float* logits, int T, int B, int V, const int* hlens_dev,
                  const int* label_off_dev, const int* label_len_dev, int Lmax, const float* nll_per_utt,
                  const float* gscale_dev, float* dlogits, const void* workspace, re2e_stream_t stream);
 
-/* ---- K7 fused location-aware attention step (model/e2e_attention.py:258-297) --------------- */
+/* ---- K7 location-aware attention step (model/e2e_attention.py:258-297) -------------------- */
 /* per utterance b: w = softmax_t(2*(gvec . tanh(W_att conv(att_prev) + pre[b,t] + W_dec z[b]) + gb)),
  * c[b] = sum_t w[t]*enc[b,t].  att_prev==NULL => uniform 1/hlen over valid frames.
- * w_decT is mlp_dec.weight TRANSPOSED, (dunits, adim) (coalesced reads; transpose once per utterance batch). */
+ * w_decT is mlp_dec.weight TRANSPOSED, (dunits, adim).  conv_out (B,T,chans) and dp_out (B,adim) are the
+ * location-conv output and W_dec z, saved for the backward; e_scratch (B,T) is scratch.
+ * The work is cut into 32-frame workgroups (grid = ceil(T/32) x B) + a per-utterance softmax/context pass. */
 int re2e_attloc_fwd(const float* pre, const float* enc, const float* z, const float* att_prev, const int* hlens_dev,
                     const float* w_decT, const float* w_att, const float* w_conv, const float* gvec, const float* gvec_b,
                     int B, int T, int eprojs, int dunits, int adim, int chans, int filts, float* w_out, float* c_out,
-                    long ldc_out, re2e_stream_t stream);
+                    long ldc_out, float* conv_out, float* dp_out, float* e_scratch, re2e_stream_t stream);
 size_t re2e_attloc_partial_floats(int adim, int chans, int filts);
-/* backward of one step; accumulates d_pre/d_enc (+=), writes d_att_prev (may be NULL for step 0),
- * d_decproj [B,adim] (for the mlp_dec GEMMs) and per-utterance weight-grad partials (+=) laid out
- * [B][gvec(adim) | gvec_b(1) | w_att(adim*chans) | w_conv(chans*(2*filts+1))] */
-int re2e_attloc_bwd(const float* pre, const float* enc, const float* z, const float* att_prev, const float* w_cur,
-                    const int* hlens_dev, const float* w_decT, const float* w_att, const float* w_conv,
-                    const float* gvec, const float* dc, long ld_dc, const float* dw_in, int B, int T, int eprojs,
-                    int dunits, int adim, int chans, int filts, float* d_pre, float* d_enc, float* d_att_prev,
-                    float* d_decproj, float* partials, re2e_stream_t stream);
+size_t re2e_attloc_workspace_bytes(int B, int T, int adim, int chans);
+/* backward of one step: accumulates d_pre (+=), writes d_att_prev (may be NULL for step 0) and d_decproj
+ * [B,adim] (for the mlp_dec GEMMs), accumulates per-utterance weight-grad partials (+=) laid out
+ * [B][gvec(adim) | gvec_b(1) | w_att(adim*chans) | w_conv(chans*(2*filts+1))].  cx_in = the forward context
+ * c (B,eprojs), conv_in / dp_in = the tensors saved by re2e_attloc_fwd.  The encoder-state gradient is NOT
+ * accumulated here: call re2e_attloc_denc once after the loop. */
+int re2e_attloc_bwd(const float* pre, const float* enc, const float* att_prev, const float* w_cur, const int* hlens_dev,
+                    const float* w_att, const float* w_conv, const float* gvec, const float* conv_in, const float* dp_in,
+                    const float* cx_in, const float* dc, long ld_dc, const float* dw_in, int B, int T, int eprojs, int adim,
+                    int chans, int filts, float* d_pre, float* d_att_prev, float* d_decproj, float* partials,
+                    void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+/* d_enc[b,t,:] = beta*d_enc + sum_i w_all[i,b,t] * dc_all[i,b,:]  (w_all (L1,B,T), dc_all (L1,B,eprojs)) */
+int re2e_attloc_denc(const float* w_all, const float* dc_all, int L1, int B, int T, int eprojs, float* d_enc, float beta,
+                     re2e_stream_t stream);
 
 /* ---- K11 optimizer (joint_train.py:131-140,188-193; Appendix A.16) ------------------------ */
 /* stats[0]=||g||_2, stats[1]=clip coefficient (<=1), stats[2]=1 if finite else 0; from sumsq[0];

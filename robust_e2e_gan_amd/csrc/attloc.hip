@@ -1,131 +1,143 @@
-// K7: fused location-aware attention step (AttLoc.forward, model/e2e_attention.py:258-297) and
-// its backward.  One workgroup (512 threads = 8 wavefronts) per utterance keeps the whole step on
-// one CU: previous attention weights, the location convolution (k = 2*filts+1 taps), the energy
-// vector and the softmax live in LDS; softmax / dot-product reductions use wavefront shuffles;
-// pre_compute_enc_h and enc_h rows are streamed with coalesced (row-contiguous) loads.
+// K7: location-aware attention step (AttLoc.forward, model/e2e_attention.py:258-297) and its backward.
 //
 //   w = softmax_t( 2 * ( gvec . tanh( W_att conv(att_prev)[t] + pre[b,t] + W_dec z[b] ) + gb ) )
 //   c = sum_t w[t] * enc[b,t]          (softmax over ALL T frames incl. padding, Appendix A.9)
+//
+// A single CU streams only ~30 GB/s from beyond its L2 (latency-bound), and one decoder step touches
+// ~0.7 MB (forward) / ~2 MB (backward) per utterance, so the step is cut along the frame axis into
+// workgroups of 32 frames (grid = frame-chunks x utterances: 224 workgroups at T'=200, B=32) and a
+// small per-utterance kernel for the parts that need all frames:
+//   forward : attloc_energy (chunk x b)  -> e[b,t], conv[b,t,:], dec_proj[b,:]
+//             attloc_context (E/64 x b)  -> softmax over T (recomputed per workgroup, 200 values),
+//                                           w[b,:], c[b, 64-column slice]
+//   backward: attloc_bwd_frames (chunk x b): softmax + energy backward for its frames.  The softmax
+//             normaliser sum_t w[t] dw[t] = w . dw_in + dc . c needs no cross-workgroup reduction
+//             because the forward context c is saved.  Writes d_conv, accumulates d_pre, emits
+//             per-chunk partial sums of the weight gradients.
+//             attloc_bwd_conv (b): transposed location conv -> d att_prev, dW_conv, and the fixed-order
+//             sum of the chunk partials -> d dec_proj, dgvec, dgb, dW_att.
+//   after the loop: attloc_denc (chunk x b): d_enc[b,t,:] = sum_i w_i[b,t] dc_i[b,:] in one pass
+//             instead of a 13 MB read-modify-write per step.
+// Wavefront shuffles do the dot products / softmax reductions; pre/enc rows are read with
+// row-contiguous (coalesced) loads, two frames in flight per wavefront.
 #include "common.h"
 
 namespace {
-constexpr int NT = 512;
-constexpr int NW = NT / 64;
-constexpr int CG = 5;       // channels per conv work item
+constexpr int TCH = 32;        // frames per workgroup
+constexpr int NTH = 256;       // threads per workgroup (4 wavefronts)
+constexpr int NWV = NTH / 64;
+constexpr int CG = 5;          // conv channels per work item
+constexpr int CMAX = 12;       // max conv channels held in registers
+constexpr int AIMAX = 5;       // max ceil(adim/64)
 
-struct Lds {
-  float *zs, *dp, *ap, *conv, *e, *w, *scr, *red;
-};
 __device__ __forceinline__ int cpad(int C) { return (C + 3) & ~3; }
 
-// common prologue: z -> LDS, att_prev (or uniform init) -> padded LDS, dec_proj, location conv
-__device__ void prologue(const Lds& L, const float* z, const float* att_prev, int hl, const float* w_decT, const float* w_conv,
-                         int b, int T, int D, int A, int C, int F) {
+// ---------------------------------------------------------------------------------------------
+// forward, part 1: energies for one chunk of frames
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restrict__ pre, const float* __restrict__ z,
+                                                            const float* __restrict__ att_prev, const int* __restrict__ hlens,
+                                                            const float* __restrict__ w_decT, const float* __restrict__ w_att,
+                                                            const float* __restrict__ w_conv, const float* __restrict__ gvec,
+                                                            const float* __restrict__ gvec_b, int B, int T, int D, int A, int C, int F,
+                                                            float* __restrict__ e_out, float* __restrict__ conv_out,
+                                                            float* __restrict__ dp_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int CP = cpad(C), Kf = 2 * F + 1;
+  float* zs = sm;                                 // [D]
+  float* dp = zs + ((D + 3) & ~3);                // [A]
+  float* ap = dp + ((A + 3) & ~3);                // [TCH + 2F]
+  float* cv = ap + ((TCH + 2 * F + 3) & ~3);      // [TCH][CP]
+  float* wcs = cv + TCH * CP;                     // [C][Kf]  filter taps (broadcast LDS reads in the tap loop)
+  const int b = blockIdx.y, t0 = blockIdx.x * TCH;
+  const int nt = min(TCH, T - t0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int Kf = 2 * F + 1, CP = cpad(C);
-  for (int d = tid; d < D; d += NT) L.zs[d] = z ? z[(long)b * D + d] : 0.f;
-  for (int i = tid; i < T + 2 * F; i += NT) {
-    int t = i - F;
+  const int hl = hlens[b];
+  for (int d = tid; d < D; d += NTH) zs[d] = z ? z[(long)b * D + d] : 0.f;
+  for (int i = tid; i < C * Kf; i += NTH) wcs[i] = w_conv[i];
+  for (int i = tid; i < TCH + 2 * F; i += NTH) {
+    int t = t0 + i - F;
     float v = 0.f;
     if (t >= 0 && t < T) v = att_prev ? att_prev[(long)b * T + t] : (t < hl ? 1.0f / (float)hl : 0.f);
-    L.ap[i] = v;
+    ap[i] = v;
   }
   __syncthreads();
-  // dec_proj[a] = sum_d W_dec[a][d] z[d]; w_decT is W_dec transposed (D, A): lanes run over a => coalesced,
-  // independent loads (8 in flight per lane)
-  for (int a = tid; a < A; a += NT) {
+  // dec_proj[a] = sum_d W_dec[a][d] z[d]  (w_decT = W_dec^T, lanes over a: coalesced, 8 loads in flight)
+  for (int a = tid; a < A; a += NTH) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int d = 0;
     for (; d + 8 <= D; d += 8) {
       float w0 = w_decT[(long)(d + 0) * A + a], w1 = w_decT[(long)(d + 1) * A + a], w2 = w_decT[(long)(d + 2) * A + a],
             w3 = w_decT[(long)(d + 3) * A + a], w4 = w_decT[(long)(d + 4) * A + a], w5 = w_decT[(long)(d + 5) * A + a],
             w6 = w_decT[(long)(d + 6) * A + a], w7 = w_decT[(long)(d + 7) * A + a];
-      s0 += w0 * L.zs[d] + w4 * L.zs[d + 4]; s1 += w1 * L.zs[d + 1] + w5 * L.zs[d + 5];
-      s2 += w2 * L.zs[d + 2] + w6 * L.zs[d + 6]; s3 += w3 * L.zs[d + 3] + w7 * L.zs[d + 7];
+      s0 += w0 * zs[d] + w4 * zs[d + 4]; s1 += w1 * zs[d + 1] + w5 * zs[d + 5];
+      s2 += w2 * zs[d + 2] + w6 * zs[d + 6]; s3 += w3 * zs[d + 3] + w7 * zs[d + 7];
     }
-    for (; d < D; ++d) s0 += w_decT[(long)d * A + a] * L.zs[d];
-    L.dp[a] = (s0 + s1) + (s2 + s3);
+    for (; d < D; ++d) s0 += w_decT[(long)d * A + a] * zs[d];
+    float v = (s0 + s1) + (s2 + s3);
+    dp[a] = v;
+    if (blockIdx.x == 0) dp_out[(long)b * A + a] = v;
   }
-  // conv[t][c] = sum_k w_conv[c][k] * ap[t+k]; a wavefront owns one channel group so the filter
-  // taps are wave-uniform (scalar loads), lanes run over t
-  const int ncg = (C + CG - 1) / CG;
-  const int tchunks = (T + 63) / 64;
-  for (int item = wid; item < ncg * tchunks; item += NW) {
-    int cg = item % ncg, tc = item / ncg;
-    int c0 = cg * CG;
-    int t = tc * 64 + lane;
-    float acc[CG];
+  // location conv for this chunk: conv[t][c] = sum_k w_conv[c][k] * att_prev[t + k - F]; a wavefront owns a
+  // channel group (wave-uniform taps => scalar loads); lanes 0-31 = frames with the first half of the
+  // taps, lanes 32-63 = the same frames with the second half
+  {
+    const int ncg = (C + CG - 1) / CG;
+    for (int item = wid; item < ncg; item += NWV) {
+      const int c0 = item * CG;
+      const int tl = lane & 31;
+      const int tt = tl < nt ? tl : 0;
+      float acc[CG];
 #pragma unroll
-    for (int cc = 0; cc < CG; ++cc) acc[cc] = 0.f;
-    int tt = t < T ? t : T - 1;
-#pragma unroll 8
-    for (int k = 0; k < Kf; ++k) {
-      float x = L.ap[tt + k];
+      for (int cc = 0; cc < CG; ++cc) acc[cc] = 0.f;
+      const int kh = (Kf + 1) / 2;
+      const int k0 = (lane >> 5) * kh, k1 = min(Kf, k0 + kh);
+#pragma unroll 4
+      for (int k = k0; k < k1; ++k) {
+        float x = ap[tt + k];
 #pragma unroll
-      for (int cc = 0; cc < CG; ++cc)
-        if (c0 + cc < C) acc[cc] += w_conv[(c0 + cc) * Kf + k] * x;
-    }
-    if (t < T) {
+        for (int cc = 0; cc < CG; ++cc)
+          if (c0 + cc < C) acc[cc] += wcs[(c0 + cc) * Kf + k] * x;
+      }
 #pragma unroll
-      for (int cc = 0; cc < CG; ++cc)
-        if (c0 + cc < C) L.conv[t * CP + c0 + cc] = acc[cc];
+      for (int cc = 0; cc < CG; ++cc) {
+        float v = acc[cc] + __shfl_xor(acc[cc], 32, 64);
+        if (lane < nt && c0 + cc < C) cv[lane * CP + c0 + cc] = v;
+      }
     }
   }
   __syncthreads();
-}
-
-template <int CMAX, int AIMAX>
-__global__ __launch_bounds__(NT) void attloc_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ enc,
-                                                        const float* __restrict__ z, const float* __restrict__ att_prev,
-                                                        const int* __restrict__ hlens, const float* __restrict__ w_decT,
-                                                        const float* __restrict__ w_att, const float* __restrict__ w_conv,
-                                                        const float* __restrict__ gvec, const float* __restrict__ gvec_b, int B,
-                                                        int T, int E, int D, int A, int C, int F, float* __restrict__ w_out,
-                                                        float* __restrict__ c_out, long ldc_out) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int CP = cpad(C);
-  Lds L;
-  float* p = sm;
-  L.zs = p; p += (D + 3) & ~3;
-  L.dp = p; p += (A + 3) & ~3;
-  L.ap = p; p += (T + 2 * F + 3) & ~3;
-  L.conv = p; p += T * CP;
-  L.e = p; p += (T + 3) & ~3;
-  L.w = p; p += (T + 3) & ~3;
-  L.red = p; p += 32;
-  L.scr = p;     // [ntg][E] context partials
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hl = hlens[b];
-  prologue(L, z, att_prev, hl, w_decT, w_conv, b, T, D, A, C, F);
-
-  // ---- energies: one wavefront per frame, lanes over the attention dimension ----
+  for (int i = tid; i < nt * C; i += NTH) {
+    int t = i / C, c = i % C;
+    conv_out[((long)b * T + t0 + t) * C + c] = cv[t * CP + c];
+  }
+  // energies: one wavefront per frame pair, lanes over the attention dimension
   float wa[AIMAX][CMAX], gv[AIMAX], dpv[AIMAX];
 #pragma unroll
   for (int i = 0; i < AIMAX; ++i) {
     int a = lane + 64 * i;
     gv[i] = a < A ? gvec[a] : 0.f;
-    dpv[i] = a < A ? L.dp[a] : 0.f;
+    dpv[i] = a < A ? dp[a] : 0.f;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) wa[i][c] = (a < A && c < C) ? w_att[a * C + c] : 0.f;
   }
   const float gb = gvec_b[0];
-  for (int tb = wid; tb < T; tb += 2 * NW) {       // two frames per iteration: 2*AIMAX independent row loads in flight
-    const int t0 = tb, t1 = tb + NW;
-    const bool h1 = t1 < T;
+  for (int tb = wid; tb < nt; tb += 2 * NWV) {
+    const int l0 = tb, l1 = tb + NWV;
+    const bool h1 = l1 < nt;
+    const float* pr0 = pre + ((long)b * T + t0 + l0) * A;
+    const float* pr1 = pre + ((long)b * T + t0 + (h1 ? l1 : l0)) * A;
     float p0[AIMAX], p1[AIMAX];
-    const float* pr0 = pre + ((long)b * T + t0) * A;
-    const float* pr1 = pre + ((long)b * T + (h1 ? t1 : t0)) * A;
 #pragma unroll
     for (int i = 0; i < AIMAX; ++i) {
       int a = lane + 64 * i;
       p0[i] = a < A ? pr0[a] : 0.f;
       p1[i] = a < A ? pr1[a] : 0.f;
     }
-    float cv0[CMAX], cv1[CMAX];
+    float c0v[CMAX], c1v[CMAX];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) { cv0[c] = c < C ? L.conv[t0 * CP + c] : 0.f; cv1[c] = (c < C && h1) ? L.conv[t1 * CP + c] : 0.f; }
+    for (int c = 0; c < CMAX; ++c) { c0v[c] = c < C ? cv[l0 * CP + c] : 0.f; c1v[c] = (c < C && h1) ? cv[l1 * CP + c] : 0.f; }
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < AIMAX; ++i) {
@@ -133,228 +145,285 @@ __global__ __launch_bounds__(NT) void attloc_fwd_kernel(const float* __restrict_
       if (a < A) {
         float x0 = p0[i] + dpv[i], x1 = p1[i] + dpv[i];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) { x0 += wa[i][c] * cv0[c]; x1 += wa[i][c] * cv1[c]; }
+        for (int c = 0; c < CMAX; ++c) { x0 += wa[i][c] * c0v[c]; x1 += wa[i][c] * c1v[c]; }
         s0 += gv[i] * tanhf_(x0);
         s1 += gv[i] * tanhf_(x1);
       }
     }
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
-    if (lane == 0) { L.e[t0] = s0 + gb; if (h1) L.e[t1] = s1 + gb; }
-  }
-  __syncthreads();
-  // ---- softmax(2e) over all T frames ----
-  float m = -3.0e38f;
-  for (int t = tid; t < T; t += NT) m = fmaxf(m, 2.f * L.e[t]);
-  m = block_max(m, L.red);
-  float sum = 0.f;
-  for (int t = tid; t < T; t += NT) { float v = __expf(2.f * L.e[t] - m); L.w[t] = v; sum += v; }
-  sum = block_sum(sum, L.red);
-  float inv = 1.0f / sum;
-  __syncthreads();
-  for (int t = tid; t < T; t += NT) { float v = L.w[t] * inv; L.w[t] = v; w_out[(long)b * T + t] = v; }
-  __syncthreads();
-  // ---- context c = sum_t w[t] enc[b,t,:] ; float4 columns, frame groups reduced through LDS ----
-  const int per = E / 4;          // host guarantees per <= NT
-  const int ntg = NT / per;
-  if (tid < ntg * per) {
-    const int tg = tid / per, d4 = tid % per;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const f32x4* er = reinterpret_cast<const f32x4*>(enc + (long)b * T * E) + d4;
-    int t = tg;
-    for (; t + 3 * ntg < T; t += 4 * ntg) {          // 4 independent row loads in flight
-      f32x4 v0 = er[(long)t * per], v1 = er[(long)(t + ntg) * per], v2 = er[(long)(t + 2 * ntg) * per], v3 = er[(long)(t + 3 * ntg) * per];
-      acc += v0 * L.w[t] + v1 * L.w[t + ntg] + v2 * L.w[t + 2 * ntg] + v3 * L.w[t + 3 * ntg];
+    if (lane == 0) {
+      e_out[(long)b * T + t0 + l0] = s0 + gb;
+      if (h1) e_out[(long)b * T + t0 + l1] = s1 + gb;
     }
-    for (; t < T; t += ntg) acc += er[(long)t * per] * L.w[t];
-    *reinterpret_cast<f32x4*>(L.scr + (long)tg * E + d4 * 4) = acc;
-  }
-  __syncthreads();
-  for (int d = tid; d < E; d += NT) {
-    float s = 0.f;
-    for (int g = 0; g < ntg; ++g) s += L.scr[(long)g * E + d];
-    c_out[(long)b * ldc_out + d] = s;
   }
 }
 
-template <int CMAX, int AIMAX>
-__global__ __launch_bounds__(NT) void attloc_bwd_kernel(
-    const float* __restrict__ pre, const float* __restrict__ enc, const float* __restrict__ z, const float* __restrict__ att_prev,
-    const float* __restrict__ w_cur, const int* __restrict__ hlens, const float* __restrict__ w_decT, const float* __restrict__ w_att,
-    const float* __restrict__ w_conv, const float* __restrict__ gvec, const float* __restrict__ dc, long ld_dc,
-    const float* __restrict__ dw_in, int B, int T, int E, int D, int A, int C, int F, float* d_pre, float* d_enc,
-    float* __restrict__ d_att_prev, float* __restrict__ d_decproj, float* partials) {
+// ---------------------------------------------------------------------------------------------
+// forward, part 2: softmax over all T (recomputed per workgroup) + context for a 64-column slice
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void attloc_context_kernel(const float* __restrict__ e, const float* __restrict__ enc, int B, int T,
+                                                             int E, float* __restrict__ w_out, float* __restrict__ c_out, long ldc_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int CP = cpad(C), Kf = 2 * F + 1;
-  Lds L;
-  float* p = sm;
-  L.zs = p; p += (D + 3) & ~3;
-  L.dp = p; p += (A + 3) & ~3;
-  L.ap = p; p += (T + 2 * F + 3) & ~3;
-  L.conv = p; p += T * CP;
-  L.e = p; p += (T + 3) & ~3;       // dw / de
-  L.w = p; p += (T + 3) & ~3;
-  L.red = p; p += 32;
-  float* dcs = p; p += (E + 3) & ~3;                 // dc[b,:]
-  float* dcp = p; p += (T + 2 * F) * CP;             // d_conv, zero padded by F frames each side
-  float* accum = p; p += A * (CMAX + 2);             // [A][ddp | dgv | dwa[C]]
-  float* scr = p;                                    // [2][C*Kf] dw_conv halves / [ncg][T] d_att_prev partials
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hl = hlens[b];
-  prologue(L, z, att_prev, hl, w_decT, w_conv, b, T, D, A, C, F);
-  for (int d = tid; d < E; d += NT) dcs[d] = dc[(long)b * ld_dc + d];
-  for (int t = tid; t < T; t += NT) L.w[t] = w_cur[(long)b * T + t];
-  for (int i = tid; i < (T + 2 * F) * CP; i += NT) dcp[i] = 0.f;
-  for (int i = tid; i < A * (CMAX + 2); i += NT) accum[i] = 0.f;
+  float* w = sm;                         // [T]
+  float* red = w + ((T + 3) & ~3);       // [32]
+  float* scr = red + 32;                 // [16][64]
+  const int b = blockIdx.y, d0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  float m = -3.0e38f;
+  for (int t = tid; t < T; t += NTH) { float v = 2.f * e[(long)b * T + t]; w[t] = v; m = fmaxf(m, v); }
+  m = block_max(m, red);
+  float sum = 0.f;
+  for (int t = tid; t < T; t += NTH) { float v = __expf(w[t] - m); w[t] = v; sum += v; }
+  sum = block_sum(sum, red);
+  const float inv = 1.0f / sum;
   __syncthreads();
-  // ---- 1. dw[t] = dw_in[t] + dc . enc[t] ; d_enc[t] += w[t] dc ----
-  {
+  for (int t = tid; t < T; t += NTH) {
+    float v = w[t] * inv;
+    w[t] = v;
+    if (blockIdx.x == 0) w_out[(long)b * T + t] = v;
+  }
+  __syncthreads();
+  // 16 float4 columns x 16 frame groups
+  const int c4 = tid & 15, tg = tid >> 4;
+  const int ncol = min(64, E - d0);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c4 * 4 < ncol) {
+    const f32x4* er = reinterpret_cast<const f32x4*>(enc + (long)b * T * E + d0) + c4;
     const int per = E / 4;
-    for (int tb = wid; tb < T; tb += 2 * NW) {     // two frames per iteration
-      const int t0 = tb, t1 = tb + NW;
-      const bool h1 = t1 < T;
-      const f32x4* er0 = reinterpret_cast<const f32x4*>(enc + ((long)b * T + t0) * E);
-      const f32x4* er1 = reinterpret_cast<const f32x4*>(enc + ((long)b * T + (h1 ? t1 : t0)) * E);
-      f32x4* der0 = reinterpret_cast<f32x4*>(d_enc + ((long)b * T + t0) * E);
-      f32x4* der1 = reinterpret_cast<f32x4*>(d_enc + ((long)b * T + (h1 ? t1 : t0)) * E);
-      const float wt0 = L.w[t0], wt1 = h1 ? L.w[t1] : 0.f;
-      float s0 = 0.f, s1 = 0.f;
-      for (int d4 = lane; d4 < per; d4 += 64) {
-        f32x4 v0 = er0[d4], v1 = er1[d4], o0 = der0[d4], o1 = der1[d4];
-        f32x4 g = *reinterpret_cast<const f32x4*>(dcs + d4 * 4);
-        s0 += v0[0] * g[0] + v0[1] * g[1] + v0[2] * g[2] + v0[3] * g[3];
-        s1 += v1[0] * g[0] + v1[1] * g[1] + v1[2] * g[2] + v1[3] * g[3];
-        der0[d4] = o0 + g * wt0;
-        if (h1) der1[d4] = o1 + g * wt1;
-      }
-      s0 = wave_sum(s0);
-      s1 = wave_sum(s1);
-      if (lane == 0) {
-        L.e[t0] = s0 + (dw_in ? dw_in[(long)b * T + t0] : 0.f);
-        if (h1) L.e[t1] = s1 + (dw_in ? dw_in[(long)b * T + t1] : 0.f);
-      }
+    int t = tg;
+    for (; t + 48 < T; t += 64) {
+      f32x4 v0 = er[(long)t * per], v1 = er[(long)(t + 16) * per], v2 = er[(long)(t + 32) * per], v3 = er[(long)(t + 48) * per];
+      acc += v0 * w[t] + v1 * w[t + 16] + v2 * w[t + 32] + v3 * w[t + 48];
+    }
+    for (; t < T; t += 16) acc += er[(long)t * per] * w[t];
+  }
+  *reinterpret_cast<f32x4*>(scr + tg * 64 + c4 * 4) = acc;
+  __syncthreads();
+  if (tid < ncol) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += scr[g * 64 + tid];
+    c_out[(long)b * ldc_out + d0 + tid] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 1: per frame chunk
+// partial slab layout per (b, chunk): [ddp(A) | dgv(A) | dwa(A*C) | dgb(1)]
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int slab_floats(int A, int C) { return A * (2 + C) + 1; }
+
+__global__ __launch_bounds__(NTH) void attloc_bwd_frames_kernel(
+    const float* __restrict__ pre, const float* __restrict__ enc, const float* __restrict__ w_cur, const float* __restrict__ dw_in,
+    const float* __restrict__ dc, long ld_dc, const float* __restrict__ cx, const float* __restrict__ conv_in,
+    const float* __restrict__ dp_in, const float* __restrict__ w_att, const float* __restrict__ gvec, int B, int T, int E, int A, int C,
+    float* d_pre, float* __restrict__ d_conv, float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* dcs = sm;                              // [E]
+  float* de = dcs + ((E + 3) & ~3);             // [TCH]
+  float* red = de + TCH;                        // [32]
+  float* accum = red + 32;                      // [A][2+CMAX]
+  const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * TCH;
+  const int nt = min(TCH, T - t0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // softmax normaliser  s = sum_t w[t] dw[t] = w . dw_in + dc . c
+  float part = 0.f;
+  for (int d = tid; d < E; d += NTH) { float g = dc[(long)b * ld_dc + d]; dcs[d] = g; part += g * cx[(long)b * E + d]; }
+  if (dw_in)
+    for (int t = tid; t < T; t += NTH) part += w_cur[(long)b * T + t] * dw_in[(long)b * T + t];
+  for (int i = tid; i < A * (2 + CMAX); i += NTH) accum[i] = 0.f;
+  const float sdot = block_sum(part, red);     // (contains the __syncthreads that publish dcs / accum)
+  // de[t] = 2 w[t] (dw_in[t] + dc . enc[t] - s) for the frames of this chunk: one wavefront per frame pair
+  const int per = E / 4;
+  for (int tb = wid; tb < nt; tb += 2 * NWV) {
+    const int l0 = tb, l1 = tb + NWV;
+    const bool h1 = l1 < nt;
+    const f32x4* er0 = reinterpret_cast<const f32x4*>(enc + ((long)b * T + t0 + l0) * E);
+    const f32x4* er1 = reinterpret_cast<const f32x4*>(enc + ((long)b * T + t0 + (h1 ? l1 : l0)) * E);
+    float s0 = 0.f, s1 = 0.f;
+    for (int d4 = lane; d4 < per; d4 += 64) {
+      f32x4 v0 = er0[d4], v1 = er1[d4];
+      f32x4 g = *reinterpret_cast<const f32x4*>(dcs + d4 * 4);
+      s0 += v0[0] * g[0] + v0[1] * g[1] + v0[2] * g[2] + v0[3] * g[3];
+      s1 += v1[0] * g[0] + v1[1] * g[1] + v1[2] * g[2] + v1[3] * g[3];
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+      long i0 = (long)b * T + t0 + l0;
+      de[l0] = 2.f * w_cur[i0] * (s0 + (dw_in ? dw_in[i0] : 0.f) - sdot);
+      if (h1) { long i1 = (long)b * T + t0 + l1; de[l1] = 2.f * w_cur[i1] * (s1 + (dw_in ? dw_in[i1] : 0.f) - sdot); }
     }
   }
   __syncthreads();
-  // ---- 2. softmax backward (scaling 2) ----
-  float sd = 0.f;
-  for (int t = tid; t < T; t += NT) sd += L.w[t] * L.e[t];
-  sd = block_sum(sd, L.red);
-  __syncthreads();
-  for (int t = tid; t < T; t += NT) L.e[t] = 2.f * L.w[t] * (L.e[t] - sd);     // de[t]
-  __syncthreads();
-  // ---- 3. energy backward ----
+  // energy backward
   float wa[AIMAX][CMAX], gv[AIMAX], dpv[AIMAX], ddp[AIMAX], dgv[AIMAX], dwa[AIMAX][CMAX];
 #pragma unroll
   for (int i = 0; i < AIMAX; ++i) {
     int a = lane + 64 * i;
     gv[i] = a < A ? gvec[a] : 0.f;
-    dpv[i] = a < A ? L.dp[a] : 0.f;
+    dpv[i] = a < A ? dp_in[(long)b * A + a] : 0.f;
     ddp[i] = 0.f; dgv[i] = 0.f;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) { wa[i][c] = (a < A && c < C) ? w_att[a * C + c] : 0.f; dwa[i][c] = 0.f; }
   }
   float dgb = 0.f;
-  for (int t = wid; t < T; t += NW) {
-    float cv[CMAX], dcv[CMAX];
+  for (int l = wid; l < nt; l += NWV) {
+    const long row = (long)b * T + t0 + l;
+    const float* pr = pre + row * A;
+    float* dpr = d_pre + row * A;
+    float pv[AIMAX], dv[AIMAX];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) { cv[c] = c < C ? L.conv[t * CP + c] : 0.f; dcv[c] = 0.f; }
-    const float* pr = pre + ((long)b * T + t) * A;
-    float* dpr = d_pre + ((long)b * T + t) * A;
-    const float det = L.e[t];
+    for (int i = 0; i < AIMAX; ++i) {
+      int a = lane + 64 * i;
+      pv[i] = a < A ? pr[a] : 0.f;
+      dv[i] = a < A ? dpr[a] : 0.f;
+    }
+    float cvv[CMAX], dcv[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) { cvv[c] = c < C ? conv_in[row * C + c] : 0.f; dcv[c] = 0.f; }
+    const float det = de[l];
     dgb += det;
 #pragma unroll
     for (int i = 0; i < AIMAX; ++i) {
       int a = lane + 64 * i;
       if (a < A) {
-        float x = pr[a] + dpv[i];
+        float x = pv[i] + dpv[i];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) x += wa[i][c] * cv[c];
+        for (int c = 0; c < CMAX; ++c) x += wa[i][c] * cvv[c];
         float u = tanhf_(x);
         float du = det * gv[i] * (1.f - u * u);
-        dpr[a] += du;
+        dpr[a] = dv[i] + du;
         ddp[i] += du;
         dgv[i] += det * u;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) { dwa[i][c] += du * cv[c]; dcv[c] += du * wa[i][c]; }
+        for (int c = 0; c < CMAX; ++c) { dwa[i][c] += du * cvv[c]; dcv[c] += du * wa[i][c]; }
       }
     }
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
       if (c < C) {
         float v = wave_sum(dcv[c]);
-        if (lane == 0) dcp[(t + F) * CP + c] = v;
+        if (lane == 0) d_conv[row * C + c] = v;
       }
     }
   }
-  // fixed-order cross-wavefront reduction of the per-lane partial sums
-  for (int w = 0; w < NW; ++w) {
+  // fixed-order cross-wavefront reduction, then one slab per (b, chunk)
+  for (int w = 0; w < NWV; ++w) {
     if (wid == w) {
 #pragma unroll
       for (int i = 0; i < AIMAX; ++i) {
         int a = lane + 64 * i;
         if (a < A) {
-          float* q = accum + a * (CMAX + 2);
+          float* q = accum + a * (2 + CMAX);
           q[0] += ddp[i]; q[1] += dgv[i];
 #pragma unroll
           for (int c = 0; c < CMAX; ++c) if (c < C) q[2 + c] += dwa[i][c];
         }
       }
-      if (lane == 0) L.red[16 + w] = dgb;
+      if (lane == 0) red[16 + w] = dgb;
     }
     __syncthreads();
   }
-  const int P_GB = A, P_WATT = A + 1, P_WCONV = A + 1 + A * C;
-  float* part = partials + (long)b * (A + 1 + A * C + C * Kf);
-  for (int a = tid; a < A; a += NT) {
-    const float* q = accum + a * (CMAX + 2);
-    d_decproj[(long)b * A + a] = q[0];
-    part[a] += q[1];
-    for (int c = 0; c < C; ++c) part[P_WATT + a * C + c] += q[2 + c];
+  float* slab = slabs + ((long)b * gridDim.x + chunk) * slab_floats(A, C);
+  for (int a = tid; a < A; a += NTH) {
+    const float* q = accum + a * (2 + CMAX);
+    slab[a] = q[0];
+    slab[A + a] = q[1];
+    for (int c = 0; c < C; ++c) slab[2 * A + a * C + c] = q[2 + c];
   }
   if (tid == 0) {
     float s = 0.f;
-    for (int w = 0; w < NW; ++w) s += L.red[16 + w];
-    part[P_GB] += s;
+    for (int w = 0; w < NWV; ++w) s += red[16 + w];
+    slab[A * (2 + C)] = s;
   }
-  // ---- 4a. d_att_prev[t'] = sum_{c,k} w_conv[c][k] * d_conv[t'-k+F][c] ----
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 2 (per utterance): transposed conv, dW_conv, reduction of the chunk slabs
+// partials layout per utterance: [gvec(A) | gvec_b(1) | w_att(A*C) | w_conv(C*Kf)]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void attloc_bwd_conv_kernel(const float* __restrict__ att_prev, const int* __restrict__ hlens,
+                                                              const float* __restrict__ w_conv, const float* __restrict__ d_conv,
+                                                              const float* __restrict__ slabs, int nchunk, int B, int T, int A, int C,
+                                                              int F, float* __restrict__ d_att_prev, float* __restrict__ d_decproj,
+                                                              float* partials) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int CP = cpad(C), Kf = 2 * F + 1;
+  float* ap = sm;                                 // [T + 2F]
+  float* dcp = ap + ((T + 2 * F + 3) & ~3);       // [(T + 2F)][CP]   d_conv, zero padded by F frames each side
+  float* scr = dcp + (T + 2 * F) * CP;            // [ncg][T]  |  [2][C*Kf]
+  const int scr_n = max(2 * C * Kf, ((C + CG - 1) / CG) * T);
+  float* wcs = scr + scr_n;                       // [C][Kf]
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = hlens[b];
+  for (int i = tid; i < C * Kf; i += NTH) wcs[i] = w_conv[i];
+  for (int i = tid; i < T + 2 * F; i += NTH) {
+    int t = i - F;
+    float v = 0.f;
+    if (t >= 0 && t < T) v = att_prev ? att_prev[(long)b * T + t] : (t < hl ? 1.0f / (float)hl : 0.f);
+    ap[i] = v;
+  }
+  for (int i = tid; i < (T + 2 * F) * CP; i += NTH) {
+    int r = i / CP, c = i % CP, t = r - F;
+    dcp[i] = (t >= 0 && t < T && c < C) ? d_conv[((long)b * T + t) * C + c] : 0.f;
+  }
+  __syncthreads();
+  const int P_GB = A, P_WATT = A + 1, P_WCONV = A + 1 + A * C;
+  float* part = partials + (long)b * (A + 1 + A * C + C * Kf);
+  const int SF = slab_floats(A, C);
+  const float* sl = slabs + (long)b * nchunk * SF;
+  // fixed-order sum of the chunk slabs
+  for (int i = tid; i < SF; i += NTH) {
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += sl[(long)k * SF + i];
+    if (i < A) d_decproj[(long)b * A + i] = s;
+    else if (i < 2 * A) part[i - A] += s;
+    else if (i < A * (2 + C)) part[P_WATT + (i - 2 * A)] += s;
+    else part[P_GB] += s;
+  }
+  // d_att_prev[t'] = sum_{c,k} w_conv[c][k] * d_conv[t'-k+F][c]
   const int ncg = (C + CG - 1) / CG;
   const int tchunks = (T + 63) / 64;
   if (d_att_prev) {
-    for (int item = wid; item < ncg * tchunks; item += NW) {
+    for (int item = wid; item < ncg * tchunks; item += NWV) {
       int cg = item % ncg, tc = item / ncg;
       int c0 = cg * CG;
       int t = tc * 64 + lane;
       int tt = t < T ? t : T - 1;
       float acc = 0.f;
+#pragma unroll 4
       for (int k = 0; k < Kf; ++k) {
         const float* q = dcp + (tt - k + 2 * F) * CP + c0;
 #pragma unroll
         for (int cc = 0; cc < CG; ++cc)
-          if (c0 + cc < C) acc += w_conv[(c0 + cc) * Kf + k] * q[cc];
+          if (c0 + cc < C) acc += wcs[(c0 + cc) * Kf + k] * q[cc];
       }
       if (t < T) scr[cg * T + t] = acc;
     }
     __syncthreads();
-    for (int t = tid; t < T; t += NT) {
+    for (int t = tid; t < T; t += NTH) {
       float s = 0.f;
       for (int g = 0; g < ncg; ++g) s += scr[g * T + t];
       d_att_prev[(long)b * T + t] = s;
     }
     __syncthreads();
   }
-  // ---- 4b. dw_conv[c][k] = sum_t d_conv[t][c] * ap[t+k] ; two threads per tap split the frames ----
+  // dw_conv[c][k] = sum_t d_conv[t][c] * att_prev[t+k-F] ; two threads per tap split the frames
   {
     const int half = (T + 1) / 2;
-    for (int item = tid; item < 2 * Kf; item += NT) {
+    for (int item = tid; item < 2 * Kf; item += NTH) {
       int k = item % Kf, hf = item / Kf;
-      int t0 = hf * half, t1 = min(T, t0 + half);
+      int ta = hf * half, tb = min(T, ta + half);
       float acc[CMAX];
 #pragma unroll
       for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
-      for (int t = t0; t < t1; ++t) {
-        float x = L.ap[t + k];
+      for (int t = ta; t < tb; ++t) {
+        float x = ap[t + k];
         const float* q = dcp + (t + F) * CP;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) if (c < C) acc[c] += q[c] * x;
@@ -363,74 +432,115 @@ __global__ __launch_bounds__(NT) void attloc_bwd_kernel(
       for (int c = 0; c < CMAX; ++c) if (c < C) scr[hf * (C * Kf) + c * Kf + k] = acc[c];
     }
     __syncthreads();
-    for (int i = tid; i < C * Kf; i += NT) part[P_WCONV + i] += scr[i] + scr[C * Kf + i];
+    for (int i = tid; i < C * Kf; i += NTH) part[P_WCONV + i] += scr[i] + scr[C * Kf + i];
   }
 }
 
-size_t fwd_lds_floats(int T, int E, int D, int A, int C, int F) {
-  int CP = (C + 3) & ~3;
-  int per = E / 4;
-  int ntg = NT / per;
-  return (size_t)((D + 3) & ~3) + ((A + 3) & ~3) + ((T + 2 * F + 3) & ~3) + (size_t)T * CP + 2 * ((T + 3) & ~3) + 32 + (size_t)ntg * E + 16;
+// d_enc[b,t,:] = beta*d_enc + sum_i w[i,b,t] * dc[i,b,:]   (after the decoder loop)
+__global__ __launch_bounds__(NTH) void attloc_denc_kernel(const float* __restrict__ w_all, const float* __restrict__ dc_all, int L1, int B,
+                                                          int T, int E, float* d_enc, float beta) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // w chunk [L1][TCH]
+  const int b = blockIdx.y, t0 = blockIdx.x * TCH;
+  const int nt = min(TCH, T - t0);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < L1 * TCH; i += NTH) {
+    int s = i / TCH, l = i % TCH;
+    sm[i] = l < nt ? w_all[((long)s * B + b) * T + t0 + l] : 0.f;
+  }
+  __syncthreads();
+  for (int d = tid; d < E; d += NTH) {
+    float acc[TCH];
+#pragma unroll
+    for (int l = 0; l < TCH; ++l) acc[l] = 0.f;
+    for (int s = 0; s < L1; ++s) {
+      float g = dc_all[((long)s * B + b) * E + d];
+#pragma unroll
+      for (int l = 0; l < TCH; ++l) acc[l] += sm[s * TCH + l] * g;
+    }
+#pragma unroll
+    for (int l = 0; l < TCH; ++l)
+      if (l < nt) {
+        float* q = d_enc + ((long)b * T + t0 + l) * E + d;
+        *q = (beta != 0.f ? beta * (*q) : 0.f) + acc[l];
+      }
+  }
 }
-size_t bwd_lds_floats(int T, int E, int D, int A, int C, int F, int CMAX) {
-  int CP = (C + 3) & ~3, Kf = 2 * F + 1;
-  size_t scr = (size_t)2 * C * Kf;
-  size_t scr2 = (size_t)((C + CG - 1) / CG) * T;
-  if (scr2 > scr) scr = scr2;
-  return (size_t)((D + 3) & ~3) + ((A + 3) & ~3) + ((T + 2 * F + 3) & ~3) + (size_t)T * CP + 2 * ((T + 3) & ~3) + 32 + ((E + 3) & ~3) +
-         (size_t)(T + 2 * F) * CP + (size_t)A * (CMAX + 2) + scr + 16;
-}
+
+inline int nchunks(int T) { return (T + TCH - 1) / TCH; }
 }  // namespace
 
 extern "C" size_t re2e_attloc_partial_floats(int adim, int chans, int filts) {
   return (size_t)adim + 1 + (size_t)adim * chans + (size_t)chans * (2 * filts + 1);
 }
 
+extern "C" size_t re2e_attloc_workspace_bytes(int B, int T, int adim, int chans) {
+  // d_conv [B][T][C] + chunk slabs [B][nchunk][A*(2+C)+1]
+  return ((size_t)B * T * chans + (size_t)B * nchunks(T) * ((size_t)adim * (2 + chans) + 1)) * sizeof(float);
+}
+
+static int check_dims(const char* fn, int B, int T, int E, int D, int A, int C, int F) {
+  if (!(B > 0 && T > 0 && E > 0 && E % 4 == 0 && D > 0 && A > 0 && C > 0 && F >= 0)) { re2e_set_error("%s: bad shape", fn); return RE2E_EINVAL; }
+  if (C > CMAX || A > 64 * AIMAX) {
+    re2e_set_error("%s: aconv_chans <= %d and adim <= %d supported (got %d, %d)", fn, CMAX, 64 * AIMAX, C, A);
+    return RE2E_EUNSUPPORTED;
+  }
+  return RE2E_OK;
+}
+
 extern "C" int re2e_attloc_fwd(const float* pre, const float* enc, const float* z, const float* att_prev, const int* hlens,
                                const float* w_decT, const float* w_att, const float* w_conv, const float* gvec, const float* gvec_b,
                                int B, int T, int eprojs, int dunits, int adim, int chans, int filts, float* w_out, float* c_out,
-                               long ldc_out, hipStream_t stream) {
-  RE2E_CHECK_ARG(pre && enc && hlens && w_decT && w_att && w_conv && gvec && gvec_b && w_out && c_out, "null arg");
-  RE2E_CHECK_ARG(B > 0 && T > 0 && eprojs > 0 && eprojs % 4 == 0 && eprojs <= 2048 && dunits > 0 && adim > 0 && chans > 0 && filts >= 0, "bad shape");
-  if (chans > 16 || adim > 512) { re2e_set_error("re2e_attloc_fwd: chans<=16 and adim<=512 supported"); return RE2E_EUNSUPPORTED; }
-  size_t lds = fwd_lds_floats(T, eprojs, dunits, adim, chans, filts) * sizeof(float);
-  if (lds > 160 * 1024) { re2e_set_error("re2e_attloc_fwd: T=%d needs %zu bytes of LDS (>160 KiB)", T, lds); return RE2E_EUNSUPPORTED; }
-  if (chans <= 12 && adim <= 320) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_fwd_kernel<12, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attloc_fwd_kernel<12, 5>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, hlens, w_decT, w_att, w_conv,
-                       gvec, gvec_b, B, T, eprojs, dunits, adim, chans, filts, w_out, c_out, ldc_out);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_fwd_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attloc_fwd_kernel<16, 8>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, hlens, w_decT, w_att, w_conv,
-                       gvec, gvec_b, B, T, eprojs, dunits, adim, chans, filts, w_out, c_out, ldc_out);
-  }
+                               long ldc_out, float* conv_out, float* dp_out, float* e_scratch, hipStream_t stream) {
+  RE2E_CHECK_ARG(pre && enc && hlens && w_decT && w_att && w_conv && gvec && gvec_b && w_out && c_out && conv_out && dp_out && e_scratch,
+                 "null arg");
+  int rc = check_dims("re2e_attloc_fwd", B, T, eprojs, dunits, adim, chans, filts);
+  if (rc) return rc;
+  const int CP = (chans + 3) & ~3;
+  size_t lds1 = (size_t)(((dunits + 3) & ~3) + ((adim + 3) & ~3) + ((TCH + 2 * filts + 3) & ~3) + TCH * CP + chans * (2 * filts + 1) + 16) *
+                sizeof(float);
+  hipLaunchKernelGGL(attloc_energy_kernel, dim3(nchunks(T), B), dim3(NTH), lds1, stream, pre, z, att_prev, hlens, w_decT, w_att, w_conv, gvec,
+                     gvec_b, B, T, dunits, adim, chans, filts, e_scratch, conv_out, dp_out);
+  size_t lds2 = (size_t)(((T + 3) & ~3) + 32 + 16 * 64 + 16) * sizeof(float);
+  if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_context_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  hipLaunchKernelGGL(attloc_context_kernel, dim3((eprojs + 63) / 64, B), dim3(NTH), lds2, stream, (const float*)e_scratch, enc, B, T, eprojs, w_out,
+                     c_out, ldc_out);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
 
-extern "C" int re2e_attloc_bwd(const float* pre, const float* enc, const float* z, const float* att_prev, const float* w_cur,
-                               const int* hlens, const float* w_decT, const float* w_att, const float* w_conv, const float* gvec,
-                               const float* dc, long ld_dc, const float* dw_in, int B, int T, int eprojs, int dunits, int adim,
-                               int chans, int filts, float* d_pre, float* d_enc, float* d_att_prev, float* d_decproj,
-                               float* partials, hipStream_t stream) {
-  RE2E_CHECK_ARG(pre && enc && w_cur && hlens && w_decT && w_att && w_conv && gvec && dc && d_pre && d_enc && d_decproj && partials, "null arg");
-  RE2E_CHECK_ARG(B > 0 && T > 0 && eprojs > 0 && eprojs % 4 == 0 && eprojs <= 2048 && dunits > 0 && adim > 0 && chans > 0 && filts >= 0, "bad shape");
-  if (chans > 16 || adim > 512) { re2e_set_error("re2e_attloc_bwd: chans<=16 and adim<=512 supported"); return RE2E_EUNSUPPORTED; }
-  bool small = chans <= 12 && adim <= 320;
-  size_t lds = bwd_lds_floats(T, eprojs, dunits, adim, chans, filts, small ? 12 : 16) * sizeof(float);
-  if (lds > 160 * 1024) { re2e_set_error("re2e_attloc_bwd: T=%d needs %zu bytes of LDS (>160 KiB)", T, lds); return RE2E_EUNSUPPORTED; }
-  if (small) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_bwd_kernel<12, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attloc_bwd_kernel<12, 5>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, w_cur, hlens, w_decT, w_att,
-                       w_conv, gvec, dc, ld_dc, dw_in, B, T, eprojs, dunits, adim, chans, filts, d_pre, d_enc, d_att_prev, d_decproj,
-                       partials);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_bwd_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attloc_bwd_kernel<16, 8>), dim3(B), dim3(NT), lds, stream, pre, enc, z, att_prev, w_cur, hlens, w_decT, w_att,
-                       w_conv, gvec, dc, ld_dc, dw_in, B, T, eprojs, dunits, adim, chans, filts, d_pre, d_enc, d_att_prev, d_decproj,
-                       partials);
-  }
+extern "C" int re2e_attloc_bwd(const float* pre, const float* enc, const float* att_prev, const float* w_cur, const int* hlens,
+                               const float* w_att, const float* w_conv, const float* gvec, const float* conv_in, const float* dp_in,
+                               const float* cx_in, const float* dc, long ld_dc, const float* dw_in, int B, int T, int eprojs, int adim,
+                               int chans, int filts, float* d_pre, float* d_att_prev, float* d_decproj, float* partials, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(pre && enc && w_cur && hlens && w_att && w_conv && gvec && conv_in && dp_in && cx_in && dc && d_pre && d_decproj && partials &&
+                     workspace, "null arg");
+  int rc = check_dims("re2e_attloc_bwd", B, T, eprojs, 1, adim, chans, filts);
+  if (rc) return rc;
+  RE2E_CHECK_ARG(workspace_bytes >= re2e_attloc_workspace_bytes(B, T, adim, chans), "workspace too small");
+  const int CP = (chans + 3) & ~3, Kf = 2 * filts + 1, nch = nchunks(T);
+  float* d_conv = (float*)workspace;
+  float* slabs = d_conv + (size_t)B * T * chans;
+  size_t lds1 = (size_t)(((eprojs + 3) & ~3) + TCH + 32 + adim * (2 + CMAX) + 16) * sizeof(float);
+  hipLaunchKernelGGL(attloc_bwd_frames_kernel, dim3(nch, B), dim3(NTH), lds1, stream, pre, enc, w_cur, dw_in, dc, ld_dc, cx_in, conv_in, dp_in, w_att,
+                     gvec, B, T, eprojs, adim, chans, d_pre, d_conv, slabs);
+  size_t scr = (size_t)2 * chans * Kf, scr2 = (size_t)((chans + CG - 1) / CG) * T;
+  if (scr2 > scr) scr = scr2;
+  size_t lds2 = (size_t)(((T + 2 * filts + 3) & ~3) + (size_t)(T + 2 * filts) * CP + scr + (size_t)chans * Kf + 16) * sizeof(float);
+  if (lds2 > 160 * 1024) { re2e_set_error("re2e_attloc_bwd: T=%d needs %zu bytes of LDS (>160 KiB)", T, lds2); return RE2E_EUNSUPPORTED; }
+  if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_bwd_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  hipLaunchKernelGGL(attloc_bwd_conv_kernel, dim3(B), dim3(NTH), lds2, stream, att_prev, hlens, w_conv, (const float*)d_conv, (const float*)slabs, nch,
+                     B, T, adim, chans, filts, d_att_prev, d_decproj, partials);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+extern "C" int re2e_attloc_denc(const float* w_all, const float* dc_all, int L1, int B, int T, int eprojs, float* d_enc, float beta,
+                                hipStream_t stream) {
+  RE2E_CHECK_ARG(w_all && dc_all && d_enc && L1 > 0 && B > 0 && T > 0 && eprojs > 0, "bad args");
+  size_t lds = (size_t)L1 * TCH * sizeof(float);
+  RE2E_CHECK_ARG(lds <= 64 * 1024, "too many decoder steps for the LDS weight tile");
+  hipLaunchKernelGGL(attloc_denc_kernel, dim3(nchunks(T), B), dim3(NTH), lds, stream, w_all, dc_all, L1, B, T, eprojs, d_enc, beta);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

@@ -29,15 +29,17 @@ __device__ __forceinline__ void store_acc(float* red, const f32x16& acc, int lan
 
 // acc += sum_q A_q B_q with ALL fragment loads of a batch of 8 k-groups issued before the first MFMA:
 // the step kernels are latency-bound, a load -> MFMA dependency per k-group costs one L2 round trip each.
-__device__ __forceinline__ void mfma_chain(const f32x4* __restrict__ ap, const f32x4* __restrict__ bp, int QN, f32x16& acc) {
+__device__ __forceinline__ void mfma_chain(const f32x4* __restrict__ ap, const f32x4* __restrict__ bp, int QN, f32x16& acc,
+                                           int bstride = 64, bool bvalid = true) {
   constexpr int CH = 8;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   for (int q0 = 0; q0 < QN; q0 += CH) {
     f32x4 a[CH], b[CH];
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       int q = q0 + u < QN ? q0 + u : QN - 1;
       a[u] = ap[(long)q * 64];
-      b[u] = bp[(long)q * 64];
+      b[u] = bvalid ? bp[(long)q * bstride] : zero;
     }
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
@@ -66,14 +68,17 @@ __global__ void pack_w_fwd_kernel(const float* __restrict__ whh, float* __restri
     wf[e] = whh[((long)((n >> 3) * H + 8 * x + (n & 7))) * H + 8 * Q + 4 * h + i];
   }
 }
-__global__ void pack_w_bwd_kernel(const float* __restrict__ whh, float* __restrict__ wt, int H) {
-  // wt[((x*(H/2) + Q)*64 + lane)*4 + i] = whh[(8Q + 4h + i)*H + 32x + (lane&31)]   (0 beyond H)
-  int nx = (H + 31) / 32;
-  long tot = (long)nx * (H / 2) * 256;
+__global__ void pack_w_bwd_kernel(const float* __restrict__ whh, float* __restrict__ wb, int H) {
+  // backward: workgroup x owns the same 32 gate rows n as in the forward (4 gates x 8 units) as its K slice and
+  // produces partial dh over ALL j.  wb[(((x*(H/32) + jt)*4 + Q)*64 + lane)*4 + i] = whh[row(x, 8Q+4h+i)*H + 32jt + (lane&31)],
+  // row(x, m) = (m>>3)*H + 8x + (m&7)
+  const int njt = (H + 31) / 32;
+  long tot = (long)(H / 8) * njt * 1024;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
-    int i = (int)(e & 3); int lane = (int)((e >> 2) & 63); long r = e >> 8; int Q = (int)(r % (H / 2)); int x = (int)(r / (H / 2));
-    int j = 32 * x + (lane & 31), n = 8 * Q + 4 * (lane >> 5) + i;
-    wt[e] = j < H ? whh[(long)n * H + j] : 0.f;
+    int i = (int)(e & 3); int lane = (int)((e >> 2) & 63); int Q = (int)((e >> 8) & 3); long r = e >> 10; int jt = (int)(r % njt); int x = (int)(r / njt);
+    int m = 8 * Q + 4 * (lane >> 5) + i;
+    int j = 32 * jt + (lane & 31);
+    wb[e] = j < H ? whh[((long)((m >> 3) * H + 8 * x + (m & 7))) * H + j] : 0.f;
   }
 }
 
@@ -142,82 +147,107 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_step(float* xg_f, float* 
   }
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void lstm_bwd_step(float* g_f, float* g_r, const float* __restrict__ wtfrag,
-                                                            const float* __restrict__ dy, const float* __restrict__ cbuf,
-                                                            float* dc_state, float* gfrag, const int* __restrict__ lens, int T, int B,
-                                                            int H, int s) {
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [WAVES][32][33]
-  constexpr int NTH = WAVES * 64;
-  constexpr int ITER = 1024 / NTH;
-  const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y;
+// BPTT step.  Workgroup x owns hidden units j in [8x, 8x+8) for 32 utterances, exactly like the forward:
+//   consume: dh_rec[b][j] = sum over ALL workgroups x' of the partial slabs P_x'[b][j] written by the previous launch,
+//            then the cell backward -> d(gates) for its 32 gate columns n (kept in LDS, written to G);
+//   produce: P_x[b][:] = dG_x[32 b x 32 n] . W_hh[n in x][all j]  (its K slice of dh_{t-1} = dG W_hh), written in the
+//            consumer's order slab[j/8][x][b][j%8] so that the next launch reads 1 KB contiguous runs.
+// Splitting K (= 4H gate columns) over the workgroups is what spreads the MFMA work over H/8 CUs per direction
+// instead of H/32; the cross-workgroup sum rides on the kernel boundary that the recurrence needs anyway.
+template <int JT>       // N tiles (of 32 hidden units) per wave; block = 4 waves; H = 128 * JT ... handled by a loop
+__global__ __launch_bounds__(256) void lstm_bwd_step(float* g_f, float* g_r, const float* __restrict__ wb, const float* __restrict__ dy,
+                                                     const float* __restrict__ cbuf, float* dc_state, float* slabs,
+                                                     const int* __restrict__ lens, int T, int B, int H, int s) {
+  __shared__ __attribute__((aligned(16))) float dgs[32 * 36];     // d(gates) tile [b][n], padded rows
+  const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y, NX = gridDim.x;
   const int t = dir ? s : T - 1 - s;            // reverse order of the forward pass
   float* G = dir ? g_r : g_f;
-  const int j0 = x * 32, b0 = mt * 32;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lh = lane >> 5;
+  const int j0 = x * 8, b0 = mt * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int K4 = 4 * H;
-  const int QN = K4 / 8 / WAVES;
   const long H2 = 2L * H;
   const int prev_blk = dir ? t + 2 : t;
-  const long gf_sz = (long)2 * MT * K4 * 32;          // floats per parity buffer: [dir][mt][4H/4][32][4]
-  const float* gf_rd = gfrag + ((s & 1) ^ 1) * gf_sz + (long)(dir * MT + mt) * K4 * 32;
-  float* gf_wr = gfrag + (s & 1) * gf_sz + (long)(dir * MT + mt) * K4 * 32;
-  // ---- prefetch the pointwise operands ----
-  float pdy[ITER], pg[ITER][4], pc[ITER], pcp[ITER], pdc[ITER];
-  int ln[ITER];
-#pragma unroll
-  for (int it = 0; it < ITER; ++it) {
-    int idx = tid + it * NTH;
-    int bm = idx >> 5, jc = idx & 31, b = b0 + bm, j = j0 + jc;
-    bool ok = b < B && j < H;
-    long bb = ok ? b : 0; int jj = ok ? j : 0;
-    pdy[it] = dy[((long)t * B + bb) * H2 + dir * H + jj];
-    const float* gp = G + ((long)t * B + bb) * K4 + jj;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) pg[it][g] = gp[g * H];
-    pc[it] = cbuf[((long)(t + 1) * B + bb) * H2 + dir * H + jj];
-    pcp[it] = cbuf[((long)prev_blk * B + bb) * H2 + dir * H + jj];
-    pdc[it] = dc_state[bb * H2 + dir * H + jj];
-    ln[it] = lens[bb];
-  }
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if (s > 0) {
-    const int nx = gridDim.x;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wtfrag) + ((long)(dir * nx + x) * (K4 / 8) + wid * QN) * 64 + lane;
-    const f32x4* gp = reinterpret_cast<const f32x4*>(gf_rd) + ((long)(2 * wid * QN + lh)) * 32 + (lane & 31);
-    mfma_chain(gp, wp, QN, acc);
-  }
-  store_acc(red + wid * (32 * 33), acc, lane);
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < ITER; ++it) {
-    int idx = tid + it * NTH;
-    int bm = idx >> 5, jc = idx & 31, b = b0 + bm, j = j0 + jc;
-    if (b >= B || j >= H) continue;
-    float dh = pdy[it];
-    for (int w = 0; w < WAVES; ++w) dh += red[w * (32 * 33) + bm * 33 + jc];
-    float gi = pg[it][0], gf = pg[it][1], gg = pg[it][2], go = pg[it][3];
-    float dc = pdc[it];
+  const long sl_sz = (long)2 * MT * NX * NX * 256;          // floats per parity buffer: [dir][mt][x''][x][32][8]
+  const float* sl_rd = slabs + ((s & 1) ^ 1) * sl_sz + (long)(dir * MT + mt) * NX * NX * 256;
+  float* sl_wr = slabs + (s & 1) * sl_sz + (long)(dir * MT + mt) * NX * NX * 256;
+  // ---- consume + cell backward: thread = (utterance bm, unit jj) ----
+  {
+    const int bm = tid >> 3, jj = tid & 7, b = b0 + bm, j = j0 + jj;
+    const bool ok = b < B;
+    const long bb = ok ? b : 0;
+    float dh = dy[((long)t * B + bb) * H2 + dir * H + j];
+    const float* gp0 = G + ((long)t * B + bb) * K4 + j;
+    const float gi = gp0[0], gf = gp0[H], gg = gp0[2 * H], go = gp0[3 * H];
+    const float c = cbuf[((long)(t + 1) * B + bb) * H2 + dir * H + j];
+    const float cp = cbuf[((long)prev_blk * B + bb) * H2 + dir * H + j];
+    const float dc = dc_state[bb * H2 + dir * H + j];
+    const int ln = lens[bb];
+    if (s > 0) {
+      const float* q = sl_rd + (long)x * NX * 256 + tid;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int xx = 0;
+      for (; xx + 8 <= NX; xx += 8) {
+        float v0 = q[(long)(xx + 0) * 256], v1 = q[(long)(xx + 1) * 256], v2 = q[(long)(xx + 2) * 256], v3 = q[(long)(xx + 3) * 256];
+        float v4 = q[(long)(xx + 4) * 256], v5 = q[(long)(xx + 5) * 256], v6 = q[(long)(xx + 6) * 256], v7 = q[(long)(xx + 7) * 256];
+        a0 += v0 + v4; a1 += v1 + v5; a2 += v2 + v6; a3 += v3 + v7;
+      }
+      for (; xx < NX; ++xx) a0 += q[(long)xx * 256];
+      dh += (a0 + a1) + (a2 + a3);
+    }
     float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = dc;
-    if (t < ln[it]) {
-      float tc = tanhf_(pc[it]);
+    if (ok && t < ln) {
+      float tc = tanhf_(c);
       float dct = dh * go * (1.f - tc * tc) + dc;
       dout = dh * tc * go * (1.f - go);
       di = dct * gg * gi * (1.f - gi);
-      df = dct * pcp[it] * gf * (1.f - gf);
+      df = dct * cp * gf * (1.f - gf);
       dg = dct * gi * (1.f - gg * gg);
       dcp = dct * gf;
     }
-    float* gp = G + ((long)t * B + b) * K4 + j;
-    gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dout;
-    dc_state[(long)b * H2 + dir * H + j] = dcp;
-    float dv[4] = {di, df, dg, dout};
+    if (ok) {
+      float* gp = G + ((long)t * B + b) * K4 + j;
+      gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dout;
+      dc_state[(long)b * H2 + dir * H + j] = dcp;
+    }
+    dgs[bm * 36 + jj] = di; dgs[bm * 36 + 8 + jj] = df; dgs[bm * 36 + 16 + jj] = dg; dgs[bm * 36 + 24 + jj] = dout;
+  }
+  __syncthreads();
+  if (s == T - 1) return;                        // nothing consumes the last partials
+  // ---- produce: P_x = dG_x . W_hh[n in x][:] ; waves take N tiles round-robin ----
+  f32x4 a4[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      int n = g * H + j;
-      gf_wr[((long)(n >> 2) * 32 + bm) * 4 + (n & 3)] = dv[g];
+  for (int Q = 0; Q < 4; ++Q) a4[Q] = *reinterpret_cast<const f32x4*>(dgs + lr * 36 + 8 * Q + 4 * lh);
+  const int njt = (H + 31) / 32;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(wb) + ((long)(dir * NX + x) * njt) * 256 + lane;
+  for (int jt0 = wid * JT; jt0 < njt; jt0 += 4 * JT) {
+    f32x4 b4[JT][4];
+    f32x16 acc[JT];
+#pragma unroll
+    for (int u = 0; u < JT; ++u) {
+      const int jt = jt0 + u < njt ? jt0 + u : njt - 1;
+#pragma unroll
+      for (int Q = 0; Q < 4; ++Q) b4[u][Q] = wp[(long)(jt * 4 + Q) * 64];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    }
+#pragma unroll
+    for (int Q = 0; Q < 4; ++Q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int u = 0; u < JT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[Q][i], b4[u][Q][i], acc[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < JT; ++u) {
+      const int jt = jt0 + u;
+      if (jt < njt && 32 * jt + lr < H) {
+        // column j = 32 jt + lr -> consumer x'' = 4 jt + (lr >> 3), slot lr & 7 ; row b = (r&3) + 8 (r>>2) + 4 lh
+        float* dst = sl_wr + ((long)(4 * jt + (lr >> 3)) * NX + x) * 256 + (lr & 7);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          dst[row * 8] = acc[u][r];
+        }
+      }
     }
   }
 }
@@ -240,8 +270,8 @@ int pick_waves(int K, int min_kc, const char* env = nullptr) {
 //                     bwd  = wtfrag[2][nx*(H/2)*256] | gfrag[2][2][MT][4H*32]
 size_t fwd_ws_floats(int B, int H) { long MT = (B + 31) / 32; return (size_t)2 * 4 * H * H + (size_t)2 * 2 * MT * H * 32; }
 size_t bwd_ws_floats(int B, int H) {
-  long MT = (B + 31) / 32, nx = (H + 31) / 32;
-  return (size_t)2 * nx * (H / 2) * 256 + (size_t)2 * 2 * MT * 4 * H * 32;
+  long MT = (B + 31) / 32, NX = H / 8, njt = (H + 31) / 32;
+  return (size_t)2 * NX * njt * 1024 + (size_t)2 * 2 * MT * NX * NX * 256;
 }
 
 template <int W>
@@ -254,15 +284,12 @@ void launch_fwd(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, fl
   for (int s = 0; s < T; ++s)
     hipLaunchKernelGGL((lstm_fwd_step<W>), grid, dim3(W * 64), lds, st, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens, T, B, H, s);
 }
-template <int W>
-void launch_bwd(hipStream_t st, float* g_f, float* g_r, const float* wtfrag, const float* dy, const float* cbuf, float* dc, float* gfrag,
+template <int JT>
+void launch_bwd(hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs,
                 const int* lens, int T, int B, int H) {
-  size_t lds = (size_t)W * 32 * 33 * sizeof(float);
-  static bool done = false;
-  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_step<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
-  dim3 grid(cdiv(H, 32), cdiv(B, 32), 2);
+  dim3 grid(H / 8, cdiv(B, 32), 2);
   for (int s = 0; s < T; ++s)
-    hipLaunchKernelGGL((lstm_bwd_step<W>), grid, dim3(W * 64), lds, st, g_f, g_r, wtfrag, dy, cbuf, dc, gfrag, lens, T, B, H, s);
+    hipLaunchKernelGGL((lstm_bwd_step<JT>), grid, dim3(256), 0, st, g_f, g_r, wb, dy, cbuf, dc, slabs, lens, T, B, H, s);
 }
 
 }  // namespace
@@ -305,23 +332,15 @@ extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, con
   RE2E_CHECK_ARG(T > 0 && B > 0 && H > 0, "bad shape");
   if (H % 8 != 0) { re2e_set_error("re2e_lstm_seq_bwd: hidden size must be a multiple of 8 (got %d)", H); return RE2E_EUNSUPPORTED; }
   RE2E_CHECK_ARG(workspace_bytes >= bwd_ws_floats(B, H) * sizeof(float), "workspace too small");
-  long nx = cdiv(H, 32);
-  long wn = nx * (H / 2) * 256, gn = (long)2 * 2 * cdiv(B, 32) * 4 * H * 32;
-  float* wtfrag = (float*)workspace;
-  float* gfrag = wtfrag + 2 * wn;
-  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wtfrag, H);
-  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wtfrag + wn, H);
-  hipLaunchKernelGGL(zero_kernel, dim3(cdiv(gn, 256) > 1024 ? 1024 : cdiv(gn, 256)), dim3(256), 0, stream, gfrag, gn);
+  long wn = (long)(H / 8) * ((H + 31) / 32) * 1024;
+  float* wb = (float*)workspace;
+  float* slabs = wb + 2 * wn;
+  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wb, H);
+  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wb + wn, H);
   long nz = (long)B * 2 * H;
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(nz, 256)), dim3(256), 0, stream, dc_state, nz);
-  int w = pick_waves(4 * H, 64, "RE2E_LSTM_WAVES_BWD");
-  switch (w) {
-    case 16: launch_bwd<16>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
-    case 8: launch_bwd<8>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
-    case 4: launch_bwd<4>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
-    case 2: launch_bwd<2>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
-    default: launch_bwd<1>(stream, g_f, g_r, wtfrag, dy, cbuf, dc_state, gfrag, lens_dev, T, B, H); break;
-  }
+  if (H / 32 >= 8) launch_bwd<2>(stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, lens_dev, T, B, H);
+  else launch_bwd<1>(stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, lens_dev, T, B, H);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

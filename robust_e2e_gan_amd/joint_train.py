@@ -61,7 +61,8 @@ class JointTrainer(object):
                                                                                           gan_model if self.isGAN else None)
         self.criterionGAN = GANLoss(use_lsgan=not opt.no_lsgan) if self.isGAN else None
         self.asr_model.dec.return_acc_tensor = True
-        self.overlap_dstep = True          # run the D-step on a side HIP stream under the enhancer backward
+        # run the D passes on a side HIP stream under the latency-bound recurrent chains (RE2E_NO_OVERLAP=1: profiling)
+        self.overlap_dstep = os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
         self.side_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
 
     def step(self, data, sche_samp_rate, enhance_cmvn):
@@ -74,15 +75,29 @@ class JointTrainer(object):
         with torch.no_grad():
             clean_feat = self.feat_model(clean_inputs)
         enhance_loss = opt.enhance_loss_lambda * ops.mean_loss(enhance_feat, clean_feat, 0.0, _LOSS_KIND[opt.enhance_loss_type])
+        out = {}
+        gan_loss = None
+        overlap = self.isGAN and self.overlap_dstep
+        if self.isGAN:
+            # G-step discriminator pass (joint_train.py:175-182).  It depends only on enhance_feat, so with
+            # overlap it is enqueued on the side stream BEFORE the ASR forward and runs under it; autograd runs
+            # its backward on the same side stream.
+            set_requires_grad([self.gan_model], False)
+            if overlap:
+                self.side_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side_stream):
+                    enhance_feat.record_stream(self.side_stream)
+                    gan_loss = opt.gan_loss_lambda * self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
+            else:
+                gan_loss = opt.gan_loss_lambda * self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
         loss_ctc, loss_att, acc, clean_context, mix_context = self.asr_model(clean_feat, enhance_feat, targets, input_sizes, target_sizes,
                                                                               sche_samp_rate, enhance_cmvn)
         coral_loss = opt.coral_loss_lambda * CORAL(clean_context, mix_context)
         asr_loss = opt.mtlalpha * loss_ctc.view(()) + (1 - opt.mtlalpha) * loss_att
         loss = asr_loss + enhance_loss + coral_loss
-        out = {}
         if self.isGAN:
-            set_requires_grad([self.gan_model], False)
-            gan_loss = opt.gan_loss_lambda * self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
+            if overlap:
+                torch.cuda.current_stream().wait_stream(self.side_stream)
             loss = loss + gan_loss
             out['train/gan_loss'] = opt.gan_loss_lambda * gan_loss.detach()
         self.enhance_optimizer.zero_grad()

@@ -67,9 +67,11 @@ SIGNATURES = {
     're2e_ctc_workspace_bytes': (Z, [I, I, I]),
     're2e_ctc_fwd': (I, [P, I, I, I, P, P, P, P, I, P, P, P, Z, P]),
     're2e_ctc_bwd': (I, [P, I, I, I, P, P, P, P, I, P, P, P, P, P]),
-    're2e_attloc_fwd': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, L, P]),
+    're2e_attloc_fwd': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, L, P, P, P, P]),
     're2e_attloc_partial_floats': (Z, [I, I, I]),
-    're2e_attloc_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, L, P, I, I, I, I, I, I, I, P, P, P, P, P, P]),
+    're2e_attloc_workspace_bytes': (Z, [I, I, I, I]),
+    're2e_attloc_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, L, P, I, I, I, I, I, I, P, P, P, P, P, Z, P]),
+    're2e_attloc_denc': (I, [P, P, I, I, I, I, P, F, P]),
     're2e_clip_coef': (I, [P, F, P, P]),
     're2e_adadelta_step': (I, [P, P, P, P, L, F, F, F, P, P]),
     're2e_adam_step': (I, [P, P, P, P, L, F, F, F, F, I, P, P]),

@@ -761,22 +761,26 @@ class DecoderLoopFn(torch.autograd.Function):
         w_ctx = w_ih.data_ptr() + 4 * Dd            # W_ih[:, Dd:]  (4D, E) view with leading dimension Dd+E
         w_decT = empty((D, A), hmask)               # mlp_dec.weight transposed once: coalesced reads in the step kernel
         call('re2e_transpose01', Pm['mlp_dec'].data_ptr(), w_decT.data_ptr(), A, D, 1)
+        conv = empty((L1, B, T, C), hmask)          # saved for the backward (no recomputation of the location conv)
+        dpj = empty((L1, B, A), hmask)
+        e_scr = empty((B, T), hmask)
         for i in range(L1):
             call('re2e_attloc_fwd', pre.data_ptr(), hmask.data_ptr(), z[i].data_ptr(), w[i - 1].data_ptr() if i > 0 else None,
                  hlens_dev.data_ptr(), w_decT.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(),
-                 Pm['gvec_w'].data_ptr(), Pm['gvec_b'].data_ptr(), B, T, E, D, A, C, Fh, w[i].data_ptr(), cx[i].data_ptr(), E)
+                 Pm['gvec_w'].data_ptr(), Pm['gvec_b'].data_ptr(), B, T, E, D, A, C, Fh, w[i].data_ptr(), cx[i].data_ptr(), E,
+                 conv[i].data_ptr(), dpj[i].data_ptr(), e_scr.data_ptr())
             gemm(cx[i], w_ctx, gates[i], B, 4 * D, E, transb=True, ldb=ldw, beta=1.0, dev=dev)
             gemm(z[i], Pm['w_hh'], gates[i], B, 4 * D, D, transb=True, beta=1.0)
             call('re2e_lstm_cell_fwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), z[i + 1].data_ptr(), B, D)
         ctx.Pm, ctx.ids, ctx.hlens = Pm, ids_tm, hlens_dev
         ctx.dims = (B, T, E, A, Dd, D, C, Fh, L1)
-        ctx.save_for_backward(hmask, pre, emb, cx, z, c, w, gates, w_decT)
+        ctx.save_for_backward(hmask, pre, emb, cx, z, c, w, gates, conv, dpj)
         ctx.mark_non_differentiable(w)
         return z[1:], w
 
     @staticmethod
     def backward(ctx, dZ, _dw_unused):
-        hmask, pre, emb, cx, z, c, w, gates, w_decT = ctx.saved_tensors
+        hmask, pre, emb, cx, z, c, w, gates, conv, dpj = ctx.saved_tensors
         Pm = ctx.Pm
         B, T, E, A, Dd, D, C, Fh, L1 = ctx.dims
         dev = hmask.device
@@ -785,11 +789,13 @@ class DecoderLoopFn(torch.autograd.Function):
         ldw = Dd + E
         w_ctx = w_ih.data_ptr() + 4 * Dd
         d_pre = zeros((B, T, A), hmask)
-        d_enc = zeros((B, T, E), hmask)
+        d_enc = empty((B, T, E), hmask)
         npart = query('re2e_attloc_partial_floats', A, C, Fh)
         partials = zeros((B, npart), hmask)
         ddp = empty((L1, B, A), hmask)
-        d_cx = empty((B, E), hmask)
+        d_cx_all = empty((L1, B, E), hmask)
+        awsb = query('re2e_attloc_workspace_bytes', B, T, A, C)
+        aws = workspace(awsb, dev, 'attloc')
         dz_carry = zeros((B, D), hmask)
         dc_a, dc_b = zeros((B, D), hmask), empty((B, D), hmask)
         dw_a, dw_b = empty((B, T), hmask), empty((B, T), hmask)
@@ -799,15 +805,17 @@ class DecoderLoopFn(torch.autograd.Function):
             call('re2e_lstm_cell_bwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), dz_carry.data_ptr(), dc_a.data_ptr(),
                  dc_b.data_ptr(), B, D)
             dc_a, dc_b = dc_b, dc_a
+            d_cx = d_cx_all[i]
             gemm(gates[i], w_ctx, d_cx, B, E, 4 * D, ldb=ldw, dev=dev)                     # d ctx = dgates W_ih[:, Dd:]
             gemm(gates[i], Pm['w_hh'], dz_carry, B, D, 4 * D)                                # d z_{i-1} (recurrent path)
-            call('re2e_attloc_bwd', pre.data_ptr(), hmask.data_ptr(), z[i].data_ptr(), w[i - 1].data_ptr() if i > 0 else None,
-                 w[i].data_ptr(), ctx.hlens.data_ptr(), w_decT.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(),
-                 Pm['gvec_w'].data_ptr(), d_cx.data_ptr(), E, dw_a.data_ptr() if have_dw else None, B, T, E, D, A, C, Fh,
-                 d_pre.data_ptr(), d_enc.data_ptr(), dw_b.data_ptr() if i > 0 else None, ddp[i].data_ptr(), partials.data_ptr())
+            call('re2e_attloc_bwd', pre.data_ptr(), hmask.data_ptr(), w[i - 1].data_ptr() if i > 0 else None, w[i].data_ptr(),
+                 ctx.hlens.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(), Pm['gvec_w'].data_ptr(), conv[i].data_ptr(),
+                 dpj[i].data_ptr(), cx[i].data_ptr(), d_cx.data_ptr(), E, dw_a.data_ptr() if have_dw else None, B, T, E, A, C, Fh,
+                 d_pre.data_ptr(), dw_b.data_ptr() if i > 0 else None, ddp[i].data_ptr(), partials.data_ptr(), aws.data_ptr(), awsb)
             dw_a, dw_b = dw_b, dw_a
             have_dw = True
             gemm(ddp[i], Pm['mlp_dec'], dz_carry, B, D, A, beta=1.0)
+        call('re2e_attloc_denc', w.data_ptr(), d_cx_all.data_ptr(), L1, B, T, E, d_enc.data_ptr(), 0.0)
         M = L1 * B
         G2, zp2 = gates.view(M, 4 * D), z[:L1].reshape(M, D)
         if w_ih.requires_grad:
