@@ -141,11 +141,12 @@ int re2e_maxpool2_fwd(const float* in, int NI, int H, int W, int C, float* out, 
                       re2e_stream_t stream);
 int re2e_maxpool2_bwd(const float* dout, const unsigned char* idx_u8, int NI, int H, int W, int C, float* din,
                       re2e_stream_t stream);
-/* NHWC (NI,T,Fq,C) -> time-major (T,NI,C*Fq) with rows t>=lens[n] zeroed (cut + re-pad) */
-int re2e_vgg_pack_fwd(const float* in, const int* lens_dev, int NI, int T, int Fq, int C, float* out,
-                      re2e_stream_t stream);
-int re2e_vgg_pack_bwd(const float* dout, const int* lens_dev, int NI, int T, int Fq, int C, float* din,
-                      re2e_stream_t stream);
+/* NHWC (NI,T,Fq,C) -> utterances [n_off, n_off+NI) of a time-major (T,NI_total,C*Fq) tensor with rows
+ * t>=lens[n] zeroed (cut + re-pad); the offset lets two separately computed branches share one tensor */
+int re2e_vgg_pack_fwd(const float* in, const int* lens_dev, int NI, int T, int Fq, int C, float* out, int NI_total,
+                      int n_off, re2e_stream_t stream);
+int re2e_vgg_pack_bwd(const float* dout, const int* lens_dev, int NI, int T, int Fq, int C, float* din, int NI_total,
+                      int n_off, re2e_stream_t stream);
 
 /* ---- K9 BatchNorm2d (train mode) + LeakyReLU(0.2) over NHWC rows [P][C] (gan_model.py:76-88) */
 size_t re2e_bn_workspace_bytes(long P, int C);

@@ -33,20 +33,45 @@ constexpr int AIMAX = 5;       // max ceil(adim/64)
 __device__ __forceinline__ int cpad(int C) { return (C + 3) & ~3; }
 
 // ---------------------------------------------------------------------------------------------
+// forward, part 0: dec_proj[b][a] = sum_d W_dec[a][d] z[b][d].  grid (ceil(A/64), B); 64 outputs x 4 slices of d per
+// workgroup, every thread keeps a whole slice of loads in flight (the product is latency-, not bandwidth-bound)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTH) void attloc_decproj_kernel(const float* __restrict__ z, const float* __restrict__ w_decT, int D, int A,
+                                                             float* __restrict__ dp_out) {
+  __shared__ float zs[1024];
+  __shared__ float part[4][64];
+  const int b = blockIdx.y, a = blockIdx.x * 64 + (threadIdx.x & 63), dq = threadIdx.x >> 6;
+  for (int d = threadIdx.x; d < D; d += NTH) zs[d] = z ? z[(long)b * D + d] : 0.f;
+  __syncthreads();
+  const int per = (D + 3) / 4, d0 = dq * per, d1 = min(D, d0 + per);
+  float s0 = 0.f, s1 = 0.f;
+  if (a < A) {
+    int d = d0;
+    for (; d + 16 <= d1; d += 16) {
+      float w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = w_decT[(long)(d + u) * A + a];
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) { s0 += w[u] * zs[d + u]; s1 += w[u + 1] * zs[d + u + 1]; }
+    }
+    for (; d < d1; ++d) s0 += w_decT[(long)d * A + a] * zs[d];
+  }
+  part[dq][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (dq == 0 && a < A) dp_out[(long)b * A + a] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward, part 1: energies for one chunk of frames
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restrict__ pre, const float* __restrict__ z,
+__global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restrict__ pre, const float* __restrict__ dp_in,
                                                             const float* __restrict__ att_prev, const int* __restrict__ hlens,
-                                                            const float* __restrict__ w_decT, const float* __restrict__ w_att,
-                                                            const float* __restrict__ w_conv, const float* __restrict__ gvec,
-                                                            const float* __restrict__ gvec_b, int B, int T, int D, int A, int C, int F,
-                                                            float* __restrict__ e_out, float* __restrict__ conv_out,
-                                                            float* __restrict__ dp_out) {
+                                                            const float* __restrict__ w_att, const float* __restrict__ w_conv,
+                                                            const float* __restrict__ gvec, const float* __restrict__ gvec_b, int B, int T,
+                                                            int A, int C, int F, float* __restrict__ e_out, float* __restrict__ conv_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int CP = cpad(C), Kf = 2 * F + 1;
-  float* zs = sm;                                 // [D]
-  float* dp = zs + ((D + 3) & ~3);                // [A]
-  float* ap = dp + ((A + 3) & ~3);                // [TCH + 2F]
+  float* ap = sm;                                 // [TCH + 2F]
   float* cv = ap + ((TCH + 2 * F + 3) & ~3);      // [TCH][CP]
   float* wcs = cv + TCH * CP;                     // [C][Kf]  filter taps (broadcast LDS reads in the tap loop)
   const int b = blockIdx.y, t0 = blockIdx.x * TCH;
@@ -54,7 +79,6 @@ __global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hl = hlens[b];
-  for (int d = tid; d < D; d += NTH) zs[d] = z ? z[(long)b * D + d] : 0.f;
   for (int i = tid; i < C * Kf; i += NTH) wcs[i] = w_conv[i];
   for (int i = tid; i < TCH + 2 * F; i += NTH) {
     int t = t0 + i - F;
@@ -63,22 +87,6 @@ __global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restr
     ap[i] = v;
   }
   __syncthreads();
-  // dec_proj[a] = sum_d W_dec[a][d] z[d]  (w_decT = W_dec^T, lanes over a: coalesced, 8 loads in flight)
-  for (int a = tid; a < A; a += NTH) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int d = 0;
-    for (; d + 8 <= D; d += 8) {
-      float w0 = w_decT[(long)(d + 0) * A + a], w1 = w_decT[(long)(d + 1) * A + a], w2 = w_decT[(long)(d + 2) * A + a],
-            w3 = w_decT[(long)(d + 3) * A + a], w4 = w_decT[(long)(d + 4) * A + a], w5 = w_decT[(long)(d + 5) * A + a],
-            w6 = w_decT[(long)(d + 6) * A + a], w7 = w_decT[(long)(d + 7) * A + a];
-      s0 += w0 * zs[d] + w4 * zs[d + 4]; s1 += w1 * zs[d + 1] + w5 * zs[d + 5];
-      s2 += w2 * zs[d + 2] + w6 * zs[d + 6]; s3 += w3 * zs[d + 3] + w7 * zs[d + 7];
-    }
-    for (; d < D; ++d) s0 += w_decT[(long)d * A + a] * zs[d];
-    float v = (s0 + s1) + (s2 + s3);
-    dp[a] = v;
-    if (blockIdx.x == 0) dp_out[(long)b * A + a] = v;
-  }
   // location conv for this chunk: conv[t][c] = sum_k w_conv[c][k] * att_prev[t + k - F]; a wavefront owns a
   // channel group (wave-uniform taps => scalar loads); lanes 0-31 = frames with the first half of the
   // taps, lanes 32-63 = the same frames with the second half
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restr
   for (int i = 0; i < AIMAX; ++i) {
     int a = lane + 64 * i;
     gv[i] = a < A ? gvec[a] : 0.f;
-    dpv[i] = a < A ? dp[a] : 0.f;
+    dpv[i] = a < A ? dp_in[(long)b * A + a] : 0.f;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) wa[i][c] = (a < A && c < C) ? w_att[a * C + c] : 0.f;
   }
@@ -345,94 +353,113 @@ __global__ __launch_bounds__(NTH) void attloc_bwd_frames_kernel(
 // backward, part 2 (per utterance): transposed conv, dW_conv, reduction of the chunk slabs
 // partials layout per utterance: [gvec(A) | gvec_b(1) | w_att(A*C) | w_conv(C*Kf)]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTH) void attloc_bwd_conv_kernel(const float* __restrict__ att_prev, const int* __restrict__ hlens,
+constexpr int NTC = 512;      // threads of the per-utterance backward kernel
+// grid (B, 3): blockIdx.y selects one of three independent jobs so that three CUs share an utterance:
+//   0: fixed-order sum of the chunk slabs -> d dec_proj, dgvec, dgb, dW_att partials
+//   1: transposed location conv           -> d att_prev
+//   2: filter gradient                    -> dW_conv partials
+__global__ __launch_bounds__(NTC) void attloc_bwd_conv_kernel(const float* __restrict__ att_prev, const int* __restrict__ hlens,
                                                               const float* __restrict__ w_conv, const float* __restrict__ d_conv,
                                                               const float* __restrict__ slabs, int nchunk, int B, int T, int A, int C,
                                                               int F, float* __restrict__ d_att_prev, float* __restrict__ d_decproj,
                                                               float* partials) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int CP = cpad(C), Kf = 2 * F + 1;
+  const int Kf = 2 * F + 1, TP = T + 2 * F + 1;
   float* ap = sm;                                 // [T + 2F]
-  float* dcp = ap + ((T + 2 * F + 3) & ~3);       // [(T + 2F)][CP]   d_conv, zero padded by F frames each side
-  float* scr = dcp + (T + 2 * F) * CP;            // [ncg][T]  |  [2][C*Kf]
-  const int scr_n = max(2 * C * Kf, ((C + CG - 1) / CG) * T);
-  float* wcs = scr + scr_n;                       // [C][Kf]
-  const int b = blockIdx.x;
+  float* dct = ap + ((T + 2 * F + 3) & ~3);       // [C][TP]   d_conv TRANSPOSED (frame index fastest), zero padded by F each side
+  float* wcs = dct + C * TP;                      // [C][Kf]
+  float* scr = wcs + C * Kf;                      // [C][T]
+  const int b = blockIdx.x, job = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hl = hlens[b];
-  for (int i = tid; i < C * Kf; i += NTH) wcs[i] = w_conv[i];
-  for (int i = tid; i < T + 2 * F; i += NTH) {
-    int t = i - F;
-    float v = 0.f;
-    if (t >= 0 && t < T) v = att_prev ? att_prev[(long)b * T + t] : (t < hl ? 1.0f / (float)hl : 0.f);
-    ap[i] = v;
-  }
-  for (int i = tid; i < (T + 2 * F) * CP; i += NTH) {
-    int r = i / CP, c = i % CP, t = r - F;
-    dcp[i] = (t >= 0 && t < T && c < C) ? d_conv[((long)b * T + t) * C + c] : 0.f;
-  }
-  __syncthreads();
+  constexpr int NWC = NTC / 64;
   const int P_GB = A, P_WATT = A + 1, P_WCONV = A + 1 + A * C;
   float* part = partials + (long)b * (A + 1 + A * C + C * Kf);
-  const int SF = slab_floats(A, C);
-  const float* sl = slabs + (long)b * nchunk * SF;
-  // fixed-order sum of the chunk slabs
-  for (int i = tid; i < SF; i += NTH) {
-    float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += sl[(long)k * SF + i];
-    if (i < A) d_decproj[(long)b * A + i] = s;
-    else if (i < 2 * A) part[i - A] += s;
-    else if (i < A * (2 + C)) part[P_WATT + (i - 2 * A)] += s;
-    else part[P_GB] += s;
+  if (job == 0) {
+    const int SF = slab_floats(A, C);
+    const float* sl = slabs + (long)b * nchunk * SF;
+    for (int i = tid; i < SF; i += NTC) {
+      float s = 0.f;
+      for (int k = 0; k < nchunk; ++k) s += sl[(long)k * SF + i];
+      if (i < A) d_decproj[(long)b * A + i] = s;
+      else if (i < 2 * A) part[i - A] += s;
+      else if (i < A * (2 + C)) part[P_WATT + (i - 2 * A)] += s;
+      else part[P_GB] += s;
+    }
+    return;
   }
-  // d_att_prev[t'] = sum_{c,k} w_conv[c][k] * d_conv[t'-k+F][c]
-  const int ncg = (C + CG - 1) / CG;
-  const int tchunks = (T + 63) / 64;
-  if (d_att_prev) {
-    for (int item = wid; item < ncg * tchunks; item += NWV) {
-      int cg = item % ncg, tc = item / ncg;
-      int c0 = cg * CG;
-      int t = tc * 64 + lane;
-      int tt = t < T ? t : T - 1;
-      float acc = 0.f;
-#pragma unroll 4
-      for (int k = 0; k < Kf; ++k) {
-        const float* q = dcp + (tt - k + 2 * F) * CP + c0;
-#pragma unroll
-        for (int cc = 0; cc < CG; ++cc)
-          if (c0 + cc < C) acc += wcs[(c0 + cc) * Kf + k] * q[cc];
+  if (job == 1 && !d_att_prev) return;
+  const int hl = hlens[b];
+  if (job == 1) for (int i = tid; i < C * Kf; i += NTC) wcs[i] = w_conv[i];
+  if (job == 2) {
+    for (int i = tid; i < T + 2 * F; i += NTC) {
+      int t = i - F;
+      float v = 0.f;
+      if (t >= 0 && t < T) v = att_prev ? att_prev[(long)b * T + t] : (t < hl ? 1.0f / (float)hl : 0.f);
+      ap[i] = v;
+    }
+  }
+  for (int i = tid; i < C * TP; i += NTC) dct[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < T * C; i += NTC) {        // coalesced read of d_conv[b] (T, C), transposed scatter into LDS
+    int t = i / C, c = i % C;
+    dct[c * TP + t + F] = d_conv[(long)b * T * C + i];
+  }
+  __syncthreads();
+  if (job == 1) {
+    // d_att_prev[t'] = sum_{c,k} w_conv[c][k] * d_conv[t'-k+F][c] : a wavefront owns one channel and 64 frames
+    const int tchunks = (T + 63) / 64;
+    for (int item = wid; item < C * tchunks; item += NWC) {
+      const int c = item % C, tc = item / C;
+      const int t = tc * 64 + lane;
+      const int tt = t < T ? t : T - 1;
+      const float* q = dct + c * TP + tt + 2 * F;          // q[-k] = d_conv[tt - k + F][c]
+      const float* wk = wcs + c * Kf;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int k = 0;
+      for (; k + 8 <= Kf; k += 8) {
+        a0 += wk[k] * q[-k] + wk[k + 4] * q[-k - 4]; a1 += wk[k + 1] * q[-k - 1] + wk[k + 5] * q[-k - 5];
+        a2 += wk[k + 2] * q[-k - 2] + wk[k + 6] * q[-k - 6]; a3 += wk[k + 3] * q[-k - 3] + wk[k + 7] * q[-k - 7];
       }
-      if (t < T) scr[cg * T + t] = acc;
+      for (; k < Kf; ++k) a0 += wk[k] * q[-k];
+      if (t < T) scr[c * T + t] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-    for (int t = tid; t < T; t += NTH) {
+    for (int t = tid; t < T; t += NTC) {
       float s = 0.f;
-      for (int g = 0; g < ncg; ++g) s += scr[g * T + t];
+      for (int c = 0; c < C; ++c) s += scr[c * T + t];
       d_att_prev[(long)b * T + t] = s;
     }
-    __syncthreads();
+    return;
   }
-  // dw_conv[c][k] = sum_t d_conv[t][c] * att_prev[t+k-F] ; two threads per tap split the frames
+  // job 2: dw_conv[c][k] = sum_t d_conv[t][c] * att_prev[t+k-F] : thread = (tap k, channel group), frames serial (4 in flight)
   {
-    const int half = (T + 1) / 2;
-    for (int item = tid; item < 2 * Kf; item += NTH) {
-      int k = item % Kf, hf = item / Kf;
-      int ta = hf * half, tb = min(T, ta + half);
-      float acc[CMAX];
+    const int ncg = (C + CG - 1) / CG;
+    for (int item = tid; item < ncg * Kf; item += NTC) {
+      const int k = item % Kf, cg = item / Kf, c0 = cg * CG;
+      float acc[CG];
 #pragma unroll
-      for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
-      for (int t = ta; t < tb; ++t) {
-        float x = ap[t + k];
-        const float* q = dcp + (t + F) * CP;
+      for (int cc = 0; cc < CG; ++cc) acc[cc] = 0.f;
+      int t = 0;
+      for (; t + 4 <= T; t += 4) {
+        const float x0 = ap[t + k], x1 = ap[t + k + 1], x2 = ap[t + k + 2], x3 = ap[t + k + 3];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) if (c < C) acc[c] += q[c] * x;
+        for (int cc = 0; cc < CG; ++cc)
+          if (c0 + cc < C) {
+            const float* q = dct + (c0 + cc) * TP + t + F;
+            acc[cc] += q[0] * x0 + q[1] * x1 + q[2] * x2 + q[3] * x3;
+          }
+      }
+      for (; t < T; ++t) {
+        const float x = ap[t + k];
+#pragma unroll
+        for (int cc = 0; cc < CG; ++cc)
+          if (c0 + cc < C) acc[cc] += dct[(c0 + cc) * TP + t + F] * x;
       }
 #pragma unroll
-      for (int c = 0; c < CMAX; ++c) if (c < C) scr[hf * (C * Kf) + c * Kf + k] = acc[c];
+      for (int cc = 0; cc < CG; ++cc)
+        if (c0 + cc < C) part[P_WCONV + (c0 + cc) * Kf + k] += acc[cc];
     }
-    __syncthreads();
-    for (int i = tid; i < C * Kf; i += NTH) part[P_WCONV + i] += scr[i] + scr[C * Kf + i];
   }
 }
 
@@ -496,10 +523,11 @@ extern "C" int re2e_attloc_fwd(const float* pre, const float* enc, const float* 
   int rc = check_dims("re2e_attloc_fwd", B, T, eprojs, dunits, adim, chans, filts);
   if (rc) return rc;
   const int CP = (chans + 3) & ~3;
-  size_t lds1 = (size_t)(((dunits + 3) & ~3) + ((adim + 3) & ~3) + ((TCH + 2 * filts + 3) & ~3) + TCH * CP + chans * (2 * filts + 1) + 16) *
-                sizeof(float);
-  hipLaunchKernelGGL(attloc_energy_kernel, dim3(nchunks(T), B), dim3(NTH), lds1, stream, pre, z, att_prev, hlens, w_decT, w_att, w_conv, gvec,
-                     gvec_b, B, T, dunits, adim, chans, filts, e_scratch, conv_out, dp_out);
+  RE2E_CHECK_ARG(dunits <= 1024, "dunits > 1024 not supported");
+  hipLaunchKernelGGL(attloc_decproj_kernel, dim3((adim + 63) / 64, B), dim3(NTH), 0, stream, z, w_decT, dunits, adim, dp_out);
+  size_t lds1 = (size_t)(((TCH + 2 * filts + 3) & ~3) + TCH * CP + chans * (2 * filts + 1) + 16) * sizeof(float);
+  hipLaunchKernelGGL(attloc_energy_kernel, dim3(nchunks(T), B), dim3(NTH), lds1, stream, pre, (const float*)dp_out, att_prev, hlens, w_att, w_conv,
+                     gvec, gvec_b, B, T, adim, chans, filts, e_scratch, conv_out);
   size_t lds2 = (size_t)(((T + 3) & ~3) + 32 + 16 * 64 + 16) * sizeof(float);
   if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_context_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   hipLaunchKernelGGL(attloc_context_kernel, dim3((eprojs + 63) / 64, B), dim3(NTH), lds2, stream, (const float*)e_scratch, enc, B, T, eprojs, w_out,
@@ -518,18 +546,17 @@ extern "C" int re2e_attloc_bwd(const float* pre, const float* enc, const float* 
   int rc = check_dims("re2e_attloc_bwd", B, T, eprojs, 1, adim, chans, filts);
   if (rc) return rc;
   RE2E_CHECK_ARG(workspace_bytes >= re2e_attloc_workspace_bytes(B, T, adim, chans), "workspace too small");
-  const int CP = (chans + 3) & ~3, Kf = 2 * filts + 1, nch = nchunks(T);
+  const int Kf = 2 * filts + 1, nch = nchunks(T);
   float* d_conv = (float*)workspace;
   float* slabs = d_conv + (size_t)B * T * chans;
   size_t lds1 = (size_t)(((eprojs + 3) & ~3) + TCH + 32 + adim * (2 + CMAX) + 16) * sizeof(float);
   hipLaunchKernelGGL(attloc_bwd_frames_kernel, dim3(nch, B), dim3(NTH), lds1, stream, pre, enc, w_cur, dw_in, dc, ld_dc, cx_in, conv_in, dp_in, w_att,
                      gvec, B, T, eprojs, adim, chans, d_pre, d_conv, slabs);
-  size_t scr = (size_t)2 * chans * Kf, scr2 = (size_t)((chans + CG - 1) / CG) * T;
-  if (scr2 > scr) scr = scr2;
-  size_t lds2 = (size_t)(((T + 2 * filts + 3) & ~3) + (size_t)(T + 2 * filts) * CP + scr + (size_t)chans * Kf + 16) * sizeof(float);
+  size_t lds2 = (size_t)(((T + 2 * filts + 3) & ~3) + (size_t)chans * (T + 2 * filts + 1) + (size_t)chans * Kf + (size_t)chans * T + 16) *
+                sizeof(float);
   if (lds2 > 160 * 1024) { re2e_set_error("re2e_attloc_bwd: T=%d needs %zu bytes of LDS (>160 KiB)", T, lds2); return RE2E_EUNSUPPORTED; }
   if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_bwd_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-  hipLaunchKernelGGL(attloc_bwd_conv_kernel, dim3(B), dim3(NTH), lds2, stream, att_prev, hlens, w_conv, (const float*)d_conv, (const float*)slabs, nch,
+  hipLaunchKernelGGL(attloc_bwd_conv_kernel, dim3(B, 3), dim3(NTC), lds2, stream, att_prev, hlens, w_conv, (const float*)d_conv, (const float*)slabs, nch,
                      B, T, adim, chans, filts, d_att_prev, d_decproj, partials);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;

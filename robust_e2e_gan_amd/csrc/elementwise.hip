@@ -314,29 +314,33 @@ extern "C" int re2e_maxpool2_bwd(const float* dout, const unsigned char* idx, in
   return RE2E_OK;
 }
 
-// NHWC (NI,T,Fq,C) -> (T,NI,C*Fq): feature index c*Fq+f (e2e_encoder.py:274-276), zero for t>=lens[n]
+// NHWC (NI,T,Fq,C) -> rows [n_off, n_off+NI) of a time-major (T,NI_total,C*Fq) tensor: feature index c*Fq+f
+// (e2e_encoder.py:274-276), zero for t>=lens[n].  The batch offset lets two branches computed on different
+// streams land in one (T, 2B, .) tensor for the shared BLSTMP.
 __global__ void vgg_pack_kernel(const float* __restrict__ src, const int* __restrict__ lens, int NI, int T, int Fq, int C,
-                                float* __restrict__ dst, int backward) {
+                                float* __restrict__ dst, int backward, int NItot, int noff) {
   long tot = (long)T * NI * C * Fq;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
-    if (!backward) {       // i indexes dst (t, n, c, f): coalesced writes
+    if (!backward) {       // i indexes (t, n, c, f) of this branch: coalesced writes
       int f = (int)(i % Fq); long r = i / Fq; int c = (int)(r % C); r /= C; int n = (int)(r % NI); int t = (int)(r / NI);
-      dst[i] = t < lens[n] ? src[(((long)n * T + t) * Fq + f) * C + c] : 0.f;
+      dst[(((long)t * NItot + noff + n) * C + c) * Fq + f] = t < lens[n] ? src[(((long)n * T + t) * Fq + f) * C + c] : 0.f;
     } else {               // i indexes din (n, t, f, c): coalesced writes
       int c = (int)(i % C); long r = i / C; int f = (int)(r % Fq); r /= Fq; int t = (int)(r % T); int n = (int)(r / T);
-      dst[i] = t < lens[n] ? src[(((long)t * NI + n) * C + c) * Fq + f] : 0.f;
+      dst[i] = t < lens[n] ? src[(((long)t * NItot + noff + n) * C + c) * Fq + f] : 0.f;
     }
   }
 }
-extern "C" int re2e_vgg_pack_fwd(const float* in, const int* lens, int NI, int T, int Fq, int C, float* out, hipStream_t stream) {
-  RE2E_CHECK_ARG(in && lens && out && NI > 0 && T > 0 && Fq > 0 && C > 0, "bad args");
-  hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, in, lens, NI, T, Fq, C, out, 0);
+extern "C" int re2e_vgg_pack_fwd(const float* in, const int* lens, int NI, int T, int Fq, int C, float* out, int NI_total, int n_off,
+                                 hipStream_t stream) {
+  RE2E_CHECK_ARG(in && lens && out && NI > 0 && T > 0 && Fq > 0 && C > 0 && n_off >= 0 && n_off + NI <= NI_total, "bad args");
+  hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, in, lens, NI, T, Fq, C, out, 0, NI_total, n_off);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
-extern "C" int re2e_vgg_pack_bwd(const float* dout, const int* lens, int NI, int T, int Fq, int C, float* din, hipStream_t stream) {
-  RE2E_CHECK_ARG(dout && lens && din && NI > 0 && T > 0 && Fq > 0 && C > 0, "bad args");
-  hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, dout, lens, NI, T, Fq, C, din, 1);
+extern "C" int re2e_vgg_pack_bwd(const float* dout, const int* lens, int NI, int T, int Fq, int C, float* din, int NI_total, int n_off,
+                                 hipStream_t stream) {
+  RE2E_CHECK_ARG(dout && lens && din && NI > 0 && T > 0 && Fq > 0 && C > 0 && n_off >= 0 && n_off + NI <= NI_total, "bad args");
+  hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, dout, lens, NI, T, Fq, C, din, 1, NI_total, n_off);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

@@ -70,10 +70,30 @@ class JointTrainer(object):
         ``to_floats`` to log them: that is the only host synchronisation)."""
         opt = self.opt
         clean_inputs, mix_inputs, mix_log_inputs, targets, input_sizes, target_sizes = data[2], data[4], data[5], data[7], data[8], data[9]
-        enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
-        enhance_feat = self.feat_model(enhance_out)
-        with torch.no_grad():
-            clean_feat = self.feat_model(clean_inputs)
+        overlap = self.overlap_dstep
+        ops.MULTI_STREAM = bool(overlap)
+        main = torch.cuda.current_stream()
+        clean_branch = None
+        if overlap and getattr(self.asr_model, 'etype', '').startswith('vgg'):
+            # the clean branch (fbank -> CMVN -> VGG conv stack) does not depend on the enhancer: enqueue it on the side
+            # stream first so that it fills the CUs the enhancer's 1600-launch recurrent chain leaves idle
+            side = self.side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                with torch.no_grad():
+                    clean_feat = self.feat_model(clean_inputs)
+                ev_cf = torch.cuda.Event()
+                ev_cf.record()
+                clean_branch = self.asr_model.encode_clean(clean_feat, enhance_cmvn)
+            enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
+            enhance_feat = self.feat_model(enhance_out)
+            main.wait_event(ev_cf)
+            clean_feat.record_stream(main)
+        else:
+            enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
+            enhance_feat = self.feat_model(enhance_out)
+            with torch.no_grad():
+                clean_feat = self.feat_model(clean_inputs)
         enhance_loss = opt.enhance_loss_lambda * ops.mean_loss(enhance_feat, clean_feat, 0.0, _LOSS_KIND[opt.enhance_loss_type])
         out = {}
         gan_loss = None
@@ -91,7 +111,7 @@ class JointTrainer(object):
             else:
                 gan_loss = opt.gan_loss_lambda * self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
         loss_ctc, loss_att, acc, clean_context, mix_context = self.asr_model(clean_feat, enhance_feat, targets, input_sizes, target_sizes,
-                                                                              sche_samp_rate, enhance_cmvn)
+                                                                              sche_samp_rate, enhance_cmvn, clean_branch=clean_branch)
         coral_loss = opt.coral_loss_lambda * CORAL(clean_context, mix_context)
         asr_loss = opt.mtlalpha * loss_ctc.view(()) + (1 - opt.mtlalpha) * loss_att
         loss = asr_loss + enhance_loss + coral_loss
@@ -103,7 +123,9 @@ class JointTrainer(object):
         self.enhance_optimizer.zero_grad()
         self.asr_optimizer.zero_grad()
         sync = GradSync()
-        sync.arm(enhance_feat, self.asr_optimizer)
+        armed = clean_branch is None       # with the clean branch on the side stream the ASR gradients are complete only
+        if armed:                          # after that stream has been joined, so the early all-reduce hook is not used
+            sync.arm(enhance_feat, self.asr_optimizer)
         if self.isGAN and self.overlap_dstep:
             # Phase 1: backward of everything downstream of the enhancer (ASR, D, fbank) on the main stream.
             main = torch.cuda.current_stream()
@@ -112,6 +134,8 @@ class JointTrainer(object):
             (g_eo,) = torch.autograd.grad(loss, [enhance_out])
             ev_bwd1 = torch.cuda.Event()
             ev_bwd1.record(main)
+            ev_side_bwd = torch.cuda.Event()          # clean-branch conv backward (ASR gradients) enqueued on the side stream
+            ev_side_bwd.record(self.side_stream)
             # D-step (joint_train.py:195-212) on a side stream: it only needs the forward results, so it fills
             # the CUs that the latency-bound enhancer BLSTM backward (1600 dependent launches) leaves idle.
             side = self.side_stream
@@ -123,10 +147,13 @@ class JointTrainer(object):
                 loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, wait_before_update=ev_bwd1)
             # Phase 2: the enhancer backward chain on the main stream.
             enhance_out.backward(g_eo)
+            torch.cuda.current_stream().wait_event(ev_side_bwd)
         else:
             loss.backward()
             loss_D = None
-        sync.finish([self.enhance_optimizer])
+            if self.overlap_dstep:
+                torch.cuda.current_stream().wait_stream(self.side_stream)
+        sync.finish([self.enhance_optimizer] if armed else [self.asr_optimizer, self.enhance_optimizer])
         grad_norm = self.asr_optimizer.clip_grad_norm(opt.grad_clip)           # ASR params only (:188)
         self.enhance_optimizer.step(self.asr_optimizer.gate_stats())           # unclipped, same NaN gate (:189-193)
         self.asr_optimizer.step()

@@ -50,8 +50,8 @@ SIGNATURES = {
     're2e_sumsq': (I, [P, L, P, P, Z, P]),
     're2e_maxpool2_fwd': (I, [P, I, I, I, I, P, P, P]),
     're2e_maxpool2_bwd': (I, [P, P, I, I, I, I, P, P]),
-    're2e_vgg_pack_fwd': (I, [P, P, I, I, I, I, P, P]),
-    're2e_vgg_pack_bwd': (I, [P, P, I, I, I, I, P, P]),
+    're2e_vgg_pack_fwd': (I, [P, P, I, I, I, I, P, I, I, P]),
+    're2e_vgg_pack_bwd': (I, [P, P, I, I, I, I, P, I, I, P]),
     're2e_bn_workspace_bytes': (Z, [L, I]),
     're2e_bn_lrelu_fwd': (I, [P, L, I, P, P, P, P, F, F, I, P, P, P, P, Z, P]),
     're2e_bn_lrelu_bwd': (I, [P, P, L, I, P, P, P, P, P, P, P, F, P, Z, P]),

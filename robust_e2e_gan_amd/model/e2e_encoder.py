@@ -74,8 +74,8 @@ class VGG2L(torch.nn.Module):
         self.conv2_2 = ConvParams(128, 128, 3, stride=1, padding=1)
         self.in_channel = in_channel
 
-    def forward_tm(self, xs, ilens):
-        """(B,T,idim) batch-first -> time-major (T',B,128*F') with the cut + zero re-pad of :272-278."""
+    def conv_stack(self, xs):
+        """(B,T,idim) batch-first -> pooled NHWC (B, ceil(ceil(T/2)/2), ceil(ceil(idim/2)/2), 128)  (e2e_encoder.py:259-266)"""
         if self.in_channel != 1:
             raise Re2eError('VGG2L with in_channel != 1 is not on the hot path')
         B, T, Fd = xs.shape
@@ -85,10 +85,23 @@ class VGG2L(torch.nn.Module):
         h = ops.maxpool2(h)
         h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu')
         h = ops.conv2d(h, self.conv2_2.weight, self.conv2_2.bias, 1, 1, 'relu')
-        h = ops.maxpool2(h)
-        nl = [int(math.ceil(math.ceil(l / 2.0) / 2.0)) for l in lens_list(ilens)]
-        out = ops.vgg_pack(h, lens_dev(nl, xs.device))                             # (T'box, B, C*F')
+        return ops.maxpool2(h)
+
+    @staticmethod
+    def pooled_lens(ilens):
+        return [int(math.ceil(math.ceil(l / 2.0) / 2.0)) for l in lens_list(ilens)]
+
+    def pack_tm(self, hs, ilens_per_branch):
+        """pooled NHWC branches -> ONE time-major (T', sum B_k, 128*F') tensor with the cut + zero re-pad of :272-278."""
+        nls = [self.pooled_lens(il) for il in ilens_per_branch]
+        lens_d = [lens_dev(nl, hs[0].device) for nl in nls]
+        out = ops.vgg_pack_multi(hs, lens_d)
+        nl = sum(nls, [])
         return out[:max(nl)], nl
+
+    def forward_tm(self, xs, ilens):
+        """(B,T,idim) batch-first -> time-major (T',B,128*F')."""
+        return self.pack_tm([self.conv_stack(xs)], [ilens])
 
     def forward(self, xs, ilens):
         y, nl = self.forward_tm(xs, ilens)

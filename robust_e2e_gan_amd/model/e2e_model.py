@@ -92,17 +92,38 @@ class ShareE2E(E2E):
     one 2B batch, losses come from the enhanced branch exactly as E2E.forward, contexts are the
     encoder states of the valid frames of each branch."""
 
-    def forward(self, clean_feat, enhance_feat, targets, input_sizes, target_sizes, scheduled_sampling_rate=0.0, cmvn=None):
+    def encode_clean(self, clean_feat, cmvn):
+        """Clean-branch CMVN + VGG conv stack, to be enqueued on a SIDE stream while the enhancer's recurrent chain
+        occupies the main stream (the clean branch does not depend on the enhancer).  Returns a handle for
+        ``forward(..., clean_branch=handle)``."""
+        cln = to_cuda(self, clean_feat)
+        if cmvn is not None:
+            cln = ops.cmvn_pair(cln, None, to_cuda(self, cmvn).float().contiguous())
+        h = self.enc.enc1.conv_stack(cln)
+        ev = torch.cuda.Event()
+        ev.record()
+        return h, ev
+
+    def forward(self, clean_feat, enhance_feat, targets, input_sizes, target_sizes, scheduled_sampling_rate=0.0, cmvn=None,
+                clean_branch=None):
         enh = to_cuda(self, enhance_feat)
         cln = to_cuda(self, clean_feat)
         ilens = lens_list(input_sizes)
         B = enh.shape[0]
         ys = self._split_targets(targets, target_sizes)
-        if cmvn is not None:
-            x2 = ops.cmvn_pair(enh, cln, to_cuda(self, cmvn).float().contiguous())
+        cm = to_cuda(self, cmvn).float().contiguous() if cmvn is not None else None
+        if clean_branch is not None and self.etype in ('vggblstmp', 'vggblstm'):
+            # the two branches share only the recurrent stack: conv stacks separately (possibly on different streams),
+            # then ONE (T', 2B, .) tensor for the BLSTMP so that the sequential chain is paid once
+            h_cln, ev = clean_branch
+            h_enh = self.enc.enc1.conv_stack(ops.cmvn_pair(enh, None, cm) if cm is not None else enh)
+            torch.cuda.current_stream().wait_event(ev)
+            h_cln.record_stream(torch.cuda.current_stream())
+            h_in, hl2 = self.enc.enc1.pack_tm([h_enh, h_cln], [ilens, ilens])
+            h_tm2 = self.enc.enc2.forward_tm(h_in, lens_dev(hl2, enh.device))
         else:
-            x2 = torch.cat([enh, cln], 0)
-        h_tm2, hl2 = self.enc.forward_tm(x2, ilens + ilens)               # (T', 2B, E)
+            x2 = ops.cmvn_pair(enh, cln, cm) if cm is not None else torch.cat([enh, cln], 0)
+            h_tm2, hl2 = self.enc.forward_tm(x2, ilens + ilens)           # (T', 2B, E)
         hlens = hl2[:B]
         hpad2 = ops.transpose01(h_tm2)                                     # (2B, T', E)
         hpad_enh, hpad_cln = hpad2[:B], hpad2[B:]

@@ -56,12 +56,37 @@ def colsum_into(A2d, M, N, out, beta, lda=None):
     call('re2e_colsum', A2d.data_ptr(), M, N, lda if lda is not None else N, out.data_ptr(), float(beta), ws.data_ptr(), wsb)
 
 
-def grad_target(p):
-    """(tensor to accumulate into, beta) for a parameter's gradient."""
-    if p.grad is None:
-        p.grad = torch.empty_like(p)
-        return p.grad, 0.0
-    return p.grad, 1.0
+MULTI_STREAM = False     # set by JointTrainer when branches run on side streams
+
+
+class accumulate(object):
+    """``with accumulate(p) as (g, beta): <kernels that compute g = beta*g + dL/dp>``.
+
+    The kernels write straight into ``p.grad`` (autograd never sees parameter gradients), so when the two ASR
+    branches or the D passes run on different HIP streams the read-modify-write of a shared gradient must be
+    ordered by hand: wait for the event of the previous writer, record a new one when this writer is enqueued."""
+    __slots__ = ('p',)
+
+    def __init__(self, p):
+        self.p = p
+
+    def __enter__(self):
+        p = self.p
+        if MULTI_STREAM:
+            ev = getattr(p, '_re2e_ev', None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+        if p.grad is None:
+            p.grad = torch.empty_like(p)
+            return p.grad, 0.0
+        return p.grad, 1.0
+
+    def __exit__(self, *exc):
+        if MULTI_STREAM:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.p._re2e_ev = ev
+        return False
 
 
 def act_bwd(dy, y, act):
@@ -103,11 +128,11 @@ class LinearFn(torch.autograd.Function):
             gemm(dz, W, dx, M, K, N)                       # dx = dz[M,N] * W[N,K]
             dx = dx.view(ctx.xshape)
         if W.requires_grad:
-            gw, beta = grad_target(W)
-            gemm(dz, x2, gw, N, K, M, transa=True, beta=beta)   # dW = dz^T x
+            with accumulate(W) as (gw, beta):
+                gemm(dz, x2, gw, N, K, M, transa=True, beta=beta)   # dW = dz^T x
         if b is not None and b.requires_grad:
-            gb, beta = grad_target(b)
-            colsum_into(dz, M, N, gb, beta)
+            with accumulate(b) as (gb, beta):
+                colsum_into(dz, M, N, gb, beta)
         return dx, None, None, None
 
 
@@ -213,8 +238,8 @@ class MaskFcFn(torch.autograd.Function):
             gemm(dlin, W, dp, M, K, N)
             dp = dp.view(ctx.oshape[:-1] + (K,))
         if W.requires_grad:
-            gw, beta = grad_target(W)
-            gemm(dlin, p2, gw, N, K, M, transa=True, beta=beta)
+            with accumulate(W) as (gw, beta):
+                gemm(dlin, p2, gw, N, K, M, transa=True, beta=beta)
         return dp, None, None, None, None
 
 
@@ -291,14 +316,14 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad)
         if W.requires_grad:
-            gw, beta = grad_target(W)
             wsb = query('re2e_conv_wgrad_workspace_bytes', N, OH, OW, Cin, Cout, KH, KW)
             ws = workspace(wsb, x.device, 'wgrad')
-            call('re2e_conv_wgrad', x.data_ptr(), N, H, Wd, Cin, dz.data_ptr(), Cout, KH, KW, OH, OW, stride, stride, -pad, -pad,
-                 gw.data_ptr(), beta, ws.data_ptr(), wsb)
+            with accumulate(W) as (gw, beta):
+                call('re2e_conv_wgrad', x.data_ptr(), N, H, Wd, Cin, dz.data_ptr(), Cout, KH, KW, OH, OW, stride, stride, -pad, -pad,
+                     gw.data_ptr(), beta, ws.data_ptr(), wsb)
         if b is not None and b.requires_grad:
-            gb, beta = grad_target(b)
-            colsum_into(dz, N * OH * OW, Cout, gb, beta)
+            with accumulate(b) as (gb, beta):
+                colsum_into(dz, N * OH * OW, Cout, gb, beta)
         return dx, None, None, None, None, None
 
 
@@ -365,27 +390,44 @@ maxpool2 = MaxPool2Fn.apply
 
 
 class VggPackFn(torch.autograd.Function):
-    """NHWC (N,T,Fq,C) -> time-major (T,N,C*Fq), frames >= lens zeroed (e2e_encoder.py:272-278)."""
+    """NHWC branches [(N_k,T,Fq,C)] -> ONE time-major (T, sum N_k, C*Fq) tensor, frames >= lens zeroed
+    (e2e_encoder.py:272-278).  ``lens_list`` holds one int32 device tensor per branch."""
 
     @staticmethod
-    def forward(ctx, x, lens_dev):
-        x = _f32(x)
-        N, T, Fq, C = x.shape
-        y = empty((T, N, C * Fq), x)
-        call('re2e_vgg_pack_fwd', x.data_ptr(), lens_dev.data_ptr(), N, T, Fq, C, y.data_ptr())
-        ctx.lens, ctx.xshape = lens_dev, x.shape
+    def forward(ctx, lens_list, *xs):
+        xs = [_f32(x) for x in xs]
+        _, T, Fq, C = xs[0].shape
+        Ntot = sum(x.shape[0] for x in xs)
+        y = empty((T, Ntot, C * Fq), xs[0])
+        off = 0
+        for x, ld in zip(xs, lens_list):
+            call('re2e_vgg_pack_fwd', x.data_ptr(), ld.data_ptr(), x.shape[0], T, Fq, C, y.data_ptr(), Ntot, off)
+            off += x.shape[0]
+        ctx.lens, ctx.shapes, ctx.Ntot = lens_list, [x.shape for x in xs], Ntot
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        N, T, Fq, C = ctx.xshape
         dy = _f32(dy)
-        dx = empty(ctx.xshape, dy)
-        call('re2e_vgg_pack_bwd', dy.data_ptr(), ctx.lens.data_ptr(), N, T, Fq, C, dx.data_ptr())
-        return dx, None
+        outs, off = [], 0
+        for k, (shp, ld) in enumerate(zip(ctx.shapes, ctx.lens)):
+            N, T, Fq, C = shp
+            if ctx.needs_input_grad[1 + k]:
+                dx = empty(shp, dy)
+                call('re2e_vgg_pack_bwd', dy.data_ptr(), ld.data_ptr(), N, T, Fq, C, dx.data_ptr(), ctx.Ntot, off)
+                outs.append(dx)
+            else:
+                outs.append(None)
+            off += N
+        return (None,) + tuple(outs)
 
 
-vgg_pack = VggPackFn.apply
+def vgg_pack(x, lens_dev):
+    return VggPackFn.apply([lens_dev], x)
+
+
+def vgg_pack_multi(xs, lens_list):
+    return VggPackFn.apply(list(lens_list), *xs)
 
 
 class BnLreluFn(torch.autograd.Function):
@@ -419,13 +461,13 @@ class BnLreluFn(torch.autograd.Function):
         dx = empty(x.shape, x)
         wsb = query('re2e_bn_workspace_bytes', Pn, C)
         ws = workspace(wsb, x.device, 'bn')
-        dg = db = None
-        gbeta = 0.0
         if gamma.requires_grad:
-            dg, gbeta = grad_target(gamma)
-            db, _ = grad_target(beta)
-        call('re2e_bn_lrelu_bwd', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
-             dx.data_ptr(), ptr(dg), ptr(db), gbeta, ws.data_ptr(), wsb)
+            with accumulate(gamma) as (dg, gbeta), accumulate(beta) as (db, _):
+                call('re2e_bn_lrelu_bwd', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
+                     dx.data_ptr(), dg.data_ptr(), db.data_ptr(), gbeta, ws.data_ptr(), wsb)
+        else:
+            call('re2e_bn_lrelu_bwd', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
+                 dx.data_ptr(), None, None, 0.0, ws.data_ptr(), wsb)
         return dx, None, None, None, None, None, None, None
 
 
@@ -484,19 +526,19 @@ class BiLstmFn(torch.autograd.Function):
         for d in range(2):
             w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
             if w_ih.requires_grad:
-                gw, beta = grad_target(w_ih)
-                gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
+                with accumulate(w_ih) as (gw, beta):
+                    gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
             if w_hh.requires_grad:
-                gw, beta = grad_target(w_hh)
                 # h_{t-1}: forward direction = ybuf block t (y[t-1]); reverse = ybuf block t+2 (y[t+1])
                 hprev = yflat[(0 if d == 0 else 2 * B):, d * H:]
-                call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
+                with accumulate(w_hh) as (gw, beta):
+                    call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
             if b_ih.requires_grad:
-                gb, beta = grad_target(b_ih)
-                colsum_into(dG[d], M, 4 * H, gb, beta)
+                with accumulate(b_ih) as (gb, beta):
+                    colsum_into(dG[d], M, 4 * H, gb, beta)
             if b_hh.requires_grad:
-                gb, beta = grad_target(b_hh)
-                colsum_into(dG[d], M, 4 * H, gb, beta)
+                with accumulate(b_hh) as (gb, beta):
+                    colsum_into(dG[d], M, 4 * H, gb, beta)
         return (dx, None) + (None,) * len(w)
 
 
@@ -819,27 +861,27 @@ class DecoderLoopFn(torch.autograd.Function):
         M = L1 * B
         G2, zp2 = gates.view(M, 4 * D), z[:L1].reshape(M, D)
         if w_ih.requires_grad:
-            gw, beta = grad_target(w_ih)
-            gemm(G2, emb.view(M, Dd), gw, 4 * D, Dd, M, transa=True, ldc=ldw, beta=beta)                       # dW_ih[:, :Dd]
-            gemm(G2, cx.view(M, E), gw.data_ptr() + 4 * Dd, 4 * D, E, M, transa=True, ldc=ldw, beta=beta)      # dW_ih[:, Dd:]
-            gw, beta = grad_target(Pm['w_hh'])
-            gemm(G2, zp2, gw, 4 * D, D, M, transa=True, beta=beta)
+            with accumulate(w_ih) as (gw, beta):
+                gemm(G2, emb.view(M, Dd), gw, 4 * D, Dd, M, transa=True, ldc=ldw, beta=beta)                       # dW_ih[:, :Dd]
+                gemm(G2, cx.view(M, E), gw.data_ptr() + 4 * Dd, 4 * D, E, M, transa=True, ldc=ldw, beta=beta)      # dW_ih[:, Dd:]
+            with accumulate(Pm['w_hh']) as (gw, beta):
+                gemm(G2, zp2, gw, 4 * D, D, M, transa=True, beta=beta)
             for k in ('b_ih', 'b_hh'):
-                gb, beta = grad_target(Pm[k])
-                colsum_into(G2, M, 4 * D, gb, beta)
-            gw, beta = grad_target(Pm['mlp_dec'])
-            gemm(ddp.view(M, A), zp2, gw, A, D, M, transa=True, beta=beta)
+                with accumulate(Pm[k]) as (gb, beta):
+                    colsum_into(G2, M, 4 * D, gb, beta)
+            with accumulate(Pm['mlp_dec']) as (gw, beta):
+                gemm(ddp.view(M, A), zp2, gw, A, D, M, transa=True, beta=beta)
             d_emb = empty((M, Dd), hmask)
             gemm(G2, w_ih, d_emb, M, Dd, 4 * D, ldb=ldw)                                                        # dgates W_ih[:, :Dd]
-            gw, beta = grad_target(Pm['embed'])
             V = Pm['embed'].shape[0]
-            call('re2e_embedding_bwd', d_emb.data_ptr(), Dd, ctx.ids.data_ptr(), M, Dd, V, gw.data_ptr(), beta)
+            with accumulate(Pm['embed']) as (gw, beta):
+                call('re2e_embedding_bwd', d_emb.data_ptr(), Dd, ctx.ids.data_ptr(), M, Dd, V, gw.data_ptr(), beta)
             tot = empty((npart,), hmask)
             colsum_into(partials, B, npart, tot, 0.0)
             off = 0
             for k, n in (('gvec_w', A), ('gvec_b', 1), ('mlp_att', A * C), ('loc_conv', C * (2 * Fh + 1))):
-                gt, beta = grad_target(Pm[k])
-                call('re2e_axpby', 1.0, tot.data_ptr() + 4 * off, beta, gt.data_ptr(), n)
+                with accumulate(Pm[k]) as (gt, beta):
+                    call('re2e_axpby', 1.0, tot.data_ptr() + 4 * off, beta, gt.data_ptr(), n)
                 off += n
         return d_enc, d_pre, None, None, None, None
 
