@@ -175,8 +175,11 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host = 0.0
     for _ in range(a.steps):
+        h0 = time.perf_counter()
         out = tr.step(data, 0.0, cmvn_d)
+        host += time.perf_counter() - h0
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -185,7 +188,7 @@ def main():
         tmax = torch.tensor([dt], device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
-    log('timed region done: %.3fs for %d steps' % (dt, a.steps))
+    log('timed region done: %.3fs for %d steps (host enqueue %.1f ms/step)' % (dt, a.steps, host / a.steps * 1e3))
     losses = JointTrainer.to_floats(out)
     if rank != 0:
         return

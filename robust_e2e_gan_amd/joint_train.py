@@ -64,6 +64,7 @@ class JointTrainer(object):
         # run the D passes on a side HIP stream under the latency-bound recurrent chains (RE2E_NO_OVERLAP=1: profiling)
         self.overlap_dstep = os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
         self.side_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.wgrad_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
 
     def step(self, data, sche_samp_rate, enhance_cmvn):
         """One training iteration (joint_train.py:157-213).  Returns a dict of DEVICE scalars (call
@@ -72,6 +73,7 @@ class JointTrainer(object):
         clean_inputs, mix_inputs, mix_log_inputs, targets, input_sizes, target_sizes = data[2], data[4], data[5], data[7], data[8], data[9]
         overlap = self.overlap_dstep
         ops.MULTI_STREAM = bool(overlap)
+        ops.WGRAD_STREAM = self.wgrad_stream if overlap else None
         main = torch.cuda.current_stream()
         clean_branch = None
         if overlap and getattr(self.asr_model, 'etype', '').startswith('vgg'):
@@ -153,6 +155,8 @@ class JointTrainer(object):
             loss_D = None
             if self.overlap_dstep:
                 torch.cuda.current_stream().wait_stream(self.side_stream)
+        if self.overlap_dstep:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)      # deferred weight-gradient kernels
         sync.finish([self.enhance_optimizer] if armed else [self.asr_optimizer, self.enhance_optimizer])
         grad_norm = self.asr_optimizer.clip_grad_norm(opt.grad_clip)           # ASR params only (:188)
         self.enhance_optimizer.step(self.asr_optimizer.gate_stats())           # unclipped, same NaN gate (:189-193)
@@ -177,6 +181,8 @@ class JointTrainer(object):
         loss_D_fake = self.criterionGAN(self.gan_model(enhance_feat.detach(), enhance_cmvn), False)
         loss_D = (loss_D_real + loss_D_fake) * 0.5
         loss_D.backward()
+        if ops.WGRAD_STREAM is not None:
+            torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)
         GradSync().finish([self.gan_optimizer])
         self.gan_optimizer.clip_grad_norm(opt.grad_clip)
         if wait_before_update is not None:     # the G-step backward still reads D's weights on the main stream

@@ -57,6 +57,44 @@ def colsum_into(A2d, M, N, out, beta, lda=None):
 
 
 MULTI_STREAM = False     # set by JointTrainer when branches run on side streams
+WGRAD_STREAM = None      # optional stream for weight-gradient kernels (see ``param_grads``)
+
+
+class param_grads(object):
+    """``with param_grads(t1, t2, ...):`` runs the enclosed weight/bias-gradient kernels on WGRAD_STREAM.
+
+    Nothing downstream in the backward pass depends on a weight gradient, so those kernels form a reservoir of
+    MFMA work that fills the CUs left idle by the latency-bound parts of the step (recurrent chains, decoder).
+    ``t*`` are the tensors the kernels read: they are kept alive for that stream.  Ordering of the accumulation
+    into shared gradients is handled by ``accumulate``; the trainer joins the stream before the optimizer."""
+    __slots__ = ('ts', 'ctx')
+
+    def __init__(self, *tensors):
+        self.ts = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        ws = WGRAD_STREAM
+        if not MULTI_STREAM or ws is None:
+            return self
+        cur = torch.cuda.current_stream()
+        if cur == ws:
+            return self
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        ws.wait_event(ev)
+        for t in self.ts:
+            if t is not None:
+                t.record_stream(ws)
+        self.ctx = torch.cuda.stream(ws)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
 
 
 class accumulate(object):
@@ -127,12 +165,13 @@ class LinearFn(torch.autograd.Function):
             dx = empty((M, K), x2)
             gemm(dz, W, dx, M, K, N)                       # dx = dz[M,N] * W[N,K]
             dx = dx.view(ctx.xshape)
-        if W.requires_grad:
-            with accumulate(W) as (gw, beta):
-                gemm(dz, x2, gw, N, K, M, transa=True, beta=beta)   # dW = dz^T x
-        if b is not None and b.requires_grad:
-            with accumulate(b) as (gb, beta):
-                colsum_into(dz, M, N, gb, beta)
+        with param_grads(dz, x2):
+            if W.requires_grad:
+                with accumulate(W) as (gw, beta):
+                    gemm(dz, x2, gw, N, K, M, transa=True, beta=beta)   # dW = dz^T x
+            if b is not None and b.requires_grad:
+                with accumulate(b) as (gb, beta):
+                    colsum_into(dz, M, N, gb, beta)
         return dx, None, None, None
 
 
@@ -238,7 +277,7 @@ class MaskFcFn(torch.autograd.Function):
             gemm(dlin, W, dp, M, K, N)
             dp = dp.view(ctx.oshape[:-1] + (K,))
         if W.requires_grad:
-            with accumulate(W) as (gw, beta):
+            with param_grads(dlin, p2), accumulate(W) as (gw, beta):
                 gemm(dlin, p2, gw, N, K, M, transa=True, beta=beta)
         return dp, None, None, None, None
 
@@ -315,15 +354,16 @@ class Conv2dFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad)
-        if W.requires_grad:
-            wsb = query('re2e_conv_wgrad_workspace_bytes', N, OH, OW, Cin, Cout, KH, KW)
-            ws = workspace(wsb, x.device, 'wgrad')
-            with accumulate(W) as (gw, beta):
-                call('re2e_conv_wgrad', x.data_ptr(), N, H, Wd, Cin, dz.data_ptr(), Cout, KH, KW, OH, OW, stride, stride, -pad, -pad,
-                     gw.data_ptr(), beta, ws.data_ptr(), wsb)
-        if b is not None and b.requires_grad:
-            with accumulate(b) as (gb, beta):
-                colsum_into(dz, N * OH * OW, Cout, gb, beta)
+        with param_grads(dz, x):
+            if W.requires_grad:
+                wsb = query('re2e_conv_wgrad_workspace_bytes', N, OH, OW, Cin, Cout, KH, KW)
+                ws = workspace(wsb, x.device, 'wgrad')
+                with accumulate(W) as (gw, beta):
+                    call('re2e_conv_wgrad', x.data_ptr(), N, H, Wd, Cin, dz.data_ptr(), Cout, KH, KW, OH, OW, stride, stride, -pad, -pad,
+                         gw.data_ptr(), beta, ws.data_ptr(), wsb)
+            if b is not None and b.requires_grad:
+                with accumulate(b) as (gb, beta):
+                    colsum_into(dz, N * OH * OW, Cout, gb, beta)
         return dx, None, None, None, None, None
 
 
@@ -523,22 +563,23 @@ class BiLstmFn(torch.autograd.Function):
             gemm(dG[1], w[4], dx, M, I, 4 * H, beta=1.0)
             dx = dx.view(T, B, I)
         yflat = ybuf.view((T + 2) * B, 2 * H)
-        for d in range(2):
-            w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
-            if w_ih.requires_grad:
-                with accumulate(w_ih) as (gw, beta):
-                    gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
-            if w_hh.requires_grad:
-                # h_{t-1}: forward direction = ybuf block t (y[t-1]); reverse = ybuf block t+2 (y[t+1])
-                hprev = yflat[(0 if d == 0 else 2 * B):, d * H:]
-                with accumulate(w_hh) as (gw, beta):
-                    call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
-            if b_ih.requires_grad:
-                with accumulate(b_ih) as (gb, beta):
-                    colsum_into(dG[d], M, 4 * H, gb, beta)
-            if b_hh.requires_grad:
-                with accumulate(b_hh) as (gb, beta):
-                    colsum_into(dG[d], M, 4 * H, gb, beta)
+        with param_grads(g_f, g_r, x2, ybuf):
+            for d in range(2):
+                w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
+                if w_ih.requires_grad:
+                    with accumulate(w_ih) as (gw, beta):
+                        gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
+                if w_hh.requires_grad:
+                    # h_{t-1}: forward direction = ybuf block t (y[t-1]); reverse = ybuf block t+2 (y[t+1])
+                    hprev = yflat[(0 if d == 0 else 2 * B):, d * H:]
+                    with accumulate(w_hh) as (gw, beta):
+                        call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
+                if b_ih.requires_grad:
+                    with accumulate(b_ih) as (gb, beta):
+                        colsum_into(dG[d], M, 4 * H, gb, beta)
+                if b_hh.requires_grad:
+                    with accumulate(b_hh) as (gb, beta):
+                        colsum_into(dG[d], M, 4 * H, gb, beta)
         return (dx, None) + (None,) * len(w)
 
 
