@@ -65,10 +65,30 @@ class JointTrainer(object):
         self.overlap_dstep = os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
         self.side_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.wgrad_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.main_stream = None
+        if torch.cuda.is_available() and os.environ.get('RE2E_NO_PRIORITY', '0') != '1':
+            try:
+                self.main_stream = torch.cuda.Stream(priority=-1)
+            except Exception:
+                self.main_stream = None
 
     def step(self, data, sche_samp_rate, enhance_cmvn):
         """One training iteration (joint_train.py:157-213).  Returns a dict of DEVICE scalars (call
-        ``to_floats`` to log them: that is the only host synchronisation)."""
+        ``to_floats`` to log them: that is the only host synchronisation).
+
+        With overlap enabled the critical path (recurrent chains, decoder) runs on a HIGH-priority stream and the
+        filler work (clean-branch convs, discriminator passes, weight gradients) on normal-priority streams, so
+        that the short dependent launches of the chains are dispatched ahead of queued bulk kernels."""
+        if not (self.overlap_dstep and self.main_stream is not None):
+            return self._step(data, sche_samp_rate, enhance_cmvn)
+        caller = torch.cuda.current_stream()
+        self.main_stream.wait_stream(caller)
+        with torch.cuda.stream(self.main_stream):
+            out = self._step(data, sche_samp_rate, enhance_cmvn)
+        caller.wait_stream(self.main_stream)
+        return out
+
+    def _step(self, data, sche_samp_rate, enhance_cmvn):
         opt = self.opt
         clean_inputs, mix_inputs, mix_log_inputs, targets, input_sizes, target_sizes = data[2], data[4], data[5], data[7], data[8], data[9]
         overlap = self.overlap_dstep
