@@ -99,13 +99,23 @@ def conv_roofline(dev, iters=20):
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * 9 * C * K * N * H * W
     ach = flops / sec / 1e12
+    # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
+    # kernel and shape, tools/roofline_conv.py); a counter pass cannot run inside this process.
+    traffic, tsrc = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_conv1_2_pmc_traffic.json')))
+        traffic, tsrc = pj['traffic_bytes_per_launch'], 'profiles/r01_conv1_2_pmc_traffic.json'
+    except Exception:
+        pass
     return {'bound': 'mfma', 'kernel': 'igemm_kernel<ConvK,DenseK,256x64> (VGG conv1_2 fwd, 64x800x80, 64->64, 3x3)', 'achieved': round(ach, 2),
-            'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+            'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+            'traffic_unit': 'bytes per launch (FETCH_SIZE + WRITE_SIZE)', 'traffic_source': tsrc,
+            'algorithmic_bytes_per_launch': 4.0 * (N * H * W * C + N * H * W * K + K * 9 * C),
             'avg_launch_ms': round(sec * 1e3, 4), 'algorithmic_flop_per_launch': flops}
 
 
 def cpu_baseline(opt):
-    """Oracle ('port') on the host cores: one joint step on a bounded sample (B=16 of 32 utterances,
+    """Oracle ('port') on the host cores: one joint step on the full config-4 batch (B=32,
     same T/L/V/architecture) after a small warm-up step."""
     from oracle import joint as oj
     from robust_e2e_gan_amd.data.synthetic import make_batch
@@ -120,14 +130,14 @@ def cpu_baseline(opt):
                enhance_loss_type='L2')
     st = oj.JointState(sd[0], sd[2], sd[3], torch.from_numpy(mel_matrix()), cfg)
     cm = torch.stack([torch.full((80,), -8.0), torch.full((80,), 0.5)])
-    for B, T, L, timed in ((2, 200, 10, False), (16, 800, 40, True)):
+    for B, T, L, timed in ((2, 200, 10, False), (32, 800, 40, True)):
         clean, mix, mix_log, targets, il, tl = make_batch(B, T, L, opt.odim, seed=1234)
         t0 = time.time()
         oj.joint_step(st, (clean, mix, mix_log, targets, il.tolist(), tl.tolist()), cm)
         dt = time.time() - t0
         log('cpu_baseline: B=%d T=%d step took %.1fs' % (B, T, dt))
-    return {'value': round(16.0 / dt, 4), 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
-            'sample': 'oracle/joint.py joint_step, config-4 architecture, B=16 of 32 utterances, T=800, L=40, V=4233, 1 timed step after a '
+    return {'value': round(32.0 / dt, 4), 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle/joint.py joint_step, config-4 architecture, the full B=32 batch, T=800, L=40, V=4233, 1 timed step after a '
                       'B=2,T=200 warm-up; torch CPU fp32, %d threads' % cores, 'seconds': round(dt, 2)}
 
 
