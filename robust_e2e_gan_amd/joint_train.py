@@ -63,8 +63,19 @@ class JointTrainer(object):
         self.asr_model.dec.return_acc_tensor = True
         # run the D passes on a side HIP stream under the latency-bound recurrent chains (RE2E_NO_OVERLAP=1: profiling)
         self.overlap_dstep = os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
-        self.side_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
-        self.wgrad_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.side_stream = self.wgrad_stream = None
+        if torch.cuda.is_available():
+            # filler streams: optionally restricted to a subset of the CUs (RE2E_FILLER_CUS, default all) so that the
+            # chains on the main stream always find idle CUs
+            ncu = int(os.environ.get('RE2E_FILLER_CUS', '192'))     # measured best on MI355X: 101.0 -> 96.5 ms/step
+            dev = next(enhance_model.parameters()).device
+            if 0 < ncu < 256:
+                self.side_stream = lib.cu_masked_stream(ncu, 256, dev)
+                self.wgrad_stream = lib.cu_masked_stream(ncu, 256, dev)
+            if self.side_stream is None:
+                self.side_stream = torch.cuda.Stream()
+            if self.wgrad_stream is None:
+                self.wgrad_stream = torch.cuda.Stream()
         self.main_stream = None
         if torch.cuda.is_available() and os.environ.get('RE2E_NO_PRIORITY', '0') != '1':
             try:

@@ -141,3 +141,30 @@ def workspace(nbytes, device, tag='ws'):
         buf = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+_hip = None
+
+
+def cu_masked_stream(enabled_cus, total_cus=256, device=None):
+    """A HIP stream whose kernels may only run on the first ``enabled_cus`` bits of the CU mask
+    (hipExtStreamCreateWithCUMask), wrapped as a torch ExternalStream.  Used for the filler streams of the
+    joint step so that the short dependent launches of the recurrent chains always find idle CUs.
+    Returns None if the runtime refuses."""
+    global _hip
+    try:
+        if _hip is None:
+            _hip = ctypes.CDLL('libamdhip64.so')
+            _hip.hipExtStreamCreateWithCUMask.restype = c_int
+            _hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        words = (total_cus + 31) // 32
+        mask = (ctypes.c_uint32 * words)()
+        for i in range(min(enabled_cus, total_cus)):
+            mask[i // 32] |= (1 << (i % 32))
+        st = c_void_p()
+        rc = _hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)
+        if rc != 0 or not st.value:
+            return None
+        return torch.cuda.ExternalStream(st.value, device=device)
+    except Exception:
+        return None

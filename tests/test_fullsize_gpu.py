@@ -1,0 +1,98 @@
+"""GPU tests at realistic sizes: (a) the HIP joint step vs the CPU oracle at the config-4 ARCHITECTURE on a
+small batch, (b) size-independent properties at BASELINE.json's full config-4 size, (c) the long-utterance
+shape of config 5."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _build(opt):
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    torch.manual_seed(1234)
+    return [m.train() for m in (EnhanceModel(opt), FbankModel(opt), ShareE2E(opt), GANModel(opt))]
+
+
+def _data(B, T, L, V, seed=7):
+    from robust_e2e_gan_amd.data.synthetic import make_batch
+    clean, mix, mix_log, targets, il, tl = make_batch(B, T, L, V, seed=seed)
+    return clean, mix, mix_log, targets, il, tl
+
+
+def test_config4_architecture_vs_oracle():
+    """Full-width networks (enhancer 2xBLSTM-256, VGG + 3xBLSTMP-512, decoder 300, V=4233, D ndf 64) on B=3, T=96."""
+    from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
+    from oracle import joint as oj
+    opt = config4_opt(coral_loss_lambda=0.5)
+    nets = _build(opt)
+    sd = [{k: v.clone() for k, v in m.state_dict().items()} for m in nets]
+    clean, mix, mix_log, targets, il, tl = _data(3, 96, 6, opt.odim)
+    cm = torch.stack([torch.full((80,), -9.0), torch.full((80,), 0.4)])
+    cfg = dict(enhance_layers=2, elayers=3, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=0.5, gan_loss_lambda=1.0, grad_clip=5.0,
+               eps=1e-8, isGAN=True, enhance_loss_type='L2')
+    st = oj.JointState(sd[0], sd[2], sd[3], sd[1]['fc'], cfg)
+    ref = oj.joint_step(st, (clean, mix, mix_log, targets, il.tolist(), tl.tolist()), cm)
+    enh, fb, asr, gan = [m.to(DEV) for m in nets]
+    tr = JointTrainer(opt, enh, fb, asr, gan)
+    data = (None, None, clean, None, mix, mix_log, None, targets, il, tl)
+    out = JointTrainer.to_floats(tr.step(data, 0.0, cm))
+    for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'loss_D'):
+        a, b = out['train/' + k], float(ref[k])
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (k, a, b)
+    assert abs(out['grad_norm'] - ref['grad_norm_asr']) <= 2e-3 * ref['grad_norm_asr']
+    eo = tr.last['enhance_out'].cpu()
+    assert (eo - ref['enhance_out']).abs().max() <= 1e-3 * ref['enhance_out'].abs().max()
+    # gradients of a few large tensors (relative to their scale)
+    for name, g in (('enc.enc2.bilstm0.weight_ih_l0', None), ('enc.enc1.conv1_2.weight', None), ('dec.output.weight', None), ('ctc.ctc_lo.weight', None)):
+        got = dict(asr.named_parameters())[name].grad.cpu()
+        want = ref['g_asr'][name]
+        assert (got - want).abs().max() <= 2e-3 * want.abs().max() + 1e-8, name
+    got = dict(enh.named_parameters())['enc1.nblstm.weight_hh_l0'].grad.cpu()
+    want = ref['g_enh']['enc1.nblstm.weight_hh_l0']
+    assert (got - want).abs().max() <= 3e-3 * want.abs().max() + 1e-8
+
+
+def test_config4_full_size_properties():
+    """B=32, T=800, L=40: finite losses, exact zeros / log(1e-7) in the padded region, run-to-run bitwise determinism."""
+    from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
+    opt = config4_opt()
+    clean, mix, mix_log, targets, il, tl = _data(32, 800, 40, opt.odim, seed=1234)
+    cm = torch.stack([torch.full((80,), -9.0), torch.full((80,), 0.4)])
+    data = (None, None, clean.to(DEV), None, mix.to(DEV), mix_log.to(DEV), None, targets, il, tl)
+    results = []
+    for rep in range(2):
+        enh, fb, asr, gan = [m.to(DEV) for m in _build(opt)]
+        tr = JointTrainer(opt, enh, fb, asr, gan)
+        out = JointTrainer.to_floats(tr.step(data, 0.0, cm))
+        assert all(math.isfinite(v) for v in out.values()), out
+        eo, ef = tr.last['enhance_out'], tr.last['enhance_feat']
+        for b in (5, 31):
+            l = int(il[b])
+            assert (eo[b, l:] == 0).all()                                   # Appendix A.2
+            assert torch.allclose(ef[b, l:], torch.full_like(ef[b, l:], math.log(1e-7)))   # Appendix A.3
+        assert 300 < out['train/loss_att'] < 360 and 0.0 <= out['train/acc'] <= 0.01       # ~ L * ln(V) at random init
+        results.append((out, dict(asr.named_parameters())['enc.enc2.bt2.weight'].detach().clone(), tr.enhance_optimizer.flat.clone()))
+    a, b = results
+    assert a[0] == b[0], 'losses must be bitwise reproducible run to run'
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), 'updated parameters must be bitwise reproducible'
+
+
+def test_config5_long_utterances():
+    """B=8, T=3000, L=150 (config 5): the step runs and stays finite (HBM-bound BLSTM regime)."""
+    from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
+    opt = config4_opt()
+    clean, mix, mix_log, targets, il, tl = _data(8, 3000, 150, opt.odim, seed=5)
+    cm = torch.stack([torch.full((80,), -9.0), torch.full((80,), 0.4)])
+    enh, fb, asr, gan = [m.to(DEV) for m in _build(opt)]
+    tr = JointTrainer(opt, enh, fb, asr, gan)
+    data = (None, None, clean.to(DEV), None, mix.to(DEV), mix_log.to(DEV), None, targets, il, tl)
+    for _ in range(2):
+        out = JointTrainer.to_floats(tr.step(data, 0.0, cm))
+        assert all(math.isfinite(v) for v in out.values()), out
