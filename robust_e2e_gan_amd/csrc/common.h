@@ -76,3 +76,38 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   for (int i = 0; i < nw; ++i) r = fmaxf(r, red[i]);
   return r;
 }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case RE2E_ACT_TANH: return tanhf_(v);
+    case RE2E_ACT_RELU: return fmaxf(v, 0.f);
+    case RE2E_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case RE2E_ACT_SIGMOID: return sigmoidf_(v);
+    default: return v;
+  }
+}
+
+// im2col geometry over an NHWC tensor: logical pixel grid (NI, PH, PW) -> input coordinate
+// iy = py*SY + kh*DY + OY0, ix = px*SX + kw*DX + OX0 ; taps KH x KW ; C channels innermost.
+struct ConvGeom {
+  const float* in; int NI, H, W, C; int PH, PW; int KH, KW; int SY, SX, DY, DX, OY0, OX0;
+};
+
+// Output placement of a convolution row m = (n, py, px): plain (m*ldc) or, for the stride-2
+// data-gradient parity classes, ((n*OHF + py*osy+ooy)*OWF + px*osx+oox)*ldc.
+struct OutMap {
+  float* out; long ldc; int remap; int PH, PW, OHF, OWF, osy, osx, ooy, oox;
+  __device__ long off(int row) const {
+    if (!remap) return (long)row * ldc;
+    int j = row % PW; int t = row / PW; int i = t % PH; int n = t / PH;
+    return (((long)n * OHF + i * osy + ooy) * OWF + j * osx + oox) * ldc;
+  }
+};
+
+// Thin-channel convolutions (thinconv.hip): direct kernels for Cout == 1 (forward) and Cin == 1 / Cout == 1 (weight gradient), where an MFMA tile
+// would be >= 97 % padding.  thin_conv_forward returns false / thin_wgrad_slabs returns 0 when the shape is
+// not covered (the caller then uses the implicit GEMM).
+bool thin_conv_forward(const ConvGeom& g, const float* wg, int Cout, const OutMap& o, const float* bias, int act,
+                       float beta, hipStream_t st);
+int thin_wgrad_slabs(int C, int Cout, int KH, int KW, long P, long rows);
+void thin_wgrad(const ConvGeom& g, const float* dout, int Cout, float* slabs, int nslab, hipStream_t st);

@@ -38,6 +38,7 @@ struct Cfg {
 // ------------------------------------------------------------------------------------------
 struct DenseK {   // X[row*ld + k]
   static constexpr bool KMAJ = true;
+  static constexpr const char* NAME = "DenseK";
   const float* p; unsigned nbytes; long ld; int rows, K;
   struct Row { unsigned base; };     // row*ld*4, or nbytes when the row is out of range
   struct Kst { int k; };
@@ -51,6 +52,7 @@ struct DenseK {   // X[row*ld + k]
 
 struct DenseM {   // X[k*ld + row]
   static constexpr bool KMAJ = false;
+  static constexpr const char* NAME = "DenseM";
   const float* p; unsigned nbytes; long ld; int rows, K;
   struct Row { int r0; };
   struct Kst { int k; };
@@ -62,14 +64,9 @@ struct DenseM {   // X[k*ld + row]
   }
 };
 
-// im2col geometry over an NHWC tensor: logical pixel grid (NI, PH, PW) -> input coordinate
-// iy = py*SY + kh*DY + OY0, ix = px*SX + kw*DX + OX0 ; taps KH x KW ; C channels innermost.
-struct ConvGeom {
-  const float* in; int NI, H, W, C; int PH, PW; int KH, KW; int SY, SX, DY, DX, OY0, OX0;
-};
-
 struct ConvK {    // rows = pixels, k = (kh, kw, ci) with ci fastest
   static constexpr bool KMAJ = true;
+  static constexpr const char* NAME = "ConvK";
   ConvGeom g; const float* p; unsigned nbytes; int rows, K;
   struct Row { int n, iy0, ix0; };
   struct Kst { int k, ci, kh, kw; };
@@ -98,6 +95,7 @@ struct ConvK {    // rows = pixels, k = (kh, kw, ci) with ci fastest
 
 struct ConvM {    // rows = (kh, kw, ci) (ci fastest), k = pixel  (weight-gradient A operand)
   static constexpr bool KMAJ = false;
+  static constexpr const char* NAME = "ConvM";
   ConvGeom g; const float* p; unsigned nbytes; int rows, K;
   struct Row { int r0, ci, kh, kw; };
   struct Kst { int k, n, py, px; };
@@ -149,16 +147,6 @@ struct Epi {
   // split-K: when nsplit>1 raw accumulators go to ws[z][M][N]
   float* ws; int nsplit;
 };
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  switch (act) {
-    case RE2E_ACT_TANH: return tanhf_(v);
-    case RE2E_ACT_RELU: return fmaxf(v, 0.f);
-    case RE2E_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
-    case RE2E_ACT_SIGMOID: return sigmoidf_(v);
-    default: return v;
-  }
-}
 
 template <class LA, class LB, class CF, bool VEC>
 __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep, int K) {
@@ -393,6 +381,31 @@ __global__ void splitk_reduce_kernel(const float* ws, int nsplit, int M, int N, 
   C[off] = s;
 }
 
+// Same reduce for FEW outputs and MANY slabs (thin-channel weight gradients: 576 outputs x 1024 slabs):
+// 16 slab lanes per output, combined through LDS in a fixed order (still deterministic).
+__global__ __launch_bounds__(1024) void splitk_reduce_wide_kernel(const float* ws, int nsplit, int M, int N, float* C, long ldc,
+                                                                  float beta, int conv_perm, int Cin, int KHW) {
+  __shared__ float part[16][64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long tot = (long)M * N;
+  const long i = (long)blockIdx.x * 64 + e;
+  float s = 0.f;
+  if (i < tot)
+    for (int z = sl; z < nsplit; z += 16) s += ws[(long)z * tot + i];
+  part[sl][e] = s;
+  __syncthreads();
+  if (sl != 0 || i >= tot) return;
+  s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += part[q][e];
+  int m = (int)(i / N), n = (int)(i % N);
+  long off;
+  if (conv_perm) { int ci = m % Cin; int tap = m / Cin; off = ((long)n * Cin + ci) * KHW + tap; }
+  else off = (long)m * ldc + n;
+  if (beta != 0.f) s += C[off];
+  C[off] = s;
+}
+
 template <class LA, class LB, class CF, bool VEC>
 int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
   constexpr int ASZ = LA::KMAJ ? CF::BM * CF::LDK : CF::BK * (CF::BM + 4);
@@ -405,6 +418,10 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(cdiv(ep.M, CF::BM), cdiv(ep.N, CF::BN), ep.nsplit);
+  static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
+  if (log_calls)
+    fprintf(stderr, "[igemm] A=%s B=%s tile=%dx%dx%d vec=%d M=%d N=%d K=%d splits=%d\n", LA::NAME, LB::NAME, CF::BM, CF::BN,
+            CF::BK, (int)VEC, ep.M, ep.N, K, ep.nsplit);
   hipLaunchKernelGGL((igemm_kernel<LA, LB, CF, VEC>), grid, dim3(CF::THREADS), lds, st, la, lb, ep, K);
   return 0;
 }
@@ -557,6 +574,13 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
 }
 
 // ---- convolution (NHWC activations, weights pre-gathered by re2e_conv_weight_gather) ----------
+// RE2E_NO_THIN=1 routes the Cin == 1 / Cout == 1 convolutions through the implicit GEMM (A/B measurements)
+static bool thin_enabled() {
+  static int v = -1;
+  if (v < 0) v = getenv("RE2E_NO_THIN") ? 0 : 1;
+  return v == 1;
+}
+
 template <bool V>
 static void conv_dispatch(const ConvGeom& g, int M, int K, const float* wg, int Cout, Epi& ep, hipStream_t st) {
   ConvK la{g, g.in, (unsigned)((long)g.NI * g.H * g.W * g.C * 4), M, K};
@@ -585,16 +609,32 @@ extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, con
   ep.C = out; ep.ldc = Cout; ep.M = M; ep.N = Cout; ep.bias = bias; ep.act = act; ep.beta = beta; ep.nsplit = 1;
   ep.remap = 1; ep.PH = PH; ep.PW = PW; ep.OHF = OHF; ep.OWF = OWF; ep.osy = osy; ep.osx = osx; ep.ooy = ooy; ep.oox = oox;
   if (osy == 1 && osx == 1 && ooy == 0 && oox == 0 && OHF == PH && OWF == PW) ep.remap = 0;
+  if (Cout == 1 && thin_enabled()) {
+    OutMap om{out, (long)Cout, ep.remap, PH, PW, OHF, OWF, osy, osx, ooy, oox};
+    if (thin_conv_forward(g, wg, Cout, om, bias, act, beta, stream)) {
+      RE2E_LAUNCH_CHECK();
+      return RE2E_OK;
+    }
+  }
   if (C % 4 == 0 && aligned16(in) && aligned16(wg)) conv_dispatch<true>(g, M, K, wg, Cout, ep, stream);
   else conv_dispatch<false>(g, M, K, wg, Cout, ep, stream);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
 
-static int wgrad_splits(int Mrows, int Cout, long P) {
+static int wgrad_splits_mfma(int Mrows, int Cout, long P) {
   int bm, bn;
   if (Cout <= 32) { bm = 256; bn = 32; } else if (Cout <= 64) { bm = 256; bn = 64; } else { bm = 128; bn = 128; }
   return pick_splits(Mrows, Cout, (int)P, bm, bn);
+}
+
+static int wgrad_splits(int Mrows, int Cout, long P, long rows, int C, int KH, int KW, bool* thin = nullptr) {
+  if (thin) *thin = false;
+  if ((C == 1 || Cout == 1) && thin_enabled()) {
+    int s = thin_wgrad_slabs(C, Cout, KH, KW, P, rows);
+    if (s > 0) { if (thin) *thin = true; return s; }
+  }
+  return wgrad_splits_mfma(Mrows, Cout, P);
 }
 
 template <bool V>
@@ -609,7 +649,7 @@ static void wgrad_dispatch(const ConvGeom& g, int Mrows, int P, const float* dou
 extern "C" size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW) {
   int Mrows = KH * KW * C;
   long P = (long)NI * PH * PW;
-  int s = wgrad_splits(Mrows, Cout, P);
+  int s = wgrad_splits(Mrows, Cout, P, (long)NI * PH, C, KH, KW);
   return (size_t)s * Mrows * Cout * sizeof(float);   // always reduce through the workspace (layout permute)
 }
 
@@ -623,7 +663,9 @@ extern "C" int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, con
   long P = (long)NI * PH * PW;
   RE2E_CHECK_ARG(P < 2147483647L, "too many pixels");
   RE2E_CHECK_ARG((long)NI * H * W * C * 4 < 0xFFFFFFF0L && P * Cout * 4 < 0xFFFFFFF0L, "tensor larger than 4 GiB");
-  int s = wgrad_splits(Mrows, Cout, P);
+  bool thin = false;
+  int s = wgrad_splits(Mrows, Cout, P, (long)NI * PH, C, KH, KW, &thin);
+  if (thin && !(aligned16(in) && aligned16(dout))) { thin = false; s = wgrad_splits_mfma(Mrows, Cout, P); }
   RE2E_CHECK_ARG(workspace_bytes >= (size_t)s * Mrows * Cout * sizeof(float), "workspace too small");
   Epi ep;
   memset(&ep, 0, sizeof(ep));
@@ -631,11 +673,16 @@ extern "C" int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, con
   if (s == 1) {   // still go through the slab so that the reduce kernel applies the layout permute
     ep.C = (float*)workspace; ep.ldc = Cout;
   }
-  if (C % 4 == 0 && Cout % 4 == 0 && aligned16(in) && aligned16(dout)) wgrad_dispatch<true>(g, Mrows, (int)P, dout, Cout, ep, stream);
+  if (thin) thin_wgrad(g, dout, Cout, (float*)workspace, s, stream);
+  else if (C % 4 == 0 && Cout % 4 == 0 && aligned16(in) && aligned16(dout)) wgrad_dispatch<true>(g, Mrows, (int)P, dout, Cout, ep, stream);
   else wgrad_dispatch<false>(g, Mrows, (int)P, dout, Cout, ep, stream);
   long tot = (long)Mrows * Cout;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s, Mrows,
-                     Cout, dW, (long)Cout, beta, 1, C, KH * KW, (const float*)nullptr, (const float*)nullptr, RE2E_ACT_NONE);
+  if (s >= 64 && tot <= 65536)
+    hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(cdiv(tot, 64)), dim3(1024), 0, stream, (const float*)workspace, s, Mrows,
+                       Cout, dW, (long)Cout, beta, 1, C, KH * KW);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s, Mrows,
+                       Cout, dW, (long)Cout, beta, 1, C, KH * KW, (const float*)nullptr, (const float*)nullptr, RE2E_ACT_NONE);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

@@ -154,6 +154,14 @@ CONVS = [  # N, H, W, Cin, Cout, k, stride, pad, act, bias
     (3, 9, 9, 16, 32, 4, 1, 1, None, False),
     (3, 8, 8, 32, 1, 4, 1, 1, None, True),
     (2, 7, 5, 6, 10, 3, 1, 1, 'relu', True),
+    # thin-channel direct kernels (thinconv.hip): Cin == 1 / Cout == 1 at the VGG / discriminator widths,
+    # plus widths the thin weight-gradient kernels do not cover (fall back to the implicit GEMM)
+    (2, 21, 16, 1, 64, 3, 1, 1, 'relu', True),
+    (2, 37, 20, 1, 64, 4, 2, 1, 'lrelu', True),
+    (2, 12, 9, 512, 1, 4, 1, 1, None, True),
+    (2, 11, 7, 64, 1, 3, 1, 1, None, False),
+    (2, 9, 8, 1, 12, 3, 1, 1, None, True),
+    (2, 9, 8, 12, 1, 3, 1, 1, 'lrelu', True),
 ]
 
 

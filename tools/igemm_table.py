@@ -1,0 +1,51 @@
+"""Per-call table of the implicit-GEMM engine: shape, duration, TFLOP/s.
+
+Run on the GPU box:
+    RE2E_IGEMM_LOG=1 RE2E_NO_OVERLAP=1 rocprofv3 --kernel-trace --output-format csv -d OUT -- \
+        python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline 2> OUT/log.txt
+    python3 tools/igemm_table.py OUT/log.txt OUT/*/*_kernel_trace.csv
+
+The k-th "[igemm]" log line is the k-th igemm_kernel launch (single stream => launch order = trace order).
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def main(log_path, trace_path):
+    calls = []
+    for line in open(log_path, errors="replace"):
+        m = re.search(r"\[igemm\] A=(\w+) B=(\w+) tile=(\d+)x(\d+)x(\d+) vec=(\d) M=(\d+) N=(\d+) K=(\d+) splits=(\d+)", line)
+        if m:
+            a, b = m.group(1), m.group(2)
+            calls.append((a, b) + tuple(int(x) for x in m.groups()[2:]))
+    kern = []
+    for r in csv.DictReader(open(trace_path)):
+        if "igemm_kernel" in r["Kernel_Name"]:
+            kern.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    kern.sort()
+    if len(kern) != len(calls):
+        print(f"warning: {len(calls)} log lines vs {len(kern)} kernels; joining the common tail", file=sys.stderr)
+    n = min(len(kern), len(calls))
+    calls, kern = calls[-n:], kern[-n:]
+    durs = defaultdict(list)
+    for c, (t0, t1) in zip(calls, kern):
+        a, b, bm, bn, bk, vec, M, N, K, s = c
+        durs[(a, b, f"{bm}x{bn}x{bk}", vec, M, N, K, s)].append((t1 - t0) * 1e-3)
+    agg = {}
+    for key, d in durs.items():   # median per call: one-off first-launch outliers (code load) would skew a mean
+        d.sort()
+        med = d[len(d) // 2]
+        agg[key] = [len(d), med * len(d), 2.0 * key[4] * key[5] * key[6] * len(d)]
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    tot_us = sum(v[1] for _, v in rows)
+    tot_fl = sum(v[2] for _, v in rows)
+    print(f"{'A':7}{'B':7}{'tile':11}{'v':2}{'M':>9}{'N':>6}{'K':>9}{'spl':>4}{'calls':>6}{'us/call':>9}{'TF/s':>7}{'share':>7}")
+    for (a, b, tile, vec, M, N, K, s), (cnt, us, fl) in rows:
+        print(f"{a:7}{b:7}{tile:11}{vec:<2}{M:9d}{N:6d}{K:9d}{s:4d}{cnt:6d}{us / cnt:9.1f}{fl / us * 1e-6:7.1f}{us / tot_us:7.1%}")
+    print(f"total {tot_us * 1e-3:.2f} ms, {tot_fl * 1e-12:.3f} TFLOP, {tot_fl / tot_us * 1e-6:.1f} TFLOP/s average")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
