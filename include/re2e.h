@@ -77,6 +77,11 @@ int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, const float* d
                     int PW, int SY, int SX, int OY0, int OX0, float* dW, float beta, void* workspace,
                     size_t workspace_bytes, re2e_stream_t stream);
 /* dst[r][a][b][c] <- W[Cout][Cin][KH][KW] at tap (kh0+a*kstep, kw0+b*kstep); transpose=0: r=co,c=ci; 1: r=ci,c=co */
+/* Stride-2 data gradient in one launch (all four output parity classes): dx[N][H][Wd][Cin] from
+ * dz[N][OH][OW][Cout] and the PyTorch-layout weight W[Cout][Cin][KH][KW] (KH, KW even).
+ * wt_ws: caller scratch of Cin*KH*KW*Cout floats (the per-class gathered weights). */
+int re2e_conv_dgrad_s2(const float* dz, int N, int OH, int OW, int Cout, const float* W, int Cin, int KH, int KW, int H,
+                       int Wd, int pad, float* dx, float* wt_ws, re2e_stream_t stream);
 int re2e_conv_weight_gather(const float* W, float* dst, int Cout, int Cin, int KH, int KW, int transpose, int TA,
                             int TB, int kh0, int kw0, int kstep, re2e_stream_t stream);
 

@@ -39,6 +39,7 @@ struct Cfg {
 struct DenseK {   // X[row*ld + k]
   static constexpr bool KMAJ = true;
   static constexpr const char* NAME = "DenseK";
+  static constexpr bool IS_CONVK = false;
   const float* p; unsigned nbytes; long ld; int rows, K;
   struct Row { unsigned base; };     // row*ld*4, or nbytes when the row is out of range
   struct Kst { int k; };
@@ -53,6 +54,7 @@ struct DenseK {   // X[row*ld + k]
 struct DenseM {   // X[k*ld + row]
   static constexpr bool KMAJ = false;
   static constexpr const char* NAME = "DenseM";
+  static constexpr bool IS_CONVK = false;
   const float* p; unsigned nbytes; long ld; int rows, K;
   struct Row { int r0; };
   struct Kst { int k; };
@@ -67,6 +69,7 @@ struct DenseM {   // X[k*ld + row]
 struct ConvK {    // rows = pixels, k = (kh, kw, ci) with ci fastest
   static constexpr bool KMAJ = true;
   static constexpr const char* NAME = "ConvK";
+  static constexpr bool IS_CONVK = true;
   ConvGeom g; const float* p; unsigned nbytes; int rows, K;
   struct Row { int n, iy0, ix0; };
   struct Kst { int k, ci, kh, kw; };
@@ -96,6 +99,7 @@ struct ConvK {    // rows = pixels, k = (kh, kw, ci) with ci fastest
 struct ConvM {    // rows = (kh, kw, ci) (ci fastest), k = pixel  (weight-gradient A operand)
   static constexpr bool KMAJ = false;
   static constexpr const char* NAME = "ConvM";
+  static constexpr bool IS_CONVK = false;
   ConvGeom g; const float* p; unsigned nbytes; int rows, K;
   struct Row { int r0, ci, kh, kw; };
   struct Kst { int k, n, py, px; };
@@ -146,6 +150,9 @@ struct Epi {
   int remap, PH, PW, OHF, OWF, osy, osx, ooy, oox;
   // split-K: when nsplit>1 raw accumulators go to ws[z][M][N]
   float* ws; int nsplit;
+  // merged stride-2 data gradient: blockIdx.z = output parity class (ph,pw); per-class input offsets and
+  // gathered-weight sets (re2e_conv_dgrad_s2)
+  int ncls; int cls_oy0[2], cls_ox0[2]; long cls_wstride;
 };
 
 template <class LA, class LB, class CF, bool VEC>
@@ -178,12 +185,22 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
     tile_n = (pid % per_group) / gsz;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int zsplit = blockIdx.z;
+  if constexpr (LA::IS_CONVK) {
+    if (ep.ncls) {
+      const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
+      la.g.OY0 = ep.cls_oy0[ph]; la.g.OX0 = ep.cls_ox0[pw];
+      lb.p += cls * ep.cls_wstride;
+      ep.ooy = ph; ep.oox = pw;
+      zsplit = 0;
+    }
+  }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(la.p), 0, la.nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lb.p), 0, lb.nbytes, 0x00020000);
   // split-K range
   const int nkt_total = (K + BK - 1) / BK;
   const int kt_per = (nkt_total + ep.nsplit - 1) / ep.nsplit;
-  const int kt_begin = blockIdx.z * kt_per;
+  const int kt_begin = zsplit * kt_per;
   const int kt_end = min(nkt_total, kt_begin + kt_per);
   const int kbegin = kt_begin * BK;
 
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
 
   // ---------------------------------- epilogue ----------------------------------
   if (ep.nsplit > 1) {
-    float* W = ep.ws + (long)blockIdx.z * ep.M * ep.N;
+    float* W = ep.ws + (long)zsplit * ep.M * ep.N;
 #pragma unroll
     for (int a = 0; a < CF::TM; ++a)
 #pragma unroll
@@ -341,7 +358,9 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
           long off;
           if (ep.remap) {
             int j = row % ep.PW; int t = row / ep.PW; int i = t % ep.PH; int n = t / ep.PH;
-            off = (((long)n * ep.OHF + i * ep.osy + ep.ooy) * ep.OWF + j * ep.osx + ep.oox) * ep.ldc + col;
+            const int oy = i * ep.osy + ep.ooy, ox = j * ep.osx + ep.oox;
+            if (oy >= ep.OHF || ox >= ep.OWF) continue;      // phantom row of a parity class (odd H or W)
+            off = (((long)n * ep.OHF + oy) * ep.OWF + ox) * ep.ldc + col;
           } else {
             off = (long)row * ep.ldc + col;
           }
@@ -417,7 +436,7 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  dim3 grid(cdiv(ep.M, CF::BM), cdiv(ep.N, CF::BN), ep.nsplit);
+  dim3 grid(cdiv(ep.M, CF::BM), cdiv(ep.N, CF::BN), ep.ncls ? ep.ncls : ep.nsplit);
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
   if (log_calls)
     fprintf(stderr, "[igemm] A=%s B=%s tile=%dx%dx%d vec=%d M=%d N=%d K=%d splits=%d\n", LA::NAME, LB::NAME, CF::BM, CF::BN,
@@ -495,6 +514,8 @@ inline bool use_skinny(int transa, int M, int N, int K) { return !transa && M <=
 int gemm_splits(int transa, int transb, int M, int N, int K) {
   if (use_skinny(transa, M, N, K)) return pick_splits_skinny(N, K);
   if (transa && !transb) return pick_splits(M, N, K, M >= 2048 ? 256 : 128, 128);
+  // x W^T / dy W with few output tiles and a long K (decoder output layer gradient: 1312 x 300 x 4233)
+  if ((long)cdiv(M, 128) * cdiv(N, 128) <= 64) return pick_splits(M, N, K, 128, 128);
   return 1;
 }
 
@@ -552,10 +573,9 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
   memset(&ep, 0, sizeof(ep));
   ep.C = C; ep.ldc = ldc; ep.M = M; ep.N = N; ep.bias = bias; ep.bias2 = bias2; ep.act = act; ep.beta = beta;
   ep.mul = mul; ep.mask_out = mask_out; ep.lens = lens_dev; ep.T = T; ep.nsplit = 1;
-  const int s = gemm_splits(transa, transb, M, N, K);
+  const int s = act == RE2E_ACT_SIGMOID_MASK_MUL ? 1 : gemm_splits(transa, transb, M, N, K);   // mask epilogue: never split
   if (s > 1) {
     RE2E_CHECK_ARG(workspace && workspace_bytes >= (size_t)s * M * N * sizeof(float), "workspace too small");
-    RE2E_CHECK_ARG(act != RE2E_ACT_SIGMOID_MASK_MUL, "split-K form does not support the mask epilogue");
     ep.ws = (float*)workspace; ep.nsplit = s;
   }
   // 16-byte vector loads need aligned bases, leading dimensions that are multiples of 4 and no
@@ -574,6 +594,26 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
 }
 
 // ---- convolution (NHWC activations, weights pre-gathered by re2e_conv_weight_gather) ----------
+// Weight gather: dst[r][a][b][c] laid out for the implicit GEMM B operand from the PyTorch layout
+// W[Cout][Cin][KH][KW].  transpose=0: r=co, c=ci (forward) ; transpose=1: r=ci, c=co (data gradient).
+// Tap (a,b) of the destination reads source tap (kh0 + a*kstep, kw0 + b*kstep).
+__global__ void weight_gather_kernel(const float* W, float* dst, int Cout, int Cin, int KH, int KW, int transpose, int TA,
+                                     int TB, int kh0, int kw0, int kstep, int cls_pad) {
+  int R = transpose ? Cin : Cout, Cc = transpose ? Cout : Cin;
+  long tot = (long)R * TA * TB * Cc;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tot) return;
+  if (cls_pad >= 0) {   // blockIdx.y = output parity class of the stride-2 data gradient; one set per class
+    const int ph = blockIdx.y >> 1, pw = blockIdx.y & 1;
+    kh0 = (ph + cls_pad) & 1; kw0 = (pw + cls_pad) & 1;
+    dst += (long)blockIdx.y * tot;
+  }
+  int c = (int)(i % Cc); long t = i / Cc; int b = (int)(t % TB); t /= TB; int a = (int)(t % TA); int r = (int)(t / TA);
+  int co = transpose ? c : r, ci = transpose ? r : c;
+  int kh = kh0 + a * kstep, kw = kw0 + b * kstep;
+  dst[i] = W[(((long)co * Cin + ci) * KH + kh) * KW + kw];
+}
+
 // RE2E_NO_THIN=1 routes the Cin == 1 / Cout == 1 convolutions through the implicit GEMM (A/B measurements)
 static bool thin_enabled() {
   static int v = -1;
@@ -618,6 +658,37 @@ extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, con
   }
   if (C % 4 == 0 && aligned16(in) && aligned16(wg)) conv_dispatch<true>(g, M, K, wg, Cout, ep, stream);
   else conv_dispatch<false>(g, M, K, wg, Cout, ep, stream);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// Stride-2 data gradient (transposed convolution) in ONE launch: blockIdx.z walks the four output parity
+// classes (ph,pw); class taps a -> kh = 2a + ((ph+pad) & 1).  wt_ws holds the four gathered weight sets
+// [cls][Cin][KH/2][KW/2][Cout] (= Cin*KH*KW*Cout floats), written here.
+extern "C" int re2e_conv_dgrad_s2(const float* dz, int N, int OH, int OW, int Cout, const float* W, int Cin, int KH, int KW,
+                                  int H, int Wd, int pad, float* dx, float* wt_ws, hipStream_t stream) {
+  RE2E_CHECK_ARG(dz && W && dx && wt_ws, "null operand");
+  RE2E_CHECK_ARG(N > 0 && OH > 0 && OW > 0 && Cout > 0 && Cin > 0 && H > 0 && Wd > 0 && pad >= 0, "bad geometry");
+  if (KH % 2 || KW % 2) { re2e_set_error("re2e_conv_dgrad_s2: kernel sizes must be even"); return RE2E_EUNSUPPORTED; }
+  const int TA = KH / 2, TB = KW / 2, PH = (H + 1) / 2, PW = (Wd + 1) / 2;
+  RE2E_CHECK_ARG((long)N * PH * PW < 2147483647L, "too many pixels");
+  RE2E_CHECK_ARG((long)N * OH * OW * Cout * 4 < 0xFFFFFFF0L, "gradient tensor larger than 4 GiB");
+  const long wtot = (long)Cin * TA * TB * Cout;
+  hipLaunchKernelGGL(weight_gather_kernel, dim3(cdiv(wtot, 256), 4), dim3(256), 0, stream, W, wt_ws, Cout, Cin, KH, KW, 1, TA, TB,
+                     0, 0, 2, pad);
+  ConvGeom g{dz, N, OH, OW, Cout, PH, PW, TA, TB, 1, 1, -1, -1, 0, 0};
+  const int M = N * PH * PW, K = TA * TB * Cout;
+  Epi ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.C = dx; ep.ldc = Cin; ep.M = M; ep.N = Cin; ep.act = RE2E_ACT_NONE; ep.nsplit = 1;
+  ep.remap = 1; ep.PH = PH; ep.PW = PW; ep.OHF = H; ep.OWF = Wd; ep.osy = 2; ep.osx = 2;
+  ep.ncls = 4; ep.cls_wstride = wtot;
+  for (int p = 0; p < 2; ++p) {   // oh = (2i + p + pad - kh)/2 = i + (p + pad - kh0)/2 - a
+    const int k0 = (p + pad) & 1;
+    ep.cls_oy0[p] = (p + pad - k0) / 2; ep.cls_ox0[p] = ep.cls_oy0[p];
+  }
+  if (Cout % 4 == 0 && aligned16(dz) && aligned16(wt_ws)) conv_dispatch<true>(g, M, K, wt_ws, Cin, ep, stream);
+  else conv_dispatch<false>(g, M, K, wt_ws, Cin, ep, stream);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
@@ -687,28 +758,13 @@ extern "C" int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, con
   return RE2E_OK;
 }
 
-// Weight gather: dst[r][a][b][c] laid out for the implicit GEMM B operand from the PyTorch layout
-// W[Cout][Cin][KH][KW].  transpose=0: r=co, c=ci (forward) ; transpose=1: r=ci, c=co (data gradient).
-// Tap (a,b) of the destination reads source tap (kh0 + a*kstep, kw0 + b*kstep).
-__global__ void weight_gather_kernel(const float* W, float* dst, int Cout, int Cin, int KH, int KW, int transpose, int TA,
-                                     int TB, int kh0, int kw0, int kstep) {
-  int R = transpose ? Cin : Cout, Cc = transpose ? Cout : Cin;
-  long tot = (long)R * TA * TB * Cc;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= tot) return;
-  int c = (int)(i % Cc); long t = i / Cc; int b = (int)(t % TB); t /= TB; int a = (int)(t % TA); int r = (int)(t / TA);
-  int co = transpose ? c : r, ci = transpose ? r : c;
-  int kh = kh0 + a * kstep, kw = kw0 + b * kstep;
-  dst[i] = W[(((long)co * Cin + ci) * KH + kh) * KW + kw];
-}
-
 extern "C" int re2e_conv_weight_gather(const float* W, float* dst, int Cout, int Cin, int KH, int KW, int transpose,
                                        int TA, int TB, int kh0, int kw0, int kstep, hipStream_t stream) {
   RE2E_CHECK_ARG(W && dst, "null operand");
   RE2E_CHECK_ARG(kh0 + (TA - 1) * kstep < KH && kw0 + (TB - 1) * kstep < KW && kh0 >= 0 && kw0 >= 0, "tap out of range");
   long tot = (long)Cout * Cin * TA * TB;
   hipLaunchKernelGGL(weight_gather_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, W, dst, Cout, Cin, KH, KW, transpose,
-                     TA, TB, kh0, kw0, kstep);
+                     TA, TB, kh0, kw0, kstep, -1);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

@@ -28,6 +28,7 @@ SIGNATURES = {
     're2e_conv_igemm': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, I, F, P]),
     're2e_conv_wgrad_workspace_bytes': (Z, [I, I, I, I, I, I, I]),
     're2e_conv_wgrad': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, P, F, P, Z, P]),
+    're2e_conv_dgrad_s2': (I, [P, I, I, I, I, P, I, I, I, I, I, I, P, P, P]),
     're2e_conv_weight_gather': (I, [P, P, I, I, I, I, I, I, I, I, I, I, P]),
     're2e_transpose01': (I, [P, P, I, I, I, P]),
     're2e_act_bwd': (I, [P, P, P, L, I, P]),

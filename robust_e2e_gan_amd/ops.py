@@ -381,7 +381,12 @@ def conv_dgrad(dz, W, xshape, stride, pad):
         return dx
     if stride != 2 or KH % 2 or KW % 2:
         raise lib.Re2eError('conv data gradient supports stride 1, or stride 2 with even kernels')
-    # stride 2: one launch per output parity class (ph,pw); taps a -> kh = 2a + ((ph+pad) % 2)
+    if Cin != 1:    # all four output parity classes in one launch
+        dx = empty((N, H, Wd, Cin), dz)
+        wt = empty((4, Cin, KH // 2, KW // 2, Cout), dz)
+        call('re2e_conv_dgrad_s2', dz.data_ptr(), N, OH, OW, Cout, W.data_ptr(), Cin, KH, KW, H, Wd, pad, dx.data_ptr(), wt.data_ptr())
+        return dx
+    # Cin == 1 (thin direct kernel): one launch per output parity class (ph,pw); taps a -> kh = 2a + ((ph+pad) % 2)
     dx = torch.zeros((N, H, Wd, Cin), dtype=torch.float32, device=dz.device) if (H % 2 or Wd % 2) else empty((N, H, Wd, Cin), dz)
     TA, TB = KH // 2, KW // 2
     wt = empty((Cin, TA, TB, Cout), dz)
