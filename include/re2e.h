@@ -94,6 +94,10 @@ int re2e_act_bwd(const float* dy, const float* y, float* dz, long n, int act, re
 size_t re2e_colsum_workspace_bytes(int M, int N);
 int re2e_colsum(const float* A, int M, int N, long lda, float* out, float beta, void* workspace,
                 size_t workspace_bytes, re2e_stream_t stream);
+/* Activation backward fused with the bias gradient: dz = dy * act'(y) (rows x N, contiguous) and
+ * out[N] = beta*out + column sums of dz, in one pass over dy/y.  Workspace as re2e_colsum. */
+int re2e_act_bwd_colsum(const float* dy, const float* y, float* dz, int M, int N, int act, float* out, float beta,
+                        void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 /* enhancer mask epilogue backward: dlin = dout * mix * m * (1-m)   (enhance_model.py:156-164) */
 int re2e_mask_mul_bwd(const float* dout, const float* mix, const float* mask, float* dlin, long n,
                       re2e_stream_t stream);

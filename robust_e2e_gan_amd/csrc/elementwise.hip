@@ -63,25 +63,116 @@ __global__ void colsum_partial_kernel(const float* __restrict__ A, int M, int N,
   __syncthreads();
   if (ry == 0 && col < N) part[(long)blockIdx.y * N + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, int N, float* out, float beta) {
-  int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
+// final stage: 64 columns x 16 chunk lanes per workgroup, lanes combined through LDS in a fixed order
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int chunks, int N, float* out, float beta) {
+  __shared__ float red[16][64];
+  const int cx = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += part[(long)c * N + col];
+  if (col < N)
+    for (int c = cl; c < chunks; c += 16) s += part[(long)c * N + col];
+  red[cl][cx] = s;
+  __syncthreads();
+  if (cl != 0 || col >= N) return;
+  s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += red[q][cx];
   out[col] = (beta != 0.f ? beta * out[col] : 0.f) + s;
 }
-static inline int colsum_chunks(int M) { int c = cdiv(M, 128); return c > 512 ? 512 : (c < 1 ? 1 : c); }
-extern "C" size_t re2e_colsum_workspace_bytes(int M, int N) { return (size_t)colsum_chunks(M) * N * sizeof(float); }
+
+// Vectorised partial stage, optionally fused with the activation backward: dz = dy * act'(y) is written and
+// its column sums (the bias gradient) accumulated in the same pass, so dz is not re-read from HBM.
+// Workgroup = one tile of `ct` columns (ct/4 float4 lanes, a power of two <= 256) x one chunk of rows.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz,
+                                                         int M, int N, int ct, int rows_per_chunk, int act, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 4];
+  const int c4t = ct >> 2, c4 = threadIdx.x % c4t, rl = threadIdx.x / c4t, rpb = 256 / c4t;
+  const int col = blockIdx.x * ct + c4 * 4;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int r = r0 + rl; r < r1; r += rpb) {
+    const long off = (long)r * N + col;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
+    if (FUSED) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        switch (act) {
+          case RE2E_ACT_TANH: g[j] *= (1.f - v[j] * v[j]); break;
+          case RE2E_ACT_RELU: g[j] = v[j] > 0.f ? g[j] : 0.f; break;
+          case RE2E_ACT_LRELU: g[j] = v[j] > 0.f ? g[j] : 0.2f * g[j]; break;
+          case RE2E_ACT_SIGMOID: g[j] *= v[j] * (1.f - v[j]); break;
+          default: break;
+        }
+      }
+      *reinterpret_cast<f32x4*>(dz + off) = g;
+    }
+    s += g;
+  }
+  *reinterpret_cast<f32x4*>(red + threadIdx.x * 4) = s;
+  __syncthreads();
+  if (rl == 0) {
+    for (int q = 1; q < rpb; ++q) s += *reinterpret_cast<const f32x4*>(red + (q * c4t + c4) * 4);
+    *reinterpret_cast<f32x4*>(part + (long)blockIdx.y * N + col) = s;
+  }
+}
+
+static inline bool aligned16e(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// column tile of the vectorised path, or 0 when the shape needs the scalar kernels
+static inline int colsum_tile(int N) {
+  if (N % 4) return 0;
+  if (N <= 1024) { int c4 = N / 4; return (c4 & (c4 - 1)) == 0 ? N : 0; }
+  return N % 1024 == 0 ? 1024 : 0;
+}
+static inline int colsum_chunks(int M, int N) {
+  int ct = colsum_tile(N);
+  if (!ct) { int c = cdiv(M, 128); return c > 512 ? 512 : (c < 1 ? 1 : c); }
+  int rpb = 256 / (ct / 4);
+  long c = cdiv(M, (long)rpb * 8);           // >= 8 passes per workgroup
+  long cap = 2048 / (N / ct);               // ~2048 workgroups in total
+  if (cap < 16) cap = 16;
+  return (int)(c < 1 ? 1 : (c > cap ? cap : c));
+}
+extern "C" size_t re2e_colsum_workspace_bytes(int M, int N) { return (size_t)colsum_chunks(M, N) * N * sizeof(float); }
+
+static void colsum_launch(const float* dy, const float* y, float* dz, int M, int N, long lda, int act, float* out, float beta,
+                          float* part, hipStream_t stream) {
+  const int chunks = colsum_chunks(M, N);
+  const int rpc = cdiv(M, chunks);
+  const int ct = colsum_tile(N);
+  const bool fused = y != nullptr;
+  const bool vec = ct && lda == N && aligned16e(dy) && (!fused || (aligned16e(y) && aligned16e(dz)));
+  if (vec) {
+    if (fused) hipLaunchKernelGGL(colsum_vec_kernel<true>, dim3(N / ct, chunks), dim3(256), 0, stream, dy, y, dz, M, N, ct, rpc, act, part);
+    else hipLaunchKernelGGL(colsum_vec_kernel<false>, dim3(N / ct, chunks), dim3(256), 0, stream, dy, y, dz, M, N, ct, rpc, act, part);
+  } else {
+    if (fused) {
+      long n = (long)M * N;
+      hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, dy, y, dz, n, act);
+      dy = dz;
+    }
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, stream, dy, M, N, lda, rpc, part);
+  }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, stream, (const float*)part, chunks, N, out, beta);
+}
+
 extern "C" int re2e_colsum(const float* A, int M, int N, long lda, float* out, float beta, void* workspace,
                            size_t workspace_bytes, hipStream_t stream) {
   RE2E_CHECK_ARG(A && out && workspace && M > 0 && N > 0, "bad args");
-  int chunks = colsum_chunks(M);
-  RE2E_CHECK_ARG(workspace_bytes >= (size_t)chunks * N * sizeof(float), "workspace too small");
-  int rpc = cdiv(M, chunks);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, stream, A, M, N, lda, rpc,
-                     (float*)workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, (const float*)workspace, chunks, N,
-                     out, beta);
+  RE2E_CHECK_ARG(workspace_bytes >= (size_t)colsum_chunks(M, N) * N * sizeof(float), "workspace too small");
+  colsum_launch(A, nullptr, nullptr, M, N, lda, RE2E_ACT_NONE, out, beta, (float*)workspace, stream);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+extern "C" int re2e_act_bwd_colsum(const float* dy, const float* y, float* dz, int M, int N, int act, float* out, float beta,
+                                   void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(dy && y && dz && out && workspace && M > 0 && N > 0, "bad args");
+  RE2E_CHECK_ARG(act > RE2E_ACT_NONE && act <= RE2E_ACT_SIGMOID, "bad activation");
+  RE2E_CHECK_ARG(workspace_bytes >= (size_t)colsum_chunks(M, N) * N * sizeof(float), "workspace too small");
+  colsum_launch(dy, y, dz, M, N, N, act, out, beta, (float*)workspace, stream);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

@@ -7,6 +7,7 @@ gating both G optimizers, D clipped separately.  Every rank runs it on its own u
 gradients are averaged by dist.GradSync (RCCL) before clipping."""
 import math
 import os
+import time
 
 import numpy as np
 import torch
@@ -63,6 +64,7 @@ class JointTrainer(object):
         self.asr_model.dec.return_acc_tensor = True
         # run the D passes on a side HIP stream under the latency-bound recurrent chains (RE2E_NO_OVERLAP=1: profiling)
         self.overlap_dstep = os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
+        self.marks = [] if os.environ.get('RE2E_TIMELINE') else None
         self.side_stream = self.wgrad_stream = None
         if torch.cuda.is_available():
             # filler streams: optionally restricted to a subset of the CUs (RE2E_FILLER_CUS, default all) so that the
@@ -99,8 +101,25 @@ class JointTrainer(object):
         caller.wait_stream(self.main_stream)
         return out
 
+    def _mark(self, label):
+        """RE2E_TIMELINE=1: remember (label, host time, event on the current stream) -- ``timeline()`` prints how far the
+        GPU runs behind the host at each phase boundary (host-bound phases show a lag near zero)."""
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((label, time.perf_counter(), ev))
+
+    def timeline(self):
+        torch.cuda.synchronize()
+        (l0, h0, e0), rows = self.marks[0], []
+        for label, h, e in self.marks:
+            rows.append((label, (h - h0) * 1e3, e0.elapsed_time(e)))
+        self.marks = []
+        return rows
+
     def _step(self, data, sche_samp_rate, enhance_cmvn):
         opt = self.opt
+        self._mark('start')
         clean_inputs, mix_inputs, mix_log_inputs, targets, input_sizes, target_sizes = data[2], data[4], data[5], data[7], data[8], data[9]
         overlap = self.overlap_dstep
         ops.MULTI_STREAM = bool(overlap)
@@ -118,7 +137,9 @@ class JointTrainer(object):
                 ev_cf = torch.cuda.Event()
                 ev_cf.record()
                 clean_branch = self.asr_model.encode_clean(clean_feat, enhance_cmvn)
+            self._mark('clean branch enqueued (side)')
             enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
+            self._mark('enhancer fwd')
             enhance_feat = self.feat_model(enhance_out)
             main.wait_event(ev_cf)
             clean_feat.record_stream(main)
@@ -143,8 +164,10 @@ class JointTrainer(object):
                     gan_loss = opt.gan_loss_lambda * self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
             else:
                 gan_loss = opt.gan_loss_lambda * self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
+        self._mark('fbank + G-step D fwd enqueued (side)')
         loss_ctc, loss_att, acc, clean_context, mix_context = self.asr_model(clean_feat, enhance_feat, targets, input_sizes, target_sizes,
                                                                               sche_samp_rate, enhance_cmvn, clean_branch=clean_branch)
+        self._mark('ASR fwd')
         coral_loss = opt.coral_loss_lambda * CORAL(clean_context, mix_context)
         asr_loss = opt.mtlalpha * loss_ctc.view(()) + (1 - opt.mtlalpha) * loss_att
         loss = asr_loss + enhance_loss + coral_loss
@@ -165,6 +188,7 @@ class JointTrainer(object):
             ev_fwd = torch.cuda.Event()
             ev_fwd.record(main)
             (g_eo,) = torch.autograd.grad(loss, [enhance_out])
+            self._mark('bwd phase 1 (ASR, D, fbank)')
             ev_bwd1 = torch.cuda.Event()
             ev_bwd1.record(main)
             ev_side_bwd = torch.cuda.Event()          # clean-branch conv backward (ASR gradients) enqueued on the side stream
@@ -178,8 +202,10 @@ class JointTrainer(object):
                     if isinstance(t_, torch.Tensor) and t_.is_cuda:
                         t_.record_stream(side)
                 loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, wait_before_update=ev_bwd1)
+            self._mark('D-step enqueued (side)')
             # Phase 2: the enhancer backward chain on the main stream.
             enhance_out.backward(g_eo)
+            self._mark('bwd phase 2 (enhancer)')
             torch.cuda.current_stream().wait_event(ev_side_bwd)
         else:
             loss.backward()
@@ -201,6 +227,7 @@ class JointTrainer(object):
         out.update({'train/loss': loss.detach(), 'train/loss_ctc': loss_ctc.detach().view(()), 'train/acc': acc, 'train/loss_att': loss_att.detach(),
                     'train/enhance_loss': enhance_loss.detach(), 'train/coral_loss': coral_loss.detach(), 'grad_norm': grad_norm})
         self.last = dict(enhance_out=enhance_out, enhance_feat=enhance_feat)
+        self._mark('optimizers')
         return out
 
     def _d_step(self, clean_feat, enhance_feat, enhance_cmvn, wait_before_update=None):

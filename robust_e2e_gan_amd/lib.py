@@ -32,6 +32,7 @@ SIGNATURES = {
     're2e_conv_weight_gather': (I, [P, P, I, I, I, I, I, I, I, I, I, I, P]),
     're2e_transpose01': (I, [P, P, I, I, I, P]),
     're2e_act_bwd': (I, [P, P, P, L, I, P]),
+    're2e_act_bwd_colsum': (I, [P, P, P, I, I, I, P, F, P, Z, P]),
     're2e_colsum_workspace_bytes': (Z, [I, I]),
     're2e_colsum': (I, [P, I, I, L, P, F, P, Z, P]),
     're2e_mask_mul_bwd': (I, [P, P, P, P, L, P]),

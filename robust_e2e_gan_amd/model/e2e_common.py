@@ -59,8 +59,28 @@ def lens_list(lens):
     return [int(v) for v in lens]
 
 
+def host_to_dev(values, device, dtype=torch.int32):
+    """Small host array -> device tensor WITHOUT stalling the host: staged in pinned memory and copied with
+    non_blocking=True.  (``torch.tensor(list, device=cuda)`` is a blocking copy: it waits for everything already
+    enqueued on the stream, which serialises the host behind the GPU in the middle of the training step.)"""
+    t = torch.as_tensor(np.asarray(values), dtype=dtype)
+    if torch.device(device).type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
+_LENS_CACHE = {}
+
+
 def lens_dev(lens, device):
-    return torch.tensor(lens_list(lens), dtype=torch.int32, device=device)
+    """int32 device copy of a length list; the same lists recur many times per step, so uploads are cached."""
+    key = (tuple(lens_list(lens)), str(device))
+    t = _LENS_CACHE.get(key)
+    if t is None:
+        if len(_LENS_CACHE) >= 256:
+            _LENS_CACHE.clear()
+        t = _LENS_CACHE[key] = host_to_dev(np.asarray(key[0], np.int32), device)
+    return t
 
 
 def lecun_normal_init_parameters(module):

@@ -4,7 +4,7 @@ import torch
 
 from .. import ops
 from ..lib import Re2eError
-from .e2e_common import LinearParams, lens_dev, lens_list
+from .e2e_common import LinearParams, host_to_dev, lens_dev, lens_list
 
 
 class CTC(torch.nn.Module):
@@ -22,10 +22,10 @@ class CTC(torch.nn.Module):
         dev = hs_tm.device
         ylist = [[int(v) for v in y.tolist() if int(v) != self.ignore_id] for y in ys]
         ll = [len(y) for y in ylist]
-        flat = torch.tensor(sum(ylist, []), dtype=torch.int32, device=dev)
-        off = torch.tensor(np.concatenate([[0], np.cumsum(ll)[:-1]]).astype(np.int32), dtype=torch.int32, device=dev)
+        flat = host_to_dev(np.asarray(sum(ylist, []), np.int32), dev)
+        off = host_to_dev(np.concatenate([[0], np.cumsum(ll)[:-1]]).astype(np.int32), dev)
         logits = ops.linear(hs_tm, self.ctc_lo.weight, self.ctc_lo.bias)           # (T',B,V): warp-ctc's layout
-        self.loss = ops.ctc_loss(logits, lens_dev(hlens, dev), flat, off, torch.tensor(ll, dtype=torch.int32, device=dev), max(ll))
+        self.loss = ops.ctc_loss(logits, lens_dev(hlens, dev), flat, off, host_to_dev(np.asarray(ll, np.int32), dev), max(ll))
         return self.loss
 
     def forward(self, hs_pad, hlens, ys_pad):

@@ -6,7 +6,7 @@ import torch
 
 from .. import ops
 from ..lib import Re2eError
-from .e2e_common import LinearParams, lens_dev, lens_list, to_cuda
+from .e2e_common import LinearParams, host_to_dev, lens_dev, lens_list, to_cuda
 
 
 class LSTMCellParams(torch.nn.Module):
@@ -44,8 +44,8 @@ def decoder_forward_hip(p, hpad, hlens, ys, eos, ss_rate=0.0, return_att=False, 
         ids_in[b, 1:len(y) + 1] = y
         ids_out[b, :len(y)] = y
         ids_out[b, len(y)] = eos
-    ids_tm = torch.from_numpy(np.ascontiguousarray(ids_in.T).reshape(-1)).to(dev)
-    tgt_tm = torch.from_numpy(np.ascontiguousarray(ids_out.T).reshape(-1)).to(dev)
+    ids_tm = host_to_dev(np.ascontiguousarray(ids_in.T).reshape(-1), dev)
+    tgt_tm = host_to_dev(np.ascontiguousarray(ids_out.T).reshape(-1), dev)
     hmask = ops.mask_rows(hpad, hl_dev)                                            # :85
     pre = ops.linear(hmask, p[prefix + 'att.mlp_enc.weight'], p[prefix + 'att.mlp_enc.bias'])
     Pm = dict(embed=p[prefix + 'dec.embed.weight'], w_ih=p[prefix + 'dec.decoder.0.weight_ih'], w_hh=p[prefix + 'dec.decoder.0.weight_hh'],

@@ -9,7 +9,7 @@ import torch
 from .. import ops
 from ..lib import Re2eError
 from .e2e_attention import AttLoc
-from .e2e_common import ModelBase, lecun_normal_init_parameters, lens_dev, lens_list, set_forget_bias_to_one, to_cuda
+from .e2e_common import ModelBase, host_to_dev, lecun_normal_init_parameters, lens_dev, lens_list, set_forget_bias_to_one, to_cuda
 from .e2e_ctc import CTC
 from .e2e_decoder import Decoder
 from .e2e_encoder import Encoder
@@ -133,7 +133,7 @@ class ShareE2E(E2E):
             loss_att, acc = None, None
         else:
             loss_att, acc = self.dec(hpad_enh, hlens, ys, scheduled_sampling_rate)
-        idx = torch.tensor([b * Tq + t for b in range(B) for t in range(hlens[b])], dtype=torch.int32, device=enh.device)
+        idx = host_to_dev(np.concatenate([b * Tq + np.arange(hlens[b], dtype=np.int32) for b in range(B)]).astype(np.int32), enh.device)
         mix_context = ops.gather_rows(hpad_enh.reshape(B * Tq, E), idx)
         clean_context = ops.gather_rows(hpad_cln.reshape(B * Tq, E), idx)
         return loss_ctc, loss_att, acc, clean_context, mix_context

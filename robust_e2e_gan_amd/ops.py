@@ -136,6 +136,20 @@ def act_bwd(dy, y, act):
     return dz
 
 
+def act_bwd_bias(dy2, y, act, b):
+    """dz = dy * act'(y) for a (rows, N) gradient and, when the bias ``b`` needs a gradient, b.grad += colsum(dz) in the
+    same pass (re2e_act_bwd_colsum).  Returns (dz, bias_done)."""
+    if act == lib.ACT_NONE or b is None or not b.requires_grad:
+        return act_bwd(dy2, y, act), False
+    M, N = dy2.shape
+    dz = torch.empty_like(dy2)
+    wsb = query('re2e_colsum_workspace_bytes', M, N)
+    ws = workspace(wsb, dy2.device, 'colsum')
+    with accumulate(b) as (gb, beta):
+        call('re2e_act_bwd_colsum', dy2.data_ptr(), y.data_ptr(), dz.data_ptr(), M, N, act, gb.data_ptr(), float(beta), ws.data_ptr(), wsb)
+    return dz, True
+
+
 # ---------------------------------------------------------------------------------------------
 # Linear (+ bias + activation)     torch.nn.Linear call sites, see include/re2e.h K3
 # ---------------------------------------------------------------------------------------------
@@ -159,7 +173,7 @@ class LinearFn(torch.autograd.Function):
         W, b = ctx.W, ctx.b
         M, K = x2.shape
         N = W.shape[0]
-        dz = act_bwd(_f32(dy).reshape(M, N), y, ctx.act)
+        dz, bias_done = act_bwd_bias(_f32(dy).reshape(M, N), y, ctx.act, b)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = empty((M, K), x2)
@@ -169,7 +183,7 @@ class LinearFn(torch.autograd.Function):
             if W.requires_grad:
                 with accumulate(W) as (gw, beta):
                     gemm(dz, x2, gw, N, K, M, transa=True, beta=beta)   # dW = dz^T x
-            if b is not None and b.requires_grad:
+            if b is not None and b.requires_grad and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, M, N, gb, beta)
         return dx, None, None, None
@@ -350,7 +364,8 @@ class Conv2dFn(torch.autograd.Function):
         N, H, Wd, Cin = x.shape
         Cout, _, KH, KW = W.shape
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(Wd, KW, stride, pad)
-        dz = act_bwd(_f32(dy), y, act)
+        dz, bias_done = act_bwd_bias(_f32(dy).reshape(N * OH * OW, Cout), y, act, b)
+        dz = dz.view(N, OH, OW, Cout)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad)
@@ -361,7 +376,7 @@ class Conv2dFn(torch.autograd.Function):
                 with accumulate(W) as (gw, beta):
                     call('re2e_conv_wgrad', x.data_ptr(), N, H, Wd, Cin, dz.data_ptr(), Cout, KH, KW, OH, OW, stride, stride, -pad, -pad,
                          gw.data_ptr(), beta, ws.data_ptr(), wsb)
-            if b is not None and b.requires_grad:
+            if b is not None and b.requires_grad and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, N * OH * OW, Cout, gb, beta)
         return dx, None, None, None, None, None

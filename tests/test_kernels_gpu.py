@@ -365,3 +365,23 @@ def test_misc_layout_kernels():
     padded = pack_pad_device(flat.to(DEV), lens, 7)
     ref = torch.stack([torch.cat([x[i, :lens[i]], torch.zeros(7 - lens[i], 13)]) for i in range(4)])
     close('pack_pad', padded, ref, tol=0, atol=0)
+
+
+@pytest.mark.parametrize('M,N', [(1000, 64), (517, 2048), (300, 1200), (77, 4233), (5000, 8), (9, 128), (40000, 256)])
+def test_colsum_and_fused_act_bwd(M, N):
+    """re2e_colsum / re2e_act_bwd_colsum: vectorised tiles (N/4 a power of two, or N % 1024 == 0) and the scalar
+    fall-back give the same column sums; the fused form also returns dz = dy * act'(y)."""
+    ops, lib = _ops()
+    dy, y = rnd(M, N, seed=5).to(DEV), rnd(M, N, seed=6).to(DEV)
+    out = torch.full((N,), 0.5, device=DEV)
+    ops.colsum_into(dy, M, N, out, 1.0)
+    close('colsum', out, 0.5 + dy.double().sum(0).float(), tol=2e-5, atol=1e-4)
+    for act, f in ((lib.ACT_RELU, lambda v: (v > 0).float()), (lib.ACT_TANH, lambda v: 1 - v * v),
+                   (lib.ACT_LRELU, lambda v: torch.where(v > 0, torch.ones_like(v), torch.full_like(v, 0.2)))):
+        b = torch.nn.Parameter(torch.zeros(N, device=DEV))
+        b.grad = torch.full((N,), 0.25, device=DEV)
+        dz, done = ops.act_bwd_bias(dy, y, act, b)
+        assert done
+        ref = dy * f(y)
+        close('dz', dz, ref, tol=1e-6)
+        close('db', b.grad, 0.25 + ref.double().sum(0).float(), tol=2e-5, atol=1e-4)
