@@ -66,30 +66,48 @@ struct DenseM {   // X[k*ld + row]
   }
 };
 
+// Conv loaders keep their addresses as 32-bit BYTE offsets split into a row part and a k part that are each
+// updated incrementally, so the per-load work of the 16-byte path is one add, two bound checks and a select
+// (tensors are < 4 GiB, checked by the callers; the split parts wrap mod 2^32 and their sum is exact whenever
+// the coordinate is inside the image).
 struct ConvK {    // rows = pixels, k = (kh, kw, ci) with ci fastest
   static constexpr bool KMAJ = true;
   static constexpr const char* NAME = "ConvK";
   static constexpr bool IS_CONVK = true;
   ConvGeom g; const float* p; unsigned nbytes; int rows, K;
-  struct Row { int n, iy0, ix0; };
-  struct Kst { int k, ci, kh, kw; };
+  struct Row { int n, iy0, ix0; unsigned base; };        // base = ((n*H + iy0)*W + ix0)*C*4
+  struct Kst { int k, ci, kh, kw, dy, dx; unsigned koff; };   // koff = ((dy*W + dx)*C + ci)*4
+  __device__ void set_base(Row& r) const { r.base = (unsigned)((((long)r.n * g.H + r.iy0) * g.W + r.ix0) * g.C * 4); }
   __device__ void init_row(Row& r, int row) const {
-    if (row >= rows) { r.n = -1; r.iy0 = 0; r.ix0 = 0; }
+    if (row >= rows) { r.n = -1; r.iy0 = -(1 << 28); r.ix0 = 0; r.base = 0; }   // iy never in range
     else {
       int px = row % g.PW; int t = row / g.PW; int py = t % g.PH; r.n = t / g.PH;
       r.iy0 = py * g.SY + g.OY0; r.ix0 = px * g.SX + g.OX0;
+      set_base(r);
     }
+  }
+  __device__ void shift_row(Row& r, int dy, int dx) const { if (r.n >= 0) { r.iy0 += dy; r.ix0 += dx; set_base(r); } }
+  __device__ void set_k(Kst& s) const {
+    s.dy = s.kh * g.DY; s.dx = s.kw * g.DX;
+    s.koff = (unsigned)(((s.dy * g.W + s.dx) * g.C + s.ci) * 4);
   }
   __device__ void init_k(Kst& s, int k) const {
     s.k = k; s.ci = k % g.C; int tap = k / g.C; s.kw = tap % g.KW; s.kh = tap / g.KW;
+    set_k(s);
   }
   __device__ void advance(Kst& s, int bk) const {
     s.k += bk; s.ci += bk;
     while (s.ci >= g.C) { s.ci -= g.C; if (++s.kw == g.KW) { s.kw = 0; ++s.kh; } }
+    set_k(s);
   }
   __device__ unsigned off(const Row& r, const Kst& s, int j) const {
-    int ci = s.ci + j, kw = s.kw, kh = s.kh;
-    while (ci >= g.C) { ci -= g.C; if (++kw == g.KW) { kw = 0; ++kh; } }     // j>0 only on the scalar path
+    if (j == 0) {                                          // the 16-byte path only ever asks for j = 0
+      const int iy = r.iy0 + s.dy, ix = r.ix0 + s.dx;
+      const bool ok = (s.k < K) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+      return ok ? r.base + s.koff : nbytes;
+    }
+    int ci = s.ci + j, kw = s.kw, kh = s.kh;               // scalar path: element k+j may sit in the next tap
+    while (ci >= g.C) { ci -= g.C; if (++kw == g.KW) { kw = 0; ++kh; } }
     const int iy = r.iy0 + kh * g.DY, ix = r.ix0 + kw * g.DX;
     const bool ok = (r.n >= 0) & (s.k + j < K) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
     return ok ? (unsigned)(((((long)r.n * g.H + iy) * g.W + ix) * g.C + ci) * 4) : nbytes;
@@ -101,21 +119,34 @@ struct ConvM {    // rows = (kh, kw, ci) (ci fastest), k = pixel  (weight-gradie
   static constexpr const char* NAME = "ConvM";
   static constexpr bool IS_CONVK = false;
   ConvGeom g; const float* p; unsigned nbytes; int rows, K;
-  struct Row { int r0, ci, kh, kw; };
-  struct Kst { int k, n, py, px; };
+  struct Row { int r0, ci, kh, kw, dy, dx; unsigned roff; };   // roff = ((dy*W + dx)*C + ci)*4
+  struct Kst { int k, n, py, px, iy0, ix0; unsigned base; };    // base = ((n*H + iy0)*W + ix0)*C*4
   __device__ void init_row(Row& r, int row0) const {
     r.r0 = row0;
     int rr = row0 < rows ? row0 : 0;
     r.ci = rr % g.C; int tap = rr / g.C; r.kw = tap % g.KW; r.kh = tap / g.KW;
+    r.dy = r.kh * g.DY; r.dx = r.kw * g.DX;
+    r.roff = (unsigned)(((r.dy * g.W + r.dx) * g.C + r.ci) * 4);
+  }
+  __device__ void set_k(Kst& s) const {
+    s.iy0 = s.py * g.SY + g.OY0; s.ix0 = s.px * g.SX + g.OX0;
+    s.base = (unsigned)((((long)s.n * g.H + s.iy0) * g.W + s.ix0) * g.C * 4);
   }
   __device__ void init_k(Kst& s, int k) const {
     s.k = k; s.px = k % g.PW; int t = k / g.PW; s.py = t % g.PH; s.n = t / g.PH;
+    set_k(s);
   }
   __device__ void advance(Kst& s, int bk) const {
     s.k += bk; s.px += bk;
     while (s.px >= g.PW) { s.px -= g.PW; if (++s.py == g.PH) { s.py = 0; ++s.n; } }
+    set_k(s);
   }
   __device__ unsigned off(const Row& r, const Kst& s, int j) const {
+    if (j == 0) {
+      const int iy = s.iy0 + r.dy, ix = s.ix0 + r.dx;
+      const bool ok = (s.k < K) & (r.r0 < rows) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+      return ok ? s.base + r.roff : nbytes;
+    }
     int ci = r.ci + j, kw = r.kw, kh = r.kh;
     while (ci >= g.C) { ci -= g.C; if (++kw == g.KW) { kw = 0; ++kh; } }
     const int iy = s.py * g.SY + kh * g.DY + g.OY0, ix = s.px * g.SX + kw * g.DX + g.OX0;
@@ -153,6 +184,7 @@ struct Epi {
   // merged stride-2 data gradient: blockIdx.z = output parity class (ph,pw); per-class input offsets and
   // gathered-weight sets (re2e_conv_dgrad_s2)
   int ncls; int cls_oy0[2], cls_ox0[2]; long cls_wstride;
+  int nomem;
 };
 
 template <class LA, class LB, class CF, bool VEC>
@@ -185,18 +217,23 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
     tile_n = (pid % per_group) / gsz;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  int zsplit = blockIdx.z;
+  // NB: the by-value kernel arguments (la, lb, ep) are never written: a modified argument struct is demoted
+  // to scratch memory.  Per-class values live in scalars instead.
+  int zsplit = blockIdx.z, ooy = ep.ooy, oox = ep.oox, cls_dy = 0, cls_dx = 0;
+  const float* pB = lb.p;
   if constexpr (LA::IS_CONVK) {
     if (ep.ncls) {
       const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
-      la.g.OY0 = ep.cls_oy0[ph]; la.g.OX0 = ep.cls_ox0[pw];
-      lb.p += cls * ep.cls_wstride;
-      ep.ooy = ph; ep.oox = pw;
+      cls_dy = ph ? ep.cls_oy0[1] : ep.cls_oy0[0]; cls_dx = pw ? ep.cls_ox0[1] : ep.cls_ox0[0];
+      pB += cls * ep.cls_wstride;
+      ooy = ph; oox = pw;
       zsplit = 0;
     }
   }
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(la.p), 0, la.nbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lb.p), 0, lb.nbytes, 0x00020000);
+  // ep.nomem (RE2E_IGEMM_NOMEM=1, timing experiments only): zero-record descriptors -- every load is dropped by the
+  // range check and returns 0, the instruction stream is unchanged: prices the memory side of the loop.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(la.p), 0, ep.nomem ? 0 : la.nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pB), 0, ep.nomem ? 0 : lb.nbytes, 0x00020000);
   // split-K range
   const int nkt_total = (K + BK - 1) / BK;
   const int kt_per = (nkt_total + ep.nsplit - 1) / ep.nsplit;
@@ -222,6 +259,7 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
     if (LA::KMAJ) {
       int r = idx / KQ, kq = idx % KQ;
       la.init_row(ra_row[LA::KMAJ ? i : 0], m0 + r);
+      if constexpr (LA::IS_CONVK) { if (ep.ncls) la.shift_row(ra_row[i], cls_dy, cls_dx); }
       if (i == 0) la.init_k(ra_k[0], kbegin + kq * 4);
       a_lds[i] = r * LDK + kq * 4;
     } else {
@@ -358,7 +396,7 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
           long off;
           if (ep.remap) {
             int j = row % ep.PW; int t = row / ep.PW; int i = t % ep.PH; int n = t / ep.PH;
-            const int oy = i * ep.osy + ep.ooy, ox = j * ep.osx + ep.oox;
+            const int oy = i * ep.osy + ooy, ox = j * ep.osx + oox;
             if (oy >= ep.OHF || ox >= ep.OWF) continue;      // phantom row of a parity class (odd H or W)
             off = (((long)n * ep.OHF + oy) * ep.OWF + ox) * ep.ldc + col;
           } else {
@@ -430,6 +468,8 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
   constexpr int ASZ = LA::KMAJ ? CF::BM * CF::LDK : CF::BK * (CF::BM + 4);
   constexpr int BSZ = LB::KMAJ ? CF::BN * CF::LDK : CF::BK * (CF::BN + 4);
   size_t lds = (size_t)2 * (ASZ + BSZ) * sizeof(float);
+  static const size_t lds_floor = getenv("RE2E_IGEMM_LDS_FLOOR") ? (size_t)atol(getenv("RE2E_IGEMM_LDS_FLOOR")) : 0;   // occupancy experiments
+  if (lds < lds_floor) lds = lds_floor;
   static bool attr_done = false;   // idempotent; racing writers set the same value
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<LA, LB, CF, VEC>),
@@ -437,6 +477,8 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(cdiv(ep.M, CF::BM), cdiv(ep.N, CF::BN), ep.ncls ? ep.ncls : ep.nsplit);
+  static const bool nomem = getenv("RE2E_IGEMM_NOMEM") != nullptr;
+  ep.nomem = nomem ? 1 : 0;
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
   if (log_calls)
     fprintf(stderr, "[igemm] A=%s B=%s tile=%dx%dx%d vec=%d M=%d N=%d K=%d splits=%d\n", LA::NAME, LB::NAME, CF::BM, CF::BN,

@@ -11,7 +11,8 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libre2e_hip.so')
+# RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
+LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1 = range(3)
