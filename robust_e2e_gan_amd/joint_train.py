@@ -78,6 +78,11 @@ class JointTrainer(object):
                 self.side_stream = torch.cuda.Stream()
             if self.wgrad_stream is None:
                 self.wgrad_stream = torch.cuda.Stream()
+            # NB: no further streams.  A process gets 4 hardware queues by default; a fifth stream (default + main + side
+            # + wgrad + one more) is multiplexed onto an occupied queue and serialises against it (measured with a
+            # dedicated D-step stream: 91 -> 155 ms/step).  Measured and rejected as well: running the D-step's
+            # forward/backward early, under the ASR forward (+2.3 ms/step: it slows the encoder chain more than it
+            # relieves the backward).
         self.main_stream = None
         if torch.cuda.is_available() and os.environ.get('RE2E_NO_PRIORITY', '0') != '1':
             try:
@@ -124,6 +129,7 @@ class JointTrainer(object):
         overlap = self.overlap_dstep
         ops.MULTI_STREAM = bool(overlap)
         ops.WGRAD_STREAM = self.wgrad_stream if overlap else None
+        ops.AUX_STREAM = self.side_stream if (overlap and os.environ.get('RE2E_CTC_MAIN') != '1') else None
         main = torch.cuda.current_stream()
         clean_branch = None
         if overlap and getattr(self.asr_model, 'etype', '').startswith('vgg'):

@@ -128,11 +128,27 @@ class ShareE2E(E2E):
         hpad2 = ops.transpose01(h_tm2)                                     # (2B, T', E)
         hpad_enh, hpad_cln = hpad2[:B], hpad2[B:]
         Tq, E = hpad2.shape[1], hpad2.shape[2]
-        loss_ctc = self.ctc.forward(hpad_enh, hlens, ys) if self.mtlalpha != 0 else None
+        # CTC and the attention decoder only share the encoder output: with a filler stream available the CTC branch
+        # (ctc_lo GEMM, softmax, alpha/beta; autograd runs its backward on the same stream) goes beside the decoder's
+        # 41 latency-bound steps instead of in front of them.
+        aux = ops.AUX_STREAM if (ops.MULTI_STREAM and self.mtlalpha not in (0, 1)) else None
+        loss_ctc = None
+        if self.mtlalpha != 0:
+            if aux is not None:
+                cur = torch.cuda.current_stream()
+                aux.wait_stream(cur)
+                with torch.cuda.stream(aux):
+                    hpad2.record_stream(aux)
+                    loss_ctc = self.ctc.forward(hpad_enh, hlens, ys)
+            else:
+                loss_ctc = self.ctc.forward(hpad_enh, hlens, ys)
         if self.mtlalpha == 1:
             loss_att, acc = None, None
         else:
             loss_att, acc = self.dec(hpad_enh, hlens, ys, scheduled_sampling_rate)
+        if aux is not None:
+            torch.cuda.current_stream().wait_stream(aux)
+            loss_ctc.record_stream(torch.cuda.current_stream())
         idx = host_to_dev(np.concatenate([b * Tq + np.arange(hlens[b], dtype=np.int32) for b in range(B)]).astype(np.int32), enh.device)
         mix_context = ops.gather_rows(hpad_enh.reshape(B * Tq, E), idx)
         clean_context = ops.gather_rows(hpad_cln.reshape(B * Tq, E), idx)

@@ -58,6 +58,7 @@ def colsum_into(A2d, M, N, out, beta, lda=None):
 
 MULTI_STREAM = False     # set by JointTrainer when branches run on side streams
 WGRAD_STREAM = None      # optional stream for weight-gradient kernels (see ``param_grads``)
+AUX_STREAM = None        # optional filler stream for independent branches inside a module (ShareE2E: the CTC branch)
 
 
 class param_grads(object):
@@ -136,10 +137,12 @@ def act_bwd(dy, y, act):
     return dz
 
 
-def act_bwd_bias(dy2, y, act, b):
+def act_bwd_bias(dy2, y, act, b, b_needs_grad=None):
     """dz = dy * act'(y) for a (rows, N) gradient and, when the bias ``b`` needs a gradient, b.grad += colsum(dz) in the
     same pass (re2e_act_bwd_colsum).  Returns (dz, bias_done)."""
-    if act == lib.ACT_NONE or b is None or not b.requires_grad:
+    if b_needs_grad is None:
+        b_needs_grad = b is not None and b.requires_grad
+    if act == lib.ACT_NONE or b is None or not b_needs_grad:
         return act_bwd(dy2, y, act), False
     M, N = dy2.shape
     dz = torch.empty_like(dy2)
@@ -173,17 +176,21 @@ class LinearFn(torch.autograd.Function):
         W, b = ctx.W, ctx.b
         M, K = x2.shape
         N = W.shape[0]
-        dz, bias_done = act_bwd_bias(_f32(dy).reshape(M, N), y, ctx.act, b)
+        # which parameters get gradients was fixed when the graph was built (ctx.needs_input_grad), NOT by the
+        # parameters' requires_grad flags at backward time: the trainer re-enables D's parameters for the D-step
+        # while the G-step backward through D may still be pending
+        need_w, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dz, bias_done = act_bwd_bias(_f32(dy).reshape(M, N), y, ctx.act, b, need_b)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = empty((M, K), x2)
             gemm(dz, W, dx, M, K, N)                       # dx = dz[M,N] * W[N,K]
             dx = dx.view(ctx.xshape)
         with param_grads(dz, x2):
-            if W.requires_grad:
+            if need_w:
                 with accumulate(W) as (gw, beta):
                     gemm(dz, x2, gw, N, K, M, transa=True, beta=beta)   # dW = dz^T x
-            if b is not None and b.requires_grad and not bias_done:
+            if b is not None and need_b and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, M, N, gb, beta)
         return dx, None, None, None
@@ -290,7 +297,7 @@ class MaskFcFn(torch.autograd.Function):
             dp = empty((M, K), p2)
             gemm(dlin, W, dp, M, K, N)
             dp = dp.view(ctx.oshape[:-1] + (K,))
-        if W.requires_grad:
+        if ctx.needs_input_grad[1]:
             with param_grads(dlin, p2), accumulate(W) as (gw, beta):
                 gemm(dlin, p2, gw, N, K, M, transa=True, beta=beta)
         return dp, None, None, None, None
@@ -364,19 +371,20 @@ class Conv2dFn(torch.autograd.Function):
         N, H, Wd, Cin = x.shape
         Cout, _, KH, KW = W.shape
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(Wd, KW, stride, pad)
-        dz, bias_done = act_bwd_bias(_f32(dy).reshape(N * OH * OW, Cout), y, act, b)
+        need_w, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]      # fixed at graph construction (see LinearFn)
+        dz, bias_done = act_bwd_bias(_f32(dy).reshape(N * OH * OW, Cout), y, act, b, need_b)
         dz = dz.view(N, OH, OW, Cout)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad)
         with param_grads(dz, x):
-            if W.requires_grad:
+            if need_w:
                 wsb = query('re2e_conv_wgrad_workspace_bytes', N, OH, OW, Cin, Cout, KH, KW)
                 ws = workspace(wsb, x.device, 'wgrad')
                 with accumulate(W) as (gw, beta):
                     call('re2e_conv_wgrad', x.data_ptr(), N, H, Wd, Cin, dz.data_ptr(), Cout, KH, KW, OH, OW, stride, stride, -pad, -pad,
                          gw.data_ptr(), beta, ws.data_ptr(), wsb)
-            if b is not None and b.requires_grad and not bias_done:
+            if b is not None and need_b and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, N * OH * OW, Cout, gb, beta)
         return dx, None, None, None, None, None
@@ -521,7 +529,7 @@ class BnLreluFn(torch.autograd.Function):
         dx = empty(x.shape, x)
         wsb = query('re2e_bn_workspace_bytes', Pn, C)
         ws = workspace(wsb, x.device, 'bn')
-        if gamma.requires_grad:
+        if ctx.needs_input_grad[1]:
             with accumulate(gamma) as (dg, gbeta), accumulate(beta) as (db, _):
                 call('re2e_bn_lrelu_bwd', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
                      dx.data_ptr(), dg.data_ptr(), db.data_ptr(), gbeta, ws.data_ptr(), wsb)
@@ -586,18 +594,19 @@ class BiLstmFn(torch.autograd.Function):
         with param_grads(g_f, g_r, x2, ybuf):
             for d in range(2):
                 w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
-                if w_ih.requires_grad:
+                n_ih, n_hh, n_bi, n_bh = ctx.needs_input_grad[2 + 4 * d:6 + 4 * d]
+                if n_ih:
                     with accumulate(w_ih) as (gw, beta):
                         gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
-                if w_hh.requires_grad:
+                if n_hh:
                     # h_{t-1}: forward direction = ybuf block t (y[t-1]); reverse = ybuf block t+2 (y[t+1])
                     hprev = yflat[(0 if d == 0 else 2 * B):, d * H:]
                     with accumulate(w_hh) as (gw, beta):
                         call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
-                if b_ih.requires_grad:
+                if n_bi:
                     with accumulate(b_ih) as (gb, beta):
                         colsum_into(dG[d], M, 4 * H, gb, beta)
-                if b_hh.requires_grad:
+                if n_bh:
                     with accumulate(b_hh) as (gb, beta):
                         colsum_into(dG[d], M, 4 * H, gb, beta)
         return (dx, None) + (None,) * len(w)
