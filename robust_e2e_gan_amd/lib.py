@@ -4,6 +4,7 @@ The product path has NO fallback: if the shared library is missing or the device
 every op raises.  ``load()`` only dlopen()s the library and checks the exported symbols (usable
 on a CPU-only box for the build/ABI checks); the first kernel call needs a GPU.
 """
+import atexit
 import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
@@ -149,6 +150,23 @@ def workspace(nbytes, device, tag='ws'):
 _hip = None
 
 
+_masked_streams = []
+
+
+def _destroy_masked_streams():
+    """The runtime does not own streams created through hipExtStreamCreateWithCUMask: drain and destroy them before
+    interpreter teardown (left alive they crash library finalisation under rocprofv3)."""
+    try:
+        _hip.hipStreamSynchronize.argtypes = [c_void_p]
+        _hip.hipStreamDestroy.argtypes = [c_void_p]
+        for h in _masked_streams:
+            _hip.hipStreamSynchronize(c_void_p(h))
+            _hip.hipStreamDestroy(c_void_p(h))
+    except Exception:
+        pass
+    del _masked_streams[:]
+
+
 def cu_masked_stream(enabled_cus, total_cus=256, device=None):
     """A HIP stream whose kernels may only run on the first ``enabled_cus`` bits of the CU mask
     (hipExtStreamCreateWithCUMask), wrapped as a torch ExternalStream.  Used for the filler streams of the
@@ -168,6 +186,9 @@ def cu_masked_stream(enabled_cus, total_cus=256, device=None):
         rc = _hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)
         if rc != 0 or not st.value:
             return None
+        if not _masked_streams:
+            atexit.register(_destroy_masked_streams)
+        _masked_streams.append(st.value)
         return torch.cuda.ExternalStream(st.value, device=device)
     except Exception:
         return None
