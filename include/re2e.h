@@ -194,6 +194,10 @@ int re2e_embedding_fwd(const float* table, const int* ids_dev, int n, int D, flo
 /* dtable[v][:] = beta*dtable + sum_{i: ids[i]==v} dout[i][:] in index order (deterministic) */
 int re2e_embedding_bwd(const float* dout, long ldo, const int* ids_dev, int n, int D, int V, float* dtable,
                        float beta, re2e_stream_t stream);
+/* Row-wise arg-max (lowest index on ties) of x[R][V] (leading dimension ldx): the token that scheduled
+ * sampling and Decoder.calculate_all_attentions feed back (e2e_decoder.py:123-127, :408-412 `y_i.topk(1)`). */
+int re2e_argmax_rows(const float* x, int R, int V, long ldx, int* out_ids, re2e_stream_t stream);
+
 /* F.cross_entropy(ignore_index=-1, mean) * scale and th_accuracy (e2e_decoder.py:155-161).
  * out[0]=loss, out[1]=#correct, out[2]=#valid ; lse [R] saved for the backward */
 int re2e_ce_fwd(const float* logits, const int* targets_dev, int R, int V, float scale, float* out, float* lse,

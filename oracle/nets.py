@@ -174,8 +174,11 @@ def ctc_forward(p, hpad, hlens, ys):
 # --------------------------------------------------------------------------------------
 # F8/F9  AttLoc + Decoder   model/e2e_attention.py:236-299, model/e2e_decoder.py:78-168
 # --------------------------------------------------------------------------------------
-def decoder_forward(p, hpad, hlens, ys, sos_eos, ss_rate=0.0, return_att=False):
-    assert ss_rate == 0.0, 'oracle restates the teacher-forced path (Appendix A.11)'
+def decoder_forward(p, hpad, hlens, ys, sos_eos, ss_rate=0.0, return_att=False, sample_steps=None):
+    """Decoder.forward (model/e2e_decoder.py:78-168).  ``sample_steps[i]`` True: step i feeds the arg-max of step i-1's
+    output (scheduled sampling :123-127 fires for the whole batch on one draw; calculate_all_attentions :408-412 does it
+    at every i > 0).  The caller decides the steps -- the reference draws ``random.random() < rate`` once per step."""
+    assert ss_rate == 0.0, 'pass the drawn steps as sample_steps'
     hlens = [int(l) for l in hlens]
     hpad = mask_by_length(hpad, hlens, 0.0)
     B, T, _ = hpad.shape
@@ -201,7 +204,12 @@ def decoder_forward(p, hpad, hlens, ys, sos_eos, ss_rate=0.0, return_att=False):
         e = F.linear(torch.tanh(conv + pre + dec), p['att.gvec.weight'], p['att.gvec.bias']).squeeze(2)
         att_w = F.softmax(2.0 * e, dim=1)
         att_c = (hpad * att_w.unsqueeze(2)).sum(1)
-        ey = torch.cat([eys[:, i], att_c], 1)
+        if sample_steps is not None and i > 0 and sample_steps[i]:
+            y_prev = F.linear(zs[-1], p['dec.output.weight'], p['dec.output.bias'])
+            e_i = F.embedding(y_prev.argmax(1), p['dec.embed.weight'])
+        else:
+            e_i = eys[:, i]
+        ey = torch.cat([e_i, att_c], 1)
         gates = F.linear(ey, p['dec.decoder.0.weight_ih'], p['dec.decoder.0.bias_ih']) + \
             F.linear(z, p['dec.decoder.0.weight_hh'], p['dec.decoder.0.bias_hh'])
         gi, gf, gg, go = gates.chunk(4, 1)
@@ -227,13 +235,13 @@ def split_targets(targets, target_sizes):
     return ys
 
 
-def e2e_forward(p, feats, targets, lens, tlens, elayers, mtlalpha=0.5):
+def e2e_forward(p, feats, targets, lens, tlens, elayers, mtlalpha=0.5, sample_steps=None):
     """E2E.forward   model/e2e_model.py:169-202"""
     ys = split_targets(targets, tlens)
     V = p['dec.output.weight'].size(0)
     hpad, hlens = encoder_forward(p, feats, lens, elayers)
     loss_ctc = ctc_forward(p, hpad, hlens, ys) if mtlalpha != 0 else None
-    loss_att, acc = decoder_forward(p, hpad, hlens, ys, V - 1) if mtlalpha != 1 else (None, None)
+    loss_att, acc = decoder_forward(p, hpad, hlens, ys, V - 1, sample_steps=sample_steps) if mtlalpha != 1 else (None, None)
     return loss_ctc, loss_att, acc, hpad, hlens
 
 

@@ -99,6 +99,27 @@ extern "C" int re2e_embedding_bwd(const float* dout, long ldo, const int* ids, i
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
+// arg-max of each row (lowest index on ties): the token fed back by scheduled sampling / greedy attention passes
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int R, int V, long ldx, int* __restrict__ out) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* xr = x + (long)row * ldx;
+  float m = -3.0e38f; int am = 0x7fffffff;
+  for (int v = lane; v < V; v += 64) { float xv = xr[v]; if (xv > m) { m = xv; am = v; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float m2 = __shfl_xor(m, o, 64); int a2 = __shfl_xor(am, o, 64);
+    if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+  }
+  if (lane == 0) out[row] = am;
+}
+extern "C" int re2e_argmax_rows(const float* x, int R, int V, long ldx, int* out_ids, hipStream_t stream) {
+  RE2E_CHECK_ARG(x && out_ids && R > 0 && V > 0 && ldx >= V, "bad args");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, stream, x, R, V, ldx, out_ids);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
 extern "C" int re2e_ce_fwd(const float* logits, const int* targets, int R, int V, float scale, float* out, float* lse, void* workspace,
                            size_t workspace_bytes, hipStream_t stream) {
   RE2E_CHECK_ARG(logits && targets && out && lse && workspace && R > 0 && V > 0, "bad args");

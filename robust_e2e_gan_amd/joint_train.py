@@ -254,9 +254,44 @@ class JointTrainer(object):
         self.gan_optimizer.step()
         return loss_D
 
+    def validate(self, data, enhance_cmvn, want_attention=False):
+        """One validation batch (joint_train.py:245-275): no-grad pass with enhancer / fbank / ASR in eval mode.  As in the
+        reference the discriminator is NOT switched to eval (its BatchNorm keeps using batch statistics and moves its
+        running statistics).  Returns the ``val/*`` meters as device scalars; ``want_attention`` adds ``att_ws`` =
+        ``calculate_all_attentions(enhance_feat, ...)`` (numpy, (B, Lmax+1, T'))."""
+        opt = self.opt
+        clean_inputs, mix_inputs, mix_log_inputs, targets, input_sizes, target_sizes = data[2], data[4], data[5], data[7], data[8], data[9]
+        nets = [self.enhance_model, self.feat_model, self.asr_model]
+        modes = [m.training for m in nets]
+        for m in nets:
+            m.eval()
+        ops.MULTI_STREAM, ops.WGRAD_STREAM, ops.AUX_STREAM = False, None, None
+        try:
+            with torch.no_grad():
+                enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
+                enhance_feat = self.feat_model(enhance_out)
+                clean_feat = self.feat_model(clean_inputs)
+                enhance_loss = ops.mean_loss(enhance_feat, clean_feat, 0.0, _LOSS_KIND[opt.enhance_loss_type])
+                errors = {}
+                if self.isGAN:
+                    gan_loss = self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
+                    enhance_loss = enhance_loss + opt.gan_loss_lambda * gan_loss
+                    errors['val/gan_loss'] = opt.gan_loss_lambda * gan_loss
+                loss_ctc, loss_att, acc, _, _ = self.asr_model(clean_feat, enhance_feat, targets, input_sizes, target_sizes, 0.0, enhance_cmvn)
+                asr_loss = opt.mtlalpha * loss_ctc.view(()) + (1 - opt.mtlalpha) * loss_att
+                enhance_loss = opt.enhance_loss_lambda * enhance_loss
+                errors.update({'val/loss': asr_loss + enhance_loss, 'val/loss_ctc': loss_ctc.view(()), 'val/acc': acc, 'val/loss_att': loss_att,
+                               'val/enhance_loss': enhance_loss})
+                if want_attention and opt.mtlalpha != 1.0:
+                    errors['att_ws'] = self.asr_model.calculate_all_attentions(enhance_feat, targets, input_sizes, target_sizes, enhance_cmvn)
+        finally:
+            for m, t in zip(nets, modes):
+                m.train(t)
+        return errors
+
     @staticmethod
     def to_floats(errors):
-        keys = list(errors.keys())
+        keys = [k for k, v in errors.items() if isinstance(v, torch.Tensor)]      # (att_ws is a numpy array)
         vals = torch.stack([errors[k].detach().float().reshape(()) for k in keys]).cpu().tolist()
         return dict(zip(keys, vals))
 

@@ -27,11 +27,11 @@ class EmbeddingParams(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.randn(n, d))
 
 
-def decoder_forward_hip(p, hpad, hlens, ys, eos, ss_rate=0.0, return_att=False, prefix=''):
-    """Teacher-forced decoder pass on the GPU.  ``p`` maps reference state_dict names
-    (att.* / dec.*) to Parameters; ``ys`` is a list of 1-D label tensors (host or device)."""
-    if ss_rate > 0.0 and random.random() < 2.0:      # any sampling event needs the per-step argmax path
-        raise Re2eError('scheduled sampling (ss_rate>0, e2e_decoder.py:123-127) is not built yet; run with rate 0.0')
+def decoder_forward_hip(p, hpad, hlens, ys, eos, ss_rate=0.0, return_att=False, prefix='', greedy=False):
+    """Decoder pass on the GPU.  ``p`` maps reference state_dict names (att.* / dec.*) to Parameters; ``ys`` is a
+    list of 1-D label tensors (host or device).  Teacher forced, except at the steps where scheduled sampling
+    fires (e2e_decoder.py:123: ``random.random() < rate and i > 0`` -- one draw of Python's RNG per step, for the
+    whole batch) or, with ``greedy`` (calculate_all_attentions :408-412), at every step i > 0."""
     dev = hpad.device
     B, T, E = hpad.shape
     hl = lens_list(hlens)
@@ -52,7 +52,15 @@ def decoder_forward_hip(p, hpad, hlens, ys, eos, ss_rate=0.0, return_att=False, 
               b_ih=p[prefix + 'dec.decoder.0.bias_ih'], b_hh=p[prefix + 'dec.decoder.0.bias_hh'], mlp_dec=p[prefix + 'att.mlp_dec.weight'],
               mlp_att=p[prefix + 'att.mlp_att.weight'], loc_conv=p[prefix + 'att.loc_conv.weight'], gvec_w=p[prefix + 'att.gvec.weight'],
               gvec_b=p[prefix + 'att.gvec.bias'])
-    z_all, w_all = ops.decoder_loop(hmask, pre, ids_tm, hl_dev, L1, Pm)            # (L1,B,D), (L1,B,T)
+    if greedy:
+        sample_steps = tuple(i > 0 for i in range(L1))
+    else:
+        sample_steps = tuple((random.random() < ss_rate) and i > 0 for i in range(L1)) if ss_rate > 0.0 else None
+    if sample_steps is not None and any(sample_steps):
+        Pm.update(out_w=p[prefix + 'dec.output.weight'], out_b=p[prefix + 'dec.output.bias'])
+    else:
+        sample_steps = None
+    z_all, w_all = ops.decoder_loop(hmask, pre, ids_tm, hl_dev, L1, Pm, sample_steps)   # (L1,B,D), (L1,B,T)
     D = z_all.shape[2]
     logits = ops.linear(z_all.reshape(L1 * B, D), p[prefix + 'dec.output.weight'], p[prefix + 'dec.output.bias'])
     scale = float(np.mean([len(y) + 1 for y in ylist])) - 1.0                      # :159
@@ -89,9 +97,10 @@ class Decoder(torch.nn.Module):
         return loss, (acc if self.return_acc_tensor else float(acc))
 
     def calculate_all_attentions(self, hpad, hlen, ys):
-        """e2e_decoder.py:371-461 -- attention weights (B, Lmax+1, T') of the teacher-forced pass."""
+        """e2e_decoder.py:371-461 -- attention weights (B, Lmax+1, T').  NB the reference's pass is GREEDY: for i > 0 it
+        feeds the arg-max of its own previous output (:408-412), the labels only fix the number of steps."""
         p = {'dec.' + k: v for k, v in self.named_parameters() if not k.startswith('att.')}
         p.update({'att.' + k: v for k, v in self.att.named_parameters()})
         with torch.no_grad():
-            _, _, att = decoder_forward_hip(p, hpad, hlen, ys, self.eos, 0.0, return_att=True)
+            _, _, att = decoder_forward_hip(p, hpad, hlen, ys, self.eos, 0.0, return_att=True, greedy=True)
         return att.cpu().numpy()

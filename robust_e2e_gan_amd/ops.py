@@ -846,10 +846,15 @@ class DecoderLoopFn(torch.autograd.Function):
       embed, w_ih, w_hh, b_ih, b_hh, mlp_dec, mlp_att, loc_conv, gvec_w, gvec_b
     Teacher forcing makes the embedding half of the LSTMCell input projection independent of the
     recurrence, so it is ONE batched GEMM over all (L+1)*B tokens before the loop; inside the loop only
-    the context (K=eprojs) and recurrent (K=dunits) halves remain (skinny split-K GEMMs)."""
+    the context (K=eprojs) and recurrent (K=dunits) halves remain (skinny split-K GEMMs).
+
+    ``sample_steps`` (optional tuple of L1 bools): step i feeds back the arg-max of step i-1's output layer instead
+    of the reference label (scheduled sampling e2e_decoder.py:123-127, and the greedy pass of
+    calculate_all_attentions :408-412); needs ``out_w`` / ``out_b`` in ``P``.  The fed-back token is an integer, so
+    no gradient flows through the arg-max -- only into the embedding row that was used."""
 
     @staticmethod
-    def forward(ctx, hmask, pre, ids_tm, hlens_dev, L1, Pm):
+    def forward(ctx, hmask, pre, ids_tm, hlens_dev, L1, Pm, sample_steps=None):
         _need_gpu(hmask)
         hmask, pre = _f32(hmask), _f32(pre)
         dev = hmask.device
@@ -876,7 +881,18 @@ class DecoderLoopFn(torch.autograd.Function):
         conv = empty((L1, B, T, C), hmask)          # saved for the backward (no recomputation of the location conv)
         dpj = empty((L1, B, A), hmask)
         e_scr = empty((B, T), hmask)
+        sampled = sample_steps is not None and any(sample_steps[1:])
+        if sampled:
+            ids_tm = ids_tm.clone()                 # becomes the list of tokens actually fed
+            V = Pm['out_w'].shape[0]
+            logits = empty((B, V), hmask)
         for i in range(L1):
+            if sampled and i > 0 and sample_steps[i]:
+                gemm(z[i], Pm['out_w'], logits, B, V, D, transb=True, bias=Pm['out_b'])          # y_{i-1} = output(z_{i-1})
+                ids_i = ids_tm.data_ptr() + 4 * i * B
+                call('re2e_argmax_rows', logits.data_ptr(), B, V, V, ids_i)
+                call('re2e_embedding_fwd', Pm['embed'].data_ptr(), ids_i, B, Dd, emb[i].data_ptr(), Dd)
+                gemm(emb[i], w_ih, gates[i], B, 4 * D, Dd, transb=True, ldb=ldw, bias=Pm['b_ih'], bias2=Pm['b_hh'])
             call('re2e_attloc_fwd', pre.data_ptr(), hmask.data_ptr(), z[i].data_ptr(), w[i - 1].data_ptr() if i > 0 else None,
                  hlens_dev.data_ptr(), w_decT.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(),
                  Pm['gvec_w'].data_ptr(), Pm['gvec_b'].data_ptr(), B, T, E, D, A, C, Fh, w[i].data_ptr(), cx[i].data_ptr(), E,
@@ -953,7 +969,7 @@ class DecoderLoopFn(torch.autograd.Function):
                 with accumulate(Pm[k]) as (gt, beta):
                     call('re2e_axpby', 1.0, tot.data_ptr() + 4 * off, beta, gt.data_ptr(), n)
                 off += n
-        return d_enc, d_pre, None, None, None, None
+        return d_enc, d_pre, None, None, None, None, None
 
 
 decoder_loop = DecoderLoopFn.apply

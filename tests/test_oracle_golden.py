@@ -142,3 +142,101 @@ def test_joint_step(golden_dir):
                                        err_msg=n)
     for k, v in st.gan_buf.items():
         np.testing.assert_allclose(v.numpy(), fx['gan_after.' + k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+# ---- the other trainers' steps and the validation pass (tests/golden/make_fixtures_trainers.py) ----
+def _after_close(params, fx, prefix, rtol=1e-3, atol=2e-5):
+    for k, v in params.items():
+        np.testing.assert_allclose(v.detach().numpy(), fx[prefix + k], rtol=rtol, atol=atol, err_msg=prefix + k)
+
+
+def _tr_batch(fx):
+    return (torch.from_numpy(fx['clean']), torch.from_numpy(fx['mix']), torch.from_numpy(fx['mix_log']), torch.from_numpy(fx['cos']),
+            fx['lens'].tolist())
+
+
+def test_enhance_base_step(golden_dir):
+    from oracle import trainers
+    fx, cfg = _load(golden_dir, 'trainers_tiny.npz'), joint_cfg()
+    enh = trainers.leaf(_sub(fx, 'base.p.'))
+    out = trainers.enhance_base_step(enh, joint.Adadelta(enh, eps=cfg['eps']), _tr_batch(fx), cfg)
+    np.testing.assert_allclose(out['loss'].numpy().reshape(-1), fx['base.loss'], rtol=3e-4)
+    assert abs(out['grad_norm'] - float(fx['base.grad_norm'])) < 2e-3 * float(fx['base.grad_norm'])
+    _after_close(enh, fx, 'base.after.')
+
+
+def test_enhance_fbank_step(golden_dir):
+    from oracle import trainers
+    fx = _load(golden_dir, 'trainers_tiny.npz')
+    W = torch.from_numpy(fx['fbank_W'])
+    for kind in ('L2', 'L1', 'smooth_L1'):
+        cfg = dict(joint_cfg(), enhance_loss_type=kind)
+        enh = trainers.leaf(_sub(fx, 'fbank.p.'))
+        out = trainers.enhance_fbank_step(enh, joint.Adadelta(enh, eps=cfg['eps']), W, _tr_batch(fx), cfg)
+        np.testing.assert_allclose(out['loss'].numpy().reshape(-1), fx['fbank.%s.loss' % kind], rtol=3e-4, err_msg=kind)
+        assert abs(out['grad_norm'] - float(fx['fbank.%s.grad_norm' % kind])) < 2e-3 * float(fx['fbank.%s.grad_norm' % kind])
+        _after_close(enh, fx, 'fbank.%s.after.' % kind)
+
+
+def test_enhance_gan_step(golden_dir):
+    from oracle import trainers
+    fx, cfg = _load(golden_dir, 'trainers_tiny.npz'), joint_cfg()
+    enh, gan = trainers.leaf(_sub(fx, 'gan.enh.p.')), trainers.leaf(_sub(fx, 'gan.d.p.'))
+    buf = trainers.buffers(_sub(fx, 'gan.d.p.'))
+    out = trainers.enhance_gan_step(enh, gan, buf, joint.Adadelta(enh, eps=cfg['eps']), joint.Adadelta(gan, eps=cfg['eps']),
+                                    torch.from_numpy(fx['fbank_W']), _tr_batch(fx), torch.from_numpy(fx['cmvn']), cfg)
+    for k in ('loss', 'gan_loss', 'enhance_loss', 'loss_D'):
+        np.testing.assert_allclose(out[k].numpy().reshape(-1), fx['gan.' + k], rtol=3e-4, err_msg=k)
+    assert abs(out['grad_norm'] - float(fx['gan.grad_norm'])) < 2e-3 * float(fx['gan.grad_norm'])
+    assert abs(out['grad_norm_D'] - float(fx['gan.grad_norm_D'])) < 2e-3 * float(fx['gan.grad_norm_D'])
+    _after_close(enh, fx, 'gan.enh.after.')
+    _after_close(gan, fx, 'gan.d.after.')
+    for k, v in buf.items():
+        np.testing.assert_allclose(v.numpy(), fx['gan.d.after.' + k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_asr_step(golden_dir):
+    from oracle import trainers
+    fx, cfg = _load(golden_dir, 'trainers_tiny.npz'), joint_cfg()
+    asr = trainers.leaf({k: v for k, v in _sub(fx, 'asr.p.').items() if not k.startswith('dec.att.')})
+    out = trainers.asr_step(asr, joint.Adadelta(asr, eps=cfg['eps']), torch.from_numpy(fx['asr.feats']), torch.from_numpy(fx['targets']),
+                            fx['lens'].tolist(), fx['tlens'].tolist(), cfg)
+    for k in ('loss', 'loss_ctc', 'loss_att'):
+        np.testing.assert_allclose(out[k].numpy().reshape(-1), fx['asr.' + k], rtol=3e-4, err_msg=k)
+    assert abs(out['acc'] - float(fx['asr.acc'])) < 1e-9
+    assert abs(out['grad_norm'] - float(fx['asr.grad_norm'])) < 2e-3 * float(fx['asr.grad_norm'])
+    for n in ('enc.enc2.bt0.weight', 'dec.output.bias', 'ctc.ctc_lo.weight', 'att.mlp_enc.weight'):
+        np.testing.assert_allclose(asr[n].detach().numpy(), fx['asr.after.' + n], rtol=1e-3, atol=2e-5, err_msg=n)
+
+
+def test_joint_validate(golden_dir):
+    from oracle import trainers
+    fx, cfg = _load(golden_dir, 'trainers_tiny.npz'), joint_cfg()
+    enh = _sub(fx, 'val.enh.')
+    asr = {k: v for k, v in _sub(fx, 'val.asr.').items() if not k.startswith('dec.att.')}
+    gan, buf = _sub(fx, 'val.gan.'), trainers.buffers(_sub(fx, 'val.gan.'))
+    batch = (torch.from_numpy(fx['clean']), torch.from_numpy(fx['mix']), torch.from_numpy(fx['mix_log']), torch.from_numpy(fx['targets']),
+             fx['lens'].tolist(), fx['tlens'].tolist())
+    out = trainers.joint_validate(enh, asr, gan, buf, torch.from_numpy(fx['fbank_W']), batch, torch.from_numpy(fx['cmvn']), cfg)
+    for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'gan_loss'):
+        np.testing.assert_allclose(out[k].numpy().reshape(-1), fx['val.' + k], rtol=3e-4, err_msg=k)
+    assert abs(out['acc'] - float(fx['val.acc'])) < 1e-9
+    np.testing.assert_allclose(out['att_ws'].numpy(), fx['val.att_ws'], rtol=1e-3, atol=1e-6)
+    for k, v in buf.items():
+        np.testing.assert_allclose(v.numpy(), fx['val.gan_after.' + k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_scheduled_sampling_forward_backward(golden_dir):
+    """Rate 1.0: every decoder step i > 0 feeds back its own arg-max (e2e_decoder.py:123-127)."""
+    fx, cfg = _load(golden_dir, 'trainers_tiny.npz'), joint_cfg()
+    asr = {k: v.clone().requires_grad_(True) for k, v in _sub(fx, 'asr.p.').items() if v.dtype.is_floating_point and not k.startswith('dec.att.')}
+    L1 = int(fx['tlens'].max()) + 1
+    loss_ctc, loss_att, acc, _, _ = nets.e2e_forward(asr, torch.from_numpy(fx['asr.feats']), torch.from_numpy(fx['targets']), fx['lens'].tolist(),
+                                                     fx['tlens'].tolist(), cfg['elayers'], cfg['mtlalpha'], sample_steps=[i > 0 for i in range(L1)])
+    (cfg['mtlalpha'] * loss_ctc + (1 - cfg['mtlalpha']) * loss_att).backward()
+    np.testing.assert_allclose(loss_att.detach().numpy().reshape(-1), fx['ss.loss_att'], rtol=3e-4)
+    assert abs(acc - float(fx['ss.acc'])) < 1e-9
+    for n in ('dec.embed.weight', 'dec.decoder.0.weight_ih', 'att.mlp_dec.weight', 'dec.output.weight', 'enc.enc2.bt0.weight'):
+        ref = fx['ss.g.' + n]
+        err = np.abs(asr[n].grad.numpy() - ref).max()
+        assert err <= 1e-3 * np.abs(ref).max() + 1e-7, (n, err)
