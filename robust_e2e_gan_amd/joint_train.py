@@ -289,6 +289,88 @@ class JointTrainer(object):
                 m.train(t)
         return errors
 
+    def fit(self, train_loader, val_loader, visualizer, train_sampler=None, start_epoch=0, iters=0, best_loss=float('inf'), best_acc=0.0,
+            max_iters=None):
+        """The reference's training loop (joint_train.py:145-329) around ``step`` / ``validate``: CMVN estimate before
+        training and after every validation, scheduled-sampling rate updated only at validation time, ``print_freq``
+        logging + 'latest' checkpoint, ``validate_freq`` validation + model selection (``opt.criterion`` 'acc' / 'loss';
+        a worse score decays Adadelta's eps, a better one is saved as model.{acc,loss}.best) with the reference's
+        checkpoint keys.  The per-step meters are read back one iteration late, after the next step has been enqueued,
+        so that logging never drains the GPU.  Returns (iters, best_loss, best_acc)."""
+        from .utils import utils
+        opt = self.opt
+        enhance_cmvn = compute_cmvn_epoch(opt, train_loader, self.enhance_model, self.feat_model)
+        rampup = utils.ScheSampleRampup(opt.sche_samp_start_iter, opt.sche_samp_final_iter, opt.sche_samp_final_rate)
+        sche_samp_rate = rampup.update(iters)
+        acc_report = loss_report = None
+        for m in (self.enhance_model, self.feat_model, self.asr_model):
+            m.train()
+        pending = None
+
+        def flush():
+            nonlocal pending
+            if pending is not None:
+                visualizer.set_current_errors(self.to_floats(pending))
+                pending = None
+
+        for epoch in range(start_epoch, opt.epochs):
+            if train_sampler is not None and epoch > opt.shuffle_epoch:
+                train_sampler.shuffle(epoch)
+            for data in train_loader:
+                errors = self.step(data, sche_samp_rate, enhance_cmvn)
+                flush()                                   # previous step's meters, now that this step is queued
+                pending = {k: v for k, v in errors.items() if k.startswith('train/')}
+                iters += 1
+                if iters % opt.print_freq == 0:
+                    flush()
+                    visualizer.print_current_errors(epoch, iters)
+                    st = self.state(epoch, iters, best_loss, best_acc)
+                    st.update(acc_report=acc_report, loss_report=loss_report)
+                    utils.save_checkpoint(st, opt.exp_path, filename='latest')
+                if iters % opt.validate_freq == 0:
+                    flush()
+                    sche_samp_rate = rampup.update(iters)
+                    saved = 0
+                    for vdata in val_loader:
+                        want = opt.num_save_attention > 0 and opt.mtlalpha != 1.0 and saved < opt.num_save_attention
+                        verr = self.validate(vdata, enhance_cmvn, want_attention=want)
+                        visualizer.set_current_errors(self.to_floats(verr))
+                        if want:
+                            for x in range(len(vdata[0]) if vdata[0] is not None else verr['att_ws'].shape[0]):
+                                name = vdata[0][x] if vdata[0] is not None else 'utt%d' % x
+                                visualizer.plot_attention(verr['att_ws'][x], int(vdata[9][x]), int(vdata[8][x]),
+                                                          '{}_ep{}_it{}.png'.format(name, epoch, iters))
+                                saved += 1
+                                if saved >= opt.num_save_attention:
+                                    break
+                    visualizer.print_epoch_errors(epoch, iters)
+                    acc_report = visualizer.plot_epoch_errors(epoch, iters, 'acc.png')
+                    loss_report = visualizer.plot_epoch_errors(epoch, iters, 'loss.png')
+                    val_loss, val_acc = visualizer.get_current_errors('val/loss'), visualizer.get_current_errors('val/acc')
+                    filename = None
+                    if opt.criterion == 'acc' and opt.mtlalpha != 1.0:
+                        if val_acc < best_acc:
+                            opt.eps = utils.adadelta_eps_decay(self.asr_optimizer, opt.eps_decay)
+                        else:
+                            filename = 'model.acc.best'
+                        best_acc = max(best_acc, val_acc)
+                    elif opt.criterion == 'loss':
+                        if val_loss > best_loss:
+                            opt.eps = utils.adadelta_eps_decay(self.asr_optimizer, opt.eps_decay)
+                        else:
+                            filename = 'model.loss.best'
+                        best_loss = min(val_loss, best_loss)
+                    st = self.state(epoch, iters, best_loss, best_acc)
+                    st.update(acc_report=acc_report, loss_report=loss_report)
+                    utils.save_checkpoint(st, opt.exp_path, filename=filename)
+                    visualizer.reset()
+                    enhance_cmvn = compute_cmvn_epoch(opt, train_loader, self.enhance_model, self.feat_model)
+                if max_iters is not None and iters >= max_iters:
+                    flush()
+                    return iters, best_loss, best_acc
+        flush()
+        return iters, best_loss, best_acc
+
     @staticmethod
     def to_floats(errors):
         keys = [k for k, v in errors.items() if isinstance(v, torch.Tensor)]      # (att_ws is a numpy array)

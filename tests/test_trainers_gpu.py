@@ -133,3 +133,83 @@ def test_joint_validate(golden_dir):
     for k, v in gan.state_dict().items():                       # ... but D's BatchNorm statistics move (D stays in train mode)
         if 'running' in k or 'num_batches' in k:
             rel('val.gan_after.' + k, v, fx['val.gan_after.' + k], tol=1e-4)
+
+
+def test_fit_loop_cadence(golden_dir, tmp_path):
+    """JointTrainer.fit keeps the reference loop's cadence (joint_train.py:145-329): CMVN before training and after
+    every validation, 'latest' checkpoints at print_freq, validation + model selection at validate_freq, the
+    scheduled-sampling rate refreshed at validation time only, checkpoint keys as upstream."""
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.data.synthetic import make_batch
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    opt = _opt()
+    for k, v in dict(exp_path=str(tmp_path), epochs=2, shuffle_epoch=-1, print_freq=2, validate_freq=3, num_save_attention=2, criterion='acc',
+                     eps_decay=0.01, sche_samp_start_iter=3, sche_samp_final_iter=6, sche_samp_final_rate=0.5, train_dataset_len=3,
+                     num_utt_cmvn=3).items():
+        setattr(opt, k, v)
+    torch.manual_seed(7)
+    enh, fb, asr, gan = (m.to(DEV).train() for m in (EnhanceModel(opt), FbankModel(opt), ShareE2E(opt), GANModel(opt)))
+
+    def batch(seed):
+        clean, mix, mix_log, targets, il, tl = make_batch(3, 40, 4, opt.odim, seed=seed)
+        return (['u%d_%d' % (seed, i) for i in range(3)], None, clean, None, mix, mix_log, None, targets, il, tl)
+
+    train_loader, val_loader = [batch(s) for s in (1, 2, 3)], [batch(9)]
+
+    class Rec(object):
+        def __init__(self):
+            self.sets, self.prints, self.epochs, self.atts, self.resets = [], 0, 0, [], 0
+            self.meters = {}
+
+        def set_current_errors(self, e):
+            self.sets.append(dict(e))
+            for k, v in e.items():
+                self.meters.setdefault(k, []).append(float(v))
+
+        def get_current_errors(self, k):
+            v = self.meters.get(k, [])
+            return sum(v) / len(v) if v else 0.0
+
+        def print_current_errors(self, epoch, iters):
+            self.prints += 1
+
+        def print_epoch_errors(self, epoch, iters):
+            self.epochs += 1
+
+        def plot_epoch_errors(self, epoch, iters, name):
+            return {'file': name}
+
+        def plot_attention(self, att_w, dec_len, enc_len, name):
+            self.atts.append((att_w.shape, dec_len, enc_len, name))
+
+        def reset(self):
+            self.resets += 1
+            self.meters = {}
+
+    rec = Rec()
+    tr = JointTrainer(opt, enh, fb, asr, gan)
+    rates = []
+    orig_step = tr.step
+    tr.step = lambda data, rate, cmvn: (rates.append(rate), orig_step(data, rate, cmvn))[1]
+    eps0 = tr.asr_optimizer.param_groups[0]['eps']
+    iters, best_loss, best_acc = tr.fit(train_loader, val_loader, rec)
+    assert iters == 6 and rec.prints == 3 and rec.epochs == 2 and rec.resets == 2
+    # rate is refreshed only at validation time: iters 0-2 use update(0)=0, iters 3-5 use update(3)=0, afterwards update(6)=0.5
+    assert rates == [0.0] * 6
+    train_sets = [e for e in rec.sets if any(k.startswith('train/') for k in e)]
+    assert len(train_sets) == 6 and set(train_sets[0]) == {'train/loss', 'train/loss_ctc', 'train/acc', 'train/loss_att', 'train/enhance_loss',
+                                                             'train/coral_loss', 'train/loss_D', 'train/gan_loss'}
+    val_sets = [e for e in rec.sets if any(k.startswith('val/') for k in e)]
+    assert len(val_sets) == 2 and set(val_sets[0]) == {'val/loss', 'val/loss_ctc', 'val/acc', 'val/loss_att', 'val/enhance_loss', 'val/gan_loss'}
+    assert len(rec.atts) == 4 and rec.atts[0][3] == 'u9_0_ep0_it3.png' and rec.atts[0][0][0] == 5      # Lmax + 1 decoder steps
+    import os
+    assert os.path.isfile(os.path.join(str(tmp_path), 'latest')) and os.path.isfile(os.path.join(str(tmp_path), 'enhance_cmvn.npy'))
+    st = torch.load(os.path.join(str(tmp_path), 'latest'), weights_only=False)
+    assert set(st) == {'asr_state_dict', 'fbank_state_dict', 'enhance_state_dict', 'gan_state_dict', 'opt', 'epoch', 'iters', 'eps', 'lr',
+                       'best_loss', 'best_acc', 'acc_report', 'loss_report'}
+    assert st['iters'] == 6 and best_acc >= 0.0
+    # either the first validation set the best accuracy (saved) or eps was decayed -- never both for one validation
+    assert os.path.isfile(os.path.join(str(tmp_path), 'model.acc.best')) or tr.asr_optimizer.param_groups[0]['eps'] < eps0
