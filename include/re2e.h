@@ -118,6 +118,16 @@ int re2e_mask_rows(const float* in, float* out, const int* lens_dev, int B, int 
 int re2e_pack_pad(const float* src_flat, const int* offsets_dev, const int* lens_dev, int B, int Tmax, int F,
                   float* dst, re2e_stream_t stream);
 
+/* K1, input side (data/kaldi_io.py:376-456 + data/mix_data_loader.py:198-237): decode a batch of raw Kaldi matrix records
+ * and pad them.  blob = the records' payload bytes (device); record b starts at blob + rec_off[b] and is
+ *   kind 0 ('FM'): rows*F row-major fp32 (16-byte aligned start), or
+ *   kind 2 ('CM'): kaldi CompressedMatrix format 1 -- {min f32, range f32, rows i32, cols i32}, F x 4 uint16
+ *                  percentiles, F x rows uint8 column-major.
+ * dst (B,Tmax,F) = decoded values, zero padded.  dst_log (optional) = (10*log10(max(x,1e-7)) + cmvn[0]) * cmvn[1]
+ * (cmvn (2,F), optional); when dst_log is given dst is clamped at 1e-7 too, as the reference's in-place clamp does. */
+int re2e_kaldi_decode_pad(const unsigned char* blob, const long* rec_off_dev, const int* kind_dev, const int* lens_dev, int B,
+                          int Tmax, int F, float* dst, float* dst_log, const float* cmvn, re2e_stream_t stream);
+
 /* ---- K2 fused fbank (model/feat_model.py:118-135): y = log(max((x^2) W, 1e-7)); optional
  * second output y_norm = (y + cmvn[0]) * cmvn[1].  W is given banded: for filter j the taps
  * band_w[j*maxw + i] apply to bins band_off[j]+i, i<band_len[j]. */

@@ -1,0 +1,88 @@
+// K1 input side: decode a batch of raw Kaldi matrix records on the GPU and pad them.
+//
+// The reference decodes every utterance on the host (data/kaldi_io.py:410-456: per-column numpy masks for the 8-bit
+// CompressedMatrix format), applies 10*log10(max(x,1e-7)) and CMVN there (data/mix_data_loader.py:198-237,
+// data/audioparse.py:446-459) and ships fp32 tensors.  Here the loader ships the RECORD BYTES (1 byte per element for
+// 'CM' tables) and this kernel produces, in one pass, the zero-padded linear tensor (B,Tmax,F) and optionally the
+// normalised log tensor.  HBM/PCIe-bound byte work: a workgroup transposes a 64-frame x 32-column tile through LDS
+// (CM payloads are column-major) so that both the byte reads and the fp32 writes are contiguous per wavefront.
+#include "common.h"
+
+namespace {
+
+constexpr float U16_TO_UNIT = 1.52590218966964e-05f;
+
+__global__ __launch_bounds__(256) void kaldi_decode_pad_kernel(const unsigned char* __restrict__ blob, const long* __restrict__ rec_off,
+                                                               const int* __restrict__ kind, const int* __restrict__ lens, int Tmax, int F,
+                                                               float* __restrict__ dst, float* __restrict__ dst_log,
+                                                               const float* __restrict__ cmvn) {
+  __shared__ float tile[32][65];
+  const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 32;
+  const int rows = lens[b];
+  const unsigned char* rec = blob + rec_off[b];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  if (t0 < rows) {
+    if (kind[b] == 2) {          // 'CM': [min f32][range f32][rows i32][cols i32][cols x 4 u16][cols x rows u8, column-major]
+      const float gmin = reinterpret_cast<const float*>(rec)[0], grange = reinterpret_cast<const float*>(rec)[1];
+      const unsigned short* hdr = reinterpret_cast<const unsigned short*>(rec + 16);
+      const unsigned char* data = rec + 16 + (long)F * 8;
+      const int t = t0 + tx;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + ty + 4 * i;
+        float v = 0.f;
+        if (c < F && t < rows) {
+          const float p0 = gmin + grange * U16_TO_UNIT * (float)hdr[c * 4 + 0], p25 = gmin + grange * U16_TO_UNIT * (float)hdr[c * 4 + 1];
+          const float p75 = gmin + grange * U16_TO_UNIT * (float)hdr[c * 4 + 2], p100 = gmin + grange * U16_TO_UNIT * (float)hdr[c * 4 + 3];
+          const int u = data[(long)c * rows + t];
+          if (u <= 64) v = p0 + (p25 - p0) / 64.f * (float)u;
+          else if (u <= 192) v = p25 + (p75 - p25) / 128.f * (float)(u - 64);
+          else v = p75 + (p100 - p75) / 63.f * (float)(u - 192);
+        }
+        tile[ty + 4 * i][tx] = v;
+      }
+    } else {                     // 'FM': row-major fp32 (the loader packs the data part 16-byte aligned)
+      const float* data = reinterpret_cast<const float*>(rec);
+      const int f = threadIdx.x & 31, tr = threadIdx.x >> 5;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int t = t0 + tr + 8 * i, c = c0 + f;
+        tile[f][tr + 8 * i] = (c < F && t < rows) ? data[(long)t * F + c] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  const int f = threadIdx.x & 31, tr = threadIdx.x >> 5;
+  const int c = c0 + f;
+  if (c >= F) return;
+  const float m0 = (dst_log && cmvn) ? cmvn[c] : 0.f, m1 = (dst_log && cmvn) ? cmvn[F + c] : 1.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int t = t0 + tr + 8 * i;
+    if (t >= Tmax) break;
+    const long o = ((long)b * Tmax + t) * F + c;
+    if (t < rows) {
+      float v = tile[f][tr + 8 * i];
+      if (dst_log) {               // mix_data_loader.py:200-203: the clamp is applied in place, so the linear stream sees it too
+        v = fmaxf(v, 1e-7f);
+        dst_log[o] = (10.f * log10f(v) + m0) * m1;
+      }
+      dst[o] = v;
+    } else {
+      dst[o] = 0.f;
+      if (dst_log) dst_log[o] = 0.f;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int re2e_kaldi_decode_pad(const unsigned char* blob, const long* rec_off_dev, const int* kind_dev, const int* lens_dev, int B,
+                                     int Tmax, int F, float* dst, float* dst_log, const float* cmvn, hipStream_t stream) {
+  RE2E_CHECK_ARG(blob && rec_off_dev && kind_dev && lens_dev && dst, "null operand");
+  RE2E_CHECK_ARG(B > 0 && Tmax > 0 && F > 0 && B <= 65535, "bad shape");
+  hipLaunchKernelGGL(kaldi_decode_pad_kernel, dim3(cdiv(Tmax, 64), cdiv(F, 32), B), dim3(256), 0, stream, blob, rec_off_dev, kind_dev, lens_dev,
+                     Tmax, F, dst, dst_log, cmvn);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}

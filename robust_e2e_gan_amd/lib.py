@@ -45,6 +45,7 @@ SIGNATURES = {
     're2e_scatter_rows': (I, [P, P, P, I, I, P]),
     're2e_mask_rows': (I, [P, P, P, I, I, I, P]),
     're2e_pack_pad': (I, [P, P, P, I, I, I, P, P]),
+    're2e_kaldi_decode_pad': (I, [P, P, P, P, I, I, I, P, P, P, P]),
     're2e_fbank_fwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P]),
     're2e_fbank_bwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P, P]),
     're2e_cmvn_stats': (I, [P, P, I, I, I, P, P, P]),
