@@ -207,6 +207,9 @@ int re2e_embedding_bwd(const float* dout, long ldo, const int* ids_dev, int n, i
 /* Row-wise arg-max (lowest index on ties) of x[R][V] (leading dimension ldx): the token that scheduled
  * sampling and Decoder.calculate_all_attentions feed back (e2e_decoder.py:123-127, :408-412 `y_i.topk(1)`). */
 int re2e_argmax_rows(const float* x, int R, int V, long ldx, int* out_ids, re2e_stream_t stream);
+/* out[R][V] = log_softmax(x[R][V]) row-wise (F.log_softmax of Decoder.recognize_beam e2e_decoder.py:263 and
+ * CTC.log_softmax e2e_ctc.py:68-75) */
+int re2e_log_softmax_rows(const float* x, int R, int V, long ldx, float* out, re2e_stream_t stream);
 
 /* F.cross_entropy(ignore_index=-1, mean) * scale and th_accuracy (e2e_decoder.py:155-161).
  * out[0]=loss, out[1]=#correct, out[2]=#valid ; lse [R] saved for the backward */

@@ -114,6 +114,28 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   }
   if (lane == 0) out[row] = am;
 }
+// log-softmax of each row (decoding: local attention scores and the CTC frame posteriors lpz)
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int R, int V, long ldx, float* __restrict__ out) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* xr = x + (long)row * ldx;
+  float m = -3.0e38f;
+  for (int v = lane; v < V; v += 64) m = fmaxf(m, xr[v]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int v = lane; v < V; v += 64) s += expf(xr[v] - m);
+  s = wave_sum(s);
+  const float l = m + logf(s);
+  float* o = out + (long)row * V;
+  for (int v = lane; v < V; v += 64) o[v] = xr[v] - l;
+}
+extern "C" int re2e_log_softmax_rows(const float* x, int R, int V, long ldx, float* out, hipStream_t stream) {
+  RE2E_CHECK_ARG(x && out && R > 0 && V > 0 && ldx >= V, "bad args");
+  hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, stream, x, R, V, ldx, out);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
 extern "C" int re2e_argmax_rows(const float* x, int R, int V, long ldx, int* out_ids, hipStream_t stream) {
   RE2E_CHECK_ARG(x && out_ids && R > 0 && V > 0 && ldx >= V, "bad args");
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, stream, x, R, V, ldx, out_ids);

@@ -3,7 +3,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..lib import Re2eError
+from ..lib import Re2eError, call as lib_call
 from .e2e_common import LinearParams, host_to_dev, lens_dev, lens_list
 
 
@@ -30,3 +30,12 @@ class CTC(torch.nn.Module):
 
     def forward(self, hs_pad, hlens, ys_pad):
         return self.forward_tm(ops.transpose01(hs_pad), hlens, ys_pad)
+
+    def log_softmax(self, hs_pad):
+        """e2e_ctc.py:68-75: log_softmax(ctc_lo(hs_pad), dim=2) -- frame posteriors for joint CTC/attention decoding."""
+        with torch.no_grad():
+            logits = ops.linear(hs_pad, self.ctc_lo.weight, self.ctc_lo.bias)
+            V = logits.shape[-1]
+            out = torch.empty_like(logits)
+            lib_call('re2e_log_softmax_rows', logits.data_ptr(), logits.numel() // V, V, V, out.data_ptr())
+            return out

@@ -96,6 +96,17 @@ class Decoder(torch.nn.Module):
         self.loss = loss
         return loss, (acc if self.return_acc_tensor else float(acc))
 
+    def recognize_beam(self, h, lpz, recog_args, char_list=None, rnnlm=None, fstlm=None):
+        """e2e_decoder.py:171-369 (no LM): n-best list of {'yseq', 'score'} for the encoder states ``h`` (T', eprojs) of one
+        utterance; ``lpz`` = CTC log posteriors (T', V) or None.  All live hypotheses are advanced as one GPU batch."""
+        if rnnlm is not None or fstlm is not None:
+            raise Re2eError('LM fusion at decode time is out of scope (SURVEY section 2)')
+        from .beam_search import recognize_beam
+        p = {'dec.' + k: v for k, v in self.named_parameters() if not k.startswith('att.')}
+        p.update({'att.' + k: v for k, v in self.att.named_parameters()})
+        lp = lpz.detach().cpu().numpy() if isinstance(lpz, torch.Tensor) else lpz
+        return recognize_beam(p, h, lp, recog_args, self.eos)
+
     def calculate_all_attentions(self, hpad, hlen, ys):
         """e2e_decoder.py:371-461 -- attention weights (B, Lmax+1, T').  NB the reference's pass is GREEDY: for i > 0 it
         feeds the arg-max of its own previous output (:408-412), the labels only fix the number of steps."""

@@ -63,6 +63,20 @@ class E2E(ModelBase):
             off += s
         return ys
 
+    def recognize(self, x, recog_args, char_list=None, rnnlm=None, fstlm=None):
+        """e2e_model.py:204-236: beam search for ONE utterance ``x`` (1, T, fbank_dim) -> n-best [{'yseq', 'score'}]."""
+        prev = self.training
+        self.eval()
+        try:
+            with torch.no_grad():
+                xs = to_cuda(self, x)
+                hpad, _ = self.enc(xs, [xs.shape[1]])
+                lpz = self.ctc.log_softmax(hpad)[0] if recog_args.ctc_weight > 0.0 else None
+                return self.dec.recognize_beam(hpad[0], lpz, recog_args, char_list, rnnlm, fstlm)
+        finally:
+            if prev:
+                self.train()
+
     def forward(self, inputs, targets, input_sizes, target_sizes, scheduled_sampling_rate=0.0):
         """-> (loss_ctc, loss_att, acc)   (e2e_model.py:169-202)"""
         xpad = to_cuda(self, inputs)
@@ -80,9 +94,6 @@ class E2E(ModelBase):
         with torch.no_grad():
             hpad, hlens = self.enc(to_cuda(self, inputs), lens_list(input_sizes))
             return self.dec.calculate_all_attentions(hpad, hlens, self._split_targets(targets, target_sizes))
-
-    def recognize(self, *a, **k):
-        raise Re2eError('beam-search decoding (e2e_decoder.py:171-369) is a "next" row (N3), not built yet')
 
 
 class ShareE2E(E2E):

@@ -240,3 +240,28 @@ def test_scheduled_sampling_forward_backward(golden_dir):
         ref = fx['ss.g.' + n]
         err = np.abs(asr[n].grad.numpy() - ref).max()
         assert err <= 1e-3 * np.abs(ref).max() + 1e-7, (n, err)
+
+
+# ---- beam search (tests/golden/make_fixtures_recog.py) ----
+RECOG_CONFIGS = [('att_b3', 3, 0.0, 0.0, 0.0, 0.0, 3), ('joint_b4', 4, 0.1, 0.3, 0.0, 0.0, 4), ('joint_ratio', 3, 0.0, 0.5, 0.6, 0.2, 2),
+                 ('ctc_heavy', 2, 0.2, 0.9, 0.0, 0.0, 2)]
+
+
+def check_nbest(got, fx, name, u, tol=2e-3):
+    seqs, scores = fx['%s.u%d.yseq' % (name, u)], fx['%s.u%d.score' % (name, u)]
+    assert len(got) == len(scores), (name, u, len(got), len(scores))
+    for i, h in enumerate(got):
+        want = [int(v) for v in seqs[i] if v >= 0]
+        assert h['yseq'] == want, (name, u, i, h['yseq'], want)
+        assert abs(h['score'] - scores[i]) <= tol * max(1.0, abs(scores[i])), (name, u, i, h['score'], scores[i])
+
+
+def test_beam_search(golden_dir):
+    from oracle import decode
+    fx = _load(golden_dir, 'recog_tiny.npz')
+    p = {k: v for k, v in _sub(fx, 'p.').items() if not k.startswith('dec.att.')}
+    feats = torch.from_numpy(fx['feats'])
+    for name, beam, penalty, ctcw, maxr, minr, nbest in RECOG_CONFIGS:
+        for u, T in enumerate(fx['lens'].tolist()):
+            got = decode.recognize(p, feats[u:u + 1, :T], 2, beam, penalty, ctcw, maxr, minr, nbest)
+            check_nbest(got, fx, name, u)

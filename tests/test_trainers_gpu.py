@@ -213,3 +213,21 @@ def test_fit_loop_cadence(golden_dir, tmp_path):
     assert st['iters'] == 6 and best_acc >= 0.0
     # either the first validation set the best accuracy (saved) or eps was decayed -- never both for one validation
     assert os.path.isfile(os.path.join(str(tmp_path), 'model.acc.best')) or tr.asr_optimizer.param_groups[0]['eps'] < eps0
+
+
+# ---- beam search ----
+def test_recognize_matches_reference_nbest(golden_dir):
+    """E2E.recognize (all hypotheses of a position batched on the GPU) reproduces the n-best lists of the reference's
+    one-hypothesis-at-a-time search for attention-only, joint CTC/attention, length-ratio and CTC-heavy configurations."""
+    import argparse
+    from test_oracle_golden import RECOG_CONFIGS, check_nbest
+    from robust_e2e_gan_amd.model.e2e_model import E2E
+    fx = _fx(golden_dir, 'recog_tiny.npz')
+    asr = _load(E2E(_opt()), fx, 'p.')
+    feats = torch.from_numpy(fx['feats'])
+    for name, beam, penalty, ctcw, maxr, minr, nbest in RECOG_CONFIGS:
+        args = argparse.Namespace(beam_size=beam, penalty=penalty, ctc_weight=ctcw, maxlenratio=maxr, minlenratio=minr, nbest=nbest, lm_weight=0.0)
+        for u, T in enumerate(fx['lens'].tolist()):
+            got = asr.recognize(feats[u:u + 1, :T], args, [str(i) for i in range(12)])
+            check_nbest(got, fx, name, u)
+    assert asr.training                                                  # mode restored
