@@ -218,6 +218,13 @@ int re2e_ce_fwd(const float* logits, const int* targets_dev, int R, int V, float
 /* dlogits = (*gscale_dev)*scale/#valid * (softmax - onehot) on valid rows, 0 on ignored rows */
 int re2e_ce_bwd(const float* logits, const int* targets_dev, const float* lse, const float* fwd_out, int R, int V,
                 float scale, const float* gscale_dev, float* dlogits, re2e_stream_t stream);
+/* Label-smoothing regulariser of the decoder loss (e2e_decoder.py:162-166):
+ * out[0] = -(1/nutt) * sum over ALL R rows and V labels of log_softmax(logits)[r][v] * dist[v]; workspace R floats.
+ * bwd: dlogits[r][v] = gscale[0] * (softmax[r][v] * sum(dist) - dist[v]) / nutt. */
+int re2e_lsm_fwd(const float* logits, const float* dist, int R, int V, int nutt, float* out, void* workspace,
+                 size_t workspace_bytes, re2e_stream_t stream);
+int re2e_lsm_bwd(const float* logits, const float* dist, int R, int V, int nutt, const float* gscale, float* dlogits,
+                 re2e_stream_t stream);
 
 /* ---- K6 CTC (warp-ctc call site e2e_ctc.py:63): logits (T,B,V) raw activations, blank 0,
  * loss = sum_b nll_b / B.  labels_dev: flat int32; label_off_dev/label_len_dev per utterance. */

@@ -144,11 +144,18 @@ def vgg2l_forward(p, x, lens, pre='enc.enc1.'):
 # --------------------------------------------------------------------------------------
 # F6  BLSTMP (subsample all 1)   model/e2e_encoder.py:119-150
 # --------------------------------------------------------------------------------------
-def blstmp_forward(p, x, lens, elayers, pre='enc.enc2.'):
+def blstmp_forward(p, x, lens, elayers, pre='enc.enc2.', subsample=None):
+    """BLSTMP.forward (model/e2e_encoder.py:119-150); ``subsample[l+1] > 1`` keeps every sub-th output frame of layer l
+    ('skip' type, :137-139)."""
+    lens = [int(l) for l in lens]
     for l in range(elayers):
         w = {k.replace(pre + 'bilstm%d.' % l, ''): v for k, v in p.items()
              if k.startswith(pre + 'bilstm%d.' % l)}
         y = _bilstm(x, lens, w, '', 0)
+        sub = int(subsample[l + 1]) if subsample is not None else 1
+        if sub > 1:
+            y = y[:, ::sub]
+            lens = [(i + 1) // sub for i in lens]
         B, T, _ = y.shape
         x = torch.tanh(F.linear(y.reshape(B * T, -1), p[pre + 'bt%d.weight' % l],
                                 p[pre + 'bt%d.bias' % l])).view(B, T, -1)
@@ -174,7 +181,7 @@ def ctc_forward(p, hpad, hlens, ys):
 # --------------------------------------------------------------------------------------
 # F8/F9  AttLoc + Decoder   model/e2e_attention.py:236-299, model/e2e_decoder.py:78-168
 # --------------------------------------------------------------------------------------
-def decoder_forward(p, hpad, hlens, ys, sos_eos, ss_rate=0.0, return_att=False, sample_steps=None):
+def decoder_forward(p, hpad, hlens, ys, sos_eos, ss_rate=0.0, return_att=False, sample_steps=None, labeldist=None, lsm_weight=0.0):
     """Decoder.forward (model/e2e_decoder.py:78-168).  ``sample_steps[i]`` True: step i feeds the arg-max of step i-1's
     output (scheduled sampling :123-127 fires for the whole batch on one draw; calculate_all_attentions :408-412 does it
     at every i > 0).  The caller decides the steps -- the reference draws ``random.random() < rate`` once per step."""
@@ -222,6 +229,9 @@ def decoder_forward(p, hpad, hlens, ys, sos_eos, ss_rate=0.0, return_att=False, 
     loss = F.cross_entropy(y_all, ys_out.reshape(-1), ignore_index=-1, reduction='mean')
     loss = loss * (float(np.mean([len(y) + 1 for y in ys])) - 1.0)
     acc = th_accuracy(y_all, ys_out, -1)
+    if labeldist is not None:                           # :162-166 label smoothing (sum over ALL rows / number of utterances)
+        reg = -(F.log_softmax(y_all, dim=1) * labeldist).sum() / len(ys)
+        loss = (1.0 - lsm_weight) * loss + lsm_weight * reg
     if return_att:
         return loss, acc, torch.stack(ws, 1)
     return loss, acc

@@ -81,7 +81,64 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     d[v] = g * y;
   }
 }
+// label-smoothing regulariser (e2e_decoder.py:162-166): reg = -(1/nutt) sum_r sum_v log_softmax(y)[r][v] * dist[v] over ALL rows
+// (padded ones included, as upstream).  Row value: lse_r * S - sum_v y[r][v] dist[v],  S = sum_v dist[v].
+__global__ __launch_bounds__(256) void lsm_rows_kernel(const float* __restrict__ logits, const float* __restrict__ dist, int R, int V,
+                                                       float* __restrict__ rowval) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* x = logits + (long)row * V;
+  float m = -3.0e38f;
+  for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+  m = wave_max(m);
+  float s = 0.f, dot = 0.f, S = 0.f;
+  for (int v = lane; v < V; v += 64) { float d = dist[v]; s += expf(x[v] - m); dot += x[v] * d; S += d; }
+  s = wave_sum(s); dot = wave_sum(dot); S = wave_sum(S);
+  if (lane == 0) rowval[row] = (m + logf(s)) * S - dot;
+}
+__global__ void lsm_final_kernel(const float* __restrict__ rowval, int R, float inv_nutt, float* out) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < R; i += blockDim.x) a += rowval[i];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) out[0] = a * inv_nutt;
+}
+// d reg / d y[r][v] = (softmax[r][v] * S - dist[v]) / nutt, times the incoming gradient
+__global__ __launch_bounds__(256) void lsm_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ dist, int R, int V, float inv_nutt,
+                                                      const float* __restrict__ gscale, float* __restrict__ dlogits) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* x = logits + (long)row * V;
+  float m = -3.0e38f;
+  for (int v = lane; v < V; v += 64) m = fmaxf(m, x[v]);
+  m = wave_max(m);
+  float s = 0.f, S = 0.f;
+  for (int v = lane; v < V; v += 64) { s += expf(x[v] - m); S += dist[v]; }
+  s = wave_sum(s); S = wave_sum(S);
+  const float g = (gscale ? gscale[0] : 1.f) * inv_nutt, l = m + logf(s);
+  float* d = dlogits + (long)row * V;
+  for (int v = lane; v < V; v += 64) d[v] = g * (expf(x[v] - l) * S - dist[v]);
+}
 }  // namespace
+
+extern "C" int re2e_lsm_fwd(const float* logits, const float* dist, int R, int V, int nutt, float* out, void* workspace, size_t workspace_bytes,
+                            hipStream_t stream) {
+  RE2E_CHECK_ARG(logits && dist && out && workspace && R > 0 && V > 0 && nutt > 0, "bad args");
+  RE2E_CHECK_ARG(workspace_bytes >= (size_t)R * sizeof(float), "workspace too small (R floats)");
+  hipLaunchKernelGGL(lsm_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, stream, logits, dist, R, V, (float*)workspace);
+  hipLaunchKernelGGL(lsm_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, R, 1.0f / nutt, out);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+extern "C" int re2e_lsm_bwd(const float* logits, const float* dist, int R, int V, int nutt, const float* gscale, float* dlogits,
+                            hipStream_t stream) {
+  RE2E_CHECK_ARG(logits && dist && dlogits && R > 0 && V > 0 && nutt > 0, "bad args");
+  hipLaunchKernelGGL(lsm_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, stream, logits, dist, R, V, 1.0f / nutt, gscale, dlogits);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
 
 extern "C" int re2e_embedding_fwd(const float* table, const int* ids, int n, int D, float* out, long ldo, hipStream_t stream) {
   RE2E_CHECK_ARG(table && ids && out && n > 0 && D > 0 && ldo >= D, "bad args");

@@ -67,6 +67,8 @@ SIGNATURES = {
     're2e_lstm_cell_bwd': (I, [P, P, P, P, P, P, I, I, P]),
     're2e_embedding_fwd': (I, [P, P, I, I, P, L, P]),
     're2e_embedding_bwd': (I, [P, L, P, I, I, I, P, F, P]),
+    're2e_lsm_fwd': (I, [P, P, I, I, I, P, P, Z, P]),
+    're2e_lsm_bwd': (I, [P, P, I, I, I, P, P, P]),
     're2e_log_softmax_rows': (I, [P, I, I, L, P, P]),
     're2e_argmax_rows': (I, [P, I, I, L, P, P]),
     're2e_ce_fwd': (I, [P, P, I, I, F, P, P, P, Z, P]),

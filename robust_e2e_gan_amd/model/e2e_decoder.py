@@ -27,7 +27,7 @@ class EmbeddingParams(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.randn(n, d))
 
 
-def decoder_forward_hip(p, hpad, hlens, ys, eos, ss_rate=0.0, return_att=False, prefix='', greedy=False):
+def decoder_forward_hip(p, hpad, hlens, ys, eos, ss_rate=0.0, return_att=False, prefix='', greedy=False, labeldist=None, lsm_weight=0.0):
     """Decoder pass on the GPU.  ``p`` maps reference state_dict names (att.* / dec.*) to Parameters; ``ys`` is a
     list of 1-D label tensors (host or device).  Teacher forced, except at the steps where scheduled sampling
     fires (e2e_decoder.py:123: ``random.random() < rate and i > 0`` -- one draw of Python's RNG per step, for the
@@ -65,6 +65,9 @@ def decoder_forward_hip(p, hpad, hlens, ys, eos, ss_rate=0.0, return_att=False, 
     logits = ops.linear(z_all.reshape(L1 * B, D), p[prefix + 'dec.output.weight'], p[prefix + 'dec.output.bias'])
     scale = float(np.mean([len(y) + 1 for y in ylist])) - 1.0                      # :159
     loss, stats = ops.cross_entropy(logits, tgt_tm, scale)
+    if labeldist is not None:                                                      # :162-166 label smoothing
+        reg = ops.label_smoothing(logits, labeldist, B)
+        loss = (1.0 - lsm_weight) * loss + lsm_weight * reg
     acc = stats[1] / stats[2]                                                      # th_accuracy (device scalar)
     if return_att:
         return loss.view(()), acc, w_all.transpose(0, 1)
@@ -77,8 +80,7 @@ class Decoder(torch.nn.Module):
         super(Decoder, self).__init__()
         if dlayers != 1:
             raise Re2eError('dlayers > 1 is outside the round-1 hot path')
-        if labeldist is not None:
-            raise Re2eError('label smoothing (e2e_decoder.py:162-166) is a "next" row (N4), not built yet')
+        self.labeldist, self.lsm_weight, self.vlabeldist = labeldist, lsm_weight, None
         self.dunits, self.dlayers = dunits, dlayers
         self.embed = EmbeddingParams(odim, dunits)
         self.decoder = torch.nn.ModuleList([LSTMCellParams(dunits + eprojs, dunits)])
@@ -92,7 +94,10 @@ class Decoder(torch.nn.Module):
     def forward(self, hpad, hlen, ys, scheduled_sampling_rate=0.0, att_params=None):
         p = {'dec.' + k: v for k, v in self.named_parameters() if not k.startswith('att.')}
         p.update({'att.' + k: v for k, v in self.att.named_parameters()})
-        loss, acc = decoder_forward_hip(p, hpad, hlen, ys, self.eos, scheduled_sampling_rate)
+        if self.labeldist is not None and (self.vlabeldist is None or self.vlabeldist.device != hpad.device):
+            self.vlabeldist = torch.as_tensor(np.asarray(self.labeldist), dtype=torch.float32).to(hpad.device).contiguous()
+        loss, acc = decoder_forward_hip(p, hpad, hlen, ys, self.eos, scheduled_sampling_rate, labeldist=self.vlabeldist,
+                                        lsm_weight=self.lsm_weight)
         self.loss = loss
         return loss, (acc if self.return_acc_tensor else float(acc))
 

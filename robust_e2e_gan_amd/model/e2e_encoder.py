@@ -48,21 +48,33 @@ class BLSTMP(torch.nn.Module):
             setattr(self, 'bt%d' % i, LinearParams(2 * cdim, hdim))
         self.elayers, self.cdim = elayers, cdim
         self.subsample, self.subsample_type = subsample, subsample_type
-        if any(int(s) > 1 for s in subsample[1:elayers + 1]):
-            raise Re2eError('BLSTMP frame subsampling (e2e_encoder.py:133-143) is a "next" row (N4), not built yet')
+        self.subsampling = any(int(s) > 1 for s in subsample[1:elayers + 1])
+        if self.subsampling and subsample_type != 'skip':
+            raise Re2eError('BLSTMP subsample_type %r: only "skip" (e2e_encoder.py:137-139) is built' % subsample_type)
 
-    def forward_tm(self, x_tm, lens_d):
+    def forward_tm(self, x_tm, lens_d, lens=None):
+        """Time-major (T,B,idim) -> (T',B,hdim).  With frame subsampling configured (``subsample[l+1] > 1``: every sub-th
+        frame of layer l's output is kept, lengths become (len+1)//sub, e2e_encoder.py:133-139) the host length list
+        ``lens`` is required and the result is ``(y, new_lens)``; without it the lengths do not change and ``y`` is returned."""
+        if self.subsampling and lens is None:
+            raise Re2eError('BLSTMP with frame subsampling needs the host length list (forward_tm(x, lens_dev, lens))')
+        cur = list(lens) if lens is not None else None
         for l in range(self.elayers):
             y = ops.bilstm(x_tm, lens_d, getattr(self, 'bilstm%d' % l).layer_weights(0))
+            sub = int(self.subsample[l + 1])
+            if sub > 1:
+                y = y[::sub].contiguous()
+                cur = [(i + 1) // sub for i in cur]
+                lens_d = lens_dev(cur, y.device)
             bt = getattr(self, 'bt%d' % l)
             x_tm = ops.linear(y, bt.weight, bt.bias, 'tanh')      # applied to padded rows too (:145-147)
-        return x_tm
+        return (x_tm, cur) if lens is not None else x_tm
 
     def forward(self, xpad, ilens):
         lens = lens_list(ilens)
         T = max(lens)
-        y = self.forward_tm(ops.transpose01(xpad)[:T], lens_dev(lens, xpad.device))
-        return ops.transpose01(y), lens
+        y, nl = self.forward_tm(ops.transpose01(xpad)[:T], lens_dev(lens, xpad.device), lens)
+        return ops.transpose01(y), nl
 
 
 class VGG2L(torch.nn.Module):
@@ -135,8 +147,12 @@ class Encoder(torch.nn.Module):
         if self.etype in ('blstm', 'blstmp'):
             lens = lens_list(ilens)
             x_tm = ops.transpose01(xs)[:max(lens)]
+            if self.etype == 'blstmp':
+                return self.enc1.forward_tm(x_tm, lens_dev(lens, xs.device), lens)
             return self.enc1.forward_tm(x_tm, lens_dev(lens, xs.device)), lens
         h_tm, nl = self.enc1.forward_tm(xs, ilens)
+        if self.etype == 'vggblstmp':
+            return self.enc2.forward_tm(h_tm, lens_dev(nl, xs.device), nl)
         return self.enc2.forward_tm(h_tm, lens_dev(nl, xs.device)), nl
 
     def forward(self, xs, ilens):

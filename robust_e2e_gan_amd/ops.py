@@ -776,6 +776,34 @@ def cross_entropy(logits, targets_dev, scale=1.0):
     return CeFn.apply(logits, targets_dev, scale)
 
 
+class LabelSmoothFn(torch.autograd.Function):
+    """-(1/nutt) * sum(log_softmax(logits) * dist) over all rows  (label-smoothing term, e2e_decoder.py:162-166)."""
+
+    @staticmethod
+    def forward(ctx, logits, dist, nutt):
+        _need_gpu(logits)
+        logits = _f32(logits)
+        R, V = logits.shape
+        out = empty((1,), logits)
+        ws = workspace(R * 4, logits.device, 'lsm')
+        call('re2e_lsm_fwd', logits.data_ptr(), dist.data_ptr(), R, V, int(nutt), out.data_ptr(), ws.data_ptr(), R * 4)
+        ctx.save_for_backward(logits, dist)
+        ctx.nutt = int(nutt)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, dist = ctx.saved_tensors
+        R, V = logits.shape
+        g = _f32(g).reshape(1)
+        d = empty((R, V), logits)
+        call('re2e_lsm_bwd', logits.data_ptr(), dist.data_ptr(), R, V, ctx.nutt, g.data_ptr(), d.data_ptr())
+        return d, None, None
+
+
+label_smoothing = LabelSmoothFn.apply
+
+
 # ---------------------------------------------------------------------------------------------
 # K7 + K8 decoder loop: AttLoc step -> LSTMCell, teacher forced  (e2e_decoder.py:121-152)
 # ---------------------------------------------------------------------------------------------

@@ -265,3 +265,41 @@ def test_beam_search(golden_dir):
         for u, T in enumerate(fx['lens'].tolist()):
             got = decode.recognize(p, feats[u:u + 1, :T], 2, beam, penalty, ctcw, maxr, minr, nbest)
             check_nbest(got, fx, name, u)
+
+
+# ---- frame subsampling and label smoothing (tests/golden/make_fixtures_n4.py) ----
+def _e2e_grads_close(p, fx, pre, names):
+    for n in names:
+        ref = fx[pre + 'g.' + n]
+        err = np.abs(p[n].grad.numpy() - ref).max()
+        assert err <= 1e-3 * np.abs(ref).max() + 1e-7, (n, err)
+
+
+def test_blstmp_subsampling(golden_dir):
+    fx = _load(golden_dir, 'n4_tiny.npz')
+    p = {k: v.clone().requires_grad_(True) for k, v in _sub(fx, 'sub.p.').items() if v.dtype.is_floating_point and not k.startswith('dec.att.')}
+    feats, lens = torch.from_numpy(fx['feats']), fx['lens'].tolist()
+    ys = nets.split_targets(torch.from_numpy(fx['targets']), fx['tlens'].tolist())
+    hpad, hlens = nets.blstmp_forward(p, feats, lens, 3, pre='enc.enc1.', subsample=[1, 2, 2, 1, 1])
+    assert list(hlens) == fx['sub.hlens'].tolist()
+    np.testing.assert_allclose(hpad.detach().numpy(), fx['sub.hpad'], **TOL)
+    loss_ctc = nets.ctc_forward(p, hpad, hlens, ys)
+    loss_att, acc = nets.decoder_forward(p, hpad, hlens, ys, 11)
+    np.testing.assert_allclose(loss_ctc.detach().numpy().reshape(-1), fx['sub.loss_ctc'], rtol=3e-4)
+    np.testing.assert_allclose(loss_att.detach().numpy().reshape(-1), fx['sub.loss_att'], rtol=3e-4)
+    (0.5 * loss_ctc + 0.5 * loss_att).backward()
+    _e2e_grads_close(p, fx, 'sub.', ['enc.enc1.bilstm0.weight_ih_l0', 'enc.enc1.bt1.weight', 'enc.enc1.bilstm2.weight_hh_l0_reverse',
+                                      'dec.output.weight', 'ctc.ctc_lo.weight'])
+
+
+def test_label_smoothing(golden_dir):
+    fx = _load(golden_dir, 'n4_tiny.npz')
+    p = {k: v.clone().requires_grad_(True) for k, v in _sub(fx, 'lsm.p.').items() if v.dtype.is_floating_point and not k.startswith('dec.att.')}
+    feats, lens = torch.from_numpy(fx['feats']), fx['lens'].tolist()
+    ys = nets.split_targets(torch.from_numpy(fx['targets']), fx['tlens'].tolist())
+    hpad, hlens = nets.encoder_forward(p, feats, lens, 2)
+    loss_ctc = nets.ctc_forward(p, hpad, hlens, ys)
+    loss_att, acc = nets.decoder_forward(p, hpad, hlens, ys, 11, labeldist=torch.from_numpy(fx['lsm.labeldist']), lsm_weight=0.1)
+    np.testing.assert_allclose(loss_att.detach().numpy().reshape(-1), fx['lsm.loss_att'], rtol=3e-4)
+    (0.5 * loss_ctc + 0.5 * loss_att).backward()
+    _e2e_grads_close(p, fx, 'lsm.', ['dec.output.weight', 'dec.output.bias', 'dec.embed.weight', 'enc.enc2.bt0.weight'])

@@ -231,3 +231,36 @@ def test_recognize_matches_reference_nbest(golden_dir):
             got = asr.recognize(feats[u:u + 1, :T], args, [str(i) for i in range(12)])
             check_nbest(got, fx, name, u)
     assert asr.training                                                  # mode restored
+
+
+# ---- frame subsampling and label smoothing ----
+def _e2e_case(golden_dir, pre, overrides, names):
+    import argparse
+    from robust_e2e_gan_amd.model.e2e_model import E2E
+    fx = _fx(golden_dir, 'n4_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), **overrides})
+    asr = _load(E2E(opt), fx, pre + 'p.')
+    feats = torch.from_numpy(fx['feats'])
+    lens, tl = torch.IntTensor(fx['lens']), torch.IntTensor(fx['tlens'])
+    hpad, hl = asr.enc(feats.to(DEV), lens)
+    assert list(hl) == fx[pre + 'hlens'].tolist()
+    rel(pre + 'hpad', hpad, fx[pre + 'hpad'])
+    lc, la, acc = asr(feats, torch.from_numpy(fx['targets']), lens, tl, 0.0)
+    rel(pre + 'loss_ctc', lc.view(1), fx[pre + 'loss_ctc'])
+    rel(pre + 'loss_att', la.view(1), fx[pre + 'loss_att'])
+    assert abs(float(acc) - float(fx[pre + 'acc'])) < 1e-6
+    (0.5 * lc.view(()) + 0.5 * la.view(())).backward()
+    named = dict(asr.named_parameters())
+    for n in names:
+        rel(pre + 'g.' + n, named[n].grad, fx[pre + 'g.' + n], tol=3e-3)
+
+
+def test_blstmp_frame_subsampling(golden_dir):
+    _e2e_case(golden_dir, 'sub.', dict(etype='blstmp', elayers=3, subsample='1_2_2_1_1'),
+              ['enc.enc1.bilstm0.weight_ih_l0', 'enc.enc1.bt1.weight', 'enc.enc1.bilstm2.weight_hh_l0_reverse', 'dec.output.weight', 'ctc.ctc_lo.weight'])
+
+
+def test_label_smoothing(golden_dir):
+    fx = _fx(golden_dir, 'n4_tiny.npz')
+    _e2e_case(golden_dir, 'lsm.', dict(lsm_type='unigram', lsm_weight=0.1, labeldist=fx['lsm.labeldist']),
+              ['dec.output.weight', 'dec.output.bias', 'dec.embed.weight', 'enc.enc2.bt0.weight'])
