@@ -62,6 +62,7 @@ class GradSync:
         self.pending = []
 
     def arm(self, boundary_tensor, early_opt):
+        self._early = None
         if world_size() == 1 or not boundary_tensor.requires_grad:
             self._early = None
             return

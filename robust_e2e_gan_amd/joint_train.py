@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import lib, ops
+from . import dist as rdist
 from .dist import GradSync
 from .model.e2e_common import set_requires_grad
 from .model.gan_model import CORAL, GANLoss
@@ -209,6 +210,20 @@ class JointTrainer(object):
                         t_.record_stream(side)
                 loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, wait_before_update=ev_bwd1)
             self._mark('D-step enqueued (side)')
+            if not armed and rdist.world_size() > 1:
+                # Data parallel: every ASR gradient kernel has been enqueued (phase 1 on main, the clean-branch / CTC
+                # backward on side, the weight gradients on wgrad), so the 116 MB ASR all-reduce starts as soon as those
+                # finish and runs over xGMI UNDER the enhancer's backward chain instead of after it.  RCCL orders its
+                # stream behind the stream the collective is issued from: issue it from the wgrad stream, behind events
+                # of the other two.
+                ws = self.wgrad_stream
+                with torch.cuda.stream(ws):
+                    ws.wait_event(ev_bwd1)
+                    ws.wait_event(ev_side_bwd)
+                    work = rdist.allreduce_mean_(self.asr_optimizer.grad, async_op=True)
+                if work is not None:
+                    sync.pending.append(work)
+                armed = True
             # Phase 2: the enhancer backward chain on the main stream.
             enhance_out.backward(g_eo)
             self._mark('bwd phase 2 (enhancer)')
