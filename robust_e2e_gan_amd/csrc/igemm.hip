@@ -293,32 +293,43 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Pipeline (one register set, two LDS buffers): tile t+1 is written to LDS right AFTER the barrier that opens iteration
+  // t, the loads of tile t+2 are issued immediately behind it, then tile t is computed -- so every global load has a whole
+  // MFMA block plus a barrier to land before its LDS store needs it.
   f32x4 ra[AIT], rb[BIT];
-  if (kt_begin < kt_end) {
+  auto fetch_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < AIT; ++i) ra[i] = fetch<VEC>(la, rsA, ra_row[LA::KMAJ ? i : 0], ra_k[LA::KMAJ ? 0 : i]);
 #pragma unroll
     for (int i = 0; i < BIT; ++i) rb[i] = fetch<VEC>(lb, rsB, rb_row[LB::KMAJ ? i : 0], rb_k[LB::KMAJ ? 0 : i]);
+  };
+  auto advance_k = [&]() {
 #pragma unroll
-    for (int i = 0; i < AIT; ++i) *reinterpret_cast<f32x4*>(As + a_lds[i]) = ra[i];
+    for (int i = 0; i < NKA; ++i) la.advance(ra_k[i], BK);
 #pragma unroll
-    for (int i = 0; i < BIT; ++i) *reinterpret_cast<f32x4*>(Bs + b_lds[i]) = rb[i];
+    for (int i = 0; i < NKB; ++i) lb.advance(rb_k[i], BK);
+  };
+  auto store_tile = [&](int buf) {
+    float* An = As + buf * ASZ;
+    float* Bn = Bs + buf * BSZ;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) *reinterpret_cast<f32x4*>(An + a_lds[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) *reinterpret_cast<f32x4*>(Bn + b_lds[i]) = rb[i];
+  };
+  if (kt_begin < kt_end) {
+    fetch_tile();
+    store_tile(0);
+    if (kt_begin + 1 < kt_end) { advance_k(); fetch_tile(); }
   }
-  __syncthreads();
 
   const int lr = lane & 31, lh = lane >> 5;
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = (kt + 1 < kt_end);
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < NKA; ++i) la.advance(ra_k[i], BK);
-#pragma unroll
-      for (int i = 0; i < NKB; ++i) lb.advance(rb_k[i], BK);
-#pragma unroll
-      for (int i = 0; i < AIT; ++i) ra[i] = fetch<VEC>(la, rsA, ra_row[LA::KMAJ ? i : 0], ra_k[LA::KMAJ ? 0 : i]);
-#pragma unroll
-      for (int i = 0; i < BIT; ++i) rb[i] = fetch<VEC>(lb, rsB, rb_row[LB::KMAJ ? i : 0], rb_k[LB::KMAJ ? 0 : i]);
+    __syncthreads();                                   // tile kt is complete in buffer cur; buffer cur^1 is free
+    if (kt + 1 < kt_end) {
+      store_tile(cur ^ 1);
+      if (kt + 2 < kt_end) { advance_k(); fetch_tile(); }
     }
     const float* Ac = As + cur * ASZ;
     const float* Bc = Bs + cur * BSZ;
@@ -351,15 +362,6 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
           for (int b = 0; b < CF::TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
     }
-    if (more) {
-      float* An = As + (cur ^ 1) * ASZ;
-      float* Bn = Bs + (cur ^ 1) * BSZ;
-#pragma unroll
-      for (int i = 0; i < AIT; ++i) *reinterpret_cast<f32x4*>(An + a_lds[i]) = ra[i];
-#pragma unroll
-      for (int i = 0; i < BIT; ++i) *reinterpret_cast<f32x4*>(Bn + b_lds[i]) = rb[i];
-    }
-    __syncthreads();
     cur ^= 1;
   }
 
