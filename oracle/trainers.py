@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from . import nets
-from .joint import Adadelta, _grads, _zero, clip_grad_norm
+from .joint import _grads, _zero, clip_grad_norm
 
 
 def leaf(d):

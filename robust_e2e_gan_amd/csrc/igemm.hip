@@ -5,8 +5,10 @@
 // convolution weight-gradient (im2col gather as the A operand over the pixel (=K) axis,
 // split-K partial slabs + deterministic reduce).  Wave = 64 lanes computes TMxTN tiles of 32x32;
 // the k index inside a group of 8 is assigned k = 8q + 4*(lane>>5) + j so that a lane fetches
-// its 4 k-values for 4 consecutive MFMAs with ONE ds_read_b128 (LDS rows padded to 36 floats:
-// conflict-free for the b128 lane groups).
+// its 4 k-values for 4 consecutive MFMAs with ONE ds_read_b128 (LDS rows padded to BK+4 floats:
+// conflict-free for the b128 lane groups).  Thin problems (Cin or Cout of 1) are
+// routed to the direct kernels of thinconv.hip; the stride-2 data gradient runs its four output
+// parity classes as blockIdx.z of one launch; workgroups are ordered XCD-aware (see the kernel).
 //
 // Replaces (reference, stock ATen ops): torch.nn.Linear / torch.mm call sites in
 // model/e2e_encoder.py:145-147,173-174, model/e2e_ctc.py:51, model/e2e_attention.py:256,

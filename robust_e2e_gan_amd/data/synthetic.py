@@ -1,5 +1,4 @@
 """Synthetic AISHELL-shaped batches: identical on the CPU-oracle and GPU paths."""
-import numpy as np
 import torch
 
 CONFIGS = {   # name: (B, Tmax, L, joint?)

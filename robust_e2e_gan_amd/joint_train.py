@@ -5,7 +5,6 @@
 order of operations (Appendix A.12-14): freeze toggling, clip on the ASR net only, NaN guard
 gating both G optimizers, D clipped separately.  Every rank runs it on its own utterance shard;
 gradients are averaged by dist.GradSync (RCCL) before clipping."""
-import math
 import os
 import time
 

@@ -9,7 +9,7 @@ detection) stays on the host and follows the reference line by line, so the n-be
 import numpy as np
 import torch
 
-from .. import lib, ops
+from .. import ops
 from ..lib import call
 from .e2e_common import host_to_dev, lens_dev
 

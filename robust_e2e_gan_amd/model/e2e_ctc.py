@@ -4,7 +4,7 @@ import torch
 
 from .. import ops
 from ..lib import Re2eError, call as lib_call
-from .e2e_common import LinearParams, host_to_dev, lens_dev, lens_list
+from .e2e_common import LinearParams, host_to_dev, lens_dev
 
 
 class CTC(torch.nn.Module):

@@ -6,7 +6,7 @@ import torch
 
 from .. import ops
 from ..lib import Re2eError
-from .e2e_common import LinearParams, host_to_dev, lens_dev, lens_list, to_cuda
+from .e2e_common import LinearParams, host_to_dev, lens_dev, lens_list
 
 
 class LSTMCellParams(torch.nn.Module):

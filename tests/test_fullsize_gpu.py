@@ -3,7 +3,6 @@ small batch, (b) size-independent properties at BASELINE.json's full config-4 si
 shape of config 5."""
 import math
 
-import numpy as np
 import pytest
 import torch
 

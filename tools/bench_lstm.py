@@ -6,7 +6,6 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from robust_e2e_gan_amd import lib
 from robust_e2e_gan_amd.lib import call, query
 
 
@@ -43,6 +42,5 @@ if __name__ == '__main__':
     for (T, B, H) in ((800, 32, 256), (200, 64, 512)):
         for wf in (4, 8, 16):
             os.environ['RE2E_LSTM_WAVES_FWD'] = str(wf)
-            os.environ['RE2E_LSTM_WAVES_BWD'] = str(wf)
             r = run(T, B, H)
             print('T=%d B=%d H=%d waves=%2d: fwd %.2f us/step  bwd %.2f us/step (wall, incl. launch gaps)' % (T, B, H, wf, r['fwd'], r['bwd']), flush=True)

@@ -7,7 +7,6 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from robust_e2e_gan_amd import lib
 from robust_e2e_gan_amd.lib import call, query
 
 
