@@ -193,7 +193,11 @@ class JointTrainer(object):
             main = torch.cuda.current_stream()
             ev_fwd = torch.cuda.Event()
             ev_fwd.record(main)
-            (g_eo,) = torch.autograd.grad(loss, [enhance_out])
+            # The ASR parameters are listed as inputs so that autograd also runs the nodes that lead ONLY to them (the
+            # clean branch's conv stack reaches the loss through CORAL but not enhance_out and would be pruned);
+            # the fused ops accumulate parameter gradients themselves and hand None back for them.
+            asr_params = [p for p in self.asr_model.parameters() if p.requires_grad]
+            g_eo = torch.autograd.grad(loss, [enhance_out] + asr_params, allow_unused=True)[0]
             self._mark('bwd phase 1 (ASR, D, fbank)')
             ev_bwd1 = torch.cuda.Event()
             ev_bwd1.record(main)

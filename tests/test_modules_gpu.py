@@ -160,3 +160,32 @@ def test_joint_step(golden_dir):
         for k, v in m.state_dict().items():
             if v.dtype.is_floating_point:
                 rel(pre + k, v, fx[pre + k], tol=1e-3, atol=2e-5)
+
+
+def test_joint_step_overlap_equals_single_stream(golden_dir):
+    """The multi-stream schedule (two-phase backward, side / weight-gradient streams) must produce the gradients of the
+    plain single-stream ``loss.backward()`` step: every parameter of the four nets after one update, to rounding."""
+    import __graft_entry__ as g
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    fx = _fx(golden_dir, 'joint_tiny.npz')
+    W = _fx(golden_dir, 'fbank_tiny.npz')['W']
+    t = lambda k: torch.from_numpy(fx[k])
+    data = (None, None, t('clean'), None, t('mix'), t('mix_log'), None, t('targets'), torch.IntTensor(fx['lens']), torch.IntTensor(fx['tlens']))
+    grads = {}
+    for overlap in (False, True):
+        opt = g._tiny_opt()
+        opt.coral_loss_lambda = 50.0            # makes the clean branch's (CORAL-only) contribution to the gradients large
+        enh, asr, gan = _load(EnhanceModel(opt), fx, 'enh.'), _load(ShareE2E(opt), fx, 'asr.'), _load(GANModel(opt), fx, 'gan.')
+        fb = FbankModel(opt)
+        fb.load_state_dict({'fc': torch.from_numpy(W)})
+        tr = JointTrainer(opt, enh, fb.to(DEV).train(), asr, gan)
+        tr.overlap_dstep = overlap
+        tr.step(data, 0.0, t('cmvn'))
+        torch.cuda.synchronize()
+        grads[overlap] = {n + '.' + k: p.grad.clone() for n, m in (('enh', enh), ('asr', asr), ('gan', gan)) for k, p in m.named_parameters()}
+    for k, ref in grads[False].items():
+        rel(k, grads[True][k], ref.cpu().numpy(), tol=2e-5, atol=1e-9)
