@@ -159,8 +159,10 @@ _masked_streams = []
 
 
 def _destroy_masked_streams():
-    """The runtime does not own streams created through hipExtStreamCreateWithCUMask: drain and destroy them before
-    interpreter teardown (left alive they crash library finalisation under rocprofv3)."""
+    """Registered only under rocprofv3 (its tool library is in LD_PRELOAD): streams created through
+    hipExtStreamCreateWithCUMask that are still alive crash the profiler's finalisation, so they are drained and
+    destroyed at exit.  NOT done otherwise: a tensor that outlives this handler (module-level objects, a failing test's
+    traceback) would have the caching allocator record events on a destroyed stream."""
     try:
         _hip.hipStreamSynchronize.argtypes = [c_void_p]
         _hip.hipStreamDestroy.argtypes = [c_void_p]
@@ -191,7 +193,7 @@ def cu_masked_stream(enabled_cus, total_cus=256, device=None):
         rc = _hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)
         if rc != 0 or not st.value:
             return None
-        if not _masked_streams:
+        if not _masked_streams and 'rocprof' in os.environ.get('LD_PRELOAD', ''):
             atexit.register(_destroy_masked_streams)
         _masked_streams.append(st.value)
         return torch.cuda.ExternalStream(st.value, device=device)
