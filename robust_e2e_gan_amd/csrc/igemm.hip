@@ -138,10 +138,21 @@ struct ConvM {    // rows = (kh, kw, ci) (ci fastest), k = pixel  (weight-gradie
     s.k = k; s.px = k % g.PW; int t = k / g.PW; s.py = t % g.PH; s.n = t / g.PH;
     set_k(s);
   }
-  __device__ void advance(Kst& s, int bk) const {
+  __device__ void advance(Kst& s, int bk) const {       // incremental: adds only, no multiplies on the common path
     s.k += bk; s.px += bk;
-    while (s.px >= g.PW) { s.px -= g.PW; if (++s.py == g.PH) { s.py = 0; ++s.n; } }
-    set_k(s);
+    s.ix0 += bk * g.SX;
+    s.base += (unsigned)(bk * g.SX * g.C * 4);
+    while (s.px >= g.PW) {
+      s.px -= g.PW;
+      s.ix0 -= g.PW * g.SX;
+      s.iy0 += g.SY;
+      s.base += (unsigned)((g.SY * g.W - g.PW * g.SX) * g.C * 4);
+      if (++s.py == g.PH) {
+        s.py = 0; ++s.n;
+        s.iy0 -= g.PH * g.SY;
+        s.base += (unsigned)(((g.H - g.PH * g.SY) * g.W) * g.C * 4);
+      }
+    }
   }
   __device__ unsigned off(const Row& r, const Kst& s, int j) const {
     if (j == 0) {
@@ -326,6 +337,8 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   }
 
   const int lr = lane & 31, lh = lane >> 5;
+  // (measured and rejected: skipping the MFMA block of a wave whose slab lies outside a ragged matrix edge -- the
+  //  per-iteration branch costs every kernel 10-20 %)
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     __syncthreads();                                   // tile kt is complete in buffer cur; buffer cur^1 is free
