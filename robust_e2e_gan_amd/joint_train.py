@@ -15,7 +15,7 @@ from . import lib, ops
 from . import dist as rdist
 from .dist import GradSync
 from .model.e2e_common import set_requires_grad
-from .model.gan_model import CORAL, GANLoss
+from .model.gan_model import CORAL, GANLoss, replay_running_stats
 from .optim import FlatOptimizer
 
 _LOSS_KIND = {'L2': lib.LOSS_L2, 'L1': lib.LOSS_L1, 'smooth_L1': lib.LOSS_SMOOTH_L1}
@@ -65,6 +65,8 @@ class JointTrainer(object):
         # run the D passes on a side HIP stream under the latency-bound recurrent chains (RE2E_NO_OVERLAP=1: profiling)
         self.overlap_dstep = os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
         self.marks = [] if os.environ.get('RE2E_TIMELINE') else None
+        # the D-step's D(fake) forward equals the G-step's (same input, same weights): keep that graph and walk it twice
+        self.reuse_dfake = os.environ.get('RE2E_NO_DFAKE_REUSE', '0') != '1' 
         self.side_stream = self.wgrad_stream = None
         if torch.cuda.is_available():
             # filler streams: optionally restricted to a subset of the CUs (RE2E_FILLER_CUS, default all) so that the
@@ -162,14 +164,27 @@ class JointTrainer(object):
             # G-step discriminator pass (joint_train.py:175-182).  It depends only on enhance_feat, so with
             # overlap it is enqueued on the side stream BEFORE the ASR forward and runs under it; autograd runs
             # its backward on the same side stream.
-            set_requires_grad([self.gan_model], False)
+            reuse = self.reuse_dfake
+            # upstream freezes D here (:176); with ``reuse`` the graph is built with trainable parameters instead and the
+            # G-step backward is told not to produce their gradients (ops.FROZEN_PARAMS below) -- same arithmetic
+            set_requires_grad([self.gan_model], reuse)
+            fake_stats = [] if reuse else None
+
+            def d_fake_forward():
+                ops.BN_STATS_SINK = fake_stats
+                try:
+                    d = self.gan_model(enhance_feat, enhance_cmvn)
+                finally:
+                    ops.BN_STATS_SINK = None
+                return d, opt.gan_loss_lambda * self.criterionGAN(d, True)
             if overlap:
                 self.side_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.side_stream):
                     enhance_feat.record_stream(self.side_stream)
-                    gan_loss = opt.gan_loss_lambda * self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
+                    d_fake, gan_loss = d_fake_forward()
             else:
-                gan_loss = opt.gan_loss_lambda * self.criterionGAN(self.gan_model(enhance_feat, enhance_cmvn), True)
+                d_fake, gan_loss = d_fake_forward()
+            fake_bn_layers = list(self.gan_model._bn_layers_last)
         self._mark('fbank + G-step D fwd enqueued (side)')
         loss_ctc, loss_att, acc, clean_context, mix_context = self.asr_model(clean_feat, enhance_feat, targets, input_sizes, target_sizes,
                                                                               sche_samp_rate, enhance_cmvn, clean_branch=clean_branch)
@@ -197,7 +212,12 @@ class JointTrainer(object):
             # clean branch's conv stack reaches the loss through CORAL but not enhance_out and would be pruned);
             # the fused ops accumulate parameter gradients themselves and hand None back for them.
             asr_params = [p for p in self.asr_model.parameters() if p.requires_grad]
-            g_eo = torch.autograd.grad(loss, [enhance_out] + asr_params, allow_unused=True)[0]
+            reuse = self.isGAN and self.reuse_dfake
+            ops.FROZEN_PARAMS = frozenset(id(p) for p in self.gan_model.parameters()) if reuse else frozenset()
+            try:
+                g_eo = torch.autograd.grad(loss, [enhance_out] + asr_params, allow_unused=True, retain_graph=reuse)[0]
+            finally:
+                ops.FROZEN_PARAMS = frozenset()
             self._mark('bwd phase 1 (ASR, D, fbank)')
             ev_bwd1 = torch.cuda.Event()
             ev_bwd1.record(main)
@@ -211,7 +231,8 @@ class JointTrainer(object):
                 for t_ in (enhance_feat, clean_feat, enhance_cmvn):
                     if isinstance(t_, torch.Tensor) and t_.is_cuda:
                         t_.record_stream(side)
-                loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, wait_before_update=ev_bwd1)
+                loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, wait_before_update=ev_bwd1,
+                                      d_fake=d_fake if reuse else None, fake_stats=fake_stats, fake_bn=fake_bn_layers)
             self._mark('D-step enqueued (side)')
             if not armed and rdist.world_size() > 1:
                 # Data parallel: every ASR gradient kernel has been enqueued (phase 1 on main, the clean-branch / CTC
@@ -232,7 +253,12 @@ class JointTrainer(object):
             self._mark('bwd phase 2 (enhancer)')
             torch.cuda.current_stream().wait_event(ev_side_bwd)
         else:
-            loss.backward()
+            reuse = self.isGAN and self.reuse_dfake
+            ops.FROZEN_PARAMS = frozenset(id(p) for p in self.gan_model.parameters()) if reuse else frozenset()
+            try:
+                loss.backward(retain_graph=reuse)
+            finally:
+                ops.FROZEN_PARAMS = frozenset()
             loss_D = None
             if self.overlap_dstep:
                 torch.cuda.current_stream().wait_stream(self.side_stream)
@@ -244,7 +270,8 @@ class JointTrainer(object):
         self.asr_optimizer.step()
         if self.isGAN:
             if loss_D is None:
-                loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn)
+                loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, d_fake=d_fake if self.reuse_dfake else None,
+                                      fake_stats=fake_stats, fake_bn=fake_bn_layers)
             else:
                 torch.cuda.current_stream().wait_stream(self.side_stream)
             out['train/loss_D'] = loss_D.detach()
@@ -254,15 +281,27 @@ class JointTrainer(object):
         self._mark('optimizers')
         return out
 
-    def _d_step(self, clean_feat, enhance_feat, enhance_cmvn, wait_before_update=None):
-        """Discriminator update (joint_train.py:195-212) on the CURRENT stream."""
+    def _d_step(self, clean_feat, enhance_feat, enhance_cmvn, wait_before_update=None, d_fake=None, fake_stats=None, fake_bn=None):
+        """Discriminator update (joint_train.py:195-212) on the CURRENT stream.  ``d_fake``: D(enhance_feat) of the G-step
+        (same input, same weights as upstream's second evaluation) -- its graph is walked again for the parameter
+        gradients instead of recomputing the forward; the BatchNorm running statistics get the update that forward would
+        have applied (``fake_stats``), in upstream's order (after the D(real) pass)."""
         opt = self.opt
         set_requires_grad([self.gan_model], True)
         self.gan_optimizer.zero_grad()
         loss_D_real = self.criterionGAN(self.gan_model(clean_feat.detach(), enhance_cmvn), True)
-        loss_D_fake = self.criterionGAN(self.gan_model(enhance_feat.detach(), enhance_cmvn), False)
-        loss_D = (loss_D_real + loss_D_fake) * 0.5
-        loss_D.backward()
+        if d_fake is not None:
+            replay_running_stats(fake_stats)
+            for bn in fake_bn:
+                bn.num_batches_tracked += 1
+            loss_D_fake = self.criterionGAN(d_fake, False)
+            loss_D = (loss_D_real + loss_D_fake) * 0.5
+            gan_params = [p for p in self.gan_model.parameters() if p.requires_grad]
+            torch.autograd.grad(loss_D, gan_params, allow_unused=True)      # the fused ops accumulate the gradients themselves
+        else:
+            loss_D_fake = self.criterionGAN(self.gan_model(enhance_feat.detach(), enhance_cmvn), False)
+            loss_D = (loss_D_real + loss_D_fake) * 0.5
+            loss_D.backward()
         if ops.WGRAD_STREAM is not None:
             torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)
         GradSync().finish([self.gan_optimizer])

@@ -77,6 +77,7 @@ class GANModel(ModelBase):
         else:
             h = x.permute(0, 2, 3, 1).contiguous()
         mods = list(self.model)
+        self._bn_layers_last = []
         i = 0
         while i < len(mods):
             m = mods[i]
@@ -90,6 +91,7 @@ class GANModel(ModelBase):
                     h = ops.bn_lrelu(h, nxt.weight, nxt.bias, nxt.running_mean, nxt.running_var, self.training, nxt.momentum, nxt.eps)
                     if self.training:
                         nxt.num_batches_tracked += 1
+                        self._bn_layers_last.append(nxt)
                     i += 3
                 else:
                     h = ops.conv2d(h, m.weight, m.bias, m.stride, m.padding, None)
@@ -97,6 +99,19 @@ class GANModel(ModelBase):
             else:
                 i += 1
         return h.permute(0, 3, 1, 2)                      # logical NCHW like the reference (view, Cout == 1)
+
+
+def replay_running_stats(stats):
+    """Apply once more the BatchNorm running-statistics update of a forward pass whose batch statistics were captured in
+    ``ops.BN_STATS_SINK`` (momentum update with the unbiased batch variance, as bn_finalize does).  The trainer uses the
+    G-step's D(fake) activations again for the D-step instead of recomputing them; upstream runs that forward twice and
+    therefore moves the running statistics twice."""
+    with torch.no_grad():
+        for rm, rv, mean, invstd, P, momentum, eps in stats:
+            var_b = 1.0 / (invstd * invstd) - eps
+            unb = var_b * (float(P) / float(P - 1)) if P > 1 else var_b
+            rm.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            rv.mul_(1.0 - momentum).add_(unb, alpha=momentum)
 
 
 class GANLoss(torch.nn.Module):

@@ -59,6 +59,13 @@ def colsum_into(A2d, M, N, out, beta, lda=None):
 MULTI_STREAM = False     # set by JointTrainer when branches run on side streams
 WGRAD_STREAM = None      # optional stream for weight-gradient kernels (see ``param_grads``)
 AUX_STREAM = None        # optional filler stream for independent branches inside a module (ShareE2E: the CTC branch)
+FROZEN_PARAMS = frozenset()   # id()s of parameters whose gradients must NOT be produced by the backward now running (the trainer
+#                               builds D's graph once with trainable parameters and walks it twice: G-step = input gradient only)
+BN_STATS_SINK = None     # optional list: every BatchNorm forward appends (running_mean, running_var, mean, invstd, P, momentum, eps)
+
+
+def _wants(ctx, i, p):
+    return ctx.needs_input_grad[i] and (p is None or id(p) not in FROZEN_PARAMS)
 
 
 class param_grads(object):
@@ -179,7 +186,7 @@ class LinearFn(torch.autograd.Function):
         # which parameters get gradients was fixed when the graph was built (ctx.needs_input_grad), NOT by the
         # parameters' requires_grad flags at backward time: the trainer re-enables D's parameters for the D-step
         # while the G-step backward through D may still be pending
-        need_w, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_w, need_b = _wants(ctx, 1, W), _wants(ctx, 2, b)
         dz, bias_done = act_bwd_bias(_f32(dy).reshape(M, N), y, ctx.act, b, need_b)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -371,7 +378,7 @@ class Conv2dFn(torch.autograd.Function):
         N, H, Wd, Cin = x.shape
         Cout, _, KH, KW = W.shape
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(Wd, KW, stride, pad)
-        need_w, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]      # fixed at graph construction (see LinearFn)
+        need_w, need_b = _wants(ctx, 1, W), _wants(ctx, 2, b)      # fixed at graph construction (see LinearFn)
         dz, bias_done = act_bwd_bias(_f32(dy).reshape(N * OH * OW, Cout), y, act, b, need_b)
         dz = dz.view(N, OH, OW, Cout)
         dx = None
@@ -515,6 +522,8 @@ class BnLreluFn(torch.autograd.Function):
              float(eps), int(train), y.data_ptr(), sm.data_ptr(), si.data_ptr(), ws.data_ptr(), wsb)
         ctx.gamma, ctx.beta, ctx.train = gamma, beta, train
         ctx.save_for_backward(x, sm, si)
+        if BN_STATS_SINK is not None and train:
+            BN_STATS_SINK.append((rm, rv, sm, si, Pn, float(momentum), float(eps)))
         return y
 
     @staticmethod
@@ -529,7 +538,7 @@ class BnLreluFn(torch.autograd.Function):
         dx = empty(x.shape, x)
         wsb = query('re2e_bn_workspace_bytes', Pn, C)
         ws = workspace(wsb, x.device, 'bn')
-        if ctx.needs_input_grad[1]:
+        if _wants(ctx, 1, gamma):
             with accumulate(gamma) as (dg, gbeta), accumulate(beta) as (db, _):
                 call('re2e_bn_lrelu_bwd', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
                      dx.data_ptr(), dg.data_ptr(), db.data_ptr(), gbeta, ws.data_ptr(), wsb)
