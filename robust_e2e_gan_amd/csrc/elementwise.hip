@@ -471,11 +471,22 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, const float* __re
   }
 }
 // stats[0..C) = result of slot 0 summed over chunks * scale0 ; stats[C..2C) = slot 1 * scale1
-__global__ void bn_combine_kernel(const float* __restrict__ part, int chunks, int C, float scale0, float scale1, float* out0, float* out1) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 64 channels x 16 chunk lanes per workgroup, lanes combined through LDS in a fixed order (the serial loop over up to
+// 512 chunks made this tiny kernel 60 us)
+__global__ __launch_bounds__(1024) void bn_combine_kernel(const float* __restrict__ part, int chunks, int C, float scale0, float scale1,
+                                                          float* out0, float* out1) {
+  __shared__ float r0[16][64], r1[16][64];
+  const int cx = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   float s0 = 0.f, s1 = 0.f;
-  for (int k = 0; k < chunks; ++k) { s0 += part[((long)k * 2 + 0) * C + c]; s1 += part[((long)k * 2 + 1) * C + c]; }
+  if (c < C)
+    for (int k = cl; k < chunks; k += 16) { s0 += part[((long)k * 2 + 0) * C + c]; s1 += part[((long)k * 2 + 1) * C + c]; }
+  r0[cl][cx] = s0; r1[cl][cx] = s1;
+  __syncthreads();
+  if (cl != 0 || c >= C) return;
+  s0 = 0.f; s1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { s0 += r0[q][cx]; s1 += r1[q][cx]; }
   if (out0) out0[c] = s0 * scale0;
   if (out1) out1[c] = s1 * scale1;
 }
@@ -518,11 +529,11 @@ extern "C" int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gam
   if (train) {
     hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 0, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
-    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
                        0.f, tmp, (float*)nullptr);
     hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 1, (const float*)tmp,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
-    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
                        0.f, tmp + C, (float*)nullptr);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)tmp, (const float*)(tmp + C), P, C,
                        momentum, eps, running_mean, running_var, save_mean, save_invstd);
@@ -566,7 +577,7 @@ extern "C" int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C,
   float* tmp = part + (size_t)chunks * 2 * C;
   dim3 g(cdiv(C, 64), chunks);
   hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part);
-  hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)part, chunks, C, 1.0f, 1.0f, tmp, tmp + C);
+  hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f, 1.0f, tmp, tmp + C);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, dy, x, P, C, save_mean, save_invstd, gamma,
                      beta, (const float*)tmp, (const float*)(tmp + C), dx);
   if (dgamma && dbeta)
