@@ -71,7 +71,7 @@ class JointTrainer(object):
         if torch.cuda.is_available():
             # filler streams: optionally restricted to a subset of the CUs (RE2E_FILLER_CUS, default all) so that the
             # chains on the main stream always find idle CUs
-            ncu = int(os.environ.get('RE2E_FILLER_CUS', '192'))     # measured best on MI355X: 101.0 -> 96.5 ms/step
+            ncu = int(os.environ.get('RE2E_FILLER_CUS', '224'))     # MI355X sweep: 128: 112.5, 160: 103.1, 192: 99.6, 224: 98.0, 256: 99.5 ms/step
             dev = next(enhance_model.parameters()).device
             if 0 < ncu < 256:
                 self.side_stream = lib.cu_masked_stream(ncu, 256, dev)
