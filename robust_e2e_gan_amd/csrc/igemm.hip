@@ -203,7 +203,7 @@ struct Epi {
 template <class LA, class LB, class CF, bool VEC>
 __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep, int K) {
   constexpr int BM = CF::BM, BN = CF::BN, TH = CF::THREADS, BK = CF::BK, LDK = CF::LDK;
-  constexpr int LDA_M = BM + 4, LDB_M = BN + 4;   // row strides of row-major (MMAJ) LDS tiles
+  constexpr int LDA_M = BM + 8, LDB_M = BN + 8;   // row strides of row-major (MMAJ) LDS tiles: 4*stride = 32 mod 64 banks, so the two k-halves of a b32 fragment read (lanes 0-31 / 32-63) use disjoint banks
   constexpr int ASZ = LA::KMAJ ? BM * LDK : BK * LDA_M;
   constexpr int BSZ = LB::KMAJ ? BN * LDK : BK * LDB_M;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(1024) void splitk_reduce_wide_kernel(const float* w
 
 template <class LA, class LB, class CF, bool VEC>
 int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
-  constexpr int ASZ = LA::KMAJ ? CF::BM * CF::LDK : CF::BK * (CF::BM + 4);
-  constexpr int BSZ = LB::KMAJ ? CF::BN * CF::LDK : CF::BK * (CF::BN + 4);
+  constexpr int ASZ = LA::KMAJ ? CF::BM * CF::LDK : CF::BK * (CF::BM + 8);
+  constexpr int BSZ = LB::KMAJ ? CF::BN * CF::LDK : CF::BK * (CF::BN + 8);
   size_t lds = (size_t)2 * (ASZ + BSZ) * sizeof(float);
   static const size_t lds_floor = getenv("RE2E_IGEMM_LDS_FLOOR") ? (size_t)atol(getenv("RE2E_IGEMM_LDS_FLOOR")) : 0;   // occupancy experiments
   if (lds < lds_floor) lds = lds_floor;
