@@ -95,3 +95,93 @@ def test_config5_long_utterances():
     for _ in range(2):
         out = JointTrainer.to_floats(tr.step(data, 0.0, cm))
         assert all(math.isfinite(v) for v in out.values()), out
+
+
+# ---- the other BASELINE.json configurations at full size: size-independent properties of the N1 trainers ----
+def _two_runs(make_trainer, steps=2):
+    """Run the same seeded trainer twice; return the per-step float meters and the final parameters of both runs."""
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    runs = []
+    for _ in range(2):
+        tr, nets, step = make_trainer()
+        meters = [JointTrainer.to_floats(step(tr)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        runs.append((meters, [p.detach().clone() for m in nets for p in m.parameters()]))
+    return runs
+
+
+def _check_runs(runs):
+    (m0, p0), (m1, p1) = runs
+    for a in m0:
+        for k, v in a.items():
+            assert math.isfinite(v), (k, v)
+    assert m0 == m1                                             # bitwise run-to-run equality of every logged scalar ...
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))       # ... and of every updated parameter
+    assert m0[0] != m0[-1]                                      # the update changed something
+
+
+def test_config1_enhance_base_full_size():
+    """BASELINE config 1: enhance_base_train step, B=4, T=200, 257 bins, enhancer 2xBLSTM-256."""
+    from robust_e2e_gan_amd.joint_train import config4_opt
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.trainers import EnhanceBaseTrainer
+    opt = config4_opt()
+    clean, mix, mix_log, targets, il, tl = _data(4, 200, 10, opt.odim)
+    cos = torch.cos(torch.linspace(-1.0, 1.0, clean.numel()).view_as(clean))
+    data = (None, None, clean, None, mix, mix_log, cos, targets, il, tl)
+
+    def make():
+        torch.manual_seed(11)
+        enh = EnhanceModel(opt).to(DEV).train()
+        return EnhanceBaseTrainer(opt, enh), [enh], (lambda tr: tr.step(data))
+    runs = _two_runs(make)
+    _check_runs(runs)
+    tr, _, _ = make()
+    tr.step(data)
+    eo = tr.last['enhance_out'].detach()
+    for b, l in enumerate(il.tolist()):
+        assert float(eo[b, l:].abs().sum()) == 0.0              # mask rows beyond each length are exactly zero
+
+
+def test_config3_enhance_gan_full_size():
+    """BASELINE config 3: enhance_gan_train step (G then D) at B=32, T=800."""
+    from robust_e2e_gan_amd.joint_train import config4_opt
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    from robust_e2e_gan_amd.trainers import EnhanceGanTrainer
+    opt = config4_opt()
+    clean, mix, mix_log, targets, il, tl = _data(32, 800, 40, opt.odim)
+    cos = torch.ones_like(clean)
+    data = (None, None, clean.to(DEV), None, mix.to(DEV), mix_log.to(DEV), cos.to(DEV), targets, il, tl)
+    cm = torch.stack([torch.full((80,), -9.0), torch.full((80,), 0.4)]).to(DEV)
+
+    def make():
+        torch.manual_seed(12)
+        enh, fb, gan = EnhanceModel(opt).to(DEV).train(), FbankModel(opt).to(DEV).train(), GANModel(opt).to(DEV).train()
+        return EnhanceGanTrainer(opt, enh, fb, gan), [enh, gan], (lambda tr: tr.step(data, cm))
+    _check_runs(_two_runs(make))
+
+
+def test_config2_asr_full_size():
+    """BASELINE config 2: asr_train step on fbank features, B=16, T=500, L=25 (one encoder pass, no enhancer / D)."""
+    from robust_e2e_gan_amd.joint_train import config4_opt
+    from robust_e2e_gan_amd.model.e2e_model import E2E
+    from robust_e2e_gan_amd.trainers import AsrTrainer
+    opt = config4_opt()
+    g = torch.Generator().manual_seed(3)
+    lens = sorted([500 - 11 * i for i in range(16)], reverse=True)
+    feats = torch.randn(16, 500, 80, generator=g)
+    for b, l in enumerate(lens):
+        feats[b, l:] = 0
+    targets = torch.randint(1, opt.odim - 1, (16 * 25,), generator=g)
+    data = (None, None, feats.to(DEV), targets, torch.IntTensor(lens), torch.IntTensor([25] * 16))
+
+    def make():
+        torch.manual_seed(13)
+        asr = E2E(opt).to(DEV).train()
+        return AsrTrainer(opt, asr), [asr], (lambda tr: tr.step(data, 0.0))
+    runs = _two_runs(make)
+    _check_runs(runs)
+    first = runs[0][0][0]
+    assert 150.0 < first['train/loss_att'] < 260.0             # ~ L * ln(V) = 25 * 8.35 for a random-initialised model
