@@ -36,6 +36,13 @@ def init_NLayerDiscriminator(input_nc, ndf=64, n_layers=3):
     return torch.nn.Sequential(*seq)
 
 
+def init_PixelDiscriminator(input_nc, ndf=64):
+    """gan_model.py:98-116 (1x1 PatchGAN) with norm_layer = BatchNorm2d: only the first conv has a bias."""
+    return torch.nn.Sequential(ConvParams(input_nc, ndf, 1, stride=1, padding=0), _Act(),
+                               ConvParams(ndf, ndf * 2, 1, bias=False, stride=1, padding=0), BatchNormParams(ndf * 2), _Act(),
+                               ConvParams(ndf * 2, 1, 1, bias=False, stride=1, padding=0))
+
+
 def init_net(net, gain=0.02):
     """gan_model.py:18-39 ('normal'): conv weights ~ N(0, gain), biases 0, BN gamma ~ N(1, gain)."""
     for m in net.modules():
@@ -61,7 +68,9 @@ class GANModel(ModelBase):
         elif args.netD_type == 'n_layers':
             self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, args.n_layers_D)
         elif args.netD_type == 'pixel':
-            raise Re2eError('netD_type pixel is a "next" row (N4), not built yet')
+            # the module itself is built; upstream's joint loop cannot drive it (joint_train.py:178 reads an undefined
+            # mix_feat at train time and applies the 80-wide CMVN to the 160-wide concatenation)
+            self.model = init_PixelDiscriminator(args.input_nc, args.ndf)
         else:
             raise NotImplementedError('Discriminator model name [%s] is not recognized' % args.netD_type)
         init_net(self.model, 0.02)

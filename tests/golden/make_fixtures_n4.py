@@ -60,6 +60,23 @@ def main():
     fx['lsm.labeldist'] = dist
     fx.update(mf.sd_np('lsm.p.', asr))
     run(asr, feats, targets, input_sizes, target_sizes, fx, 'lsm.', ['dec.output.weight', 'dec.output.bias', 'dec.embed.weight', 'enc.enc2.bt0.weight'])
+    # pixel discriminator (gan_model.py:98-116) on a (B, T, 160) "fake_AB" input, LSGAN real + fake, one backward
+    from model.gan_model import GANModel, GANLoss
+    pix_opt = argparse.Namespace(**{**vars(opt), 'netD_type': 'pixel'})
+    torch.manual_seed(709)
+    gan = GANModel(pix_opt)
+    gan.train()
+    crit = GANLoss(use_lsgan=True)
+    fx.update(mf.sd_np('pix.p.', gan))
+    xin = torch.cat([feats, feats * 0.5 + 0.1], 2).clone().requires_grad_(True)
+    d = gan(xin)
+    loss = (crit(d, True) + crit(gan(xin * 0.9), False)) * 0.5
+    gan.zero_grad()
+    loss.backward()
+    fx.update({'pix.x': xin.detach().numpy(), 'pix.d_out': d.detach().numpy(), 'pix.loss': loss.detach().numpy().reshape(-1),
+               'pix.dx': xin.grad.numpy()})
+    fx.update(mf.grads_np('pix.g.', gan))
+    fx.update(mf.sd_np('pix.after.', gan))
     np.savez_compressed(os.path.join(HERE, 'n4_tiny.npz'), **fx)
     print('written n4_tiny.npz; sub hlens', fx['sub.hlens'], 'lsm loss_att', fx['lsm.loss_att'])
 

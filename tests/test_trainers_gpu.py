@@ -264,3 +264,26 @@ def test_label_smoothing(golden_dir):
     fx = _fx(golden_dir, 'n4_tiny.npz')
     _e2e_case(golden_dir, 'lsm.', dict(lsm_type='unigram', lsm_weight=0.1, labeldist=fx['lsm.labeldist']),
               ['dec.output.weight', 'dec.output.bias', 'dec.embed.weight', 'enc.enc2.bt0.weight'])
+
+
+def test_pixel_discriminator(golden_dir):
+    """GANModel(netD_type='pixel') (1x1 convs + BatchNorm, gan_model.py:98-116): logits, LSGAN loss, all gradients and the
+    BatchNorm running statistics after two forwards."""
+    import argparse
+    from robust_e2e_gan_amd.model.gan_model import GANModel, GANLoss
+    fx = _fx(golden_dir, 'n4_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), 'netD_type': 'pixel'})
+    gan = _load(GANModel(opt), fx, 'pix.p.')
+    crit = GANLoss(use_lsgan=True)
+    x = torch.from_numpy(fx['pix.x']).to(DEV).requires_grad_(True)
+    d = gan(x)
+    rel('pix.d_out', d, fx['pix.d_out'])
+    loss = (crit(d, True) + crit(gan(x * 0.9), False)) * 0.5
+    rel('pix.loss', loss.view(1), fx['pix.loss'])
+    loss.backward()
+    rel('pix.dx', x.grad, fx['pix.dx'], tol=3e-3)
+    for k, p in gan.named_parameters():
+        rel('pix.g.' + k, p.grad, fx['pix.g.' + k], tol=3e-3)
+    for k, v in gan.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            rel('pix.after.' + k, v, fx['pix.after.' + k], tol=1e-4)
