@@ -58,6 +58,9 @@ class JointTrainer(object):
         self.opt = opt
         self.enhance_model, self.feat_model, self.asr_model, self.gan_model = enhance_model, feat_model, asr_model, gan_model
         self.isGAN = bool(getattr(opt, 'isGAN', False)) and gan_model is not None
+        if self.isGAN and getattr(opt, 'netD_type', 'basic') == 'pixel':
+            raise lib.Re2eError('the joint loop cannot drive netD_type pixel: upstream reads an undefined mix_feat for it '
+                                '(joint_train.py:178) and applies the 80-wide CMVN to the 160-wide concatenation')
         self.enhance_optimizer, self.asr_optimizer, self.gan_optimizer = build_optimizers(opt, enhance_model, asr_model,
                                                                                           gan_model if self.isGAN else None)
         self.criterionGAN = GANLoss(use_lsgan=not opt.no_lsgan) if self.isGAN else None
