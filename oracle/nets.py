@@ -144,7 +144,7 @@ def vgg2l_forward(p, x, lens, pre='enc.enc1.'):
 # --------------------------------------------------------------------------------------
 # F6  BLSTMP (subsample all 1)   model/e2e_encoder.py:119-150
 # --------------------------------------------------------------------------------------
-def blstmp_forward(p, x, lens, elayers, pre='enc.enc2.', subsample=None):
+def blstmp_forward(p, x, lens, elayers, pre='enc.enc2.', subsample=None, subsample_type='skip'):
     """BLSTMP.forward (model/e2e_encoder.py:119-150); ``subsample[l+1] > 1`` keeps every sub-th output frame of layer l
     ('skip' type, :137-139)."""
     lens = [int(l) for l in lens]
@@ -153,9 +153,12 @@ def blstmp_forward(p, x, lens, elayers, pre='enc.enc2.', subsample=None):
              if k.startswith(pre + 'bilstm%d.' % l)}
         y = _bilstm(x, lens, w, '', 0)
         sub = int(subsample[l + 1]) if subsample is not None else 1
-        if sub > 1:
+        if sub > 1 and subsample_type == 'skip':
             y = y[:, ::sub]
             lens = [(i + 1) // sub for i in lens]
+        elif sub > 1:                                   # 'maxpooling' (:140-143)
+            y = F.max_pool1d(y.transpose(1, 2), sub, stride=sub).transpose(1, 2)
+            lens = [i // sub for i in lens]
         B, T, _ = y.shape
         x = torch.tanh(F.linear(y.reshape(B * T, -1), p[pre + 'bt%d.weight' % l],
                                 p[pre + 'bt%d.bias' % l])).view(B, T, -1)

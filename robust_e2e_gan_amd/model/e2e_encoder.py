@@ -49,8 +49,10 @@ class BLSTMP(torch.nn.Module):
         self.elayers, self.cdim = elayers, cdim
         self.subsample, self.subsample_type = subsample, subsample_type
         self.subsampling = any(int(s) > 1 for s in subsample[1:elayers + 1])
-        if self.subsampling and subsample_type != 'skip':
-            raise Re2eError('BLSTMP subsample_type %r: only "skip" (e2e_encoder.py:137-139) is built' % subsample_type)
+        if self.subsampling and subsample_type not in ('skip', 'maxpooling'):
+            raise Re2eError('BLSTMP subsample_type %r is not known (e2e_encoder.py:137-143: skip | maxpooling)' % subsample_type)
+        if self.subsampling and subsample_type == 'maxpooling' and any(int(s) not in (1, 2) for s in subsample[1:elayers + 1]):
+            raise Re2eError('BLSTMP maxpooling subsampling is built for factor 2 (the 2x2 pooling kernel over a width-1 image)')
 
     def forward_tm(self, x_tm, lens_d, lens=None):
         """Time-major (T,B,idim) -> (T',B,hdim).  With frame subsampling configured (``subsample[l+1] > 1``: every sub-th
@@ -62,9 +64,16 @@ class BLSTMP(torch.nn.Module):
         for l in range(self.elayers):
             y = ops.bilstm(x_tm, lens_d, getattr(self, 'bilstm%d' % l).layer_weights(0))
             sub = int(self.subsample[l + 1])
-            if sub > 1:
+            if sub > 1 and self.subsample_type == 'skip':
                 y = y[::sub].contiguous()
                 cur = [(i + 1) // sub for i in cur]
+                lens_d = lens_dev(cur, y.device)
+            elif sub > 1:
+                # F.max_pool1d(kernel 2, stride 2) over time (:140-143; floor mode: an odd last frame is dropped).  The
+                # time-major (T, B*2H) tensor is a width-1 NHWC image with B*2H channels for the 2x2 pooling kernel.
+                T2, Bc, Cc = y.shape[0] // 2, y.shape[1], y.shape[2]
+                y = ops.maxpool2(y[:2 * T2].contiguous().view(1, 2 * T2, 1, Bc * Cc)).view(T2, Bc, Cc)
+                cur = [i // sub for i in cur]
                 lens_d = lens_dev(cur, y.device)
             bt = getattr(self, 'bt%d' % l)
             x_tm = ops.linear(y, bt.weight, bt.bias, 'tanh')      # applied to padded rows too (:145-147)

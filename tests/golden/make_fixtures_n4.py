@@ -51,6 +51,14 @@ def main():
     run(asr, feats, targets, input_sizes, target_sizes, fx, 'sub.',
         ['enc.enc1.bilstm0.weight_ih_l0', 'enc.enc1.bt1.weight', 'enc.enc1.bilstm2.weight_hh_l0_reverse', 'dec.output.weight', 'ctc.ctc_lo.weight'])
 
+    mp_opt = argparse.Namespace(**{**vars(opt), 'etype': 'blstmp', 'elayers': 3, 'subsample': '1_2_2_1_1', 'subsample_type': 'maxpooling'})
+    torch.manual_seed(707)
+    random.seed(0)
+    asr = E2E(mp_opt)            # same initial parameters as sub.p.
+    asr.train()
+    run(asr, feats, targets, input_sizes, target_sizes, fx, 'mp.',
+        ['enc.enc1.bilstm0.weight_ih_l0', 'enc.enc1.bt1.weight', 'enc.enc1.bilstm2.weight_hh_l0_reverse', 'dec.output.weight', 'ctc.ctc_lo.weight'])
+
     dist = np.random.default_rng(4).dirichlet(np.ones(opt.odim)).astype(np.float32)
     lsm_opt = argparse.Namespace(**{**vars(opt), 'lsm_type': 'unigram', 'lsm_weight': 0.1, 'labeldist': dist})
     torch.manual_seed(708)

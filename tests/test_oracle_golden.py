@@ -292,6 +292,22 @@ def test_blstmp_subsampling(golden_dir):
                                       'dec.output.weight', 'ctc.ctc_lo.weight'])
 
 
+def test_blstmp_maxpooling_subsampling(golden_dir):
+    fx = _load(golden_dir, 'n4_tiny.npz')
+    p = {k: v.clone().requires_grad_(True) for k, v in _sub(fx, 'sub.p.').items() if v.dtype.is_floating_point and not k.startswith('dec.att.')}
+    ys = nets.split_targets(torch.from_numpy(fx['targets']), fx['tlens'].tolist())
+    hpad, hlens = nets.blstmp_forward(p, torch.from_numpy(fx['feats']), fx['lens'].tolist(), 3, pre='enc.enc1.', subsample=[1, 2, 2, 1, 1],
+                                      subsample_type='maxpooling')
+    assert list(hlens) == fx['mp.hlens'].tolist()
+    np.testing.assert_allclose(hpad.detach().numpy(), fx['mp.hpad'], **TOL)
+    loss_ctc = nets.ctc_forward(p, hpad, hlens, ys)
+    loss_att, acc = nets.decoder_forward(p, hpad, hlens, ys, 11)
+    np.testing.assert_allclose(loss_att.detach().numpy().reshape(-1), fx['mp.loss_att'], rtol=3e-4)
+    (0.5 * loss_ctc + 0.5 * loss_att).backward()
+    _e2e_grads_close(p, fx, 'mp.', ['enc.enc1.bilstm0.weight_ih_l0', 'enc.enc1.bt1.weight', 'enc.enc1.bilstm2.weight_hh_l0_reverse',
+                                     'dec.output.weight', 'ctc.ctc_lo.weight'])
+
+
 def test_label_smoothing(golden_dir):
     fx = _load(golden_dir, 'n4_tiny.npz')
     p = {k: v.clone().requires_grad_(True) for k, v in _sub(fx, 'lsm.p.').items() if v.dtype.is_floating_point and not k.startswith('dec.att.')}

@@ -234,10 +234,10 @@ def test_recognize_matches_reference_nbest(golden_dir):
 
 
 # ---- frame subsampling and label smoothing ----
-def _e2e_case(golden_dir, pre, overrides, names):
+def _e2e_case(golden_dir, pre, overrides, names, name='n4_tiny.npz'):
     import argparse
     from robust_e2e_gan_amd.model.e2e_model import E2E
-    fx = _fx(golden_dir, 'n4_tiny.npz')
+    fx = _fx(golden_dir, name)
     opt = argparse.Namespace(**{**vars(_opt()), **overrides})
     asr = _load(E2E(opt), fx, pre + 'p.')
     feats = torch.from_numpy(fx['feats'])
@@ -258,6 +258,16 @@ def _e2e_case(golden_dir, pre, overrides, names):
 def test_blstmp_frame_subsampling(golden_dir):
     _e2e_case(golden_dir, 'sub.', dict(etype='blstmp', elayers=3, subsample='1_2_2_1_1'),
               ['enc.enc1.bilstm0.weight_ih_l0', 'enc.enc1.bt1.weight', 'enc.enc1.bilstm2.weight_hh_l0_reverse', 'dec.output.weight', 'ctc.ctc_lo.weight'])
+
+
+def test_blstmp_maxpooling_subsampling(golden_dir):
+    import numpy as _np
+    fx = _fx(golden_dir, 'n4_tiny.npz')
+    fx2 = {('mp.p.' + k[len('sub.p.'):] if k.startswith('sub.p.') else k): v for k, v in fx.items()}
+    _np.savez('/tmp/n4_mp.npz', **fx2)
+    _e2e_case('/tmp', 'mp.', dict(etype='blstmp', elayers=3, subsample='1_2_2_1_1', subsample_type='maxpooling'),
+              ['enc.enc1.bilstm0.weight_ih_l0', 'enc.enc1.bt1.weight', 'enc.enc1.bilstm2.weight_hh_l0_reverse', 'dec.output.weight', 'ctc.ctc_lo.weight'],
+              name='n4_mp.npz')
 
 
 def test_label_smoothing(golden_dir):
