@@ -189,3 +189,49 @@ def test_joint_step_overlap_equals_single_stream(golden_dir):
         grads[overlap] = {n + '.' + k: p.grad.clone() for n, m in (('enh', enh), ('asr', asr), ('gan', gan)) for k, p in m.named_parameters()}
     for k, ref in grads[False].items():
         rel(k, grads[True][k], ref.cpu().numpy(), tol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('lens,tls', [([33], [1]), ([37, 6], [2, 1]), ([33, 33, 32, 17, 5], [4, 1, 3, 2, 1]), ([64, 8], [7, 1])])
+def test_joint_step_ragged_shapes_vs_oracle(golden_dir, lens, tls):
+    """Edge shapes against the CPU oracle: a single utterance, lengths that are not multiples of 4 (ceil-mode pooling),
+    one-label targets, a batch mixing long and very short utterances (T' as small as 2; the discriminator needs T >= 32)."""
+    import __graft_entry__ as g
+    from oracle import joint as oj
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    fx = _fx(golden_dir, 'joint_tiny.npz')
+    W = torch.from_numpy(_fx(golden_dir, 'fbank_tiny.npz')['W'])
+    opt = g._tiny_opt()
+    B, T = len(lens), max(lens)
+    gen = torch.Generator().manual_seed(100 + sum(lens))
+    clean = torch.rand(B, T, 257, generator=gen) * 300
+    mix = clean + torch.rand(B, T, 257, generator=gen) * 100
+    mix_log = torch.randn(B, T, 257, generator=gen)
+    for b, l in enumerate(lens):
+        clean[b, l:], mix[b, l:], mix_log[b, l:] = 0, 0, 0
+    targets = torch.randint(1, opt.odim - 1, (sum(tls),), generator=gen)
+    cm = torch.from_numpy(fx['cmvn'])
+    enh, asr, gan = _load(EnhanceModel(opt), fx, 'enh.'), _load(ShareE2E(opt), fx, 'asr.'), _load(GANModel(opt), fx, 'gan.')
+    fb = FbankModel(opt)
+    fb.load_state_dict({'fc': W})
+    cfg = dict(enhance_layers=2, elayers=2, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=0.5, gan_loss_lambda=1.0, grad_clip=5.0,
+               eps=1e-8, isGAN=True, enhance_loss_type='L2')
+    sub = lambda pre: {k[len(pre):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith(pre)}
+    st = oj.JointState(sub('enh.'), sub('asr.'), sub('gan.'), W, cfg)
+    ref = oj.joint_step(st, (clean, mix, mix_log, targets, lens, tls), cm)
+    tr = JointTrainer(opt, enh, fb.to(DEV).train(), asr, gan)
+    data = (None, None, clean, None, mix, mix_log, None, targets, torch.IntTensor(lens), torch.IntTensor(tls))
+    out = JointTrainer.to_floats(tr.step(data, 0.0, cm))
+    for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'loss_D'):
+        a, b = out['train/' + k], float(ref[k])
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (k, a, b)
+    assert abs(out['train/acc'] - ref['acc']) < 1e-6
+    assert abs(out['grad_norm'] - ref['grad_norm_asr']) <= 3e-3 * ref['grad_norm_asr']
+    rel('enhance_out', tr.last['enhance_out'], ref['enhance_out'].numpy())
+    for pre, m, gd in (('enh', enh, ref['g_enh']), ('asr', asr, ref['g_asr']), ('gan', gan, ref['g_gan'])):
+        for k, p in m.named_parameters():
+            if k in gd:
+                rel(pre + '.' + k, p.grad, gd[k].numpy(), tol=4e-3, atol=1e-7)
