@@ -204,8 +204,16 @@ template <class LA, class LB, class CF, bool VEC>
 __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep, int K) {
   constexpr int BM = CF::BM, BN = CF::BN, TH = CF::THREADS, BK = CF::BK, LDK = CF::LDK;
   constexpr int LDA_M = BM + 8, LDB_M = BN + 8;   // row strides of row-major (MMAJ) LDS tiles: 4*stride = 32 mod 64 banks, so the two k-halves of a b32 fragment read (lanes 0-31 / 32-63) use disjoint banks
-  constexpr int ASZ = LA::KMAJ ? BM * LDK : BK * LDA_M;
-  constexpr int BSZ = LB::KMAJ ? BN * LDK : BK * LDB_M;
+  // TS ("transposing stage"): in the weight-gradient kernels BOTH operands are row-major (k = pixel is the slow axis).
+  // There a float4 (4 consecutive rows at one k) is transposed while it is staged -- 4 ds_write_b32 at (row+j)*LDK + k with
+  // lane -> (k = lane % BK, row quad = lane / BK), which spreads a wavefront's 64 writes over all 64 banks -- so that the
+  // LDS tiles are k-major and the MFMA fragments are read with ds_read_b128 like the k-major operands (+3..5 % on dy^T x
+  // and the conv weight gradients).  It is not used for the row-major B of dy W (its lanes would walk k through the small
+  // weight matrix at a row-pitch stride: -2..12 %) nor on the scalar-load path.
+  constexpr bool TS = VEC && !LA::KMAJ && !LB::KMAJ;
+  constexpr bool AKL = LA::KMAJ || TS, BKL = LB::KMAJ || TS;            // operand tile is k-major in LDS
+  constexpr int ASZ = AKL ? BM * LDK : BK * LDA_M;
+  constexpr int BSZ = BKL ? BN * LDK : BK * LDB_M;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][ASZ]
   float* Bs = smem + 2 * ASZ;       // [2][BSZ]
@@ -258,9 +266,9 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   constexpr int KQ = BK / 4;
   constexpr int AIT = BM * KQ / TH, BIT = BN * KQ / TH;
   static_assert(AIT >= 1 && BIT >= 1 && (BM * KQ) % TH == 0 && (BN * KQ) % TH == 0, "tile / thread-count mismatch");
-  static_assert(TH % KQ == 0 && TH % (BM / 4) == 0 && TH % (BN / 4) == 0, "per-thread k / row state must be item-invariant");
-  constexpr int NRA = LA::KMAJ ? AIT : 1, NKA = LA::KMAJ ? 1 : AIT;
-  constexpr int NRB = LB::KMAJ ? BIT : 1, NKB = LB::KMAJ ? 1 : BIT;
+  static_assert(TH % KQ == 0 && TH % BK == 0 && TH % (BM / 4) == 0 && TH % (BN / 4) == 0, "per-thread k / row state must be item-invariant");
+  constexpr int NRA = AKL ? AIT : 1, NKA = AKL ? 1 : AIT;               // k-major staging: per-item rows + ONE k state per thread
+  constexpr int NRB = BKL ? BIT : 1, NKB = BKL ? 1 : BIT;
   typename LA::Row ra_row[NRA];
   typename LA::Kst ra_k[NKA];
   typename LB::Row rb_row[NRB];
@@ -271,14 +279,19 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
     int idx = i * TH + tid;
     if (LA::KMAJ) {
       int r = idx / KQ, kq = idx % KQ;
-      la.init_row(ra_row[LA::KMAJ ? i : 0], m0 + r);
+      la.init_row(ra_row[AKL ? i : 0], m0 + r);
       if constexpr (LA::IS_CONVK) { if (ep.ncls) la.shift_row(ra_row[i], cls_dy, cls_dx); }
       if (i == 0) la.init_k(ra_k[0], kbegin + kq * 4);
       a_lds[i] = r * LDK + kq * 4;
+    } else if (TS) {
+      int kk = idx % BK, rq = idx / BK;
+      la.init_row(ra_row[AKL ? i : 0], m0 + rq * 4);
+      if (i == 0) la.init_k(ra_k[0], kbegin + kk);
+      a_lds[i] = rq * 4 * LDK + kk;
     } else {
       int kk = idx / (BM / 4), rq = idx % (BM / 4);
       if (i == 0) la.init_row(ra_row[0], m0 + rq * 4);
-      la.init_k(ra_k[LA::KMAJ ? 0 : i], kbegin + kk);
+      la.init_k(ra_k[AKL ? 0 : i], kbegin + kk);
       a_lds[i] = kk * LDA_M + rq * 4;
     }
   }
@@ -287,13 +300,18 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
     int idx = i * TH + tid;
     if (LB::KMAJ) {
       int r = idx / KQ, kq = idx % KQ;
-      lb.init_row(rb_row[LB::KMAJ ? i : 0], n0 + r);
+      lb.init_row(rb_row[BKL ? i : 0], n0 + r);
       if (i == 0) lb.init_k(rb_k[0], kbegin + kq * 4);
       b_lds[i] = r * LDK + kq * 4;
+    } else if (TS) {
+      int kk = idx % BK, rq = idx / BK;
+      lb.init_row(rb_row[BKL ? i : 0], n0 + rq * 4);
+      if (i == 0) lb.init_k(rb_k[0], kbegin + kk);
+      b_lds[i] = rq * 4 * LDK + kk;
     } else {
       int kk = idx / (BN / 4), rq = idx % (BN / 4);
       if (i == 0) lb.init_row(rb_row[0], n0 + rq * 4);
-      lb.init_k(rb_k[LB::KMAJ ? 0 : i], kbegin + kk);
+      lb.init_k(rb_k[BKL ? 0 : i], kbegin + kk);
       b_lds[i] = kk * LDB_M + rq * 4;
     }
   }
@@ -312,9 +330,9 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   f32x4 ra[AIT], rb[BIT];
   auto fetch_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < AIT; ++i) ra[i] = fetch<VEC>(la, rsA, ra_row[LA::KMAJ ? i : 0], ra_k[LA::KMAJ ? 0 : i]);
+    for (int i = 0; i < AIT; ++i) ra[i] = fetch<VEC>(la, rsA, ra_row[AKL ? i : 0], ra_k[AKL ? 0 : i]);
 #pragma unroll
-    for (int i = 0; i < BIT; ++i) rb[i] = fetch<VEC>(lb, rsB, rb_row[LB::KMAJ ? i : 0], rb_k[LB::KMAJ ? 0 : i]);
+    for (int i = 0; i < BIT; ++i) rb[i] = fetch<VEC>(lb, rsB, rb_row[BKL ? i : 0], rb_k[BKL ? 0 : i]);
   };
   auto advance_k = [&]() {
 #pragma unroll
@@ -326,9 +344,21 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
     float* An = As + buf * ASZ;
     float* Bn = Bs + buf * BSZ;
 #pragma unroll
-    for (int i = 0; i < AIT; ++i) *reinterpret_cast<f32x4*>(An + a_lds[i]) = ra[i];
+    for (int i = 0; i < AIT; ++i) {
+      if (!TS) *reinterpret_cast<f32x4*>(An + a_lds[i]) = ra[i];
+      else {
 #pragma unroll
-    for (int i = 0; i < BIT; ++i) *reinterpret_cast<f32x4*>(Bn + b_lds[i]) = rb[i];
+        for (int j = 0; j < 4; ++j) An[a_lds[i] + j * LDK] = ra[i][j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) {
+      if (!TS) *reinterpret_cast<f32x4*>(Bn + b_lds[i]) = rb[i];
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bn[b_lds[i] + j * LDK] = rb[i][j];
+      }
+    }
   };
   if (kt_begin < kt_end) {
     fetch_tile();
@@ -354,7 +384,7 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
 #pragma unroll
       for (int i = 0; i < CF::TM; ++i) {
         int r = (wm * CF::TM + i) * 32 + lr;
-        if (LA::KMAJ) fa[i] = *reinterpret_cast<const f32x4*>(Ac + r * LDK + q * 8 + lh * 4);
+        if (AKL) fa[i] = *reinterpret_cast<const f32x4*>(Ac + r * LDK + q * 8 + lh * 4);
         else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) fa[i][j] = Ac[(q * 8 + lh * 4 + j) * LDA_M + r];
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
 #pragma unroll
       for (int i = 0; i < CF::TN; ++i) {
         int r = (wn * CF::TN + i) * 32 + lr;
-        if (LB::KMAJ) fb[i] = *reinterpret_cast<const f32x4*>(Bc + r * LDK + q * 8 + lh * 4);
+        if (BKL) fb[i] = *reinterpret_cast<const f32x4*>(Bc + r * LDK + q * 8 + lh * 4);
         else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) fb[i][j] = Bc[(q * 8 + lh * 4 + j) * LDB_M + r];
@@ -482,8 +512,9 @@ __global__ __launch_bounds__(1024) void splitk_reduce_wide_kernel(const float* w
 
 template <class LA, class LB, class CF, bool VEC>
 int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
-  constexpr int ASZ = LA::KMAJ ? CF::BM * CF::LDK : CF::BK * (CF::BM + 8);
-  constexpr int BSZ = LB::KMAJ ? CF::BN * CF::LDK : CF::BK * (CF::BN + 8);
+  constexpr bool TS = VEC && !LA::KMAJ && !LB::KMAJ;      // see igemm_kernel
+  constexpr int ASZ = (LA::KMAJ || TS) ? CF::BM * CF::LDK : CF::BK * (CF::BM + 8);
+  constexpr int BSZ = (LB::KMAJ || TS) ? CF::BN * CF::LDK : CF::BK * (CF::BN + 8);
   size_t lds = (size_t)2 * (ASZ + BSZ) * sizeof(float);
   static const size_t lds_floor = getenv("RE2E_IGEMM_LDS_FLOOR") ? (size_t)atol(getenv("RE2E_IGEMM_LDS_FLOOR")) : 0;   // occupancy experiments
   if (lds < lds_floor) lds = lds_floor;
