@@ -266,7 +266,9 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   constexpr int KQ = BK / 4;
   constexpr int AIT = BM * KQ / TH, BIT = BN * KQ / TH;
   static_assert(AIT >= 1 && BIT >= 1 && (BM * KQ) % TH == 0 && (BN * KQ) % TH == 0, "tile / thread-count mismatch");
-  static_assert(TH % KQ == 0 && TH % BK == 0 && TH % (BM / 4) == 0 && TH % (BN / 4) == 0, "per-thread k / row state must be item-invariant");
+  static_assert(TH % KQ == 0 && TH % BK == 0, "per-thread k state must be item-invariant");
+  static_assert(AKL || TH % (BM / 4) == 0, "per-thread row state of a row-major A tile must be item-invariant");
+  static_assert(BKL || TH % (BN / 4) == 0, "per-thread row state of a row-major B tile must be item-invariant");
   constexpr int NRA = AKL ? AIT : 1, NKA = AKL ? 1 : AIT;               // k-major staging: per-item rows + ONE k state per thread
   constexpr int NRB = BKL ? BIT : 1, NKB = BKL ? 1 : BIT;
   typename LA::Row ra_row[NRA];
@@ -538,6 +540,7 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
 constexpr int BKD = 16;              // k-tile: 16 keeps LDS <= 46 KB per block => 2-3 blocks per CU
 using C128 = Cfg<2, 2, 2, 2, BKD>;    // 128 x 128
 using C256x64 = Cfg<4, 1, 2, 2, BKD>;
+using C192x64 = Cfg<2, 2, 3, 1, BKD>;   // 576-row weight gradients (9 taps x 64 channels): 3 exact tiles instead of 2.25 of 256
 using C256x32 = Cfg<4, 1, 2, 1, 32>;   // BN=32 needs BK=32 to give every thread a B item
 using C32x128 = Cfg<1, 4, 1, 1, 32>;   // skinny (M<=32) GEMMs of the decoder loop, always split-K
 // tuning variants (tools/bench_gemm.py, env RE2E_IGEMM_VARIANT): 1 = BK 32, 2 = 8-wave 256x128 tile
@@ -785,7 +788,7 @@ extern "C" int re2e_conv_dgrad_s2(const float* dz, int N, int OH, int OW, int Co
 
 static int wgrad_splits_mfma(int Mrows, int Cout, long P) {
   int bm, bn;
-  if (Cout <= 32) { bm = 256; bn = 32; } else if (Cout <= 64) { bm = 256; bn = 64; } else { bm = 128; bn = 128; }
+  if (Cout <= 32) { bm = 256; bn = 32; } else if (Cout <= 64) { bm = (Mrows % 192 == 0 && Mrows % 256 != 0) ? 192 : 256; bn = 64; } else if (Mrows % 192 == 0 && Mrows % 128 != 0) { bm = 192; bn = 64; } else { bm = 128; bn = 128; }
   return pick_splits(Mrows, Cout, (int)P, bm, bn);
 }
 
@@ -803,8 +806,18 @@ static void wgrad_dispatch(const ConvGeom& g, int Mrows, int P, const float* dou
   ConvM la{g, g.in, (unsigned)((long)g.NI * g.H * g.W * g.C * 4), Mrows, P};
   DenseM lb{dout, kbytes(P, Cout, Cout), (long)Cout, Cout, P};
   if (Cout <= 32) launch_igemm<ConvM, DenseM, C256x32, V>(la, lb, ep, P, st);
-  else if (Cout <= 64) launch_n64<ConvM, DenseM, V>(la, lb, ep, P, st);
-  else launch_big<ConvM, DenseM, V, false>(la, lb, ep, P, st);
+  else if (Cout <= 64) {
+    if constexpr (V) {
+      if (Mrows % 192 == 0 && Mrows % 256 != 0) { launch_igemm<ConvM, DenseM, C192x64, V>(la, lb, ep, P, st); return; }
+    }
+    launch_n64<ConvM, DenseM, V>(la, lb, ep, P, st);
+  }
+  else {
+    if constexpr (V) {
+      if (Mrows % 192 == 0 && Mrows % 128 != 0) { launch_igemm<ConvM, DenseM, C192x64, V>(la, lb, ep, P, st); return; }   // conv2_1: 576 x 128
+    }
+    launch_big<ConvM, DenseM, V, false>(la, lb, ep, P, st);
+  }
 }
 
 extern "C" size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW) {
