@@ -130,6 +130,7 @@ class JointTrainer(object):
     def _step(self, data, sche_samp_rate, enhance_cmvn):
         opt = self.opt
         self._mark('start')
+        ops.MARKS = self.marks
         clean_inputs, mix_inputs, mix_log_inputs, targets, input_sizes, target_sizes = data[2], data[4], data[5], data[7], data[8], data[9]
         overlap = self.overlap_dstep
         ops.MULTI_STREAM = bool(overlap)
@@ -151,7 +152,9 @@ class JointTrainer(object):
             self._mark('clean branch enqueued (side)')
             enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
             self._mark('enhancer fwd')
+            ops.mark_grad(enhance_out, 'enhance_out (fbank bwd done)')
             enhance_feat = self.feat_model(enhance_out)
+            ops.mark_grad(enhance_feat, 'enhance_feat (VGG, D, L1 bwd done)')
             main.wait_event(ev_cf)
             clean_feat.record_stream(main)
         else:
@@ -185,6 +188,7 @@ class JointTrainer(object):
                 with torch.cuda.stream(self.side_stream):
                     enhance_feat.record_stream(self.side_stream)
                     d_fake, gan_loss = d_fake_forward()
+                    ops.mark_grad(d_fake, 'd_fake (side: G-step D bwd starts)')
             else:
                 d_fake, gan_loss = d_fake_forward()
             fake_bn_layers = list(self.gan_model._bn_layers_last)
@@ -217,15 +221,36 @@ class JointTrainer(object):
             asr_params = [p for p in self.asr_model.parameters() if p.requires_grad]
             reuse = self.isGAN and self.reuse_dfake
             ops.FROZEN_PARAMS = frozenset(id(p) for p in self.gan_model.parameters()) if reuse else frozenset()
+            cut = getattr(self.asr_model, 'clean_cut', None) if clean_branch is not None else None
+            self.asr_model.clean_cut = None
+            ev_cut, cut_fired = torch.cuda.Event(), []
+            if cut is not None:
+                def on_cut_grad(g):            # BLSTMP backward enqueued on main: d(loss)/d(leaf) is on its way
+                    ev_cut.record(main)
+                    cut_fired.append(True)
+                cut[1].register_hook(on_cut_grad)
             try:
-                g_eo = torch.autograd.grad(loss, [enhance_out] + asr_params, allow_unused=True, retain_graph=reuse)[0]
+                gs = torch.autograd.grad(loss, [enhance_out] + ([cut[1]] if cut else []) + asr_params, allow_unused=True, retain_graph=reuse)
             finally:
                 ops.FROZEN_PARAMS = frozenset()
+            g_eo = gs[0]
             self._mark('bwd phase 1 (ASR, D, fbank)')
             ev_bwd1 = torch.cuda.Event()
             ev_bwd1.record(main)
+            if cut is not None and gs[1] is not None:
+                # the clean branch's conv-stack backward (reached through CORAL and the shared BLSTMP): side stream, not
+                # joined into main before the enhancer's backward chain starts -- it runs under that chain
+                side = self.side_stream
+                side.wait_event(ev_cut if cut_fired else ev_bwd1)
+                with torch.cuda.stream(side):
+                    gs[1].record_stream(side)
+                    torch.autograd.backward([cut[0]], [gs[1]])
             ev_side_bwd = torch.cuda.Event()          # clean-branch conv backward (ASR gradients) enqueued on the side stream
             ev_side_bwd.record(self.side_stream)
+            if self.marks is not None:
+                for st_, nm_ in ((self.side_stream, 'side'), (self.wgrad_stream, 'wgrad')):
+                    with torch.cuda.stream(st_):
+                        self._mark('  %s stream: phase-1 work done' % nm_)
             # D-step (joint_train.py:195-212) on a side stream: it only needs the forward results, so it fills
             # the CUs that the latency-bound enhancer BLSTM backward (1600 dependent launches) leaves idle.
             side = self.side_stream
@@ -237,6 +262,9 @@ class JointTrainer(object):
                 loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, wait_before_update=ev_bwd1,
                                       d_fake=d_fake if reuse else None, fake_stats=fake_stats, fake_bn=fake_bn_layers)
             self._mark('D-step enqueued (side)')
+            if self.marks is not None:
+                with torch.cuda.stream(side):
+                    self._mark('  side stream: D-step done')
             if not armed and rdist.world_size() > 1:
                 # Data parallel: every ASR gradient kernel has been enqueued (phase 1 on main, the clean-branch / CTC
                 # backward on side, the weight gradients on wgrad), so the 116 MB ASR all-reduce starts as soon as those
@@ -254,6 +282,9 @@ class JointTrainer(object):
             # Phase 2: the enhancer backward chain on the main stream.
             enhance_out.backward(g_eo)
             self._mark('bwd phase 2 (enhancer)')
+            if self.marks is not None:
+                with torch.cuda.stream(self.wgrad_stream):
+                    self._mark('  wgrad stream: all weight gradients done')
             torch.cuda.current_stream().wait_event(ev_side_bwd)
         else:
             reuse = self.isGAN and self.reuse_dfake

@@ -130,6 +130,15 @@ class ShareE2E(E2E):
             h_enh = self.enc.enc1.conv_stack(ops.cmvn_pair(enh, None, cm) if cm is not None else enh)
             torch.cuda.current_stream().wait_event(ev)
             h_cln.record_stream(torch.cuda.current_stream())
+            if torch.is_grad_enabled() and h_cln.requires_grad:
+                # cut the graph at the clean conv stack's output: the caller runs that backward itself
+                # (``clean_cut`` = (graph tensor, leaf); d(loss)/d(leaf) -> backward of the graph tensor) so that it can put
+                # it on the side stream WITHOUT the end-of-backward join autograd would add between the two streams
+                leaf = h_cln.detach().requires_grad_(True)
+                self.clean_cut = (h_cln, leaf)
+                h_cln = leaf
+            ops.mark_grad(h_enh, 'h_enh (BLSTMP bwd done, main)')
+            ops.mark_grad(h_cln, 'h_cln (side: clean conv bwd starts)')
             h_in, hl2 = self.enc.enc1.pack_tm([h_enh, h_cln], [ilens, ilens])
             h_tm2 = self.enc.enc2.forward_tm(h_in, lens_dev(hl2, enh.device))
         else:
@@ -137,6 +146,7 @@ class ShareE2E(E2E):
             h_tm2, hl2 = self.enc.forward_tm(x2, ilens + ilens)           # (T', 2B, E)
         hlens = hl2[:B]
         hpad2 = ops.transpose01(h_tm2)                                     # (2B, T', E)
+        ops.mark_grad(hpad2, 'hpad2 (decoder, CTC, CORAL bwd done)')
         hpad_enh, hpad_cln = hpad2[:B], hpad2[B:]
         Tq, E = hpad2.shape[1], hpad2.shape[2]
         # CTC and the attention decoder only share the encoder output: with a filler stream available the CTC branch

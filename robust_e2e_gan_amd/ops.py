@@ -6,6 +6,7 @@ accumulated by the kernels straight into ``param.grad`` (GEMM/conv epilogue ``be
 what lets the optimizer and the RCCL all-reduce work on one flat buffer per network
 (robust_e2e_gan_amd/optim.py, dist.py).
 """
+import time
 import torch
 
 from . import lib
@@ -61,7 +62,22 @@ WGRAD_STREAM = None      # optional stream for weight-gradient kernels (see ``pa
 AUX_STREAM = None        # optional filler stream for independent branches inside a module (ShareE2E: the CTC branch)
 FROZEN_PARAMS = frozenset()   # id()s of parameters whose gradients must NOT be produced by the backward now running (the trainer
 #                               builds D's graph once with trainable parameters and walks it twice: G-step = input gradient only)
+MARKS = None             # RE2E_TIMELINE: list of (label, host time, event) shared with JointTrainer (see ``mark_grad``)
 BN_STATS_SINK = None     # optional list: every BatchNorm forward appends (running_mean, running_var, mean, invstd, P, momentum, eps)
+
+
+def mark_grad(t, label):
+    """RE2E_TIMELINE: note when the backward pass has produced the gradient of ``t`` -- an event on the stream autograd
+    runs that node on, i.e. behind everything enqueued on it so far."""
+    if MARKS is not None and isinstance(t, torch.Tensor) and t.requires_grad:
+        marks = MARKS
+
+        def hook(g):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(('  grad of ' + label, time.perf_counter(), ev))
+        t.register_hook(hook)
+    return t
 
 
 def _wants(ctx, i, p):
