@@ -69,6 +69,7 @@ class JointTrainer(object):
         self.overlap_dstep = os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
         self.marks = [] if os.environ.get('RE2E_TIMELINE') else None
         # the D-step's D(fake) forward equals the G-step's (same input, same weights): keep that graph and walk it twice
+        self.early_dreal = os.environ.get('RE2E_NO_EARLY_DREAL', '0') != '1'     # D-step real half under the enhancer's forward chain
         self.reuse_dfake = os.environ.get('RE2E_NO_DFAKE_REUSE', '0') != '1' 
         self.side_stream = self.wgrad_stream = None
         if torch.cuda.is_available():
@@ -137,7 +138,7 @@ class JointTrainer(object):
         ops.WGRAD_STREAM = self.wgrad_stream if overlap else None
         ops.AUX_STREAM = self.side_stream if (overlap and os.environ.get('RE2E_CTC_MAIN') != '1') else None
         main = torch.cuda.current_stream()
-        clean_branch = None
+        clean_branch, d_real_part = None, None
         if overlap and getattr(self.asr_model, 'etype', '').startswith('vgg'):
             # the clean branch (fbank -> CMVN -> VGG conv stack) does not depend on the enhancer: enqueue it on the side
             # stream first so that it fills the CUs the enhancer's 1600-launch recurrent chain leaves idle
@@ -149,6 +150,10 @@ class JointTrainer(object):
                 ev_cf = torch.cuda.Event()
                 ev_cf.record()
                 clean_branch = self.asr_model.encode_clean(clean_feat, enhance_cmvn)
+                if self.isGAN and self.reuse_dfake and self.early_dreal:
+                    # D-step, real half (joint_train.py:198-201): needs only clean_feat and D's current weights, so it goes
+                    # here, under the enhancer's forward chain, instead of under the (already saturated) backward chain
+                    d_real_part = self._d_real(clean_feat, enhance_cmvn)
             self._mark('clean branch enqueued (side)')
             enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
             self._mark('enhancer fwd')
@@ -260,7 +265,7 @@ class JointTrainer(object):
                     if isinstance(t_, torch.Tensor) and t_.is_cuda:
                         t_.record_stream(side)
                 loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, wait_before_update=ev_bwd1,
-                                      d_fake=d_fake if reuse else None, fake_stats=fake_stats, fake_bn=fake_bn_layers)
+                                      d_fake=d_fake if reuse else None, fake_stats=fake_stats, fake_bn=fake_bn_layers, real_part=d_real_part)
             self._mark('D-step enqueued (side)')
             if self.marks is not None:
                 with torch.cuda.stream(side):
@@ -315,15 +320,38 @@ class JointTrainer(object):
         self._mark('optimizers')
         return out
 
-    def _d_step(self, clean_feat, enhance_feat, enhance_cmvn, wait_before_update=None, d_fake=None, fake_stats=None, fake_bn=None):
+    def _d_real(self, clean_feat, enhance_cmvn):
+        """Real half of the discriminator update on the CURRENT stream, ahead of the G-step: forward of D(clean) with the
+        BatchNorm running-statistics update deferred (upstream applies it AFTER the G-step's D(fake) pass; ``_d_step``
+        replays it there), then the backward of 0.5 * loss_D_real into D's (freshly zeroed) gradient buffers -- the same
+        terms, in the same accumulation order (real before fake), as the single backward of 0.5 * (real + fake)."""
+        set_requires_grad([self.gan_model], True)
+        self.gan_optimizer.zero_grad()
+        stats = []
+        ops.BN_STATS_SINK, ops.BN_DEFER_RUNNING = stats, True
+        try:
+            d_real = self.gan_model(clean_feat.detach(), enhance_cmvn)
+        finally:
+            ops.BN_STATS_SINK, ops.BN_DEFER_RUNNING = None, False
+        loss_D_real = self.criterionGAN(d_real, True)
+        gan_params = [p for p in self.gan_model.parameters() if p.requires_grad]
+        torch.autograd.grad(loss_D_real * 0.5, gan_params, allow_unused=True)
+        return loss_D_real.detach(), stats
+
+    def _d_step(self, clean_feat, enhance_feat, enhance_cmvn, wait_before_update=None, d_fake=None, fake_stats=None, fake_bn=None,
+                real_part=None):
         """Discriminator update (joint_train.py:195-212) on the CURRENT stream.  ``d_fake``: D(enhance_feat) of the G-step
         (same input, same weights as upstream's second evaluation) -- its graph is walked again for the parameter
         gradients instead of recomputing the forward; the BatchNorm running statistics get the update that forward would
         have applied (``fake_stats``), in upstream's order (after the D(real) pass)."""
         opt = self.opt
         set_requires_grad([self.gan_model], True)
-        self.gan_optimizer.zero_grad()
-        loss_D_real = self.criterionGAN(self.gan_model(clean_feat.detach(), enhance_cmvn), True)
+        if real_part is not None:
+            loss_D_real, real_stats = real_part
+            replay_running_stats(real_stats)
+        else:
+            self.gan_optimizer.zero_grad()
+            loss_D_real = self.criterionGAN(self.gan_model(clean_feat.detach(), enhance_cmvn), True)
         if d_fake is not None:
             replay_running_stats(fake_stats)
             for bn in fake_bn:

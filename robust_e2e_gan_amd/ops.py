@@ -63,6 +63,7 @@ AUX_STREAM = None        # optional filler stream for independent branches insid
 FROZEN_PARAMS = frozenset()   # id()s of parameters whose gradients must NOT be produced by the backward now running (the trainer
 #                               builds D's graph once with trainable parameters and walks it twice: G-step = input gradient only)
 MARKS = None             # RE2E_TIMELINE: list of (label, host time, event) shared with JointTrainer (see ``mark_grad``)
+BN_DEFER_RUNNING = False  # with a sink: leave the running statistics alone in this forward (the owner replays the update later, in order)
 BN_STATS_SINK = None     # optional list: every BatchNorm forward appends (running_mean, running_var, mean, invstd, P, momentum, eps)
 
 
@@ -534,8 +535,9 @@ class BnLreluFn(torch.autograd.Function):
         sm, si = empty((C,), x), empty((C,), x)
         wsb = query('re2e_bn_workspace_bytes', Pn, C)
         ws = workspace(wsb, x.device, 'bn')
-        call('re2e_bn_lrelu_fwd', x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), float(momentum),
-             float(eps), int(train), y.data_ptr(), sm.data_ptr(), si.data_ptr(), ws.data_ptr(), wsb)
+        defer = BN_DEFER_RUNNING and BN_STATS_SINK is not None and train      # momentum 0 keeps running_mean / running_var bit-identical
+        call('re2e_bn_lrelu_fwd', x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+             0.0 if defer else float(momentum), float(eps), int(train), y.data_ptr(), sm.data_ptr(), si.data_ptr(), ws.data_ptr(), wsb)
         ctx.gamma, ctx.beta, ctx.train = gamma, beta, train
         ctx.save_for_backward(x, sm, si)
         if BN_STATS_SINK is not None and train:
