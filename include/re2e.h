@@ -249,16 +249,23 @@ int re2e_attloc_fwd(const float* pre, const float* enc, const float* z, const fl
                     long ldc_out, float* conv_out, float* dp_out, float* e_scratch, re2e_stream_t stream);
 size_t re2e_attloc_partial_floats(int adim, int chans, int filts);
 size_t re2e_attloc_workspace_bytes(int B, int T, int adim, int chans);
-/* backward of one step: accumulates d_pre (+=), writes d_att_prev (may be NULL for step 0) and d_decproj
- * [B,adim] (for the mlp_dec GEMMs), accumulates per-utterance weight-grad partials (+=) laid out
+/* backward of one step: writes de_out (B,T) = d(energy) of this step (kept by the caller for re2e_attloc_dpre),
+ * d_att_prev (may be NULL for step 0) and d_decproj [B,adim] (for the mlp_dec GEMMs), accumulates the location-filter
+ * part of the per-utterance weight-grad partials (+=), which are laid out
  * [B][gvec(adim) | gvec_b(1) | w_att(adim*chans) | w_conv(chans*(2*filts+1))].  cx_in = the forward context
- * c (B,eprojs), conv_in / dp_in = the tensors saved by re2e_attloc_fwd.  The encoder-state gradient is NOT
- * accumulated here: call re2e_attloc_denc once after the loop. */
+ * c (B,eprojs), conv_in / dp_in = the tensors saved by re2e_attloc_fwd.  Neither the encoder-state gradient nor
+ * d_pre / dgvec / dW_att are produced here: call re2e_attloc_denc and re2e_attloc_dpre once after the loop. */
 int re2e_attloc_bwd(const float* pre, const float* enc, const float* att_prev, const float* w_cur, const int* hlens_dev,
                     const float* w_att, const float* w_conv, const float* gvec, const float* conv_in, const float* dp_in,
                     const float* cx_in, const float* dc, long ld_dc, const float* dw_in, int B, int T, int eprojs, int adim,
-                    int chans, int filts, float* d_pre, float* d_att_prev, float* d_decproj, float* partials,
+                    int chans, int filts, float* de_out, float* d_att_prev, float* d_decproj, float* partials,
                     void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+/* after the loop: d_pre (B,T,adim) = sum over the L1 steps of d(pre-activation) (overwritten), and the gvec / gvec_b /
+ * w_att parts of the partials (+=), recomputed from pre, conv_all (L1,B,T,chans), dp_all (L1,B,adim) (the tensors saved
+ * by re2e_attloc_fwd, stacked over the steps) and de_all (L1,B,T) (written by re2e_attloc_bwd). */
+int re2e_attloc_dpre(const float* pre, const float* conv_all, const float* dp_all, const float* de_all, const float* w_att,
+                     const float* gvec, int L1, int B, int T, int adim, int chans, int filts, float* d_pre, float* partials,
+                     void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 /* d_enc[b,t,:] = beta*d_enc + sum_i w_all[i,b,t] * dc_all[i,b,:]  (w_all (L1,B,T), dc_all (L1,B,eprojs)) */
 int re2e_attloc_denc(const float* w_all, const float* dc_all, int L1, int B, int T, int eprojs, float* d_enc, float beta,
                      re2e_stream_t stream);

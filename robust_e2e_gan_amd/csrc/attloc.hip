@@ -217,135 +217,227 @@ __global__ __launch_bounds__(NTH) void attloc_context_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, part 1: per frame chunk
-// partial slab layout per (b, chunk): [ddp(A) | dgv(A) | dwa(A*C) | dgb(1)]
+// backward, part 1: per frame chunk.  ONLY what the recurrence needs leaves this kernel every step:
+//   de[b,t]      (saved: attloc_dpre recomputes everything that depends on it after the loop)
+//   d_conv[b,t,c] = sum_a du[t][a] W_att[a][c]      -> transposed location conv -> d att_prev
+//   slab[b,chunk][a] = sum_{t in chunk} du[t][a]    -> d dec_proj
+// with du[t][a] = de[t] gvec[a] (1 - tanh^2(x[t][a])).  The 16 MB read-modify-write of d_pre and the weight-gradient
+// sums that the first version carried on this latency-critical path are done ONCE after the loop (attloc_dpre).
+// Every global load of the kernel is issued before the first dependent use (pre rows of all 8 frames of a wavefront at
+// kernel entry, enc rows four frames at a time); du goes through LDS so that both contractions read it without a
+// single cross-lane reduction.
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int slab_floats(int A, int C) { return A * (2 + C) + 1; }
+constexpr int FPW = TCH / NWV;     // frames per wavefront
+__host__ __device__ __forceinline__ int du_stride(int A) { return A | 1; }      // odd: column reads hit 32 different banks
 
 __global__ __launch_bounds__(NTH) void attloc_bwd_frames_kernel(
     const float* __restrict__ pre, const float* __restrict__ enc, const float* __restrict__ w_cur, const float* __restrict__ dw_in,
     const float* __restrict__ dc, long ld_dc, const float* __restrict__ cx, const float* __restrict__ conv_in,
     const float* __restrict__ dp_in, const float* __restrict__ w_att, const float* __restrict__ gvec, int B, int T, int E, int A, int C,
-    float* d_pre, float* __restrict__ d_conv, float* __restrict__ slabs) {
+    float* __restrict__ de_out, float* __restrict__ d_conv, float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int AS = du_stride(A);
   float* dcs = sm;                              // [E]
   float* de = dcs + ((E + 3) & ~3);             // [TCH]
   float* red = de + TCH;                        // [32]
-  float* accum = red + 32;                      // [A][2+CMAX]
+  float* cvs = red + 32;                        // [TCH][CMAX]   conv_in rows of the chunk
+  float* was = cvs + TCH * CMAX;                // [A][CMAX]     W_att
+  float* du = was + A * CMAX;                   // [TCH][AS]
+  float* pc = du + TCH * AS;                    // [8][TCH][CMAX] partial d_conv per a-range
   const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * TCH;
   const int nt = min(TCH, T - t0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // pre rows of this wavefront's frames: in flight while the softmax terms are computed
+  float pv[FPW][AIMAX];
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) {
+    const int l = wid + NWV * k;
+    const float* pr = pre + ((long)b * T + t0 + (l < nt ? l : 0)) * A;
+#pragma unroll
+    for (int i = 0; i < AIMAX; ++i) { int a = lane + 64 * i; pv[k][i] = a < A ? pr[a] : 0.f; }
+  }
   // softmax normaliser  s = sum_t w[t] dw[t] = w . dw_in + dc . c
   float part = 0.f;
   for (int d = tid; d < E; d += NTH) { float g = dc[(long)b * ld_dc + d]; dcs[d] = g; part += g * cx[(long)b * E + d]; }
   if (dw_in)
     for (int t = tid; t < T; t += NTH) part += w_cur[(long)b * T + t] * dw_in[(long)b * T + t];
-  for (int i = tid; i < A * (2 + CMAX); i += NTH) accum[i] = 0.f;
-  const float sdot = block_sum(part, red);     // (contains the __syncthreads that publish dcs / accum)
-  // de[t] = 2 w[t] (dw_in[t] + dc . enc[t] - s) for the frames of this chunk: one wavefront per frame pair
+  for (int i = tid; i < TCH * CMAX; i += NTH) {
+    int l = i / CMAX, c = i % CMAX;
+    cvs[i] = (l < nt && c < C) ? conv_in[((long)b * T + t0 + l) * C + c] : 0.f;
+  }
+  for (int i = tid; i < A * CMAX; i += NTH) { int a = i / CMAX, c = i % CMAX; was[i] = c < C ? w_att[a * C + c] : 0.f; }
+  const float sdot = block_sum(part, red);     // (contains the __syncthreads that publish dcs / cvs / was)
+  // de[t] = 2 w[t] (dw_in[t] + dc . enc[t] - s): a wavefront takes four of its frames at a time
   const int per = E / 4;
-  for (int tb = wid; tb < nt; tb += 2 * NWV) {
-    const int l0 = tb, l1 = tb + NWV;
-    const bool h1 = l1 < nt;
-    const f32x4* er0 = reinterpret_cast<const f32x4*>(enc + ((long)b * T + t0 + l0) * E);
-    const f32x4* er1 = reinterpret_cast<const f32x4*>(enc + ((long)b * T + t0 + (h1 ? l1 : l0)) * E);
-    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int k0 = 0; k0 < FPW; k0 += 4) {
+    float sacc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int d4 = lane; d4 < per; d4 += 64) {
-      f32x4 v0 = er0[d4], v1 = er1[d4];
-      f32x4 g = *reinterpret_cast<const f32x4*>(dcs + d4 * 4);
-      s0 += v0[0] * g[0] + v0[1] * g[1] + v0[2] * g[2] + v0[3] * g[3];
-      s1 += v1[0] * g[0] + v1[1] * g[1] + v1[2] * g[2] + v1[3] * g[3];
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = wid + NWV * (k0 + u);
+        v[u] = reinterpret_cast<const f32x4*>(enc + ((long)b * T + t0 + (l < nt ? l : 0)) * E)[d4];
+      }
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dcs + d4 * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sacc[u] += v[u][0] * g[0] + v[u][1] * g[1] + v[u][2] * g[2] + v[u][3] * g[3];
     }
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
-    if (lane == 0) {
-      long i0 = (long)b * T + t0 + l0;
-      de[l0] = 2.f * w_cur[i0] * (s0 + (dw_in ? dw_in[i0] : 0.f) - sdot);
-      if (h1) { long i1 = (long)b * T + t0 + l1; de[l1] = 2.f * w_cur[i1] * (s1 + (dw_in ? dw_in[i1] : 0.f) - sdot); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int l = wid + NWV * (k0 + u);
+      const float sv = wave_sum(sacc[u]);
+      if (lane == 0 && l < nt) {
+        const long i0 = (long)b * T + t0 + l;
+        const float v = 2.f * w_cur[i0] * (sv + (dw_in ? dw_in[i0] : 0.f) - sdot);
+        de[l] = v;
+        de_out[i0] = v;
+      }
     }
   }
   __syncthreads();
-  // energy backward
-  float wa[AIMAX][CMAX], gv[AIMAX], dpv[AIMAX], ddp[AIMAX], dgv[AIMAX], dwa[AIMAX][CMAX];
-#pragma unroll
-  for (int i = 0; i < AIMAX; ++i) {
-    int a = lane + 64 * i;
-    gv[i] = a < A ? gvec[a] : 0.f;
-    dpv[i] = a < A ? dp_in[(long)b * A + a] : 0.f;
-    ddp[i] = 0.f; dgv[i] = 0.f;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) { wa[i][c] = (a < A && c < C) ? w_att[a * C + c] : 0.f; dwa[i][c] = 0.f; }
-  }
-  float dgb = 0.f;
-  for (int l = wid; l < nt; l += NWV) {
-    const long row = (long)b * T + t0 + l;
-    const float* pr = pre + row * A;
-    float* dpr = d_pre + row * A;
-    float pv[AIMAX], dv[AIMAX];
+  // du[t][a] for the frames of this wavefront -> LDS
+  {
+    float gv[AIMAX], dpv[AIMAX];
 #pragma unroll
     for (int i = 0; i < AIMAX; ++i) {
       int a = lane + 64 * i;
-      pv[i] = a < A ? pr[a] : 0.f;
-      dv[i] = a < A ? dpr[a] : 0.f;
-    }
-    float cvv[CMAX], dcv[CMAX];
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) { cvv[c] = c < C ? conv_in[row * C + c] : 0.f; dcv[c] = 0.f; }
-    const float det = de[l];
-    dgb += det;
-#pragma unroll
-    for (int i = 0; i < AIMAX; ++i) {
-      int a = lane + 64 * i;
-      if (a < A) {
-        float x = pv[i] + dpv[i];
-#pragma unroll
-        for (int c = 0; c < CMAX; ++c) x += wa[i][c] * cvv[c];
-        float u = tanhf_(x);
-        float du = det * gv[i] * (1.f - u * u);
-        dpr[a] = dv[i] + du;
-        ddp[i] += du;
-        dgv[i] += det * u;
-#pragma unroll
-        for (int c = 0; c < CMAX; ++c) { dwa[i][c] += du * cvv[c]; dcv[c] += du * wa[i][c]; }
-      }
+      gv[i] = a < A ? gvec[a] : 0.f;
+      dpv[i] = a < A ? dp_in[(long)b * A + a] : 0.f;
     }
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
-      if (c < C) {
-        float v = wave_sum(dcv[c]);
-        if (lane == 0) d_conv[row * C + c] = v;
-      }
-    }
-  }
-  // fixed-order cross-wavefront reduction, then one slab per (b, chunk)
-  for (int w = 0; w < NWV; ++w) {
-    if (wid == w) {
+    for (int k = 0; k < FPW; ++k) {
+      const int l = wid + NWV * k;
+      const float det = l < nt ? de[l] : 0.f;
+      float cvv[CMAX];
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) cvv[c] = cvs[l * CMAX + c];
 #pragma unroll
       for (int i = 0; i < AIMAX; ++i) {
         int a = lane + 64 * i;
         if (a < A) {
-          float* q = accum + a * (2 + CMAX);
-          q[0] += ddp[i]; q[1] += dgv[i];
+          float x = pv[k][i] + dpv[i];
 #pragma unroll
-          for (int c = 0; c < CMAX; ++c) if (c < C) q[2 + c] += dwa[i][c];
+          for (int c = 0; c < CMAX; ++c) x += was[a * CMAX + c] * cvv[c];
+          float u = tanhf_(x);
+          du[l * AS + a] = det * gv[i] * (1.f - u * u);
         }
       }
-      if (lane == 0) red[16 + w] = dgb;
+    }
+  }
+  __syncthreads();
+  // d_conv[t][c] = sum_a du[t][a] W_att[a][c]: thread = (frame, one of 8 a-ranges), then a fixed-order sum of the 8 parts
+  {
+    const int l = tid & 31, p = tid >> 5;
+    const int ap = (A + 7) / 8, a0 = p * ap, a1 = min(A, a0 + ap);
+    float acc[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
+    for (int a = a0; a < a1; ++a) {
+      const float d = du[l * AS + a];
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) acc[c] += d * was[a * CMAX + c];
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) pc[(p * TCH + l) * CMAX + c] = acc[c];
+  }
+  // slab[a] = sum_t du[t][a]
+  float* slab = slabs + ((long)b * gridDim.x + chunk) * A;
+  for (int a = tid; a < A; a += NTH) {
+    float s = 0.f;
+    for (int l = 0; l < nt; ++l) s += du[l * AS + a];
+    slab[a] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < nt * C; i += NTH) {
+    const int l = i / C, c = i % C;
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) s += pc[(p * TCH + l) * CMAX + c];
+    d_conv[((long)b * T + t0 + l) * C + c] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// after the decoder loop: everything of the energy backward that no later step needs, for ALL steps at once.
+//   d_pre[b,t,a]  = sum_i du_i[t][a]
+//   slab[b,chunk] = [ dgvec(A) = sum de_i[t] tanh(x_i) | dW_att(A*C) = sum du_i[t][a] conv_i[t][c] | dgb = sum de_i[t] ]
+// x_i is recomputed from pre, the saved dec_proj_i and conv_i (10 FMAs + one tanh per element and step) instead of
+// streaming 16 MB through d_pre on every one of the L1 steps.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int dpre_slab_floats(int A, int C) { return A * (1 + C) + 1; }
+
+constexpr int TCD = 16;          // frames per workgroup; thread = one attention unit a, all TCD frames in registers
+__global__ __launch_bounds__(64 * AIMAX) void attloc_dpre_kernel(const float* __restrict__ pre, const float* __restrict__ conv_all,
+                                                                 const float* __restrict__ dp_all, const float* __restrict__ de_all,
+                                                                 const float* __restrict__ w_att, const float* __restrict__ gvec, int L1, int B,
+                                                                 int T, int A, int C, float* __restrict__ d_pre, float* __restrict__ slabs) {
+  __shared__ float des[TCD];
+  __shared__ float cvs[TCD * CMAX];
+  const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * TCD;
+  const int nt = min(TCD, T - t0);
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int a = tid;
+  const bool on = a < A;
+  float pv[TCD], acc[TCD], wa[CMAX], dwa[CMAX];
+#pragma unroll
+  for (int l = 0; l < TCD; ++l) {
+    pv[l] = (on && l < nt) ? pre[((long)b * T + t0 + l) * A + a] : 0.f;
+    acc[l] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) { wa[c] = (on && c < C) ? w_att[a * C + c] : 0.f; dwa[c] = 0.f; }
+  const float gv = on ? gvec[a] : 0.f;
+  float dgv = 0.f, dgb = 0.f;
+  for (int s = 0; s < L1; ++s) {
+    const float dpv = on ? dp_all[((long)s * B + b) * A + a] : 0.f;
+    __syncthreads();
+    if (tid < TCD) des[tid] = tid < nt ? de_all[((long)s * B + b) * T + t0 + tid] : 0.f;
+    for (int i = tid; i < TCD * CMAX; i += nth) {
+      int l = i / CMAX, c = i % CMAX;
+      cvs[i] = (l < nt && c < C) ? conv_all[(((long)s * B + b) * T + t0 + l) * C + c] : 0.f;
     }
     __syncthreads();
+#pragma unroll
+    for (int l = 0; l < TCD; ++l) {
+      const float det = des[l];                   // 0 beyond the last frame
+      float x = pv[l] + dpv;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) x += wa[c] * cvs[l * CMAX + c];
+      const float u = tanhf_(x);
+      const float d = det * gv * (1.f - u * u);
+      acc[l] += d;
+      dgv += det * u;
+      dgb += det;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) dwa[c] += d * cvs[l * CMAX + c];
+      __builtin_amdgcn_sched_barrier(0);          // one frame at a time: hoisting all 16 x 12 LDS reads costs 192 registers
+    }
   }
-  float* slab = slabs + ((long)b * gridDim.x + chunk) * slab_floats(A, C);
-  for (int a = tid; a < A; a += NTH) {
-    const float* q = accum + a * (2 + CMAX);
-    slab[a] = q[0];
-    slab[A + a] = q[1];
-    for (int c = 0; c < C; ++c) slab[2 * A + a * C + c] = q[2 + c];
+  float* slab = slabs + ((long)b * gridDim.x + chunk) * dpre_slab_floats(A, C);
+  if (on) {
+#pragma unroll
+    for (int l = 0; l < TCD; ++l)
+      if (l < nt) d_pre[((long)b * T + t0 + l) * A + a] = acc[l];
+    slab[a] = dgv;
+    for (int c = 0; c < C; ++c) slab[A + a * C + c] = dwa[c];
   }
-  if (tid == 0) {
+  if (tid == 0) slab[A * (1 + C)] = dgb;
+}
+
+// partials[b][gvec | gvec_b | w_att] += fixed-order sum of the chunk slabs of attloc_dpre
+__global__ __launch_bounds__(NTH) void attloc_dpre_reduce_kernel(const float* __restrict__ slabs, int nchunk, int A, int C, int npart,
+                                                                 float* partials) {
+  const int b = blockIdx.x, SF = dpre_slab_floats(A, C);
+  const float* sl = slabs + (long)b * nchunk * SF;
+  float* part = partials + (long)b * npart;
+  for (int i = threadIdx.x; i < SF; i += NTH) {
     float s = 0.f;
-    for (int w = 0; w < NWV; ++w) s += red[16 + w];
-    slab[A * (2 + C)] = s;
+    for (int k = 0; k < nchunk; ++k) s += sl[(long)k * SF + i];
+    if (i < A) part[i] += s;                              // gvec
+    else if (i < A * (1 + C)) part[A + 1 + (i - A)] += s; // w_att
+    else part[A] += s;                                    // gvec_b
   }
 }
 
@@ -355,7 +447,7 @@ __global__ __launch_bounds__(NTH) void attloc_bwd_frames_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int NTC = 512;      // threads of the per-utterance backward kernel
 // grid (B, 3): blockIdx.y selects one of three independent jobs so that three CUs share an utterance:
-//   0: fixed-order sum of the chunk slabs -> d dec_proj, dgvec, dgb, dW_att partials
+//   0: fixed-order sum of the chunk slabs -> d dec_proj
 //   1: transposed location conv           -> d att_prev
 //   2: filter gradient                    -> dW_conv partials
 __global__ __launch_bounds__(NTC) void attloc_bwd_conv_kernel(const float* __restrict__ att_prev, const int* __restrict__ hlens,
@@ -373,18 +465,14 @@ __global__ __launch_bounds__(NTC) void attloc_bwd_conv_kernel(const float* __res
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NWC = NTC / 64;
-  const int P_GB = A, P_WATT = A + 1, P_WCONV = A + 1 + A * C;
+  const int P_WCONV = A + 1 + A * C;
   float* part = partials + (long)b * (A + 1 + A * C + C * Kf);
   if (job == 0) {
-    const int SF = slab_floats(A, C);
-    const float* sl = slabs + (long)b * nchunk * SF;
-    for (int i = tid; i < SF; i += NTC) {
+    const float* sl = slabs + (long)b * nchunk * A;
+    for (int i = tid; i < A; i += NTC) {
       float s = 0.f;
-      for (int k = 0; k < nchunk; ++k) s += sl[(long)k * SF + i];
-      if (i < A) d_decproj[(long)b * A + i] = s;
-      else if (i < 2 * A) part[i - A] += s;
-      else if (i < A * (2 + C)) part[P_WATT + (i - 2 * A)] += s;
-      else part[P_GB] += s;
+      for (int k = 0; k < nchunk; ++k) s += sl[(long)k * A + i];
+      d_decproj[(long)b * A + i] = s;
     }
     return;
   }
@@ -501,8 +589,8 @@ extern "C" size_t re2e_attloc_partial_floats(int adim, int chans, int filts) {
 }
 
 extern "C" size_t re2e_attloc_workspace_bytes(int B, int T, int adim, int chans) {
-  // d_conv [B][T][C] + chunk slabs [B][nchunk][A*(2+C)+1]
-  return ((size_t)B * T * chans + (size_t)B * nchunks(T) * ((size_t)adim * (2 + chans) + 1)) * sizeof(float);
+  // d_conv [B][T][C] + per-step chunk slabs [B][nchunk][A] + attloc_dpre chunk slabs [B][ceil(T/16)][A*(1+C)+1]
+  return ((size_t)B * T * chans + (size_t)B * nchunks(T) * adim + (size_t)B * ((T + TCD - 1) / TCD) * ((size_t)adim * (1 + chans) + 1)) * sizeof(float);
 }
 
 static int check_dims(const char* fn, int B, int T, int E, int D, int A, int C, int F) {
@@ -539,9 +627,9 @@ extern "C" int re2e_attloc_fwd(const float* pre, const float* enc, const float* 
 extern "C" int re2e_attloc_bwd(const float* pre, const float* enc, const float* att_prev, const float* w_cur, const int* hlens,
                                const float* w_att, const float* w_conv, const float* gvec, const float* conv_in, const float* dp_in,
                                const float* cx_in, const float* dc, long ld_dc, const float* dw_in, int B, int T, int eprojs, int adim,
-                               int chans, int filts, float* d_pre, float* d_att_prev, float* d_decproj, float* partials, void* workspace,
+                               int chans, int filts, float* de_out, float* d_att_prev, float* d_decproj, float* partials, void* workspace,
                                size_t workspace_bytes, hipStream_t stream) {
-  RE2E_CHECK_ARG(pre && enc && w_cur && hlens && w_att && w_conv && gvec && conv_in && dp_in && cx_in && dc && d_pre && d_decproj && partials &&
+  RE2E_CHECK_ARG(pre && enc && w_cur && hlens && w_att && w_conv && gvec && conv_in && dp_in && cx_in && dc && de_out && d_decproj && partials &&
                      workspace, "null arg");
   int rc = check_dims("re2e_attloc_bwd", B, T, eprojs, 1, adim, chans, filts);
   if (rc) return rc;
@@ -549,15 +637,34 @@ extern "C" int re2e_attloc_bwd(const float* pre, const float* enc, const float* 
   const int Kf = 2 * filts + 1, nch = nchunks(T);
   float* d_conv = (float*)workspace;
   float* slabs = d_conv + (size_t)B * T * chans;
-  size_t lds1 = (size_t)(((eprojs + 3) & ~3) + TCH + 32 + adim * (2 + CMAX) + 16) * sizeof(float);
+  size_t lds1 = (size_t)(((eprojs + 3) & ~3) + TCH + 32 + TCH * CMAX + adim * CMAX + TCH * du_stride(adim) + 8 * TCH * CMAX + 16) * sizeof(float);
+  if (lds1 > 160 * 1024) { re2e_set_error("re2e_attloc_bwd: eprojs=%d adim=%d need %zu bytes of LDS (>160 KiB)", eprojs, adim, lds1); return RE2E_EUNSUPPORTED; }
+  if (lds1 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_bwd_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
   hipLaunchKernelGGL(attloc_bwd_frames_kernel, dim3(nch, B), dim3(NTH), lds1, stream, pre, enc, w_cur, dw_in, dc, ld_dc, cx_in, conv_in, dp_in, w_att,
-                     gvec, B, T, eprojs, adim, chans, d_pre, d_conv, slabs);
+                     gvec, B, T, eprojs, adim, chans, de_out, d_conv, slabs);
   size_t lds2 = (size_t)(((T + 2 * filts + 3) & ~3) + (size_t)chans * (T + 2 * filts + 1) + (size_t)chans * Kf + (size_t)chans * T + 16) *
                 sizeof(float);
   if (lds2 > 160 * 1024) { re2e_set_error("re2e_attloc_bwd: T=%d needs %zu bytes of LDS (>160 KiB)", T, lds2); return RE2E_EUNSUPPORTED; }
   if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attloc_bwd_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   hipLaunchKernelGGL(attloc_bwd_conv_kernel, dim3(B, 3), dim3(NTC), lds2, stream, att_prev, hlens, w_conv, (const float*)d_conv, (const float*)slabs, nch,
                      B, T, adim, chans, filts, d_att_prev, d_decproj, partials);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+extern "C" int re2e_attloc_dpre(const float* pre, const float* conv_all, const float* dp_all, const float* de_all, const float* w_att,
+                                const float* gvec, int L1, int B, int T, int adim, int chans, int filts, float* d_pre, float* partials,
+                                void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(pre && conv_all && dp_all && de_all && w_att && gvec && d_pre && partials && workspace && L1 > 0, "bad args");
+  int rc = check_dims("re2e_attloc_dpre", B, T, 4, 1, adim, chans, filts);
+  if (rc) return rc;
+  RE2E_CHECK_ARG(workspace_bytes >= re2e_attloc_workspace_bytes(B, T, adim, chans), "workspace too small");
+  const int nch = nchunks(T), ncd = (T + TCD - 1) / TCD;
+  float* slabs = (float*)workspace + (size_t)B * T * chans + (size_t)B * nch * adim;
+  hipLaunchKernelGGL(attloc_dpre_kernel, dim3(ncd, B), dim3(64 * ((adim + 63) / 64)), 0, stream, pre, conv_all, dp_all, de_all, w_att, gvec, L1, B, T,
+                     adim, chans, d_pre, slabs);
+  hipLaunchKernelGGL(attloc_dpre_reduce_kernel, dim3(B), dim3(NTH), 0, stream, (const float*)slabs, ncd, adim, chans,
+                     (int)re2e_attloc_partial_floats(adim, chans, filts), partials);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

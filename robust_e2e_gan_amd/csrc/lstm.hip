@@ -147,6 +147,125 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_step(float* xg_f, float* 
   }
 }
 
+// ---- persistent forward: the whole sequence in ONE launch ----------------------------------------------------------
+// Same decomposition as lstm_fwd_step (workgroup = 8 hidden units x 4 gates x 32 utterances, waves split K = H), but the
+// workgroups stay resident for all T steps: the recurrent weights live in registers (QN float4 per lane), the cell state
+// in a register of the thread that owns it, the next step's gate pre-activations are prefetched one step ahead, and
+// h_t travels between workgroups as 8-byte {step tag, value} granules -- one write-through (sc1) store each, swept with
+// sc1 loads until every tag matches (MI355X_MICROARCH.md "R2": the data is the flag, no fence, placement-independent).
+// What this removes per step: the kernel boundary, the grid ramp / drain, and re-reading 32 KB of weights per workgroup
+// from an L2 that the concurrent filler kernels keep evicting.  Requires every workgroup to be resident (checked by the
+// launcher: grid <= CUs); spins are bounded and poison the output instead of hanging.
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+constexpr unsigned kSpinLimit = 1u << 16;      // sweeps (~1 us each) before a workgroup gives up on a peer
+
+template <int WAVES, int QN>
+__global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, float* xg_r, const float* __restrict__ wfrag, float* ybuf,
+                                                               float* cbuf, u64* hx_, unsigned* err, const int* __restrict__ lens,
+                                                               int T, int B, int H) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [WAVES][32][33] | abort flag
+  static_assert(WAVES >= 4, "256 threads own the 32 x 8 cell updates");
+  const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y, NX = gridDim.x;
+  float* xg = dir ? xg_r : xg_f;
+  const int j0 = x * 8, b0 = mt * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  constexpr int kAbort = WAVES * 32 * 33;            // red[kAbort] != 0: a sweep timed out
+  if (tid == 0) red[kAbort] = 0.f;
+  const long H2 = 2L * H;
+  // recurrent weights of this wave's K range: registers for the whole sequence
+  f32x4 w[QN];
+  {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wfrag) + ((long)(dir * NX + x) * NX + wid * QN) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < QN; ++q) w[q] = wp[q * 64];
+  }
+  // exchange buffer: [parity][dir][mt][producer x'][lh][b][i] granules; producer x' == k-group Q of the consumers
+  gu64* hx = (gu64*)hx_;
+  const long par_sz = (long)2 * MT * NX * 256;
+  const long grp = (long)(dir * MT + mt) * NX * 256;
+  const long rd_off = grp + (long)(wid * QN) * 256 + (lh * 32 + lr) * 4;
+  const bool pw = tid < 256;
+  const int bm = (tid >> 3) & 31, jj = tid & 7, b = b0 + bm, j = j0 + jj;
+  const bool ok = pw && b < B;
+  const int ln = ok ? lens[b] : 0;
+  const long wr_off = grp + (long)x * 256 + ((jj >> 2) * 32 + bm) * 4 + (jj & 3);
+  float c = 0.f, pre[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    const float* gp = xg + ((long)(dir ? T - 1 : 0) * B + b) * 4 * H + j;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = gp[g * H];
+  }
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (s > 0) {
+      const gu64* src = hx + ((s & 1) ^ 1) * par_sz + rd_off;
+      float hv[QN][4];
+      for (unsigned spins = 0;; ++spins) {
+        bool good = true;
+#pragma unroll
+        for (int q = 0; q < QN; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const u64 g = __hip_atomic_load(src + q * 256 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hv[q][i] = __uint_as_float((unsigned)g);
+            good &= (unsigned)(g >> 32) == (unsigned)s;
+          }
+        if (__all(good)) break;
+        if (spins > kSpinLimit) { if (lane == 0) { red[kAbort] = 1.f; atomicExch(err, 1u); } break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int q = 0; q < QN; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[q][i], w[q][i], acc, 0, 0, 0);
+    }
+    float nxt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok && s + 1 < T) {                       // next step's pre-activations: HBM latency hidden behind this step
+      const float* gp = xg + ((long)(dir ? t - 1 : t + 1) * B + b) * 4 * H + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) nxt[g] = gp[g * H];
+    }
+    store_acc(red + wid * (32 * 33), acc, lane);
+    __syncthreads();
+    if (red[kAbort] != 0.f) break;
+    if (pw) {
+      float v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float a = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) a += red[wv * (32 * 33) + bm * 33 + g * 8 + jj];
+        v[g] = a + pre[g];
+      }
+      float gi = sigmoidf_(v[0]), gf = sigmoidf_(v[1]), gg = tanhf_(v[2]), go = sigmoidf_(v[3]);
+      float cn = gf * c + gi * gg;
+      float h = go * tanhf_(cn);
+      if (t >= ln) { cn = 0.f; h = 0.f; }        // packed semantics (also rows b >= B: ln = 0)
+      c = cn;
+      if (s + 1 < T)
+        __hip_atomic_store(hx + (s & 1) * par_sz + wr_off, ((u64)(unsigned)(s + 1) << 32) | (u64)__float_as_uint(h), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      if (ok) {
+        float* go_ = xg + ((long)t * B + b) * 4 * H + j;
+        go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
+        cbuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = cn;
+        ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = h;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = nxt[g];
+    __syncthreads();
+  }
+  if (red[kAbort] != 0.f && ok) {                         // a peer never published: make the failure visible downstream
+    for (int t = 0; t < T; ++t) ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = __uint_as_float(0x7fc00000u);
+  }
+}
+
 // BPTT step.  Workgroup x owns hidden units j in [8x, 8x+8) for 32 utterances, exactly like the forward:
 //   consume: dh_rec[b][j] = sum over ALL workgroups x' of the partial slabs P_x'[b][j] written by the previous launch,
 //            then the cell backward -> d(gates) for its 32 gate columns n (kept in LDS, written to G);
@@ -269,6 +388,8 @@ int pick_waves(int K, int min_kc, const char* env = nullptr) {
 // workspace (floats): fwd  = wfrag[2][4H*H] | hfrag[2][2][MT][H*32]
 //                     bwd  = wtfrag[2][nx*(H/2)*256] | gfrag[2][2][MT][4H*32]
 size_t fwd_ws_floats(int B, int H) { long MT = (B + 31) / 32; return (size_t)2 * 4 * H * H + (size_t)2 * 2 * MT * H * 32; }
+// persistent forward: + hx header (16 B: error word) + granules [2][2][MT][H/8][256] x 8 B
+size_t fwd_hx_bytes(int B, int H) { long MT = (B + 31) / 32; return 16 + (size_t)2 * 2 * MT * (H / 8) * 256 * 8; }
 size_t bwd_ws_floats(int B, int H) {
   long MT = (B + 31) / 32, NX = H / 8, njt = (H + 31) / 32;
   return (size_t)2 * NX * njt * 1024 + (size_t)2 * 2 * MT * NX * NX * 256;
@@ -292,11 +413,44 @@ void launch_bwd(hipStream_t st, float* g_f, float* g_r, const float* wb, const f
     hipLaunchKernelGGL((lstm_bwd_step<JT>), grid, dim3(256), 0, st, g_f, g_r, wb, dy, cbuf, dc, slabs, lens, T, B, H, s);
 }
 
+int cu_count() {
+  static int n = 0;
+  if (!n) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; else n = 1; }
+  return n;
+}
+
+template <int W, int QN>
+bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, float* ybuf, float* cbuf, void* hxmem, size_t hxbytes,
+                        const int* lens, int T, int B, int H) {
+  size_t lds = (size_t)W * 32 * 33 * sizeof(float) + 16;
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  dim3 grid(H / 8, cdiv(B, 32), 2);
+  if ((long)grid.x * grid.y * grid.z > cu_count()) return false;          // every workgroup must be resident
+  (void)hipMemsetAsync(hxmem, 0, hxbytes, st);                             // tags and the error word start at zero, every call
+  unsigned* err = (unsigned*)hxmem;
+  u64* hx = (u64*)((char*)hxmem + 16);
+  hipLaunchKernelGGL((lstm_fwd_persist<W, QN>), grid, dim3(W * 64), lds, st, xg_f, xg_r, wfrag, ybuf, cbuf, hx, err, lens, T, B, H);
+  return true;
+}
+
+// RE2E_LSTM_PERSIST=0 keeps the launch-per-step form (also used for shapes the persistent kernel does not cover)
+bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, float* ybuf, float* cbuf, void* hxmem, size_t hxbytes,
+                     const int* lens, int T, int B, int H) {
+  const char* v = getenv("RE2E_LSTM_PERSIST");
+  if ((v && atoi(v) == 0) || T < 2) return false;
+  const int NX = H / 8;
+#define RE2E_TRY(W, Q) if (NX == (W) * (Q)) return launch_fwd_persist<W, Q>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H)
+  RE2E_TRY(16, 4); RE2E_TRY(8, 5); RE2E_TRY(8, 4); RE2E_TRY(8, 3); RE2E_TRY(4, 4); RE2E_TRY(4, 2); RE2E_TRY(4, 1);
+#undef RE2E_TRY
+  return false;
+}
+
 }  // namespace
 
 extern "C" size_t re2e_lstm_workspace_bytes(int B, int H) {
-  size_t a = fwd_ws_floats(B, H), b = bwd_ws_floats(B, H);
-  return (a > b ? a : b) * sizeof(float);
+  size_t a = fwd_ws_floats(B, H) * sizeof(float) + fwd_hx_bytes(B, H), b = bwd_ws_floats(B, H) * sizeof(float);
+  return a > b ? a : b;
 }
 
 extern "C" int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
@@ -305,12 +459,17 @@ extern "C" int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, c
   RE2E_CHECK_ARG(xg_f && xg_r && whh_f && whh_r && ybuf && cbuf && lens_dev && workspace, "null arg");
   RE2E_CHECK_ARG(T > 0 && B > 0 && H > 0, "bad shape");
   if (H % 8 != 0) { re2e_set_error("re2e_lstm_seq_fwd: hidden size must be a multiple of 8 (got %d)", H); return RE2E_EUNSUPPORTED; }
-  RE2E_CHECK_ARG(workspace_bytes >= fwd_ws_floats(B, H) * sizeof(float), "workspace too small");
+  RE2E_CHECK_ARG(workspace_bytes >= fwd_ws_floats(B, H) * sizeof(float) + fwd_hx_bytes(B, H), "workspace too small");
   float* wfrag = (float*)workspace;
   float* hfrag = wfrag + (size_t)2 * 4 * H * H;
+  void* hxmem = (char*)workspace + fwd_ws_floats(B, H) * sizeof(float);
   long wn = (long)4 * H * H, hn = (long)2 * 2 * cdiv(B, 32) * H * 32;
   hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wfrag, H);
   hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wfrag + wn, H);
+  if (try_fwd_persist(stream, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, fwd_hx_bytes(B, H), lens_dev, T, B, H)) {
+    RE2E_LAUNCH_CHECK();
+    return RE2E_OK;
+  }
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(hn, 256) > 1024 ? 1024 : cdiv(hn, 256)), dim3(256), 0, stream, hfrag, hn);
   int w = pick_waves(H, 32, "RE2E_LSTM_WAVES_FWD");
   switch (w) {

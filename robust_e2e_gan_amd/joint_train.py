@@ -88,7 +88,9 @@ class JointTrainer(object):
             # + wgrad + one more) is multiplexed onto an occupied queue and serialises against it (measured with a
             # dedicated D-step stream: 91 -> 155 ms/step).  Measured and rejected as well: running the D-step's
             # forward/backward early, under the ASR forward (+2.3 ms/step: it slows the encoder chain more than it
-            # relieves the backward).
+            # relieves the backward); a dedicated stream for the recurrent sequences masked to the 32 CUs the fillers leave
+            # alone (GPU_MAX_HW_QUEUES=8): the chains are no faster there (16.9 vs 18 ms for the enhancer forward under the
+            # D(real) filler -- the slowdown under load is not CU sharing) and 256-workgroup sequences do not fit 32 CUs.
         self.main_stream = None
         if torch.cuda.is_available() and os.environ.get('RE2E_NO_PRIORITY', '0') != '1':
             try:

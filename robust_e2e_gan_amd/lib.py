@@ -80,6 +80,7 @@ SIGNATURES = {
     're2e_attloc_partial_floats': (Z, [I, I, I]),
     're2e_attloc_workspace_bytes': (Z, [I, I, I, I]),
     're2e_attloc_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, L, P, I, I, I, I, I, I, P, P, P, P, P, Z, P]),
+    're2e_attloc_dpre': (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, Z, P]),
     're2e_attloc_denc': (I, [P, P, I, I, I, I, P, F, P]),
     're2e_clip_coef': (I, [P, F, P, P]),
     're2e_adadelta_step': (I, [P, P, P, P, L, F, F, F, P, P]),
@@ -174,8 +175,8 @@ def _destroy_masked_streams():
     del _masked_streams[:]
 
 
-def cu_masked_stream(enabled_cus, total_cus=256, device=None):
-    """A HIP stream whose kernels may only run on the first ``enabled_cus`` bits of the CU mask
+def cu_masked_stream(enabled_cus, total_cus=256, device=None, first=0):
+    """A HIP stream whose kernels may only run on bits ``first .. first + enabled_cus - 1`` of the CU mask
     (hipExtStreamCreateWithCUMask), wrapped as a torch ExternalStream.  Used for the filler streams of the
     joint step so that the short dependent launches of the recurrent chains always find idle CUs.
     Returns None if the runtime refuses."""
@@ -187,7 +188,7 @@ def cu_masked_stream(enabled_cus, total_cus=256, device=None):
             _hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         words = (total_cus + 31) // 32
         mask = (ctypes.c_uint32 * words)()
-        for i in range(min(enabled_cus, total_cus)):
+        for i in range(first, min(first + enabled_cus, total_cus)):   # bit i = CU i // 8 of XCD i % 8 (tools/micro/cumask_probe.hip)
             mask[i // 32] |= (1 << (i % 32))
         st = c_void_p()
         rc = _hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)

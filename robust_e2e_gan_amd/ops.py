@@ -971,7 +971,8 @@ class DecoderLoopFn(torch.autograd.Function):
         w_ih = Pm['w_ih']
         ldw = Dd + E
         w_ctx = w_ih.data_ptr() + 4 * Dd
-        d_pre = zeros((B, T, A), hmask)
+        d_pre = empty((B, T, A), hmask)
+        de_all = empty((L1, B, T), hmask)
         d_enc = empty((B, T, E), hmask)
         npart = query('re2e_attloc_partial_floats', A, C, Fh)
         partials = zeros((B, npart), hmask)
@@ -994,11 +995,13 @@ class DecoderLoopFn(torch.autograd.Function):
             call('re2e_attloc_bwd', pre.data_ptr(), hmask.data_ptr(), w[i - 1].data_ptr() if i > 0 else None, w[i].data_ptr(),
                  ctx.hlens.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(), Pm['gvec_w'].data_ptr(), conv[i].data_ptr(),
                  dpj[i].data_ptr(), cx[i].data_ptr(), d_cx.data_ptr(), E, dw_a.data_ptr() if have_dw else None, B, T, E, A, C, Fh,
-                 d_pre.data_ptr(), dw_b.data_ptr() if i > 0 else None, ddp[i].data_ptr(), partials.data_ptr(), aws.data_ptr(), awsb)
+                 de_all[i].data_ptr(), dw_b.data_ptr() if i > 0 else None, ddp[i].data_ptr(), partials.data_ptr(), aws.data_ptr(), awsb)
             dw_a, dw_b = dw_b, dw_a
             have_dw = True
             gemm(ddp[i], Pm['mlp_dec'], dz_carry, B, D, A, beta=1.0)
         call('re2e_attloc_denc', w.data_ptr(), d_cx_all.data_ptr(), L1, B, T, E, d_enc.data_ptr(), 0.0)
+        call('re2e_attloc_dpre', pre.data_ptr(), conv.data_ptr(), dpj.data_ptr(), de_all.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['gvec_w'].data_ptr(),
+             L1, B, T, A, C, Fh, d_pre.data_ptr(), partials.data_ptr(), aws.data_ptr(), awsb)
         M = L1 * B
         G2, zp2 = gates.view(M, 4 * D), z[:L1].reshape(M, D)
         if w_ih.requires_grad:

@@ -232,7 +232,10 @@ def test_bn_lrelu():
     close('running_var', rv, bn.running_var, tol=1e-5)
 
 
-@pytest.mark.parametrize('B,T,I,H,lens', [(3, 11, 20, 16, [11, 7, 4]), (40, 9, 33, 64, None), (5, 6, 257, 24, [6, 6, 5, 2, 1])])
+@pytest.mark.parametrize('B,T,I,H,lens', [(3, 11, 20, 16, [11, 7, 4]), (40, 9, 33, 64, None), (5, 6, 257, 24, [6, 6, 5, 2, 1]),
+                                          # shapes the persistent (one launch per sequence) forward covers: (waves, k-groups per wave)
+                                          (40, 23, 17, 256, None), (33, 14, 9, 320, None), (64, 12, 12, 512, None), (5, 19, 8, 32, [19, 19, 7, 2, 1]),
+                                          (7, 13, 8, 128, None), (2, 10, 8, 192, [10, 4])])
 def test_bilstm(B, T, I, H, lens):
     ops, lib = _ops()
     if lens is None:
@@ -259,6 +262,36 @@ def test_bilstm(B, T, I, H, lens):
         for n in names:
             close(n + sfx, ws[i].grad, getattr(lstm, n + sfx).grad, tol=3e-4)
             i += 1
+
+
+@pytest.mark.parametrize('B,T,H', [(32, 60, 256), (40, 37, 320), (64, 25, 512), (3, 21, 32)])
+def test_lstm_persistent_vs_stepwise(B, T, H, monkeypatch):
+    """K4 forward: the persistent kernel (workgroups resident for the whole sequence, h_t handed over as tagged granules)
+    against the launch-per-step kernels on the same inputs -- every output buffer, ragged lengths."""
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    xg0 = [(torch.randn(T * B, 4 * H, generator=g) * 0.5).to(DEV) for _ in range(2)]
+    whh = [(torch.randn(4 * H, H, generator=g) / H ** 0.5).to(DEV) for _ in range(2)]
+    lens = torch.randint(1, T + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = T
+    lens = lens.to(DEV)
+    wsb = lib.query('re2e_lstm_workspace_bytes', B, H)
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('RE2E_LSTM_PERSIST', mode)
+        xg = [x.clone() for x in xg0]
+        ws = torch.full((wsb // 4 + 16,), float('nan'), device=DEV)          # poisoned workspace: nothing may be read before it is written
+        ybuf, cbuf = torch.zeros(T + 2, B, 2 * H, device=DEV), torch.zeros(T + 2, B, 2 * H, device=DEV)
+        for _ in range(2):                                                    # twice: stale tags of the first call must not satisfy the second
+            for d in range(2):
+                xg[d].copy_(xg0[d])
+            lib.call('re2e_lstm_seq_fwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), ybuf.data_ptr(), cbuf.data_ptr(),
+                     lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+        torch.cuda.synchronize()
+        outs[mode] = (xg[0], xg[1], ybuf, cbuf)
+    for name, a, b in zip(('gates_f', 'gates_r', 'y', 'c'), outs['0'], outs['1']):
+        assert torch.isfinite(b).all(), name
+        close(name, b, a, tol=2e-6)
 
 
 def test_ctc():
