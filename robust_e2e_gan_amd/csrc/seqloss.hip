@@ -14,17 +14,30 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int*
     out[(long)r * ldo + d] = table[(long)ids[r] * D + d];
   }
 }
-// one block per vocabulary row; scans the id list in order => bitwise reproducible
-__global__ void embedding_bwd_kernel(const float* __restrict__ dout, long ldo, const int* __restrict__ ids, int n, int D,
-                                     float* __restrict__ dtable, float beta) {
-  extern __shared__ int sid[];
-  int v = blockIdx.x;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) sid[i] = ids[i];
+// one block per vocabulary row.  Wavefront 0 compacts the positions whose id is this row into an LDS list IN ORDER (ballot +
+// prefix count), then every thread sums its columns over that short list => bitwise reproducible, and the id list is
+// scanned once per row instead of once per column group.
+__global__ __launch_bounds__(128) void embedding_bwd_kernel(const float* __restrict__ dout, long ldo, const int* __restrict__ ids, int n, int D,
+                                                            float* __restrict__ dtable, float beta) {
+  extern __shared__ int hits[];        // [n] worst case
+  __shared__ int nhit;
+  const int v = blockIdx.x, lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const bool m = i < n && ids[i] == v;
+      const unsigned long long mask = __ballot(m);
+      if (m) hits[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+      cnt += __popcll(mask);
+    }
+    if (lane == 0) nhit = cnt;
+  }
   __syncthreads();
+  const int nh = nhit;
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
     float acc = 0.f;
-    for (int i = 0; i < n; ++i)
-      if (sid[i] == v) acc += dout[(long)i * ldo + d];
+    for (int k = 0; k < nh; ++k) acc += dout[(long)hits[k] * ldo + d];
     float* q = dtable + (long)v * D + d;
     *q = (beta != 0.f ? beta * (*q) : 0.f) + acc;
   }

@@ -152,13 +152,15 @@ class JointTrainer(object):
                 ev_cf = torch.cuda.Event()
                 ev_cf.record()
                 clean_branch = self.asr_model.encode_clean(clean_feat, enhance_cmvn)
-                if self.isGAN and self.reuse_dfake and self.early_dreal:
-                    # D-step, real half (joint_train.py:198-201): needs only clean_feat and D's current weights, so it goes
-                    # here, under the enhancer's forward chain, instead of under the (already saturated) backward chain
-                    d_real_part = self._d_real(clean_feat, enhance_cmvn)
             self._mark('clean branch enqueued (side)')
             enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
             self._mark('enhancer fwd')
+            if self.isGAN and self.reuse_dfake and self.early_dreal:
+                # D-step, real half (joint_train.py:198-201): needs only clean_feat and D's current weights, so it goes
+                # under the enhancer's forward chain instead of under the (already saturated) backward chain.  Enqueued
+                # AFTER the enhancer: its ~2.5 ms of host launches must not delay the start of that chain.
+                with torch.cuda.stream(side):
+                    d_real_part = self._d_real(clean_feat, enhance_cmvn)
             ops.mark_grad(enhance_out, 'enhance_out (fbank bwd done)')
             enhance_feat = self.feat_model(enhance_out)
             ops.mark_grad(enhance_feat, 'enhance_feat (VGG, D, L1 bwd done)')
