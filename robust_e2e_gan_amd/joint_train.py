@@ -92,9 +92,14 @@ class JointTrainer(object):
             # alone (GPU_MAX_HW_QUEUES=8): the chains are no faster there (16.9 vs 18 ms for the enhancer forward under the
             # D(real) filler -- the slowdown under load is not CU sharing) and 256-workgroup sequences do not fit 32 CUs.
         self.main_stream = None
-        if torch.cuda.is_available() and os.environ.get('RE2E_NO_PRIORITY', '0') != '1':
+        if torch.cuda.is_available():
+            # The step runs on its OWN stream, never on the legacy default stream (which synchronises implicitly with
+            # the blocking CU-masked filler streams: 91 -> 140 ms).  It is a high-priority stream (RE2E_MAIN_PRIORITY,
+            # default -1): the launch-per-step chains gain from it (91.4 vs 92.4 ms).  A fifth, normal-priority stream for
+            # the persistent sequences (GPU_MAX_HW_QUEUES=8) changed nothing: what slows a resident chain beside the
+            # fillers is two of its workgroups sharing a CU (tools/bench_fill_under_chain.py), not the queue it came from.
             try:
-                self.main_stream = torch.cuda.Stream(priority=-1)
+                self.main_stream = torch.cuda.Stream(priority=int(os.environ.get('RE2E_MAIN_PRIORITY', '-1')))
             except Exception:
                 self.main_stream = None
 
