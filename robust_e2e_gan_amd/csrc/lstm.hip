@@ -379,6 +379,167 @@ __global__ __launch_bounds__(256) void lstm_bwd_step(float* g_f, float* g_r, con
   }
 }
 
+// ---- persistent backward: the whole BPTT sequence in ONE launch -------------------------------------------------------
+// Same K-split decomposition as lstm_bwd_step (workgroup x = 32 gate rows = 8 hidden units x 4 gates for 32 utterances;
+// consume the sum of everybody's partials for its own 8 units, cell backward, produce its partial dG_x . W_hh[x,:] for ALL
+// units), but resident for all T steps: W_hh[x,:] lives in registers, dc in a register of the thread that owns it, the
+// next step's operands (gates, dy, c) are prefetched one step ahead.  The partials are 32 KB per workgroup and step, so
+// they are handed over in the flagged form (MI355X_MICROARCH.md hand-off "R1"): 16-byte write-through (sc1) stores,
+// every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane publishes the step tag in the workgroup's
+// flag word (own 128-byte line); the consumer's first wave polls the NX flags (one lane each, sc1), workgroup barrier,
+// then every load of the partials is an sc1 load.  Two parity buffers; flags zeroed per call; bounded spins.
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ void store16_sc1(float* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int TPW>       // 32-unit output tiles per wave (4 waves): H <= 128 * TPW
+__global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, const float* __restrict__ wb, const float* __restrict__ dy,
+                                                        const float* __restrict__ cbuf, float* dc_state, float* xbuf, unsigned* flags_,
+                                                        unsigned* err, const int* __restrict__ lens, int T, int B, int H) {
+  __shared__ __attribute__((aligned(16))) float dgs[32 * 36];     // d(gates) tile [b][n], padded rows
+  __shared__ int aborted;
+  const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y, NX = gridDim.x;
+  float* G = dir ? g_r : g_f;
+  const int j0 = x * 8, b0 = mt * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int K4 = 4 * H;
+  const long H2 = 2L * H;
+  const int njt = (H + 31) / 32;
+  if (tid == 0) aborted = 0;
+  // W_hh rows of this workgroup, tiles of this wave: registers for the whole sequence
+  f32x4 wreg[TPW][4];
+  {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wb) + ((long)(dir * NX + x) * njt) * 256 + lane;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const int jt = min(wid + 4 * u, njt - 1);
+#pragma unroll
+      for (int Q = 0; Q < 4; ++Q) wreg[u][Q] = wp[(long)(jt * 4 + Q) * 64];
+    }
+  }
+  const long grp = (long)(dir * MT + mt);
+  const long x_par = (long)2 * MT * NX * NX * 256;             // floats per parity buffer: [dir][mt][consumer][producer][8 j][32 b]
+  float* xg = xbuf + grp * NX * NX * 256;
+  gu32* flags = (gu32*)flags_;
+  const long f_par = (long)2 * MT * NX * 32;                    // words per parity: one 128-byte line per producer
+  const long f_grp = grp * NX * 32;
+  // cell-backward ownership: thread = (utterance bm, unit jj)
+  const int bm = tid >> 3, jj = tid & 7, b = b0 + bm, j = j0 + jj;
+  const bool ok = b < B;
+  const long bb = ok ? b : 0;
+  const int ln = lens[bb];
+  float dcr = 0.f;                                              // d(cell state) carried across steps
+  // operands of the first step
+  float n_dy, n_g[4], n_c, n_cp;
+  {
+    const int t = dir ? 0 : T - 1;
+    const int prev_blk = dir ? t + 2 : t;
+    n_dy = dy[((long)t * B + bb) * H2 + dir * H + j];
+    const float* gp0 = G + ((long)t * B + bb) * K4 + j;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) n_g[g] = gp0[g * H];
+    n_c = cbuf[((long)(t + 1) * B + bb) * H2 + dir * H + j];
+    n_cp = cbuf[((long)prev_blk * B + bb) * H2 + dir * H + j];
+  }
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? s : T - 1 - s;
+    float dh = n_dy;
+    const float gi = n_g[0], gf = n_g[1], gg = n_g[2], go = n_g[3], c = n_c, cp = n_cp;
+    if (s + 1 < T) {                               // next step's operands: in flight during this step
+      const int tn = dir ? t + 1 : t - 1;
+      const int pbn = dir ? tn + 2 : tn;
+      n_dy = dy[((long)tn * B + bb) * H2 + dir * H + j];
+      const float* gpn = G + ((long)tn * B + bb) * K4 + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) n_g[g] = gpn[g * H];
+      n_c = cbuf[((long)(tn + 1) * B + bb) * H2 + dir * H + j];
+      n_cp = cbuf[((long)pbn * B + bb) * H2 + dir * H + j];
+    }
+    if (s > 0) {
+      // ---- wait for the NX producers of step s-1, then sum their partials for (b, j) ----
+      if (wid == 0) {
+        const gu32* fl = flags + ((s & 1) ^ 1) * f_par + f_grp + (long)(lane < NX ? lane : 0) * 32;
+        const gu32* fl2 = flags + ((s & 1) ^ 1) * f_par + f_grp + (long)(lane + 64 < NX ? lane + 64 : 0) * 32;
+        for (unsigned spins = 0;; ++spins) {
+          bool good = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)s;
+          if (NX > 64) good &= __hip_atomic_load(fl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)s;
+          if (__all(good)) break;
+          if (spins > kSpinLimit) { if (lane == 0) { aborted = 1; atomicExch(err, 1u); } break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      if (aborted) break;
+      const gu32* q = (const gu32*)(xg + ((s & 1) ^ 1) * x_par) + (long)x * NX * 256 + jj * 32 + bm;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int xx = 0;
+      for (; xx + 8 <= NX; xx += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __uint_as_float(__hip_atomic_load(q + (long)(xx + u) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        a0 += v[0] + v[4]; a1 += v[1] + v[5]; a2 += v[2] + v[6]; a3 += v[3] + v[7];
+      }
+      for (; xx < NX; ++xx) a0 += __uint_as_float(__hip_atomic_load(q + (long)xx * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      dh += (a0 + a1) + (a2 + a3);
+    }
+    // ---- cell backward ----
+    float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = dcr;
+    if (ok && t < ln) {
+      float tc = tanhf_(c);
+      float dct = dh * go * (1.f - tc * tc) + dcr;
+      dout = dh * tc * go * (1.f - go);
+      di = dct * gg * gi * (1.f - gi);
+      df = dct * cp * gf * (1.f - gf);
+      dg = dct * gi * (1.f - gg * gg);
+      dcp = dct * gf;
+    }
+    dcr = dcp;
+    if (ok) {
+      float* gp = G + ((long)t * B + b) * K4 + j;
+      gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dout;
+    }
+    dgs[bm * 36 + jj] = di; dgs[bm * 36 + 8 + jj] = df; dgs[bm * 36 + 16 + jj] = dg; dgs[bm * 36 + 24 + jj] = dout;
+    __syncthreads();
+    if (s == T - 1) break;                         // nothing consumes the last partials
+    // ---- produce: P_x = dG_x . W_hh[n in x][:] , written write-through in the consumers' order ----
+    f32x4 a4[4];
+#pragma unroll
+    for (int Q = 0; Q < 4; ++Q) a4[Q] = *reinterpret_cast<const f32x4*>(dgs + lr * 36 + 8 * Q + 4 * lh);
+    float* xw = xg + (s & 1) * x_par;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const int jt = wid + 4 * u;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int Q = 0; Q < 4; ++Q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[Q][i], wreg[u][Q][i], acc, 0, 0, 0);
+      if (jt < njt && 32 * jt + lr < H) {
+        // column j = 32 jt + lr -> consumer x'' = 4 jt + (lr >> 3), unit lr & 7; rows (r&3) + 8 (r>>2) + 4 lh: 4 consecutive b per store
+        float* dst = xw + ((long)(4 * jt + (lr >> 3)) * NX + x) * 256 + (lr & 7) * 32 + 4 * lh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f32x4 v = {acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]};
+          store16_sc1(dst + 8 * k, v);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains before the barrier ...
+    __syncthreads();
+    if (tid == 0)                                               // ... behind which ONE lane publishes the step tag
+      __hip_atomic_store(flags + (s & 1) * f_par + f_grp + (long)x * 32, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (ok) dc_state[(long)b * H2 + dir * H + j] = dcr;
+  if (aborted && ok) {                              // a peer never published: make the failure visible downstream
+    for (int t = 0; t < T; ++t) G[((long)t * B + b) * K4 + j] = __uint_as_float(0x7fc00000u);
+  }
+}
+
 __global__ void zero_kernel(float* p, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
 }
@@ -402,6 +563,8 @@ size_t bwd_ws_floats(int B, int H) {
   long MT = (B + 31) / 32, NX = H / 8, njt = (H + 31) / 32;
   return (size_t)2 * NX * njt * 1024 + (size_t)2 * 2 * MT * NX * NX * 256;
 }
+// persistent backward: + header (16 B: error word) + flag lines [2][2][MT][NX] x 128 B
+size_t bwd_flag_bytes(int B, int H) { long MT = (B + 31) / 32, NX = H / 8; return 16 + (size_t)2 * 2 * MT * NX * 128; }
 
 template <int W>
 void launch_fwd(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, float* ybuf, float* cbuf, float* hfrag, const int* lens,
@@ -442,6 +605,33 @@ bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* w
   return true;
 }
 
+template <int TPW>
+bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs,
+                        void* flagmem, size_t flagbytes, const int* lens, int T, int B, int H) {
+  dim3 grid(H / 8, cdiv(B, 32), 2);
+  if ((long)grid.x * grid.y * grid.z > cu_count()) return false;          // every workgroup must be resident
+  (void)hipMemsetAsync(flagmem, 0, flagbytes, st);
+  unsigned* err = (unsigned*)flagmem;
+  unsigned* flags = (unsigned*)((char*)flagmem + 16);
+  hipLaunchKernelGGL((lstm_bwd_persist<TPW>), grid, dim3(256), 0, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
+  return true;
+}
+
+bool try_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs,
+                     void* flagmem, size_t flagbytes, const int* lens, int T, int B, int H) {
+  const char* v = getenv("RE2E_LSTM_PERSIST_BWD");
+  const char* mh = getenv("RE2E_LSTM_PERSIST_BWD_MAXH");
+  if ((v && atoi(v) == 0) || T < 2 || H / 8 > 128 || H > (mh ? atoi(mh) : 384)) return false;   // wider layers are bound by the slab traffic: launch per step is faster there
+  const int njt = (H + 31) / 32, tpw = (njt + 3) / 4;
+  switch (tpw) {
+    case 1: return launch_bwd_persist<1>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
+    case 2: return launch_bwd_persist<2>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
+    case 3: return launch_bwd_persist<3>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
+    case 4: return launch_bwd_persist<4>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
+    default: return false;
+  }
+}
+
 // RE2E_LSTM_PERSIST=0 keeps the launch-per-step form (also used for shapes the persistent kernel does not cover)
 bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, float* ybuf, float* cbuf, void* hxmem, size_t hxbytes,
                      const int* lens, int T, int B, int H) {
@@ -457,7 +647,7 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
 }  // namespace
 
 extern "C" size_t re2e_lstm_workspace_bytes(int B, int H) {
-  size_t a = fwd_ws_floats(B, H) * sizeof(float) + fwd_hx_bytes(B, H), b = bwd_ws_floats(B, H) * sizeof(float);
+  size_t a = fwd_ws_floats(B, H) * sizeof(float) + fwd_hx_bytes(B, H), b = bwd_ws_floats(B, H) * sizeof(float) + bwd_flag_bytes(B, H);
   return a > b ? a : b;
 }
 
@@ -498,7 +688,7 @@ extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, con
   RE2E_CHECK_ARG(g_f && g_r && whh_f && whh_r && dy && cbuf && dc_state && lens_dev && workspace, "null arg");
   RE2E_CHECK_ARG(T > 0 && B > 0 && H > 0, "bad shape");
   if (H % 8 != 0) { re2e_set_error("re2e_lstm_seq_bwd: hidden size must be a multiple of 8 (got %d)", H); return RE2E_EUNSUPPORTED; }
-  RE2E_CHECK_ARG(workspace_bytes >= bwd_ws_floats(B, H) * sizeof(float), "workspace too small");
+  RE2E_CHECK_ARG(workspace_bytes >= bwd_ws_floats(B, H) * sizeof(float) + bwd_flag_bytes(B, H), "workspace too small");
   long wn = (long)(H / 8) * ((H + 31) / 32) * 1024;
   float* wb = (float*)workspace;
   float* slabs = wb + 2 * wn;
@@ -506,6 +696,11 @@ extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, con
   hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wb + wn, H);
   long nz = (long)B * 2 * H;
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(nz, 256)), dim3(256), 0, stream, dc_state, nz);
+  void* flagmem = (char*)workspace + bwd_ws_floats(B, H) * sizeof(float);
+  if (try_bwd_persist(stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, flagmem, bwd_flag_bytes(B, H), lens_dev, T, B, H)) {
+    RE2E_LAUNCH_CHECK();
+    return RE2E_OK;
+  }
   if (H / 32 >= 8) launch_bwd<2>(stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, lens_dev, T, B, H);
   else launch_bwd<1>(stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, lens_dev, T, B, H);
   RE2E_LAUNCH_CHECK();

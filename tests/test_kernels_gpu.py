@@ -292,6 +292,23 @@ def test_lstm_persistent_vs_stepwise(B, T, H, monkeypatch):
     for name, a, b in zip(('gates_f', 'gates_r', 'y', 'c'), outs['0'], outs['1']):
         assert torch.isfinite(b).all(), name
         close(name, b, a, tol=2e-6)
+    # backward: persistent (flagged write-through hand-off of the partial slabs) against launch-per-step, from the same forward state
+    gf, gr, ybuf, cbuf = outs['0']
+    dy = (torch.randn(T * B, 2 * H, generator=g) * 0.3).to(DEV)
+    bouts = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('RE2E_LSTM_PERSIST_BWD', mode)
+        ws = torch.full((wsb // 4 + 16,), float('nan'), device=DEV)
+        for _ in range(2):
+            G = [gf.clone(), gr.clone()]
+            dc = torch.full((B, 2 * H), float('nan'), device=DEV)
+            lib.call('re2e_lstm_seq_bwd', G[0].data_ptr(), G[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
+                     cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+        torch.cuda.synchronize()
+        bouts[mode] = (G[0], G[1])
+    for name, a, b in zip(('dgates_f', 'dgates_r'), bouts['0'], bouts['1']):
+        assert torch.isfinite(b).all(), name
+        close(name, b, a, tol=5e-6)
 
 
 def test_ctc():

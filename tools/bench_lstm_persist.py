@@ -49,6 +49,30 @@ def run(T, B, H, ragged=False, which='fwd'):
             res.append(best)
         out[mode] = (xg, ybuf, cbuf)
         print('T=%d B=%d H=%d %s persist=%s: %.2f us/step alone, %.2f us/step beside filler GEMMs' % (T, B, H, 'ragged' if ragged else 'full', mode, res[0], res[1]), flush=True)
+    # backward: persistent vs stepwise from the forward state of the last run
+    xgf, ybuf, cbuf = out['1']
+    dy = torch.randn(T * B, 2 * H, device=dev) * 0.3
+    bout = {}
+    prio = torch.cuda.Stream()
+    for mode in ('0', '1'):
+        os.environ['RE2E_LSTM_PERSIST_BWD'] = mode
+        best = 1e9
+        for rep in range(3):
+            G = [x.clone() for x in xgf]
+            dc = torch.zeros(B, 2 * H, device=dev)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(prio):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                call('re2e_lstm_seq_bwd', G[0].data_ptr(), G[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
+                     cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+                e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / T)
+        bout[mode] = G
+        print('T=%d B=%d H=%d bwd persist=%s: %.2f us/step alone' % (T, B, H, mode, best), flush=True)
+    bd = [float((bout['0'][d] - bout['1'][d]).abs().max()) for d in range(2)]
+    print('   bwd max |diff| dgates_f %.3g dgates_r %.3g%s' % (bd[0], bd[1], '' if all(torch.isfinite(t).all() for t in bout['1']) else '  NON-FINITE'), flush=True)
     a, b = out['0'], out['1']
     diffs = [float((a[0][0] - b[0][0]).abs().max()), float((a[0][1] - b[0][1]).abs().max()), float((a[1] - b[1]).abs().max()),
              float((a[2] - b[2]).abs().max())]
