@@ -26,6 +26,7 @@ namespace {
 constexpr int TCH = 32;        // frames per workgroup
 constexpr int NTH = 256;       // threads per workgroup (4 wavefronts)
 constexpr int NWV = NTH / 64;
+constexpr int FPW = TCH / NWV; // frames per wavefront
 constexpr int CG = 5;          // conv channels per work item
 constexpr int CMAX = 12;       // max conv channels held in registers
 constexpr int AIMAX = 5;       // max ceil(adim/64)
@@ -79,6 +80,15 @@ __global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hl = hlens[b];
+  // pre rows of this wavefront's 8 frames: issued first, in flight while the location conv runs
+  float pv[FPW][AIMAX];
+#pragma unroll
+  for (int k = 0; k < FPW; ++k) {
+    const int l = wid + NWV * k;
+    const float* pr = pre + ((long)b * T + t0 + (l < nt ? l : 0)) * A;
+#pragma unroll
+    for (int i = 0; i < AIMAX; ++i) { int a = lane + 64 * i; pv[k][i] = a < A ? pr[a] : 0.f; }
+  }
   for (int i = tid; i < C * Kf; i += NTH) wcs[i] = w_conv[i];
   for (int i = tid; i < TCH + 2 * F; i += NTH) {
     int t = t0 + i - F;
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restr
     int t = i / C, c = i % C;
     conv_out[((long)b * T + t0 + t) * C + c] = cv[t * CP + c];
   }
-  // energies: one wavefront per frame pair, lanes over the attention dimension
+  // energies: a wavefront takes its 8 frames one after the other, lanes over the attention dimension
   float wa[AIMAX][CMAX], gv[AIMAX], dpv[AIMAX];
 #pragma unroll
   for (int i = 0; i < AIMAX; ++i) {
@@ -131,39 +141,25 @@ __global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restr
     for (int c = 0; c < CMAX; ++c) wa[i][c] = (a < A && c < C) ? w_att[a * C + c] : 0.f;
   }
   const float gb = gvec_b[0];
-  for (int tb = wid; tb < nt; tb += 2 * NWV) {
-    const int l0 = tb, l1 = tb + NWV;
-    const bool h1 = l1 < nt;
-    const float* pr0 = pre + ((long)b * T + t0 + l0) * A;
-    const float* pr1 = pre + ((long)b * T + t0 + (h1 ? l1 : l0)) * A;
-    float p0[AIMAX], p1[AIMAX];
 #pragma unroll
-    for (int i = 0; i < AIMAX; ++i) {
-      int a = lane + 64 * i;
-      p0[i] = a < A ? pr0[a] : 0.f;
-      p1[i] = a < A ? pr1[a] : 0.f;
-    }
-    float c0v[CMAX], c1v[CMAX];
+  for (int k = 0; k < FPW; ++k) {
+    const int l = wid + NWV * k;
+    float cvv[CMAX];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) { c0v[c] = c < C ? cv[l0 * CP + c] : 0.f; c1v[c] = (c < C && h1) ? cv[l1 * CP + c] : 0.f; }
-    float s0 = 0.f, s1 = 0.f;
+    for (int c = 0; c < CMAX; ++c) cvv[c] = (c < C && l < nt) ? cv[l * CP + c] : 0.f;
+    float sv = 0.f;
 #pragma unroll
     for (int i = 0; i < AIMAX; ++i) {
       int a = lane + 64 * i;
       if (a < A) {
-        float x0 = p0[i] + dpv[i], x1 = p1[i] + dpv[i];
+        float x = pv[k][i] + dpv[i];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) { x0 += wa[i][c] * c0v[c]; x1 += wa[i][c] * c1v[c]; }
-        s0 += gv[i] * tanhf_(x0);
-        s1 += gv[i] * tanhf_(x1);
+        for (int c = 0; c < CMAX; ++c) x += wa[i][c] * cvv[c];
+        sv += gv[i] * tanhf_(x);
       }
     }
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
-    if (lane == 0) {
-      e_out[(long)b * T + t0 + l0] = s0 + gb;
-      if (h1) e_out[(long)b * T + t0 + l1] = s1 + gb;
-    }
+    sv = wave_sum(sv);
+    if (lane == 0 && l < nt) e_out[(long)b * T + t0 + l] = sv + gb;
   }
 }
 
@@ -227,7 +223,6 @@ __global__ __launch_bounds__(NTH) void attloc_context_kernel(const float* __rest
 // kernel entry, enc rows four frames at a time); du goes through LDS so that both contractions read it without a
 // single cross-lane reduction.
 // ---------------------------------------------------------------------------------------------
-constexpr int FPW = TCH / NWV;     // frames per wavefront
 __host__ __device__ __forceinline__ int du_stride(int A) { return A | 1; }      // odd: column reads hit 32 different banks
 
 __global__ __launch_bounds__(NTH) void attloc_bwd_frames_kernel(

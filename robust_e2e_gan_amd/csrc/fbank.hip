@@ -62,34 +62,38 @@ __global__ __launch_bounds__(256) void fbank_bwd_kernel(const float* __restrict_
       if (f >= so[j] && f < so[j] + sl[j]) { lo = j < lo ? j : lo; hi = j; }
     jlo[f] = lo; jhi[f] = hi;
   }
+  // thread = (row r of the group, lane q of 32): no integer division anywhere, every global access a 128-byte row segment
+  const int r = threadIdx.x >> 5, q = threadIdx.x & 31;
   long ngroups = (rows + RB - 1) / RB;
   for (long gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
     long r0 = gi * RB;
     int nr = (int)((rows - r0) < RB ? (rows - r0) : RB);
+    const bool on = r < nr;
     __syncthreads();
-    for (int i = threadIdx.x; i < nr * F; i += blockDim.x) xs[i / F][i % F] = x[r0 * F + i];
+    if (on)
+      for (int f = q; f < F; f += 32) xs[r][f] = x[(r0 + r) * F + f];
     __syncthreads();
-    for (int i = threadIdx.x; i < nr * NF; i += blockDim.x) {
-      int r = i / NF, j = i % NF;
-      float s = 0.f;
-      int o = so[j], l = sl[j];
-      for (int t = 0; t < l; ++t) { float v = xs[r][o + t]; s += v * v * ws[j * maxw + t]; }
-      long oidx = (r0 + r) * NF + j;
-      float gy = 0.f;
-      if (dy_raw) gy += dy_raw[oidx];
-      if (dy_norm) gy += dy_norm[oidx] * cmvn[NF + j];
-      gs[r][j] = s > 1e-7f ? gy / s : 0.f;     // in-place clamp => zero gradient (feat_model.py:130)
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nr * F; i += blockDim.x) {
-      int r = i / F, f = i % F;
-      float s = 0.f;
-      for (int j = jlo[f]; j <= jhi[f]; ++j) {
-        int t = f - so[j];
-        if (t >= 0 && t < sl[j]) s += ws[j * maxw + t] * gs[r][j];
+    if (on)
+      for (int j = q; j < NF; j += 32) {
+        float s = 0.f;
+        int o = so[j], l = sl[j];
+        for (int t = 0; t < l; ++t) { float v = xs[r][o + t]; s += v * v * ws[j * maxw + t]; }
+        long oidx = (r0 + r) * NF + j;
+        float gy = 0.f;
+        if (dy_raw) gy += dy_raw[oidx];
+        if (dy_norm) gy += dy_norm[oidx] * cmvn[NF + j];
+        gs[r][j] = s > 1e-7f ? gy / s : 0.f;     // in-place clamp => zero gradient (feat_model.py:130)
       }
-      dx[r0 * F + i] = 2.f * xs[r][f] * s;
-    }
+    __syncthreads();
+    if (on)
+      for (int f = q; f < F; f += 32) {
+        float s = 0.f;
+        for (int j = jlo[f]; j <= jhi[f]; ++j) {
+          int t = f - so[j];
+          if (t >= 0 && t < sl[j]) s += ws[j * maxw + t] * gs[r][j];
+        }
+        dx[(r0 + r) * F + f] = 2.f * xs[r][f] * s;
+      }
   }
 }
 
@@ -131,7 +135,7 @@ extern "C" int re2e_fbank_bwd(const float* x, long rows, int F, int NF, const in
   RE2E_CHECK_ARG(rows > 0 && F > 0 && F <= MAXF && NF > 0 && NF <= MAXNF && maxw > 0 && maxw <= MAXW, "shape out of range");
   RE2E_CHECK_ARG(!dy_norm || cmvn, "dy_norm requires cmvn");
   long ngroups = (rows + RB - 1) / RB;
-  int grid = (int)(ngroups < 2048 ? ngroups : 2048);
+  int grid = (int)(ngroups < 1024 ? ngroups : 1024);     // the band-table prologue is paid once per workgroup
   hipLaunchKernelGGL(fbank_bwd_kernel, dim3(grid), dim3(256), 0, stream, x, rows, F, NF, band_off, band_len, band_w, maxw, dy_raw,
                      dy_norm, cmvn, dx);
   RE2E_LAUNCH_CHECK();
