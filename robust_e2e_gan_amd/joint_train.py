@@ -75,7 +75,10 @@ class JointTrainer(object):
         if torch.cuda.is_available():
             # filler streams: optionally restricted to a subset of the CUs (RE2E_FILLER_CUS, default all) so that the
             # chains on the main stream always find idle CUs
-            ncu = int(os.environ.get('RE2E_FILLER_CUS', '224'))     # MI355X sweep: 128: 112.5, 160: 103.1, 192: 99.6, 224: 98.0, 256: 99.5 ms/step
+            # MI355X sweeps (ms/step).  With launch-per-step recurrences: 128: 112.5, 160: 103.1, 192: 99.6, 224: 98.0, 256: 99.5.
+            # With the persistent recurrences: 192: 90.6, 208: 91.2, 224: 89.0, 240: 90.1, 256 (no mask): 88.2 -- resident
+            # chains no longer need CUs kept free for their launches, so the fillers get the whole chip.
+            ncu = int(os.environ.get('RE2E_FILLER_CUS', '256'))
             dev = next(enhance_model.parameters()).device
             if 0 < ncu < 256:
                 self.side_stream = lib.cu_masked_stream(ncu, 256, dev)
