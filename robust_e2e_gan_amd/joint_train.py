@@ -91,7 +91,8 @@ class JointTrainer(object):
             # + wgrad + one more) is multiplexed onto an occupied queue and serialises against it (measured with a
             # dedicated D-step stream: 91 -> 155 ms/step).  Measured and rejected as well: running the D-step's
             # forward/backward early, under the ASR forward (+2.3 ms/step: it slows the encoder chain more than it
-            # relieves the backward); a dedicated stream for the recurrent sequences masked to the 32 CUs the fillers leave
+            # relieves the backward) -- and again with the persistent recurrences, only the FAKE half, started exactly when the
+            # encoder's chain starts: ASR forward +3.9 ms, enhancer backward -2.7 ms, step 88.9 -> 91.0 ms; a dedicated stream for the recurrent sequences masked to the 32 CUs the fillers leave
             # alone (GPU_MAX_HW_QUEUES=8): the chains are no faster there (16.9 vs 18 ms for the enhancer forward under the
             # D(real) filler -- the slowdown under load is not CU sharing) and 256-workgroup sequences do not fit 32 CUs.
         self.main_stream = None
@@ -113,14 +114,18 @@ class JointTrainer(object):
         With overlap enabled the critical path (recurrent chains, decoder) runs on a HIGH-priority stream and the
         filler work (clean-branch convs, discriminator passes, weight gradients) on normal-priority streams, so
         that the short dependent launches of the chains are dispatched ahead of queued bulk kernels."""
-        if not (self.overlap_dstep and self.main_stream is not None):
-            return self._step(data, sche_samp_rate, enhance_cmvn)
-        caller = torch.cuda.current_stream()
-        self.main_stream.wait_stream(caller)
-        with torch.cuda.stream(self.main_stream):
-            out = self._step(data, sche_samp_rate, enhance_cmvn)
-        caller.wait_stream(self.main_stream)
-        return out
+        try:
+            if not (self.overlap_dstep and self.main_stream is not None):
+                return self._step(data, sche_samp_rate, enhance_cmvn)
+            caller = torch.cuda.current_stream()
+            self.main_stream.wait_stream(caller)
+            with torch.cuda.stream(self.main_stream):
+                out = self._step(data, sche_samp_rate, enhance_cmvn)
+            caller.wait_stream(self.main_stream)
+            return out
+        finally:
+            # the stream routing is this step's: ops used outside it (validation, other trainers, tests) stay on ONE stream
+            ops.MULTI_STREAM, ops.WGRAD_STREAM, ops.AUX_STREAM, ops.MARKS = False, None, None, None
 
     def _mark(self, label):
         """RE2E_TIMELINE=1: remember (label, host time, event on the current stream) -- ``timeline()`` prints how far the
