@@ -186,6 +186,9 @@ def test_joint_step_overlap_equals_single_stream(golden_dir):
         tr.overlap_dstep = overlap
         tr.step(data, 0.0, t('cmvn'))
         torch.cuda.synchronize()
+        from robust_e2e_gan_amd import ops
+        # the step's stream routing must not leak into whatever runs next in the process (validation, other trainers)
+        assert ops.MULTI_STREAM is False and ops.WGRAD_STREAM is None and ops.AUX_STREAM is None
         grads[overlap] = {n + '.' + k: p.grad.clone() for n, m in (('enh', enh), ('asr', asr), ('gan', gan)) for k, p in m.named_parameters()}
     for k, ref in grads[False].items():
         rel(k, grads[True][k], ref.cpu().numpy(), tol=2e-5, atol=1e-9)
