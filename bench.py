@@ -200,6 +200,12 @@ def main():
         dt = float(tmax.item())
     log('timed region done: %.3fs for %d steps (host enqueue %.1f ms/step)' % (dt, a.steps, host / a.steps * 1e3))
     losses = JointTrainer.to_floats(out)
+    from robust_e2e_gan_amd import lib as re2e_lib
+    aborts = re2e_lib.query('re2e_lstm_abort_count')
+    if aborts != 0:        # a persistent recurrence gave up on a peer workgroup: its outputs are NaN, the numbers mean nothing
+        raise SystemExit('bench: %d recurrent sequences were aborted by a persistent kernel (rank %d)' % (aborts, rank))
+    if not all(v == v and abs(v) != float('inf') for v in losses.values()):
+        raise SystemExit('bench: non-finite losses after the timed region: %r' % (losses,))
     if rank != 0:
         return
     value = B * world * a.steps / dt
@@ -211,7 +217,7 @@ def main():
                                'VGG+3xBLSTMP-512, loc-attention decoder 300, D basic ndf64, Adadelta' % (B, T, L),
                    'global_batch': B * world, 'parallelism': 'dp%d' % world, 'coral_loss_lambda': opt.coral_loss_lambda},
         'step_mfma_frac': round(value * FLOP_PER_UTT['config4'] / (world * PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if (B, T, L) == (32, 800, 40) else None,
-        'final_losses': {k: round(v, 5) for k, v in losses.items()},
+        'final_losses': {k: round(v, 5) for k, v in losses.items()}, 'persistent_kernel_aborts': aborts,
     }
     if not a.no_roofline:
         line['roofline'] = conv_roofline(dev)

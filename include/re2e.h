@@ -182,6 +182,10 @@ int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C, const floa
  * (gate order i,f,g,o) on entry and the ACTIVATED gates on exit (saved for the backward);
  * ybuf/cbuf are [(T+2)*B, 2H] with block 0 and block T+1 zero: y[t] lives in block t+1. */
 size_t re2e_lstm_workspace_bytes(int B, int H);
+/* Number of sequences (since the library was loaded) that a persistent recurrence kernel gave up on because a peer
+ * workgroup never published its step (bounded spin; the outputs of such a sequence are NaN).  0 in a healthy run.
+ * Synchronises the device; -1 if the counter cannot be read. */
+int re2e_lstm_abort_count(void);
 int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
                       const int* lens_dev, int T, int B, int H, void* workspace, size_t workspace_bytes,
                       re2e_stream_t stream);

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_step(float* xg_f, float* 
 // launcher: grid <= CUs); spins are bounded and poison the output instead of hanging.
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
+__device__ unsigned g_persist_aborts = 0;      // sequences given up because a peer workgroup never published (re2e_lstm_abort_count)
 constexpr unsigned kSpinLimit = 1u << 16;      // sweeps (~1 us each) before a workgroup gives up on a peer
 
 template <int WAVES, int QN>
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
             good &= (unsigned)(g >> 32) == (unsigned)s;
           }
         if (__all(good)) break;
-        if (spins > kSpinLimit) { if (lane == 0) { red[kAbort] = 1.f; atomicExch(err, 1u); } break; }
+        if (spins > kSpinLimit) { if (lane == 0) { red[kAbort] = 1.f; if (atomicExch(err, 1u) == 0u) atomicAdd(&g_persist_aborts, 1u); } break; }
         __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
           bool good = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)s;
           if (NX > 64) good &= __hip_atomic_load(fl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)s;
           if (__all(good)) break;
-          if (spins > kSpinLimit) { if (lane == 0) { aborted = 1; atomicExch(err, 1u); } break; }
+          if (spins > kSpinLimit) { if (lane == 0) { aborted = 1; if (atomicExch(err, 1u) == 0u) atomicAdd(&g_persist_aborts, 1u); } break; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -649,6 +650,12 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
 extern "C" size_t re2e_lstm_workspace_bytes(int B, int H) {
   size_t a = fwd_ws_floats(B, H) * sizeof(float) + fwd_hx_bytes(B, H), b = bwd_ws_floats(B, H) * sizeof(float) + bwd_flag_bytes(B, H);
   return a > b ? a : b;
+}
+
+extern "C" int re2e_lstm_abort_count(void) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_persist_aborts), sizeof(n)) != hipSuccess) return -1;     // (synchronises the device)
+  return (int)n;
 }
 
 extern "C" int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,

@@ -61,6 +61,7 @@ SIGNATURES = {
     're2e_bn_lrelu_fwd': (I, [P, L, I, P, P, P, P, F, F, I, P, P, P, P, Z, P]),
     're2e_bn_lrelu_bwd': (I, [P, P, L, I, P, P, P, P, P, P, P, F, P, Z, P]),
     're2e_lstm_workspace_bytes': (Z, [I, I]),
+    're2e_lstm_abort_count': (I, []),
     're2e_lstm_seq_fwd': (I, [P, P, P, P, P, P, P, I, I, I, P, Z, P]),
     're2e_lstm_seq_bwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P]),
     're2e_lstm_cell_fwd': (I, [P, P, P, P, I, I, P]),

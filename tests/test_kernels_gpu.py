@@ -309,6 +309,7 @@ def test_lstm_persistent_vs_stepwise(B, T, H, monkeypatch):
     for name, a, b in zip(('dgates_f', 'dgates_r'), bouts['0'], bouts['1']):
         assert torch.isfinite(b).all(), name
         close(name, b, a, tol=5e-6)
+    assert lib.query('re2e_lstm_abort_count') == 0
 
 
 def test_ctc():
