@@ -43,31 +43,29 @@ __global__ __launch_bounds__(256) void fbank_fwd_kernel(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void fbank_bwd_kernel(const float* __restrict__ x, long rows, int F, int NF,
+// Backward.  Small on purpose (128 threads, 4 frames per pass, ~14 KB of LDS, band weights read through the cache): it sits on the
+// critical path between two chip-filling phases and must find room beside the filler streams' workgroups.
+constexpr int RBB = 4;         // frames per pass of the backward kernel
+__global__ __launch_bounds__(128) void fbank_bwd_kernel(const float* __restrict__ x, long rows, int F, int NF,
                                                         const int* __restrict__ boff, const int* __restrict__ blen,
                                                         const float* __restrict__ bw, int maxw, const float* __restrict__ dy_raw,
                                                         const float* __restrict__ dy_norm, const float* __restrict__ cmvn,
                                                         float* __restrict__ dx) {
-  __shared__ float xs[RB][MAXF];      // x (not squared)
-  __shared__ float gs[RB][MAXNF];     // dL/dP_j = gy_j / P_j (0 where clamped)
-  __shared__ float ws[MAXNF * MAXW];
+  __shared__ float xs[RBB][MAXF];     // x (not squared)
+  __shared__ float gs[RBB][MAXNF];    // dL/dP_j = gy_j / P_j (0 where clamped)
   __shared__ int so[MAXNF], sl[MAXNF];
   __shared__ int jlo[MAXF], jhi[MAXF];
-  for (int i = threadIdx.x; i < NF * maxw; i += blockDim.x) ws[i] = bw[i];
   for (int i = threadIdx.x; i < NF; i += blockDim.x) { so[i] = boff[i]; sl[i] = blen[i]; }
+  for (int f = threadIdx.x; f < F; f += blockDim.x) { jlo[f] = NF; jhi[f] = -1; }
   __syncthreads();
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {     // filters covering bin f form a contiguous j range
-    int lo = NF, hi = -1;
-    for (int j = 0; j < NF; ++j)
-      if (f >= so[j] && f < so[j] + sl[j]) { lo = j < lo ? j : lo; hi = j; }
-    jlo[f] = lo; jhi[f] = hi;
-  }
-  // thread = (row r of the group, lane q of 32): no integer division anywhere, every global access a 128-byte row segment
+  for (int j = threadIdx.x; j < NF; j += blockDim.x)          // filters covering bin f form a contiguous j range
+    for (int t = 0; t < sl[j]; ++t) { atomicMin(&jlo[so[j] + t], j); atomicMax(&jhi[so[j] + t], j); }
+  // thread = (row r of the pass, lane q of 32): no integer division anywhere, every global access a 128-byte row segment
   const int r = threadIdx.x >> 5, q = threadIdx.x & 31;
-  long ngroups = (rows + RB - 1) / RB;
+  long ngroups = (rows + RBB - 1) / RBB;
   for (long gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
-    long r0 = gi * RB;
-    int nr = (int)((rows - r0) < RB ? (rows - r0) : RB);
+    long r0 = gi * RBB;
+    int nr = (int)((rows - r0) < RBB ? (rows - r0) : RBB);
     const bool on = r < nr;
     __syncthreads();
     if (on)
@@ -77,7 +75,7 @@ __global__ __launch_bounds__(256) void fbank_bwd_kernel(const float* __restrict_
       for (int j = q; j < NF; j += 32) {
         float s = 0.f;
         int o = so[j], l = sl[j];
-        for (int t = 0; t < l; ++t) { float v = xs[r][o + t]; s += v * v * ws[j * maxw + t]; }
+        for (int t = 0; t < l; ++t) { float v = xs[r][o + t]; s += v * v * bw[j * maxw + t]; }
         long oidx = (r0 + r) * NF + j;
         float gy = 0.f;
         if (dy_raw) gy += dy_raw[oidx];
@@ -90,7 +88,7 @@ __global__ __launch_bounds__(256) void fbank_bwd_kernel(const float* __restrict_
         float s = 0.f;
         for (int j = jlo[f]; j <= jhi[f]; ++j) {
           int t = f - so[j];
-          if (t >= 0 && t < sl[j]) s += ws[j * maxw + t] * gs[r][j];
+          if (t >= 0 && t < sl[j]) s += bw[j * maxw + t] * gs[r][j];
         }
         dx[(r0 + r) * F + f] = 2.f * xs[r][f] * s;
       }
@@ -134,9 +132,9 @@ extern "C" int re2e_fbank_bwd(const float* x, long rows, int F, int NF, const in
   RE2E_CHECK_ARG(x && band_off && band_len && band_w && dx && (dy_raw || dy_norm), "null arg");
   RE2E_CHECK_ARG(rows > 0 && F > 0 && F <= MAXF && NF > 0 && NF <= MAXNF && maxw > 0 && maxw <= MAXW, "shape out of range");
   RE2E_CHECK_ARG(!dy_norm || cmvn, "dy_norm requires cmvn");
-  long ngroups = (rows + RB - 1) / RB;
-  int grid = (int)(ngroups < 1024 ? ngroups : 1024);     // the band-table prologue is paid once per workgroup
-  hipLaunchKernelGGL(fbank_bwd_kernel, dim3(grid), dim3(256), 0, stream, x, rows, F, NF, band_off, band_len, band_w, maxw, dy_raw,
+  long ngroups = (rows + RBB - 1) / RBB;
+  int grid = (int)(ngroups < 2048 ? ngroups : 2048);
+  hipLaunchKernelGGL(fbank_bwd_kernel, dim3(grid), dim3(128), 0, stream, x, rows, F, NF, band_off, band_len, band_w, maxw, dy_raw,
                      dy_norm, cmvn, dx);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
