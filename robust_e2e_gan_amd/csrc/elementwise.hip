@@ -69,8 +69,17 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
   const int cx = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cx;
   float s = 0.f;
-  if (col < N)
-    for (int c = cl; c < chunks; c += 16) s += part[(long)c * N + col];
+  if (col < N) {
+    // 8 independent loads in flight per thread (a single workgroup reads up to 512 KB of partials: latency-bound otherwise)
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int c = cl;
+    for (; c + 7 * 16 < chunks; c += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += part[(long)(c + 16 * u) * N + col];
+    }
+    for (; c < chunks; c += 16) a[0] += part[(long)c * N + col];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
   red[cl][cx] = s;
   __syncthreads();
   if (cl != 0 || col >= N) return;
