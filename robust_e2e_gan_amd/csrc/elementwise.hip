@@ -488,8 +488,18 @@ __global__ __launch_bounds__(1024) void bn_combine_kernel(const float* __restric
   const int cx = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   float s0 = 0.f, s1 = 0.f;
-  if (c < C)
-    for (int k = cl; k < chunks; k += 16) { s0 += part[((long)k * 2 + 0) * C + c]; s1 += part[((long)k * 2 + 1) * C + c]; }
+  if (c < C) {
+    // 4 chunk rows x 2 slots in flight per thread: one or two workgroups read all the partials, so the loop is latency-bound
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = cl;
+    for (; k + 3 * 16 < chunks; k += 4 * 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a0[u] += part[((long)(k + 16 * u) * 2 + 0) * C + c]; a1[u] += part[((long)(k + 16 * u) * 2 + 1) * C + c]; }
+    }
+    for (; k < chunks; k += 16) { a0[0] += part[((long)k * 2 + 0) * C + c]; a1[0] += part[((long)k * 2 + 1) * C + c]; }
+    s0 = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+    s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+  }
   r0[cl][cx] = s0; r1[cl][cx] = s1;
   __syncthreads();
   if (cl != 0 || c >= C) return;
