@@ -189,9 +189,11 @@ def test_conv2d(cfg):
         close('db', bg.grad, br.grad, tol=2e-4)
 
 
-def test_pool_and_pack():
+@pytest.mark.parametrize('C', [6, 8, 64])        # scalar path (C % 4 != 0) and the four-channels-per-thread path
+def test_pool_and_pack(C):
     ops, lib = _ops()
-    x = rnd(3, 6, 37, 21)                     # NCHW
+    x = rnd(3, C, 37, 21)                     # NCHW, odd sizes: ceil-mode windows at both edges
+    x = torch.round(x * 2) / 2                # many ties inside a window: the first maximum in row-major order must win
     xr = x.clone().requires_grad_(True)
     pr = F.max_pool2d(xr, 2, stride=2, ceil_mode=True)
     lens = [19, 12, 5]
