@@ -535,6 +535,65 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, const float* __re
     part[((long)blockIdx.y * 2 + 1) * C + c] = (r1[0][cx] + r1[1][cx]) + (r1[2][cx] + r1[3][cx]);
   }
 }
+// the same for C % 4 == 0: four channels per thread (float4), 16 row lanes per workgroup, two rows in flight per thread
+__global__ __launch_bounds__(256) void bn_partial_vec_kernel(const float* __restrict__ x, const float* __restrict__ dy, long P, int C,
+                                                             long rows_per_chunk, int mode, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float r0[16][64], r1[16][64];
+  const int c4 = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4 * 4;
+  long p0 = (long)blockIdx.y * rows_per_chunk, p1 = p0 + rows_per_chunk; if (p1 > P) p1 = P;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+    const f32x4 mu = mean ? *reinterpret_cast<const f32x4*>(mean + c) : zero;
+    const f32x4 is = invstd ? *reinterpret_cast<const f32x4*>(invstd + c) : one;
+    const f32x4 ga = gamma ? *reinterpret_cast<const f32x4*>(gamma + c) : one;
+    const f32x4 be = beta ? *reinterpret_cast<const f32x4*>(beta + c) : zero;
+#define RE2E_BN_ROW(xv, dv)                                                                   \
+  do {                                                                                        \
+    const f32x4 v_ = (xv) - mu;                                                               \
+    if (mode == 0) s0 += v_;                                                                  \
+    else if (mode == 1) s0 += v_ * v_;                                                        \
+    else {                                                                                    \
+      const f32x4 xh_ = v_ * is;                                                              \
+      const f32x4 y_ = xh_ * ga + be;                                                         \
+      f32x4 dz_;                                                                              \
+      dz_[0] = y_[0] > 0.f ? (dv)[0] : 0.2f * (dv)[0]; dz_[1] = y_[1] > 0.f ? (dv)[1] : 0.2f * (dv)[1]; \
+      dz_[2] = y_[2] > 0.f ? (dv)[2] : 0.2f * (dv)[2]; dz_[3] = y_[3] > 0.f ? (dv)[3] : 0.2f * (dv)[3]; \
+      s0 += dz_; s1 += dz_ * xh_;                                                             \
+    }                                                                                         \
+  } while (0)
+    long p = p0 + ry;
+    for (; p + 16 < p1; p += 32) {
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(x + p * C + c), xb = *reinterpret_cast<const f32x4*>(x + (p + 16) * C + c);
+      f32x4 da = zero, db = zero;
+      if (mode == 2) { da = *reinterpret_cast<const f32x4*>(dy + p * C + c); db = *reinterpret_cast<const f32x4*>(dy + (p + 16) * C + c); }
+      RE2E_BN_ROW(xa, da); RE2E_BN_ROW(xb, db);
+    }
+    for (; p < p1; p += 16) {
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(x + p * C + c);
+      const f32x4 da = mode == 2 ? *reinterpret_cast<const f32x4*>(dy + p * C + c) : zero;
+      RE2E_BN_ROW(xa, da);
+    }
+#undef RE2E_BN_ROW
+  }
+  *reinterpret_cast<f32x4*>(&r0[ry][c4 * 4]) = s0;
+  *reinterpret_cast<f32x4*>(&r1[ry][c4 * 4]) = s1;
+  __syncthreads();
+  const int cx = threadIdx.x;
+  if (cx < 64 && blockIdx.x * 64 + cx < C) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { a0 += r0[q][cx]; a1 += r1[q][cx]; }
+    part[((long)blockIdx.y * 2 + 0) * C + blockIdx.x * 64 + cx] = a0;
+    part[((long)blockIdx.y * 2 + 1) * C + blockIdx.x * 64 + cx] = a1;
+  }
+}
+static inline bool bn_vec_ok(const float* x, const float* dy, int C) {
+  return C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+}
 // stats[0..C) = result of slot 0 summed over chunks * scale0 ; stats[C..2C) = slot 1 * scale1
 // 64 channels x 16 chunk lanes per workgroup, lanes combined through LDS in a fixed order (the serial loop over up to
 // 512 chunks made this tiny kernel 60 us)
@@ -590,6 +649,42 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, long P, int C, cons
     y[i] = v > 0.f ? v : 0.2f * v;
   }
 }
+// float4 forms of the two apply kernels (C % 4 == 0): the channel vectors are loaded once per thread iteration
+__global__ void bn_apply_vec_kernel(const float* __restrict__ x, long P, int C4, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    float* __restrict__ y) {
+  const long tot = P * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const f32x4 m = reinterpret_cast<const f32x4*>(mean)[c], is = reinterpret_cast<const f32x4*>(invstd)[c];
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c], be = reinterpret_cast<const f32x4*>(beta)[c];
+    f32x4 v = (reinterpret_cast<const f32x4*>(x)[i] - m) * is * ga + be;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.2f * v[k];
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+}
+__global__ void bn_bwd_apply_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x, long P, int C4,
+                                        const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, const float* __restrict__ sdz, const float* __restrict__ sdzx,
+                                        float* __restrict__ dx) {
+  const long tot = P * C4;
+  const float invP = 1.0f / (float)P;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const f32x4 m = reinterpret_cast<const f32x4*>(mean)[c], is = reinterpret_cast<const f32x4*>(invstd)[c];
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c], be = reinterpret_cast<const f32x4*>(beta)[c];
+    const f32x4 a = reinterpret_cast<const f32x4*>(sdz)[c], bq = reinterpret_cast<const f32x4*>(sdzx)[c];
+    const f32x4 xh = (reinterpret_cast<const f32x4*>(x)[i] - m) * is;
+    const f32x4 yv = xh * ga + be;
+    f32x4 dz = reinterpret_cast<const f32x4*>(dy)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dz[k] = yv[k] > 0.f ? dz[k] : 0.2f * dz[k];
+    reinterpret_cast<f32x4*>(dx)[i] = ga * is * (dz - a * invP - xh * bq * invP);
+  }
+}
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 extern "C" int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, float momentum, float eps, int train, float* y, float* save_mean,
                                  float* save_invstd, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -602,11 +697,16 @@ extern "C" int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gam
   float* tmp = part + (size_t)chunks * 2 * C;    // [mean | var]
   dim3 g(cdiv(C, 64), chunks);
   if (train) {
-    hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 0, (const float*)nullptr,
+    const bool vec = bn_vec_ok(x, nullptr, C);
+    if (vec) hipLaunchKernelGGL(bn_partial_vec_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 0, (const float*)nullptr,
+                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
+    else hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 0, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
     hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
                        0.f, tmp, (float*)nullptr);
-    hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 1, (const float*)tmp,
+    if (vec) hipLaunchKernelGGL(bn_partial_vec_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 1, (const float*)tmp,
+                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
+    else hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 1, (const float*)tmp,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
     hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
                        0.f, tmp + C, (float*)nullptr);
@@ -616,8 +716,12 @@ extern "C" int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gam
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)running_mean,
                        (const float*)running_var, C, eps, save_mean, save_invstd);
   }
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, x, P, C, (const float*)save_mean,
-                     (const float*)save_invstd, gamma, beta, y);
+  if (C % 4 == 0 && al16(x) && al16(y) && al16(save_mean) && al16(save_invstd) && al16(gamma) && al16(beta))
+    hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(grid_for(P * C / 4)), dim3(TPB), 0, stream, x, P, C / 4, (const float*)save_mean,
+                       (const float*)save_invstd, gamma, beta, y);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, x, P, C, (const float*)save_mean,
+                       (const float*)save_invstd, gamma, beta, y);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
@@ -651,10 +755,15 @@ extern "C" int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C,
   float* part = (float*)workspace;
   float* tmp = part + (size_t)chunks * 2 * C;
   dim3 g(cdiv(C, 64), chunks);
-  hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part);
+  if (bn_vec_ok(x, dy, C)) hipLaunchKernelGGL(bn_partial_vec_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part);
+  else hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part);
   hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f, 1.0f, tmp, tmp + C);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, dy, x, P, C, save_mean, save_invstd, gamma,
-                     beta, (const float*)tmp, (const float*)(tmp + C), dx);
+  if (C % 4 == 0 && al16(dy) && al16(x) && al16(dx) && al16(save_mean) && al16(save_invstd) && al16(gamma) && al16(beta) && al16(tmp))
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(grid_for(P * C / 4)), dim3(TPB), 0, stream, dy, x, P, C / 4, save_mean, save_invstd,
+                       gamma, beta, (const float*)tmp, (const float*)(tmp + C), dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, dy, x, P, C, save_mean, save_invstd, gamma,
+                       beta, (const float*)tmp, (const float*)(tmp + C), dx);
   if (dgamma && dbeta)
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)tmp, (const float*)(tmp + C), C,
                        dgamma, dbeta, gbeta);

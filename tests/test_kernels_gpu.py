@@ -211,19 +211,20 @@ def test_pool_and_pack(C):
     close('dx', xg.grad.permute(0, 3, 1, 2), xr.grad, tol=1e-6)
 
 
-def test_bn_lrelu():
+@pytest.mark.parametrize('N,C,H,W', [(3, 16, 9, 5), (3, 6, 9, 5), (5, 128, 67, 31)])     # float4 path, scalar path, many rows per chunk
+def test_bn_lrelu(N, C, H, W):
     ops, lib = _ops()
-    x = rnd(3, 16, 9, 5, scale=2.0) + 0.5
-    bn = torch.nn.BatchNorm2d(16)
+    x = rnd(N, C, H, W, scale=2.0) + 0.5
+    bn = torch.nn.BatchNorm2d(C)
     bn.weight.data.normal_(1, 0.02)
     bn.bias.data.normal_(0, 0.1)
     xr = x.clone().requires_grad_(True)
     yr = F.leaky_relu(bn(xr), 0.2)
-    go = rnd(3, 16, 9, 5, seed=3)
+    go = rnd(N, C, H, W, seed=3)
     (yr * go).sum().backward()
     xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
     gam, bet = torch.nn.Parameter(bn.weight.data.clone().to(DEV)), torch.nn.Parameter(bn.bias.data.clone().to(DEV))
-    rm, rv = torch.zeros(16, device=DEV), torch.ones(16, device=DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     y = ops.bn_lrelu(xg, gam, bet, rm, rv, True)
     (y * go.permute(0, 2, 3, 1).contiguous().to(DEV)).sum().backward()
     close('y', y.permute(0, 3, 1, 2), yr, tol=1e-5)
