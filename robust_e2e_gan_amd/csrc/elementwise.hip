@@ -486,17 +486,49 @@ __global__ void vgg_pack_kernel(const float* __restrict__ src, const int* __rest
     }
   }
 }
+// The same through an LDS tile: one workgroup per (t, n) transposes that frame's (Fq, C) block, so that BOTH the global read and
+// the global write are contiguous runs of Fq*C floats (the element-wise form reads 4 bytes every C floats).
+__global__ __launch_bounds__(256) void vgg_pack_tile_kernel(const float* __restrict__ src, const int* __restrict__ lens, int NI, int T,
+                                                            int Fq, int C, float* __restrict__ dst, int backward, int NItot, int noff) {
+  extern __shared__ float tile[];            // [Fq][C + 1]
+  const int n = blockIdx.x % NI, t = blockIdx.x / NI;
+  const int FC = Fq * C, CP = C + 1;
+  const bool live = t < lens[n];
+  const long nhwc = ((long)n * T + t) * FC;                       // (n, t, f, c)
+  const long tm = ((long)t * NItot + noff + n) * FC;              // (t, n, c, f)
+  if (!backward) {
+    if (live)
+      for (int e = threadIdx.x; e < FC; e += 256) tile[(e / C) * CP + (e % C)] = src[nhwc + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < FC; e += 256) dst[tm + e] = live ? tile[(e % Fq) * CP + (e / Fq)] : 0.f;
+  } else {
+    if (live)
+      for (int e = threadIdx.x; e < FC; e += 256) tile[(e % Fq) * CP + (e / Fq)] = src[tm + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < FC; e += 256) dst[nhwc + e] = live ? tile[(e / C) * CP + (e % C)] : 0.f;
+  }
+}
+static bool vgg_pack_tiled(const float* src, const int* lens, int NI, int T, int Fq, int C, float* dst, int backward, int NItot, int noff,
+                           hipStream_t stream) {
+  const size_t lds = (size_t)Fq * (C + 1) * sizeof(float);
+  if (lds > 48 * 1024 || (long)T * NI > 2000000000L) return false;
+  hipLaunchKernelGGL(vgg_pack_tile_kernel, dim3(T * NI), dim3(256), lds, stream, src, lens, NI, T, Fq, C, dst, backward, NItot, noff);
+  return true;
+}
+
 extern "C" int re2e_vgg_pack_fwd(const float* in, const int* lens, int NI, int T, int Fq, int C, float* out, int NI_total, int n_off,
                                  hipStream_t stream) {
   RE2E_CHECK_ARG(in && lens && out && NI > 0 && T > 0 && Fq > 0 && C > 0 && n_off >= 0 && n_off + NI <= NI_total, "bad args");
-  hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, in, lens, NI, T, Fq, C, out, 0, NI_total, n_off);
+  if (!vgg_pack_tiled(in, lens, NI, T, Fq, C, out, 0, NI_total, n_off, stream))
+    hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, in, lens, NI, T, Fq, C, out, 0, NI_total, n_off);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
 extern "C" int re2e_vgg_pack_bwd(const float* dout, const int* lens, int NI, int T, int Fq, int C, float* din, int NI_total, int n_off,
                                  hipStream_t stream) {
   RE2E_CHECK_ARG(dout && lens && din && NI > 0 && T > 0 && Fq > 0 && C > 0 && n_off >= 0 && n_off + NI <= NI_total, "bad args");
-  hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, dout, lens, NI, T, Fq, C, din, 1, NI_total, n_off);
+  if (!vgg_pack_tiled(dout, lens, NI, T, Fq, C, din, 1, NI_total, n_off, stream))
+    hipLaunchKernelGGL(vgg_pack_kernel, dim3(grid_for((long)T * NI * C * Fq)), dim3(TPB), 0, stream, dout, lens, NI, T, Fq, C, din, 1, NI_total, n_off);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
