@@ -157,6 +157,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_step(float* xg_f, float* 
 // from an L2 that the concurrent filler kernels keep evicting.  Requires every workgroup to be resident (checked by the
 // launcher: grid <= CUs); spins are bounded and poison the output instead of hanging.
 typedef unsigned long long u64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) u64 gu64;
 __device__ unsigned g_persist_aborts = 0;      // sequences given up because a peer workgroup never published (re2e_lstm_abort_count)
 constexpr unsigned kSpinLimit = 1u << 16;      // sweeps (~1 us each) before a workgroup gives up on a peer
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
   // exchange buffer: [parity][dir][mt][producer x'][lh][b][i] granules; producer x' == k-group Q of the consumers
   gu64* hx = (gu64*)hx_;
   const long par_sz = (long)2 * MT * NX * 256;
+  const __amdgpu_buffer_rsrc_t hx_rs = __builtin_amdgcn_make_buffer_rsrc(hx_, 0, (int)(2 * par_sz * 8), 0x00020000);
   const long grp = (long)(dir * MT + mt) * NX * 256;
   const long rd_off = grp + (long)(wid * QN) * 256 + (lh * 32 + lr) * 4;
   const bool pw = tid < 256;
@@ -214,16 +216,20 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
         if (__all((unsigned)(g >> 32) == (unsigned)s)) break;
         __builtin_amdgcn_s_sleep(2);
       }
+      // the validated sweep: 16-byte sc1 buffer loads, two per k-group = the lane's four {value, tag} granules (8-byte loads
+      // run at 0.54-0.70x the 16-byte rate, and the sweep is the largest part of a step: 2.2 of 4.9 us alone on the chip)
+      const unsigned rd_b = (unsigned)((((s & 1) ^ 1) * par_sz + rd_off) * 8);
       for (unsigned spins = 0;; ++spins) {
+        asm volatile("" ::: "memory");             // the loads below must be re-issued every pass
         bool good = true;
 #pragma unroll
-        for (int q = 0; q < QN; ++q)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const u64 g = __hip_atomic_load(src + q * 256 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hv[q][i] = __uint_as_float((unsigned)g);
-            good &= (unsigned)(g >> 32) == (unsigned)s;
-          }
+        for (int q = 0; q < QN; ++q) {
+          const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)q * 2048u, 0, 16);
+          const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)q * 2048u + 16u, 0, 16);
+          hv[q][0] = __uint_as_float(lo[0]); hv[q][1] = __uint_as_float(lo[2]);
+          hv[q][2] = __uint_as_float(hi[0]); hv[q][3] = __uint_as_float(hi[2]);
+          good &= (lo[1] == (unsigned)s) & (lo[3] == (unsigned)s) & (hi[1] == (unsigned)s) & (hi[3] == (unsigned)s);
+        }
         if (__all(good)) break;
         if (spins > kSpinLimit) { if (lane == 0) { red[kAbort] = 1.f; if (atomicExch(err, 1u) == 0u) atomicAdd(&g_persist_aborts, 1u); } break; }
         __builtin_amdgcn_s_sleep(1);
@@ -400,6 +406,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
                                                         const float* __restrict__ cbuf, float* dc_state, float* xbuf, unsigned* flags_,
                                                         unsigned* err, const int* __restrict__ lens, int T, int B, int H) {
   __shared__ __attribute__((aligned(16))) float dgs[32 * 36];     // d(gates) tile [b][n], padded rows
+  __shared__ __attribute__((aligned(16))) float psum[4 * 256];    // per-wave sums of the producers' partial blocks
   __shared__ int aborted;
   const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y, NX = gridDim.x;
   float* G = dir ? g_r : g_f;
@@ -423,6 +430,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
   const long grp = (long)(dir * MT + mt);
   const long x_par = (long)2 * MT * NX * NX * 256;             // floats per parity buffer: [dir][mt][consumer][producer][8 j][32 b]
   float* xg = xbuf + grp * NX * NX * 256;
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, (int)(2 * x_par * 4), 0x00020000);
   gu32* flags = (gu32*)flags_;
   const long f_par = (long)2 * MT * NX * 32;                    // words per parity: one 128-byte line per producer
   const long f_grp = grp * NX * 32;
@@ -474,17 +482,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
       }
       __syncthreads();
       if (aborted) break;
-      const gu32* q = (const gu32*)(xg + ((s & 1) ^ 1) * x_par) + (long)x * NX * 256 + jj * 32 + bm;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int xx = 0;
-      for (; xx + 8 <= NX; xx += 8) {
-        float v[8];
+      // partials of this workgroup's 8 units from every producer: 16-byte sc1 buffer loads (a producer's block is 64 x 16 B),
+      // wavefront w sums producers w, w+4, ...; the four wave sums are combined through LDS in a fixed order
+      {
+        const unsigned blk_b = (unsigned)((((s & 1) ^ 1) * x_par + grp * NX * NX * 256 + (long)x * NX * 256) * 4) + (unsigned)lane * 16u;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        int xp = wid;
+        for (; xp + 28 < NX; xp += 32) {
+          f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __uint_as_float(__hip_atomic_load(q + (long)(xx + u) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        a0 += v[0] + v[4]; a1 += v[1] + v[5]; a2 += v[2] + v[6]; a3 += v[3] + v[7];
+          for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, blk_b + (unsigned)(xp + 4 * u) * 1024u, 0, 16));
+          a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; xp < NX; xp += 4) a += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, blk_b + (unsigned)xp * 1024u, 0, 16));
+        *reinterpret_cast<f32x4*>(psum + wid * 256 + lane * 4) = a;
       }
-      for (; xx < NX; ++xx) a0 += __uint_as_float(__hip_atomic_load(q + (long)xx * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      dh += (a0 + a1) + (a2 + a3);
+      __syncthreads();
+      {
+        const int e = jj * 32 + bm;
+        dh += (psum[e] + psum[256 + e]) + (psum[512 + e] + psum[768 + e]);
+      }
     }
     // ---- cell backward ----
     float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = dcr;
