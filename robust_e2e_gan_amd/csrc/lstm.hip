@@ -211,11 +211,6 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
       // cheap wait first: ONE granule per wave-pass until the first producer of this wave's range has published (all
       // producers finish a step within a fraction of a microsecond of each other), then the full validated sweep --
       // 16 waves sweeping 1 KB each in a loop are what makes two resident workgroups on one CU 1.7x slower than one
-      for (unsigned spins = 0; spins <= kSpinLimit; ++spins) {
-        const u64 g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all((unsigned)(g >> 32) == (unsigned)s)) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
       // the validated sweep: 16-byte sc1 buffer loads, two per k-group = the lane's four {value, tag} granules (8-byte loads
       // run at 0.54-0.70x the 16-byte rate, and the sweep is the largest part of a step: 2.2 of 4.9 us alone on the chip)
       const unsigned rd_b = (unsigned)((((s & 1) ^ 1) * par_sz + rd_off) * 8);
