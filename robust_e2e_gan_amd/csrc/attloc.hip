@@ -74,7 +74,8 @@ __global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restr
   const int CP = cpad(C), Kf = 2 * F + 1;
   float* ap = sm;                                 // [TCH + 2F]
   float* cv = ap + ((TCH + 2 * F + 3) & ~3);      // [TCH][CP]
-  float* wcs = cv + TCH * CP;                     // [C][Kf]  filter taps (broadcast LDS reads in the tap loop)
+  float* wcs = cv + TCH * CP;                     // [C][Kf]  filter taps
+  float* cpart = wcs + ((C * Kf + 3) & ~3);       // [NWV][TCH][CP] per-wavefront partial conv tiles
   const int b = blockIdx.y, t0 = blockIdx.x * TCH;
   const int nt = min(TCH, T - t0);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -97,33 +98,33 @@ __global__ __launch_bounds__(NTH) void attloc_energy_kernel(const float* __restr
     ap[i] = v;
   }
   __syncthreads();
-  // location conv for this chunk: conv[t][c] = sum_k w_conv[c][k] * att_prev[t + k - F]; a wavefront owns a
-  // channel group (wave-uniform taps => scalar loads); lanes 0-31 = frames with the first half of the
-  // taps, lanes 32-63 = the same frames with the second half
+  // location conv for this chunk: conv[t][c] = sum_k att_prev[t + k - F] * w_conv[c][k] -- a 32 (frames) x C x Kf product with a
+  // Toeplitz left operand, done on the matrix core: v_mfma_f32_32x32x2 takes A[t][k] = ap[t + k] and B[k][c] = w_conv[c][k]
+  // straight from the LDS copies (one ds_read each per lane and k-pair), the four wavefronts interleave the k-pairs and their
+  // partial tiles are summed through LDS.  (The scalar tap loop this replaces was 17 of the kernel's 31 us: six dependent
+  // LDS reads per tap, two of four wavefronts idle.)
   {
-    const int ncg = (C + CG - 1) / CG;
-    for (int item = wid; item < ncg; item += NWV) {
-      const int c0 = item * CG;
-      const int tl = lane & 31;
-      const int tt = tl < nt ? tl : 0;
-      float acc[CG];
+    const int tl = lane & 31, lh = lane >> 5;
+    f32x16 acc;
 #pragma unroll
-      for (int cc = 0; cc < CG; ++cc) acc[cc] = 0.f;
-      const int kh = (Kf + 1) / 2;
-      const int k0 = (lane >> 5) * kh, k1 = min(Kf, k0 + kh);
-#pragma unroll 4
-      for (int k = k0; k < k1; ++k) {
-        float x = ap[tt + k];
-#pragma unroll
-        for (int cc = 0; cc < CG; ++cc)
-          if (c0 + cc < C) acc[cc] += wcs[(c0 + cc) * Kf + k] * x;
-      }
-#pragma unroll
-      for (int cc = 0; cc < CG; ++cc) {
-        float v = acc[cc] + __shfl_xor(acc[cc], 32, 64);
-        if (lane < nt && c0 + cc < C) cv[lane * CP + c0 + cc] = v;
-      }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nks = (Kf + 1) / 2;
+    for (int s2 = wid; s2 < nks; s2 += NWV) {
+      const int k = 2 * s2 + lh;
+      const float av = k < Kf ? ap[tl + k] : 0.f;
+      const float bv = (k < Kf && tl < C) ? wcs[tl * Kf + k] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
+    if (tl < C) {                                  // lane holds column c = tl, rows (r&3) + 8 (r>>2) + 4 lh
+      float* pp = cpart + (wid * TCH) * CP + tl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pp[((r & 3) + 8 * (r >> 2) + 4 * lh) * CP] = acc[r];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < TCH * CP; i += NTH) {
+    const int c = i % CP;
+    cv[i] = c < C ? (cpart[i] + cpart[TCH * CP + i]) + (cpart[2 * TCH * CP + i] + cpart[3 * TCH * CP + i]) : 0.f;
   }
   __syncthreads();
   for (int i = tid; i < nt * C; i += NTH) {
@@ -608,7 +609,8 @@ extern "C" int re2e_attloc_fwd(const float* pre, const float* enc, const float* 
   const int CP = (chans + 3) & ~3;
   RE2E_CHECK_ARG(dunits <= 1024, "dunits > 1024 not supported");
   hipLaunchKernelGGL(attloc_decproj_kernel, dim3((adim + 63) / 64, B), dim3(NTH), 0, stream, z, w_decT, dunits, adim, dp_out);
-  size_t lds1 = (size_t)(((TCH + 2 * filts + 3) & ~3) + TCH * CP + chans * (2 * filts + 1) + 16) * sizeof(float);
+  size_t lds1 = (size_t)(((TCH + 2 * filts + 3) & ~3) + TCH * CP + ((chans * (2 * filts + 1) + 3) & ~3) + NWV * TCH * CP + 16) * sizeof(float);
+  if (lds1 > 64 * 1024) { re2e_set_error("re2e_attloc_fwd: aconv_filts=%d needs %zu bytes of LDS (>64 KiB)", filts, lds1); return RE2E_EUNSUPPORTED; }
   hipLaunchKernelGGL(attloc_energy_kernel, dim3(nchunks(T), B), dim3(NTH), lds1, stream, pre, (const float*)dp_out, att_prev, hlens, w_att, w_conv,
                      gvec, gvec_b, B, T, adim, chans, filts, e_scratch, conv_out);
   size_t lds2 = (size_t)(((T + 3) & ~3) + 32 + 16 * 64 + 16) * sizeof(float);
