@@ -68,17 +68,17 @@ __global__ void pack_w_fwd_kernel(const float* __restrict__ whh, float* __restri
     wf[e] = whh[((long)((n >> 3) * H + 8 * x + (n & 7))) * H + 8 * Q + 4 * h + i];
   }
 }
-__global__ void pack_w_bwd_kernel(const float* __restrict__ whh, float* __restrict__ wb, int H) {
-  // backward: workgroup x owns the same 32 gate rows n as in the forward (4 gates x 8 units) as its K slice and
-  // produces partial dh over ALL j.  wb[(((x*(H/32) + jt)*4 + Q)*64 + lane)*4 + i] = whh[row(x, 8Q+4h+i)*H + 32jt + (lane&31)],
-  // row(x, m) = (m>>3)*H + 8x + (m&7)
-  const int njt = (H + 31) / 32;
-  long tot = (long)(H / 8) * njt * 1024;
+__global__ void pack_w_bwd_kernel(const float* __restrict__ whh, float* __restrict__ wb, int H, int UW) {
+  // backward: workgroup x owns the gate rows of its 8 UW units as its K slice (m = 32 u + 8 gate + unit, u < UW) and produces
+  // partial dh over ALL j.  wb[(((x*njt + jt)*4UW + Q)*64 + lane)*4 + i] = whh[row(x, 8Q+4h+i)*H + 32jt + (lane&31)],
+  // row(x, m) = ((m>>3)&3)*H + 8 UW x + 8 (m>>5) + (m&7)
+  const int njt = (H + 31) / 32, NQ = 4 * UW;
+  long tot = (long)(H / (8 * UW)) * njt * NQ * 256;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
-    int i = (int)(e & 3); int lane = (int)((e >> 2) & 63); int Q = (int)((e >> 8) & 3); long r = e >> 10; int jt = (int)(r % njt); int x = (int)(r / njt);
+    int i = (int)(e & 3); int lane = (int)((e >> 2) & 63); long r = e >> 8; int Q = (int)(r % NQ); r /= NQ; int jt = (int)(r % njt); int x = (int)(r / njt);
     int m = 8 * Q + 4 * (lane >> 5) + i;
     int j = 32 * jt + (lane & 31);
-    wb[e] = j < H ? whh[((long)((m >> 3) * H + 8 * x + (m & 7))) * H + j] : 0.f;
+    wb[e] = j < H ? whh[((long)(((m >> 3) & 3) * H + 8 * UW * x + 8 * (m >> 5) + (m & 7))) * H + j] : 0.f;
   }
 }
 
@@ -396,71 +396,86 @@ __device__ __forceinline__ void store16_sc1(float* p, const f32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
-template <int TPW>       // 32-unit output tiles per wave (4 waves): H <= 128 * TPW
+template <int TPW, int UW>       // TPW: 32-unit output tiles per wave (4 waves, H <= 128 TPW); UW: 8-unit groups per workgroup
 __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, const float* __restrict__ wb, const float* __restrict__ dy,
                                                         const float* __restrict__ cbuf, float* dc_state, float* xbuf, unsigned* flags_,
                                                         unsigned* err, const int* __restrict__ lens, int T, int B, int H) {
-  __shared__ __attribute__((aligned(16))) float dgs[32 * 36];     // d(gates) tile [b][n], padded rows
+  // UW = 2 (wide layers): a workgroup owns 16 units = 64 gate rows, so half as many workgroups exchange partial slabs of the
+  // same size -- the slab traffic through the fabric (what bounds H = 512) halves, the MFMA work per workgroup doubles.
+  constexpr int UN = 8 * UW;              // hidden units per workgroup
+  constexpr int KG = 32 * UW;             // gate rows per workgroup = K of the partial product
+  constexpr int LDG = KG + 4;             // padded row of the d(gates) tile
+  constexpr int BLK = 256 * UW;           // floats per (consumer, producer) block: [UN units][32 b]
+  __shared__ __attribute__((aligned(16))) float dgs[32 * LDG];    // d(gates) tile [b][n]
   __shared__ __attribute__((aligned(16))) float psum[4 * 256];    // per-wave sums of the producers' partial blocks
   __shared__ int aborted;
   const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y, NX = gridDim.x;
   float* G = dir ? g_r : g_f;
-  const int j0 = x * 8, b0 = mt * 32;
+  const int j0 = x * UN, b0 = mt * 32;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int K4 = 4 * H;
   const long H2 = 2L * H;
   const int njt = (H + 31) / 32;
   if (tid == 0) aborted = 0;
   // W_hh rows of this workgroup, tiles of this wave: registers for the whole sequence
-  f32x4 wreg[TPW][4];
+  f32x4 wreg[TPW][4 * UW];
   {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wb) + ((long)(dir * NX + x) * njt) * 256 + lane;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wb) + ((long)(dir * NX + x) * njt) * (4 * UW) * 64 + lane;
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       const int jt = min(wid + 4 * u, njt - 1);
 #pragma unroll
-      for (int Q = 0; Q < 4; ++Q) wreg[u][Q] = wp[(long)(jt * 4 + Q) * 64];
+      for (int Q = 0; Q < 4 * UW; ++Q) wreg[u][Q] = wp[(long)(jt * 4 * UW + Q) * 64];
     }
   }
   const long grp = (long)(dir * MT + mt);
-  const long x_par = (long)2 * MT * NX * NX * 256;             // floats per parity buffer: [dir][mt][consumer][producer][8 j][32 b]
-  float* xg = xbuf + grp * NX * NX * 256;
+  const long x_par = (long)2 * MT * NX * NX * BLK;             // floats per parity buffer: [dir][mt][consumer][producer][UN j][32 b]
+  float* xg = xbuf + grp * NX * NX * BLK;
   const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, (int)(2 * x_par * 4), 0x00020000);
   gu32* flags = (gu32*)flags_;
   const long f_par = (long)2 * MT * NX * 32;                    // words per parity: one 128-byte line per producer
   const long f_grp = grp * NX * 32;
-  // cell-backward ownership: thread = (utterance bm, unit jj)
-  const int bm = tid >> 3, jj = tid & 7, b = b0 + bm, j = j0 + jj;
+  // cell-backward ownership: thread = (utterance bm, unit jj of each of the UW groups)
+  const int bm = tid >> 3, jj = tid & 7, b = b0 + bm;
   const bool ok = b < B;
   const long bb = ok ? b : 0;
   const int ln = lens[bb];
-  float dcr = 0.f;                                              // d(cell state) carried across steps
-  // operands of the first step
-  float n_dy, n_g[4], n_c, n_cp;
-  {
+  float dcr[UW];                                                // d(cell state) carried across steps
+  float n_dy[UW], n_g[UW][4], n_c[UW], n_cp[UW];
+#pragma unroll
+  for (int u = 0; u < UW; ++u) {                                // operands of the first step
+    const int j = j0 + 8 * u + jj;
     const int t = dir ? 0 : T - 1;
     const int prev_blk = dir ? t + 2 : t;
-    n_dy = dy[((long)t * B + bb) * H2 + dir * H + j];
+    dcr[u] = 0.f;
+    n_dy[u] = dy[((long)t * B + bb) * H2 + dir * H + j];
     const float* gp0 = G + ((long)t * B + bb) * K4 + j;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) n_g[g] = gp0[g * H];
-    n_c = cbuf[((long)(t + 1) * B + bb) * H2 + dir * H + j];
-    n_cp = cbuf[((long)prev_blk * B + bb) * H2 + dir * H + j];
+    for (int g = 0; g < 4; ++g) n_g[u][g] = gp0[g * H];
+    n_c[u] = cbuf[((long)(t + 1) * B + bb) * H2 + dir * H + j];
+    n_cp[u] = cbuf[((long)prev_blk * B + bb) * H2 + dir * H + j];
   }
   __syncthreads();
   for (int s = 0; s < T; ++s) {
     const int t = dir ? s : T - 1 - s;
-    float dh = n_dy;
-    const float gi = n_g[0], gf = n_g[1], gg = n_g[2], go = n_g[3], c = n_c, cp = n_cp;
+    float dh[UW], gi[UW], gf[UW], gg[UW], go[UW], c[UW], cp[UW];
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+      dh[u] = n_dy[u]; gi[u] = n_g[u][0]; gf[u] = n_g[u][1]; gg[u] = n_g[u][2]; go[u] = n_g[u][3]; c[u] = n_c[u]; cp[u] = n_cp[u];
+    }
     if (s + 1 < T) {                               // next step's operands: in flight during this step
       const int tn = dir ? t + 1 : t - 1;
       const int pbn = dir ? tn + 2 : tn;
-      n_dy = dy[((long)tn * B + bb) * H2 + dir * H + j];
-      const float* gpn = G + ((long)tn * B + bb) * K4 + j;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) n_g[g] = gpn[g * H];
-      n_c = cbuf[((long)(tn + 1) * B + bb) * H2 + dir * H + j];
-      n_cp = cbuf[((long)pbn * B + bb) * H2 + dir * H + j];
+      for (int u = 0; u < UW; ++u) {
+        const int j = j0 + 8 * u + jj;
+        n_dy[u] = dy[((long)tn * B + bb) * H2 + dir * H + j];
+        const float* gpn = G + ((long)tn * B + bb) * K4 + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) n_g[u][g] = gpn[g * H];
+        n_c[u] = cbuf[((long)(tn + 1) * B + bb) * H2 + dir * H + j];
+        n_cp[u] = cbuf[((long)pbn * B + bb) * H2 + dir * H + j];
+      }
     }
     if (s > 0) {
       // ---- wait for the NX producers of step s-1, then sum their partials for (b, j) ----
@@ -477,50 +492,61 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
       }
       __syncthreads();
       if (aborted) break;
-      // partials of this workgroup's 8 units from every producer: 16-byte sc1 buffer loads (a producer's block is 64 x 16 B),
-      // wavefront w sums producers w, w+4, ...; the four wave sums are combined through LDS in a fixed order
+      // partials of this workgroup's units from every producer: 16-byte sc1 buffer loads.  A producer's block is UW x (64 x 16 B):
+      // wavefront w takes part w % UW of producers w / UW, w / UW + 4 / UW, ...; the wave sums are combined through LDS in a fixed order
       {
-        const unsigned blk_b = (unsigned)((((s & 1) ^ 1) * x_par + grp * NX * NX * 256 + (long)x * NX * 256) * 4) + (unsigned)lane * 16u;
+        const int part = wid % UW;
+        const unsigned blk_b = (unsigned)((((s & 1) ^ 1) * x_par + grp * NX * NX * BLK + (long)x * NX * BLK) * 4) + (unsigned)part * 1024u + (unsigned)lane * 16u;
+        constexpr int XS = 4 / UW;                 // producer stride of a wavefront
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        int xp = wid;
-        for (; xp + 28 < NX; xp += 32) {
+        int xp = wid / UW;
+        for (; xp + 7 * XS < NX; xp += 8 * XS) {
           f32x4 v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, blk_b + (unsigned)(xp + 4 * u) * 1024u, 0, 16));
+          for (int u = 0; u < 8; ++u) v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, blk_b + (unsigned)(xp + XS * u) * (unsigned)(BLK * 4), 0, 16));
           a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
-        for (; xp < NX; xp += 4) a += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, blk_b + (unsigned)xp * 1024u, 0, 16));
+        for (; xp < NX; xp += XS) a += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, blk_b + (unsigned)xp * (unsigned)(BLK * 4), 0, 16));
         *reinterpret_cast<f32x4*>(psum + wid * 256 + lane * 4) = a;
       }
       __syncthreads();
       {
         const int e = jj * 32 + bm;
-        dh += (psum[e] + psum[256 + e]) + (psum[512 + e] + psum[768 + e]);
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {             // element (8u + jj) * 32 + bm of the block lies in part u: waves u, u + UW, ...
+          if (UW == 1) dh[u] += (psum[e] + psum[256 + e]) + (psum[512 + e] + psum[768 + e]);
+          else dh[u] += psum[u * 256 + e] + psum[(u + 2) * 256 + e];
+        }
       }
     }
     // ---- cell backward ----
-    float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = dcr;
-    if (ok && t < ln) {
-      float tc = tanhf_(c);
-      float dct = dh * go * (1.f - tc * tc) + dcr;
-      dout = dh * tc * go * (1.f - go);
-      di = dct * gg * gi * (1.f - gi);
-      df = dct * cp * gf * (1.f - gf);
-      dg = dct * gi * (1.f - gg * gg);
-      dcp = dct * gf;
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+      const int j = j0 + 8 * u + jj;
+      float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = dcr[u];
+      if (ok && t < ln) {
+        float tc = tanhf_(c[u]);
+        float dct = dh[u] * go[u] * (1.f - tc * tc) + dcr[u];
+        dout = dh[u] * tc * go[u] * (1.f - go[u]);
+        di = dct * gg[u] * gi[u] * (1.f - gi[u]);
+        df = dct * cp[u] * gf[u] * (1.f - gf[u]);
+        dg = dct * gi[u] * (1.f - gg[u] * gg[u]);
+        dcp = dct * gf[u];
+      }
+      dcr[u] = dcp;
+      if (ok) {
+        float* gp = G + ((long)t * B + b) * K4 + j;
+        gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dout;
+      }
+      float* dq = dgs + bm * LDG + 32 * u + jj;
+      dq[0] = di; dq[8] = df; dq[16] = dg; dq[24] = dout;
     }
-    dcr = dcp;
-    if (ok) {
-      float* gp = G + ((long)t * B + b) * K4 + j;
-      gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dout;
-    }
-    dgs[bm * 36 + jj] = di; dgs[bm * 36 + 8 + jj] = df; dgs[bm * 36 + 16 + jj] = dg; dgs[bm * 36 + 24 + jj] = dout;
     __syncthreads();
     if (s == T - 1) break;                         // nothing consumes the last partials
     // ---- produce: P_x = dG_x . W_hh[n in x][:] , written write-through in the consumers' order ----
-    f32x4 a4[4];
+    f32x4 a4[4 * UW];
 #pragma unroll
-    for (int Q = 0; Q < 4; ++Q) a4[Q] = *reinterpret_cast<const f32x4*>(dgs + lr * 36 + 8 * Q + 4 * lh);
+    for (int Q = 0; Q < 4 * UW; ++Q) a4[Q] = *reinterpret_cast<const f32x4*>(dgs + lr * LDG + 8 * Q + 4 * lh);
     float* xw = xg + (s & 1) * x_par;
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
@@ -529,12 +555,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int Q = 0; Q < 4; ++Q)
+      for (int Q = 0; Q < 4 * UW; ++Q)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[Q][i], wreg[u][Q][i], acc, 0, 0, 0);
       if (jt < njt && 32 * jt + lr < H) {
-        // column j = 32 jt + lr -> consumer x'' = 4 jt + (lr >> 3), unit lr & 7; rows (r&3) + 8 (r>>2) + 4 lh: 4 consecutive b per store
-        float* dst = xw + ((long)(4 * jt + (lr >> 3)) * NX + x) * 256 + (lr & 7) * 32 + 4 * lh;
+        // column j = 32 jt + lr -> consumer j / UN, unit j % UN; rows (r&3) + 8 (r>>2) + 4 lh: 4 consecutive b per store
+        const int jc = 32 * jt + lr;
+        float* dst = xw + ((long)(jc / UN) * NX + x) * BLK + (jc % UN) * 32 + 4 * lh;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           f32x4 v = {acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]};
@@ -547,9 +574,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
     if (tid == 0)                                               // ... behind which ONE lane publishes the step tag
       __hip_atomic_store(flags + (s & 1) * f_par + f_grp + (long)x * 32, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (ok) dc_state[(long)b * H2 + dir * H + j] = dcr;
-  if (aborted && ok) {                              // a peer never published: make the failure visible downstream
-    for (int t = 0; t < T; ++t) G[((long)t * B + b) * K4 + j] = __uint_as_float(0x7fc00000u);
+#pragma unroll
+  for (int u = 0; u < UW; ++u) {
+    const int j = j0 + 8 * u + jj;
+    if (ok) dc_state[(long)b * H2 + dir * H + j] = dcr[u];
+    if (aborted && ok) {                            // a peer never published: make the failure visible downstream
+      for (int t = 0; t < T; ++t) G[((long)t * B + b) * K4 + j] = __uint_as_float(0x7fc00000u);
+    }
   }
 }
 
@@ -618,31 +649,41 @@ bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* w
   return true;
 }
 
-template <int TPW>
+template <int TPW, int UW>
 bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs,
                         void* flagmem, size_t flagbytes, const int* lens, int T, int B, int H) {
-  dim3 grid(H / 8, cdiv(B, 32), 2);
-  if ((long)grid.x * grid.y * grid.z > cu_count()) return false;          // every workgroup must be resident
+  dim3 grid(H / (8 * UW), cdiv(B, 32), 2);
   (void)hipMemsetAsync(flagmem, 0, flagbytes, st);
   unsigned* err = (unsigned*)flagmem;
   unsigned* flags = (unsigned*)((char*)flagmem + 16);
-  hipLaunchKernelGGL((lstm_bwd_persist<TPW>), grid, dim3(256), 0, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
+  hipLaunchKernelGGL((lstm_bwd_persist<TPW, UW>), grid, dim3(256), 0, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
   return true;
 }
 
-bool try_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs,
-                     void* flagmem, size_t flagbytes, const int* lens, int T, int B, int H) {
+// 0: launch per step; 1 / 2: persistent kernel with 8 / 16 hidden units per workgroup (the weights must be packed for that width)
+int bwd_persist_width(int T, int B, int H) {
   const char* v = getenv("RE2E_LSTM_PERSIST_BWD");
   const char* mh = getenv("RE2E_LSTM_PERSIST_BWD_MAXH");
-  if ((v && atoi(v) == 0) || T < 2 || H / 8 > 128 || H > (mh ? atoi(mh) : 384)) return false;   // wider layers are bound by the slab traffic: launch per step is faster there
+  if ((v && atoi(v) == 0) || T < 2 || H > (mh ? atoi(mh) : 1024) || (H + 31) / 32 > 16) return 0;
+  const char* wv = getenv("RE2E_LSTM_BWD_UW");      // tuning override
+  int uw = wv ? atoi(wv) : (H >= 512 ? 2 : 1);     // wide layers are bound by the slab traffic: half as many, twice as wide workgroups
+  if (uw == 2 && H % 16 != 0) uw = 1;
+  if (uw != 1 && uw != 2) uw = 1;
+  if ((long)(H / (8 * uw)) * cdiv(B, 32) * 2 > cu_count() || H / (8 * uw) > 128) return 0;      // every workgroup must be resident
+  return uw;
+}
+
+bool try_bwd_persist(int uw, hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs,
+                     void* flagmem, size_t flagbytes, const int* lens, int T, int B, int H) {
   const int njt = (H + 31) / 32, tpw = (njt + 3) / 4;
+#define RE2E_BWD(TP) \
+  case TP: return uw == 2 ? launch_bwd_persist<TP, 2>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H) \
+                          : launch_bwd_persist<TP, 1>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
   switch (tpw) {
-    case 1: return launch_bwd_persist<1>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
-    case 2: return launch_bwd_persist<2>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
-    case 3: return launch_bwd_persist<3>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
-    case 4: return launch_bwd_persist<4>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
+    RE2E_BWD(1) RE2E_BWD(2) RE2E_BWD(3) RE2E_BWD(4)
     default: return false;
   }
+#undef RE2E_BWD
 }
 
 // RE2E_LSTM_PERSIST=0 keeps the launch-per-step form (also used for shapes the persistent kernel does not cover)
@@ -711,12 +752,13 @@ extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, con
   long wn = (long)(H / 8) * ((H + 31) / 32) * 1024;
   float* wb = (float*)workspace;
   float* slabs = wb + 2 * wn;
-  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wb, H);
-  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wb + wn, H);
+  const int uw = bwd_persist_width(T, B, H);
+  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wb, H, uw ? uw : 1);
+  hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wb + wn, H, uw ? uw : 1);
   long nz = (long)B * 2 * H;
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(nz, 256)), dim3(256), 0, stream, dc_state, nz);
   void* flagmem = (char*)workspace + bwd_ws_floats(B, H) * sizeof(float);
-  if (try_bwd_persist(stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, flagmem, bwd_flag_bytes(B, H), lens_dev, T, B, H)) {
+  if (uw && try_bwd_persist(uw, stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, flagmem, bwd_flag_bytes(B, H), lens_dev, T, B, H)) {
     RE2E_LAUNCH_CHECK();
     return RE2E_OK;
   }

@@ -267,11 +267,14 @@ def test_bilstm(B, T, I, H, lens):
             i += 1
 
 
-@pytest.mark.parametrize('B,T,H', [(32, 60, 256), (40, 37, 320), (64, 25, 512), (3, 21, 32)])
-def test_lstm_persistent_vs_stepwise(B, T, H, monkeypatch):
+@pytest.mark.parametrize('B,T,H,uw', [(32, 60, 256, None), (40, 37, 320, None), (64, 25, 512, None), (3, 21, 32, None),
+                                       (40, 19, 320, '2'), (3, 9, 32, '2'), (64, 11, 512, '1')])       # forced backward widths
+def test_lstm_persistent_vs_stepwise(B, T, H, uw, monkeypatch):
     """K4 forward: the persistent kernel (workgroups resident for the whole sequence, h_t handed over as tagged granules)
     against the launch-per-step kernels on the same inputs -- every output buffer, ragged lengths."""
     ops, lib = _ops()
+    if uw is not None:
+        monkeypatch.setenv('RE2E_LSTM_BWD_UW', uw)       # 8 (1) or 16 (2) hidden units per backward workgroup
     g = torch.Generator().manual_seed(B * 1000 + T)
     xg0 = [(torch.randn(T * B, 4 * H, generator=g) * 0.5).to(DEV) for _ in range(2)]
     whh = [(torch.randn(4 * H, H, generator=g) / H ** 0.5).to(DEV) for _ in range(2)]
