@@ -612,6 +612,76 @@ int gemm_splits(int transa, int transb, int M, int N, int K) {
   return 1;
 }
 
+// ---- skinny GEMM (M <= 32) with the K split INSIDE the workgroup -------------------------------------------------------
+// The decoder loop's GEMMs (32 x 1200 x 512, 32 x 512 x 1200, ...) are latency-bound: the tiled engine ran them as split-K over
+// workgroups plus a reduce launch (6 + 1.7 + 6 us per product, 205 products per training step).  Here one workgroup owns a
+// 32 x 32 output tile, its 8 wavefronts take an eighth of K each (operand fragments straight from global memory, all loads of a
+// pass issued before its MFMAs), the eight partial tiles meet in LDS and the epilogue (bias, bias2, beta) runs in the same launch.
+// TB: B is (N, K) row-major (x W^T); otherwise (K, N).  Fixed summation order: deterministic.
+template <bool TB, bool VEC>      // VEC: 16-byte aligned operands, leading dimensions and K multiples of 4 -> float4 fragment loads
+__global__ __launch_bounds__(512) void skinny_gemm_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
+                                                          float* C, long ldc, int M, int N, int K, const float* __restrict__ bias,
+                                                          const float* __restrict__ bias2, float beta) {
+  __shared__ float red[8][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  const int kq = (K + 7) / 8;                       // k-groups of 8
+  const int per = (kq + 7) / 8;                     // k-groups per wavefront
+  const int q0 = wid * per, q1 = min(kq, q0 + per);
+  const int row = lr, col = n0 + lr;
+  const bool rok = row < M, cok = col < N;
+  const float* ap = A + (long)(rok ? row : 0) * lda;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int qb = q0; qb < q1; qb += 4) {             // four k-groups per pass
+    float av[4][4], bv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 8 * (qb + u) + 4 * lh;
+      const bool qok = qb + u < q1;
+      if (VEC) {
+        const bool kok = qok && k < K;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 a4 = (kok && rok) ? *reinterpret_cast<const f32x4*>(ap + k) : zero;
+        f32x4 b4 = zero;
+        if (TB) { if (kok && cok) b4 = *reinterpret_cast<const f32x4*>(B + (long)col * ldb + k); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          av[u][j] = a4[j];
+          bv[u][j] = TB ? b4[j] : ((kok && cok) ? B[(long)(k + j) * ldb + col] : 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool kok = qok && k + j < K;
+          av[u][j] = (kok && rok) ? ap[k + j] : 0.f;
+          bv[u][j] = (kok && cok) ? (TB ? B[(long)col * ldb + k + j] : B[(long)(k + j) * ldb + col]) : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], bv[u][j], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
+  __syncthreads();
+  for (int i = tid; i < 32 * 32; i += 512) {
+    const int m = i >> 5, n = n0 + (i & 31);
+    if (m < M && n < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[w][m][i & 31];
+      if (bias) v += bias[n];
+      if (bias2) v += bias2[n];
+      float* c = C + (long)m * ldc + n;
+      *c = (beta != 0.f ? *c : 0.f) + v;
+    }
+  }
+}
+
 }  // namespace
 
 // ============================================================================================
@@ -662,6 +732,17 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
     return RE2E_EUNSUPPORTED;
   }
   RE2E_CHECK_ARG(fits32(transa ? K : M, lda, transa ? M : K) && fits32(transb ? N : K, ldb, transb ? K : N), "operand larger than 4 GiB");
+  static const bool no_skinny_kernel = getenv("RE2E_NO_SKINNY_GEMM") != nullptr;
+  if (!no_skinny_kernel && !transa && M <= 32 && K >= 64 && K <= 8192 && act == RE2E_ACT_NONE) {
+    const bool v = K % 4 == 0 && aligned16(A) && lda % 4 == 0 && (!transb || (aligned16(B) && ldb % 4 == 0));
+    const dim3 g(cdiv(N, 32)), t(512);
+    if (transb && v) hipLaunchKernelGGL((skinny_gemm_kernel<true, true>), g, t, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, bias, bias2, beta);
+    else if (transb) hipLaunchKernelGGL((skinny_gemm_kernel<true, false>), g, t, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, bias, bias2, beta);
+    else if (v) hipLaunchKernelGGL((skinny_gemm_kernel<false, true>), g, t, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, bias, bias2, beta);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<false, false>), g, t, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, bias, bias2, beta);
+    RE2E_LAUNCH_CHECK();
+    return RE2E_OK;
+  }
   Epi ep;
   memset(&ep, 0, sizeof(ep));
   ep.C = C; ep.ldc = ldc; ep.M = M; ep.N = N; ep.bias = bias; ep.bias2 = bias2; ep.act = act; ep.beta = beta;
