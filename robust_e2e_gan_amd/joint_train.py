@@ -92,7 +92,9 @@ class JointTrainer(object):
             # dedicated D-step stream: 91 -> 155 ms/step).  Measured and rejected as well: running the D-step's
             # forward/backward early, under the ASR forward (+2.3 ms/step: it slows the encoder chain more than it
             # relieves the backward) -- and again with the persistent recurrences, only the FAKE half, started exactly when the
-            # encoder's chain starts: ASR forward +3.9 ms, enhancer backward -2.7 ms, step 88.9 -> 91.0 ms; a dedicated stream for the recurrent sequences masked to the 32 CUs the fillers leave
+            # encoder's chain starts: ASR forward +3.9 ms, enhancer backward -2.7 ms, step 88.9 -> 91.0 ms; holding the G-step's
+            # backward through D until the decoder's backward chain is done (decoder backward -1.9 ms, BLSTMP backward +1.6 ms:
+            # within the noise of the step); a dedicated stream for the recurrent sequences masked to the 32 CUs the fillers leave
             # alone (GPU_MAX_HW_QUEUES=8): the chains are no faster there (16.9 vs 18 ms for the enhancer forward under the
             # D(real) filler -- the slowdown under load is not CU sharing) and 256-workgroup sequences do not fit 32 CUs.
         self.main_stream = None
