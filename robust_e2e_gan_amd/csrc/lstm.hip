@@ -640,11 +640,12 @@ bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* w
   size_t lds = (size_t)W * 32 * 33 * sizeof(float) + 16;
   dim3 grid(H / 8, cdiv(B, 32), 2);
   if ((long)grid.x * grid.y * grid.z > cu_count()) return false;          // every workgroup must be resident
-  // A chain that fits a quarter of the chip asks for (almost) a whole CU's LDS per workgroup: nothing else can then be
+  // A chain that fits half of the chip (RE2E_LSTM_OWN_CU_FRAC, quarter: 75.5, half: 75.1 ms) asks for (almost) a whole CU's LDS per workgroup: nothing else can then be
   // co-resident on its CUs, so its MFMA pipe and memory queue are its own while the filler streams keep the other CUs.
   // (RE2E_LSTM_OWN_CU=0 turns it off, =n asks for n KB.  Step 77.9 -> 75.2 ms: enhancer forward 13.6 -> 9.6, backward 16.7 -> 13.0 ms.)
   static const int hog = getenv("RE2E_LSTM_OWN_CU") ? atoi(getenv("RE2E_LSTM_OWN_CU")) : 160;
-  if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / 4) lds = (size_t)hog * 1024;
+  static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 2;
+  if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
   static size_t lds_set = 0;
   if (lds > lds_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
   (void)hipMemsetAsync(hxmem, 0, hxbytes, st);                             // tags and the error word start at zero, every call
@@ -663,7 +664,8 @@ bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb,
   unsigned* flags = (unsigned*)((char*)flagmem + 16);
   static const int hog = getenv("RE2E_LSTM_OWN_CU") ? atoi(getenv("RE2E_LSTM_OWN_CU")) : 160;      // see launch_fwd_persist
   size_t lds = 0;
-  if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / 4) lds = (size_t)(hog - 16) * 1024;       // + ~13 KB static
+  static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 2;
+  if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)(hog - 16) * 1024;       // + ~13 KB static
   static size_t lds_set = 0;
   if (lds > lds_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persist<TPW, UW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
   hipLaunchKernelGGL((lstm_bwd_persist<TPW, UW>), grid, dim3(256), lds, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
