@@ -94,7 +94,8 @@ class JointTrainer(object):
             # relieves the backward) -- and again with the persistent recurrences, only the FAKE half, started exactly when the
             # encoder's chain starts: ASR forward +3.9 ms, enhancer backward -2.7 ms, step 88.9 -> 91.0 ms; holding the G-step's
             # backward through D until the decoder's backward chain is done (decoder backward -1.9 ms, BLSTMP backward +1.6 ms:
-            # within the noise of the step); a dedicated stream for the recurrent sequences masked to the 32 CUs the fillers leave
+            # within the noise of the step); the FAKE half of the D-step between two backward calls cut at the encoder output,
+            # i.e. under the BLSTMP's backward recurrences (75.25 -> 75.6 ms); a dedicated stream for the recurrent sequences masked to the 32 CUs the fillers leave
             # alone (GPU_MAX_HW_QUEUES=8): the chains are no faster there (16.9 vs 18 ms for the enhancer forward under the
             # D(real) filler -- the slowdown under load is not CU sharing) and 256-workgroup sequences do not fit 32 CUs.
         self.main_stream = None
