@@ -140,7 +140,7 @@ static inline int colsum_chunks(int M, int N) {
   if (!ct) { int c = cdiv(M, 128); return c > 512 ? 512 : (c < 1 ? 1 : c); }
   int rpb = 256 / (ct / 4);
   long c = cdiv(M, (long)rpb * 8);           // >= 8 passes per workgroup
-  long cap = 2048 / (N / ct);               // ~2048 workgroups in total
+  long cap = 1024 / (N / ct);               // ~1024 workgroups in total (the one-workgroup final stage reads chunks x N partials)
   if (cap < 16) cap = 16;
   return (int)(c < 1 ? 1 : (c > cap ? cap : c));
 }
