@@ -2,6 +2,7 @@
 PyTorch fp32 ops on the CPU.  GPU only.  Tolerance: 1e-3 relative to the tensor scale
 (north_star: "within 1e-3 fp32"); most kernels land at 1e-5..1e-6."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -11,6 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _ops():
@@ -316,6 +318,21 @@ def test_lstm_persistent_vs_stepwise(B, T, H, uw, monkeypatch):
         assert torch.isfinite(b).all(), name
         close(name, b, a, tol=5e-6)
     assert lib.query('re2e_lstm_abort_count') == 0
+
+
+def test_lstm_persistent_handoffs_under_load():
+    """The in-launch hand-offs of the persistent recurrences (tagged granules forward, flagged write-through slabs backward)
+    beside an uneven filler load on another stream: every output word of repeated runs equals the launch-per-step result."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('stress_lstm_persist', os.path.join(ROOT, 'tools', 'stress_lstm_persist.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        assert mod.run(60, 32, 256, 24) == 0
+        assert mod.run(24, 64, 512, 24) == 0
+    finally:
+        os.environ.pop('RE2E_LSTM_PERSIST', None)
+        os.environ.pop('RE2E_LSTM_PERSIST_BWD', None)
 
 
 def test_ctc():
