@@ -823,7 +823,7 @@ extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, con
   ep.C = out; ep.ldc = Cout; ep.M = M; ep.N = Cout; ep.bias = bias; ep.act = act; ep.beta = beta; ep.nsplit = 1;
   ep.remap = 1; ep.PH = PH; ep.PW = PW; ep.OHF = OHF; ep.OWF = OWF; ep.osy = osy; ep.osx = osx; ep.ooy = ooy; ep.oox = oox;
   if (osy == 1 && osx == 1 && ooy == 0 && oox == 0 && OHF == PH && OWF == PW) ep.remap = 0;
-  if (Cout == 1 && thin_enabled()) {
+  if ((Cout == 1 || C == 1) && thin_enabled()) {
     OutMap om{out, (long)Cout, ep.remap, PH, PW, OHF, OWF, osy, osx, ooy, oox};
     if (thin_conv_forward(g, wg, Cout, om, bias, act, beta, stream)) {
       RE2E_LAUNCH_CHECK();

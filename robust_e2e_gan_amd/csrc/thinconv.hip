@@ -239,12 +239,64 @@ void launch_cout1(const ConvGeom& g, const float* wg, int K, int M, const OutMap
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, g, wg, K, M, o, bias, act, beta);
 }
 
+// ---- Cin == 1 forward (VGG conv1_1, discriminator conv1): out[m][co] = act(b[co] + sum_taps in[pixel + tap] W[co][tap]) ----
+// K is 9 or 16, so an MFMA tile is mostly padding and the kernel is bound by writing the output (1 GB at config 4).
+// Thread = (4 output channels, pixel lane): its 4 x taps weights live in registers, pixels advance by the number of pixel lanes
+// with an incremental (n, py, px) update -- no division in the loop, one float4 store per pixel.
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_cin1_fwd_kernel(ConvGeom g, const float* __restrict__ wg, int Cout, long M, float* __restrict__ out,
+                                                            const float* __restrict__ bias, int act) {
+  constexpr int TAPS = KH * KW;
+  const int c4n = Cout >> 2, c4 = threadIdx.x % c4n, pl = threadIdx.x / c4n, npl = 256 / c4n;
+  float w[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[t][j] = wg[(4 * c4 + j) * TAPS + t];
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = f32x4{bias[4 * c4], bias[4 * c4 + 1], bias[4 * c4 + 2], bias[4 * c4 + 3]};
+  const long stride = (long)gridDim.x * npl;
+  long m = (long)blockIdx.x * npl + pl;
+  if (m >= M) return;
+  int px = (int)(m % g.PW); long r = m / g.PW; int py = (int)(r % g.PH); int n = (int)(r / g.PH);
+  const int dpx = (int)(stride % g.PW); const long rr = stride / g.PW; const int dpy = (int)(rr % g.PH), dn = (int)(rr / g.PH);
+  for (; m < M; m += stride) {
+    f32x4 acc = bv;
+    const float* ib = g.in + (long)n * g.H * g.W;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+      const int iy = py * g.SY + kh * g.DY + g.OY0;
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        const int ix = px * g.SX + kw * g.DX + g.OX0;
+        const float v = (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) ? ib[(long)iy * g.W + ix] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v * w[kh * KW + kw][j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = apply_act(acc[j], act);
+    *reinterpret_cast<f32x4*>(out + m * Cout + 4 * c4) = acc;
+    px += dpx; py += dpy; n += dn;                         // (n, py, px) += stride, with carries
+    if (px >= g.PW) { px -= g.PW; ++py; }
+    if (py >= g.PH) { py -= g.PH; ++n; }
+  }
+}
+
 }  // namespace
 
 bool thin_conv_forward(const ConvGeom& g, const float* wg, int Cout, const OutMap& o, const float* bias, int act, float beta,
                        hipStream_t st) {
   const int M = g.NI * g.PH * g.PW;
   const int K = g.KH * g.KW * g.C;
+  if (g.C == 1 && Cout % 4 == 0 && Cout <= 256 && pow2(Cout / 4) && !o.remap && o.ldc == Cout && beta == 0.f && aligned16(o.out) &&
+      ((g.KH == 3 && g.KW == 3) || (g.KH == 4 && g.KW == 4))) {
+    const int npl = 256 / (Cout / 4);
+    const int grid = (int)min((long)cdiv(M, npl * 8), 8192L);     // >= 8 pixels per thread
+    if (g.KH == 3) hipLaunchKernelGGL((conv_cin1_fwd_kernel<3, 3>), dim3(grid), dim3(256), 0, st, g, wg, Cout, (long)M, o.out, bias, act);
+    else hipLaunchKernelGGL((conv_cin1_fwd_kernel<4, 4>), dim3(grid), dim3(256), 0, st, g, wg, Cout, (long)M, o.out, bias, act);
+    return true;
+  }
   if (!(Cout == 1 && g.C % 4 == 0 && K <= 16384 && aligned16(g.in) && aligned16(wg))) return false;
   const int c4n = g.C / 4;
   int L = 1;
