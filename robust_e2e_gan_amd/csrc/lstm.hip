@@ -160,7 +160,7 @@ typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) u64 gu64;
 __device__ unsigned g_persist_aborts = 0;      // sequences given up because a peer workgroup never published (re2e_lstm_abort_count)
-constexpr unsigned kSpinLimit = 1u << 16;      // sweeps (~1 us each) before a workgroup gives up on a peer
+constexpr unsigned kSpinLimit = 1u << 18;      // polls (~1-2 us each, i.e. ~0.3-0.5 s) before a workgroup gives up on a peer
 
 template <int WAVES, int QN>
 __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, float* xg_r, const float* __restrict__ wfrag, float* ybuf,
