@@ -6,6 +6,7 @@ accumulated by the kernels straight into ``param.grad`` (GEMM/conv epilogue ``be
 what lets the optimizer and the RCCL all-reduce work on one flat buffer per network
 (robust_e2e_gan_amd/optim.py, dist.py).
 """
+import os
 import time
 import torch
 
@@ -584,8 +585,20 @@ class BiLstmFn(torch.autograd.Function):
         H = w[1].shape[1]
         x2 = x.view(T * B, I)
         xg = [empty((T * B, 4 * H), x), empty((T * B, 4 * H), x)]
-        for d in range(2):
-            gemm(x2, w[4 * d], xg[d], T * B, 4 * H, I, transb=True, bias=w[4 * d + 2], bias2=w[4 * d + 3])
+        Ip = (I + 3) & ~3
+        if Ip != I and T * B >= 1024 and os.environ.get('RE2E_NO_PAD_INPUT') != '1':
+            # an input width that is not a multiple of 4 (the enhancer's 257 bins) would send three large GEMMs of this layer down
+            # the scalar-load path of the engine: work on zero-padded copies of x and W_ih instead (exact: the extra products are 0)
+            x2p = zeros((T * B, Ip), x)
+            x2p[:, :I].copy_(x2)
+            for d in range(2):
+                wp = zeros((4 * H, Ip), x)
+                wp[:, :I].copy_(w[4 * d].detach())
+                gemm(x2p, wp, xg[d], T * B, 4 * H, Ip, transb=True, bias=w[4 * d + 2], bias2=w[4 * d + 3])
+            x2 = x2p
+        else:
+            for d in range(2):
+                gemm(x2, w[4 * d], xg[d], T * B, 4 * H, I, transb=True, bias=w[4 * d + 2], bias2=w[4 * d + 3])
         ybuf = zeros((T + 2, B, 2 * H), x)
         cbuf = zeros((T + 2, B, 2 * H), x)
         wsb = query('re2e_lstm_workspace_bytes', B, H)
@@ -622,7 +635,15 @@ class BiLstmFn(torch.autograd.Function):
             for d in range(2):
                 w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
                 n_ih, n_hh, n_bi, n_bh = ctx.needs_input_grad[2 + 4 * d:6 + 4 * d]
-                if n_ih:
+                if n_ih and x2.shape[1] != I:              # padded input copy (see forward): full-width product, then the real columns
+                    tmp = empty((4 * H, x2.shape[1]), dy)
+                    gemm(dG[d], x2, tmp, 4 * H, x2.shape[1], M, transa=True)
+                    with accumulate(w_ih) as (gw, beta):
+                        if beta == 0.0:
+                            gw.copy_(tmp[:, :I])
+                        else:
+                            gw.add_(tmp[:, :I])
+                elif n_ih:
                     with accumulate(w_ih) as (gw, beta):
                         gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
                 if n_hh:

@@ -240,7 +240,8 @@ def test_bn_lrelu(N, C, H, W):
 @pytest.mark.parametrize('B,T,I,H,lens', [(3, 11, 20, 16, [11, 7, 4]), (40, 9, 33, 64, None), (5, 6, 257, 24, [6, 6, 5, 2, 1]),
                                           # shapes the persistent (one launch per sequence) forward covers: (waves, k-groups per wave)
                                           (40, 23, 17, 256, None), (33, 14, 9, 320, None), (64, 12, 12, 512, None), (5, 19, 8, 32, [19, 19, 7, 2, 1]),
-                                          (7, 13, 8, 128, None), (2, 10, 8, 192, [10, 4])])
+                                          (7, 13, 8, 128, None), (2, 10, 8, 192, [10, 4]),
+                                          (40, 30, 257, 32, None)])       # >= 1024 rows with an odd input width: zero-padded copies of x / W_ih
 def test_bilstm(B, T, I, H, lens):
     ops, lib = _ops()
     if lens is None:
