@@ -45,16 +45,18 @@ class Adadelta:
 class JointState:
     """Parameters of the four nets as leaf tensors + optimizer state + D's BN buffers."""
 
-    def __init__(self, enh, asr, gan, fbank_W, cfg):
+    def __init__(self, enh, asr, gan, fbank_W, cfg, dtype=torch.float32):
+        """``dtype=torch.float64`` runs the same restatement in double precision: the arbiter for gradient tolerances
+        (both fp32 sides -- this oracle and the HIP path -- are compared against it; inputs must be double as well)."""
         self.cfg = cfg
-        leaf = lambda d: {k: v.clone().float().requires_grad_(True) for k, v in d.items()
+        leaf = lambda d: {k: v.clone().to(dtype).requires_grad_(True) for k, v in d.items()
                           if v.dtype.is_floating_point and 'running_' not in k}
         self.enh = leaf(enh)
         self.asr = leaf({k: v for k, v in asr.items() if not k.startswith('dec.att.')})
         self.gan = leaf(gan)
-        self.gan_buf = {k: v.clone() for k, v in gan.items()
+        self.gan_buf = {k: (v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in gan.items()
                         if 'running_' in k or 'num_batches' in k}
-        self.W = fbank_W.clone().float()
+        self.W = fbank_W.clone().to(dtype)
         self.opt_enh = Adadelta(self.enh, eps=cfg['eps'])
         self.opt_asr = Adadelta(self.asr, eps=cfg['eps'])
         self.opt_gan = Adadelta(self.gan, eps=cfg['eps'])

@@ -49,6 +49,42 @@ def allreduce_mean_(flat, async_op=False):
     return None
 
 
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def broadcast_(t, src=0):
+    """In-place broadcast of a tensor from ``src`` (no-op at world_size 1).  A CPU tensor under the nccl backend is
+    staged through the current device."""
+    if world_size() == 1:
+        return t
+    if dist.get_backend() == 'nccl' and not t.is_cuda:
+        d = t.cuda()
+        dist.broadcast(d, src)
+        t.copy_(d.cpu())
+        return t
+    dist.broadcast(t, src)
+    return t
+
+
+def average_buffers_(module):
+    """Mean over ranks of a module's floating-point buffers (the discriminator's BatchNorm running statistics: every
+    replica normalises with its own batch statistics -- standard DDP semantics -- so the running estimates drift apart;
+    averaging them before validation / checkpoints keeps replicas and saved models identical)."""
+    if world_size() == 1:
+        return
+    bufs = [b for b in module.buffers() if b.dtype.is_floating_point]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
+    allreduce_mean_(flat)
+    off = 0
+    for b in bufs:
+        n = b.numel()
+        b.copy_(flat[off:off + n].view_as(b))
+        off += n
+
+
 class GradSync:
     """Overlapped gradient averaging for the joint step.
 
@@ -61,7 +97,12 @@ class GradSync:
     def __init__(self):
         self.pending = []
 
-    def arm(self, boundary_tensor, early_opt):
+    def arm(self, boundary_tensor, early_opt, issue_stream=None, also_wait=()):
+        """``issue_stream``: the stream that carries the weight-gradient kernels of ``early_opt``'s network when the step
+        is multi-stream (ops.WGRAD_STREAM).  RCCL orders its own stream only behind the stream the collective is issued
+        from, so the hook issues the all-reduce FROM that stream, after making it wait for the stream the backward runs
+        on and for every stream in ``also_wait`` -- an in-place all-reduce issued from the backward's stream would race
+        with gradient kernels still queued on the others."""
         self._early = None
         if world_size() == 1 or not boundary_tensor.requires_grad:
             self._early = None
@@ -69,7 +110,17 @@ class GradSync:
         self._early = early_opt
 
         def hook(grad):
-            w = allreduce_mean_(early_opt.grad, async_op=True)
+            if issue_stream is not None and torch.cuda.is_available():
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                issue_stream.wait_event(ev)
+                for s in also_wait:
+                    if s is not None and s is not issue_stream:
+                        issue_stream.wait_stream(s)
+                with torch.cuda.stream(issue_stream):
+                    w = allreduce_mean_(early_opt.grad, async_op=True)
+            else:
+                w = allreduce_mean_(early_opt.grad, async_op=True)
             if w is not None:
                 self.pending.append(w)
             self._early = None

@@ -5,6 +5,8 @@
 order of operations (Appendix A.12-14): freeze toggling, clip on the ASR net only, NaN guard
 gating both G optimizers, D clipped separately.  Every rank runs it on its own utterance shard;
 gradients are averaged by dist.GradSync (RCCL) before clipping."""
+import logging
+import math
 import os
 import time
 
@@ -32,7 +34,7 @@ def compute_cmvn_epoch(opt, train_loader, enhance_model, feat_model):
             enhance_out = enhance_model(mix_inputs, mix_log_inputs, input_sizes)
             enhance_cmvn = feat_model.compute_cmvn(enhance_out, input_sizes)
             if enhance_cmvn is not None:
-                if getattr(opt, 'exp_path', None):
+                if getattr(opt, 'exp_path', None) and rdist.rank() == 0:       # one writer per experiment directory
                     os.makedirs(opt.exp_path, exist_ok=True)
                     np.save(os.path.join(opt.exp_path, 'enhance_cmvn.npy'), enhance_cmvn)
                 break
@@ -40,7 +42,8 @@ def compute_cmvn_epoch(opt, train_loader, enhance_model, feat_model):
     feat_model.train()
     if enhance_cmvn is None:
         raise RuntimeError('train_loader exhausted before cmvn_num utterances were accumulated')
-    return torch.FloatTensor(enhance_cmvn)
+    # data parallel: every rank estimated the statistics on its own shard; all replicas use rank 0's (= the saved file)
+    return rdist.broadcast_(torch.FloatTensor(enhance_cmvn), 0)
 
 
 def build_optimizers(opt, enhance_model, asr_model, gan_model=None):
@@ -234,7 +237,9 @@ class JointTrainer(object):
         sync = GradSync()
         armed = clean_branch is None       # with the clean branch on the side stream the ASR gradients are complete only
         if armed:                          # after that stream has been joined, so the early all-reduce hook is not used
-            sync.arm(enhance_feat, self.asr_optimizer)
+            # the ASR weight-gradient kernels run on the wgrad stream (and the CTC branch on the aux stream) when the step is
+            # multi-stream: the hook issues the collective from the wgrad stream, behind events of the other two
+            sync.arm(enhance_feat, self.asr_optimizer, issue_stream=ops.WGRAD_STREAM, also_wait=[ops.AUX_STREAM])
         if self.isGAN and self.overlap_dstep:
             # Phase 1: backward of everything downstream of the enhancer (ASR, D, fbank) on the main stream.
             main = torch.cuda.current_stream()
@@ -314,10 +319,22 @@ class JointTrainer(object):
         else:
             reuse = self.isGAN and self.reuse_dfake
             ops.FROZEN_PARAMS = frozenset(id(p) for p in self.gan_model.parameters()) if reuse else frozenset()
+            # ShareE2E cuts the graph at the clean conv stack's output whenever that stack ran on the side stream
+            # (clean_branch is not None), GAN or not: d(loss)/d(leaf) lands in the leaf's .grad and the conv-stack
+            # backward (reached through CORAL and the shared BLSTMP) is run here, on the side stream.
+            cut = getattr(self.asr_model, 'clean_cut', None) if clean_branch is not None else None
+            self.asr_model.clean_cut = None
             try:
                 loss.backward(retain_graph=reuse)
             finally:
                 ops.FROZEN_PARAMS = frozenset()
+            if cut is not None and cut[1].grad is not None:
+                side = self.side_stream
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    cut[1].grad.record_stream(side)
+                    torch.autograd.backward([cut[0]], [cut[1].grad])
+                cut[1].grad = None
             loss_D = None
             if self.overlap_dstep:
                 torch.cuda.current_stream().wait_stream(self.side_stream)
@@ -335,7 +352,8 @@ class JointTrainer(object):
                 torch.cuda.current_stream().wait_stream(self.side_stream)
             out['train/loss_D'] = loss_D.detach()
         out.update({'train/loss': loss.detach(), 'train/loss_ctc': loss_ctc.detach().view(()), 'train/acc': acc, 'train/loss_att': loss_att.detach(),
-                    'train/enhance_loss': enhance_loss.detach(), 'train/coral_loss': coral_loss.detach(), 'grad_norm': grad_norm})
+                    'train/enhance_loss': enhance_loss.detach(), 'train/coral_loss': coral_loss.detach(),
+                    'grad_norm': grad_norm.clone()})     # a copy: the optimizer's stats buffer is rewritten by the next step
         self.last = dict(enhance_out=enhance_out, enhance_feat=enhance_feat)
         self._mark('optimizers')
         return out
@@ -445,12 +463,26 @@ class JointTrainer(object):
         for m in (self.enhance_model, self.feat_model, self.asr_model):
             m.train()
         pending = None
+        writer = rdist.rank() == 0          # data parallel: one rank writes checkpoints / plots into exp_path
 
         def flush():
             nonlocal pending
             if pending is not None:
-                visualizer.set_current_errors(self.to_floats(pending))
+                vals = self.to_floats(pending)
+                gn = vals.pop('grad_norm', 0.0)
+                if not math.isfinite(gn):             # joint_train.py:189-193: the update was skipped on the device
+                    logging.warning('grad norm is nan. Do not update model.')
+                visualizer.set_current_errors(vals)
                 pending = None
+
+        def check_recurrences():
+            # a persistent recurrence that gave up on a peer workgroup poisons its outputs with NaN, the NaN gate then skips
+            # every update: training would "run" without learning.  (The query synchronises the device: only called where
+            # the loop reads the meters back anyway.)
+            n = lib.query('re2e_lstm_abort_count')
+            if n != 0:
+                raise lib.Re2eError('%d recurrent sequences were aborted by a persistent LSTM kernel (a peer workgroup never '
+                                    'arrived); their outputs are NaN and the updates were skipped' % n)
 
         for epoch in range(start_epoch, opt.epochs):
             if train_sampler is not None and epoch > opt.shuffle_epoch:
@@ -458,14 +490,18 @@ class JointTrainer(object):
             for data in train_loader:
                 errors = self.step(data, sche_samp_rate, enhance_cmvn)
                 flush()                                   # previous step's meters, now that this step is queued
-                pending = {k: v for k, v in errors.items() if k.startswith('train/')}
+                pending = {k: v for k, v in errors.items() if k.startswith('train/') or k == 'grad_norm'}
                 iters += 1
                 if iters % opt.print_freq == 0:
                     flush()
+                    check_recurrences()
                     visualizer.print_current_errors(epoch, iters)
-                    st = self.state(epoch, iters, best_loss, best_acc)
-                    st.update(acc_report=acc_report, loss_report=loss_report)
-                    utils.save_checkpoint(st, opt.exp_path, filename='latest')
+                    if self.isGAN:
+                        rdist.average_buffers_(self.gan_model)
+                    if writer:
+                        st = self.state(epoch, iters, best_loss, best_acc)
+                        st.update(acc_report=acc_report, loss_report=loss_report)
+                        utils.save_checkpoint(st, opt.exp_path, filename='latest')
                 if iters % opt.validate_freq == 0:
                     flush()
                     sche_samp_rate = rampup.update(iters)
@@ -499,9 +535,13 @@ class JointTrainer(object):
                         else:
                             filename = 'model.loss.best'
                         best_loss = min(val_loss, best_loss)
-                    st = self.state(epoch, iters, best_loss, best_acc)
-                    st.update(acc_report=acc_report, loss_report=loss_report)
-                    utils.save_checkpoint(st, opt.exp_path, filename=filename)
+                    check_recurrences()
+                    if self.isGAN:
+                        rdist.average_buffers_(self.gan_model)
+                    if writer:
+                        st = self.state(epoch, iters, best_loss, best_acc)
+                        st.update(acc_report=acc_report, loss_report=loss_report)
+                        utils.save_checkpoint(st, opt.exp_path, filename=filename)
                     visualizer.reset()
                     enhance_cmvn = compute_cmvn_epoch(opt, train_loader, self.enhance_model, self.feat_model)
                 if max_iters is not None and iters >= max_iters:

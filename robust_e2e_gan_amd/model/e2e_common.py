@@ -73,13 +73,32 @@ _LENS_CACHE = {}
 
 
 def lens_dev(lens, device):
-    """int32 device copy of a length list; the same lists recur many times per step, so uploads are cached."""
+    """int32 device copy of a length list; the same lists recur many times per step, so uploads are cached.  An entry
+    remembers the stream its (non-blocking) upload was enqueued on and an event behind that copy: a user on ANOTHER
+    stream (the CTC branch on the aux stream, the decoder on main) waits for the event and tells the caching allocator
+    about its use, so neither a read ahead of the copy nor a reuse of the block under a late reader can happen."""
     key = (tuple(lens_list(lens)), str(device))
-    t = _LENS_CACHE.get(key)
-    if t is None:
+    ent = _LENS_CACHE.get(key)
+    cuda = torch.device(device).type == 'cuda'
+    if ent is None:
         if len(_LENS_CACHE) >= 256:
             _LENS_CACHE.clear()
-        t = _LENS_CACHE[key] = host_to_dev(np.asarray(key[0], np.int32), device)
+        t = host_to_dev(np.asarray(key[0], np.int32), device)
+        if cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            ent = (t, ev, torch.cuda.current_stream().cuda_stream, set())
+        else:
+            ent = (t, None, None, set())
+        _LENS_CACHE[key] = ent
+        return t
+    t, ev, sid, seen = ent
+    if cuda:
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream != sid and cur.cuda_stream not in seen:
+            cur.wait_event(ev)
+            t.record_stream(cur)
+            seen.add(cur.cuda_stream)
     return t
 
 

@@ -83,6 +83,80 @@ def test_config4_full_size_properties():
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), 'updated parameters must be bitwise reproducible'
 
 
+def _grad_report(named_params, ref_grads, tol, floor=1e-8):
+    bad = []
+    for k, p in named_params:
+        if k not in ref_grads:
+            continue
+        want = ref_grads[k]
+        err, scale = float((p.grad.cpu() - want).abs().max()), float(want.abs().max())
+        if err > tol * scale + floor:
+            bad.append((k, err / max(scale, 1e-30)))
+    return bad
+
+
+def test_config4_full_size_vs_oracle():
+    """NUMERICAL parity at BASELINE.json's headline size (B=32, T=800, L=40, V=4233, full-width networks): one joint step
+    against oracle.joint.joint_step on the same batch, weights and cmvn (~80 s of host time).  800-step fp32
+    recurrences, the 2B=64 shared BLSTMP and the 41-step decoder are where accumulation error grows; north_star's bar is
+    1e-3 on losses and masks.  Gradients: every parameter tensor of the three nets, relative to the tensor's max, within
+    2e-3 (two independent fp32 roundings of the same quantity, each up to ~1e-3 from the exact value at this depth: see
+    test_fp32_sides_within_1e3_of_fp64 for the arbitration at a size where float64 is affordable)."""
+    from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
+    from oracle import joint as oj
+    opt = config4_opt()
+    nets = _build(opt)
+    sd = [{k: v.clone() for k, v in m.state_dict().items()} for m in nets]
+    clean, mix, mix_log, targets, il, tl = _data(32, 800, 40, opt.odim, seed=1234)
+    cm = torch.stack([torch.linspace(-10.0, -7.0, 80), torch.linspace(0.3, 0.5, 80)])
+    enh, fb, asr, gan = [m.to(DEV) for m in nets]
+    tr = JointTrainer(opt, enh, fb, asr, gan)
+    data = (None, None, clean, None, mix, mix_log, None, targets, il, tl)
+    out = JointTrainer.to_floats(tr.step(data, 0.0, cm))
+    torch.cuda.synchronize()
+    cfg = dict(enhance_layers=2, elayers=3, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=opt.coral_loss_lambda, gan_loss_lambda=1.0,
+               grad_clip=5.0, eps=1e-8, isGAN=True, enhance_loss_type='L2')
+    torch.set_num_threads(max(1, min(64, len(__import__('os').sched_getaffinity(0)))))
+    ref = oj.joint_step(oj.JointState(sd[0], sd[2], sd[3], sd[1]['fc'], cfg), (clean, mix, mix_log, targets, il.tolist(), tl.tolist()), cm,
+                        update=False)
+    for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'gan_loss', 'loss_D'):
+        a, b = out['train/' + k], float(ref[k])
+        assert abs(a - b) <= 1e-3 * abs(b), (k, a, b)
+    assert abs(out['train/acc'] - ref['acc']) < 1e-9
+    assert abs(out['grad_norm'] - ref['grad_norm_asr']) <= 1e-3 * ref['grad_norm_asr']
+    eo, ef = tr.last['enhance_out'].cpu(), tr.last['enhance_feat'].cpu()
+    assert (eo - ref['enhance_out']).abs().max() <= 1e-3 * ref['enhance_out'].abs().max()      # the masks (x mix)
+    assert (ef - ref['enhance_feat']).abs().max() <= 1e-3 * ref['enhance_feat'].abs().max()
+    bad = _grad_report(asr.named_parameters(), ref['g_asr'], 2e-3) + _grad_report(enh.named_parameters(), ref['g_enh'], 2e-3) + \
+        _grad_report(gan.named_parameters(), ref['g_gan'], 2e-3)
+    assert not bad, sorted(bad, key=lambda r: -r[1])[:8]
+
+
+def test_config5_forward_vs_oracle():
+    """Config 5's shape (B=8, T=3000): the enhancer's mask product and the fbank features after a 3000-step bidirectional
+    recurrence, against oracle.nets (forward only: ~15 s of host time)."""
+    from robust_e2e_gan_amd.joint_train import config4_opt
+    from oracle import nets as on
+    opt = config4_opt()
+    enh, fb, _, _ = _build(opt)
+    sd = {k: v.clone() for k, v in enh.state_dict().items()}
+    W = fb.state_dict()['fc'].clone()
+    clean, mix, mix_log, targets, il, tl = _data(8, 3000, 150, opt.odim, seed=5)
+    with torch.no_grad():
+        ref_eo = on.enhance_forward(sd, mix, mix_log, il.tolist(), 2)
+        ref_ef = on.fbank_forward(ref_eo, W)
+        enh, fb = enh.to(DEV), fb.to(DEV)
+        eo = enh(mix, mix_log, il)
+        ef = fb(eo)
+    assert (eo.cpu() - ref_eo).abs().max() <= 1e-3 * ref_eo.abs().max()
+    # mask itself (enhance_out / mix where mix is not tiny): the quantity north_star names
+    big = mix > 1.0
+    assert ((eo.cpu() - ref_eo)[big] / mix[big]).abs().max() <= 1e-3
+    assert (ef.cpu() - ref_ef).abs().max() <= 1e-3 * ref_ef.abs().max()
+    for b, l in enumerate(il.tolist()):
+        assert float(eo[b, l:].abs().sum()) == 0.0
+
+
 def test_config5_long_utterances():
     """B=8, T=3000, L=150 (config 5): the step runs and stays finite (HBM-bound BLSTM regime)."""
     from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt

@@ -162,6 +162,44 @@ def test_joint_step(golden_dir):
                 rel(pre + k, v, fx[pre + k], tol=1e-3, atol=2e-5)
 
 
+def test_joint_step_gradients_vs_fp64_reference(golden_dir):
+    """Arbitrated gradient bar: every parameter gradient of the composed step within 1e-3 (relative to the tensor's max) of
+    the REFERENCE modules run in float64 (tests/golden/make_fixtures_fp64.py).  The fp32 reference run itself sits at up
+    to 5.3e-4 from these vectors (tests/test_oracle_golden.py::test_fp32_sides_within_1e3_of_fp64), which is why the
+    HIP-vs-fp32-fixture comparisons elsewhere in this file allow up to 3e-3: two fp32 roundings of the same quantity."""
+    import __graft_entry__ as g
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    fx = _fx(golden_dir, 'joint_tiny.npz')
+    f64 = _fx(golden_dir, 'joint_tiny_fp64.npz')
+    W = _fx(golden_dir, 'fbank_tiny.npz')['W']
+    opt = g._tiny_opt()
+    enh, asr, gan = _load(EnhanceModel(opt), fx, 'enh.'), _load(ShareE2E(opt), fx, 'asr.'), _load(GANModel(opt), fx, 'gan.')
+    fb = FbankModel(opt)
+    fb.load_state_dict({'fc': torch.from_numpy(W)})
+    tr = JointTrainer(opt, enh, fb.to(DEV).train(), asr, gan)
+    t = lambda k: torch.from_numpy(fx[k])
+    data = (None, None, t('clean'), None, t('mix'), t('mix_log'), None, t('targets'), torch.IntTensor(fx['lens']), torch.IntTensor(fx['tlens']))
+    out = JointTrainer.to_floats(tr.step(data, 0.0, t('cmvn')))
+    for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'loss_D'):
+        assert abs(out['train/' + k] - float(f64[k])) <= 1e-4 * max(1.0, abs(float(f64[k]))), (k, out['train/' + k], f64[k])
+    assert abs(out['grad_norm'] - float(f64['grad_norm_asr'])) <= 1e-3 * float(f64['grad_norm_asr'])
+    rel('enhance_out', tr.last['enhance_out'], f64['enhance_out'], tol=1e-4)
+    worst = (0.0, None)
+    for pre, m in (('genh.', enh), ('gasr.', asr), ('ggan.', gan)):
+        for k, p in m.named_parameters():
+            ref = f64[pre + k]
+            err, scale = np.abs(p.grad.double().cpu().numpy() - ref).max(), np.abs(ref).max()
+            if scale < 1e-12:          # att.gvec.bias: the true gradient is 0 (softmax shift invariance)
+                assert err < 1e-7, (k, err)
+                continue
+            worst = max(worst, (err / scale, pre + k))
+    assert worst[0] < 1e-3, worst
+
+
 def test_joint_step_overlap_equals_single_stream(golden_dir):
     """The multi-stream schedule (two-phase backward, side / weight-gradient streams) must produce the gradients of the
     plain single-stream ``loss.backward()`` step: every parameter of the four nets after one update, to rounding."""
@@ -192,6 +230,53 @@ def test_joint_step_overlap_equals_single_stream(golden_dir):
         grads[overlap] = {n + '.' + k: p.grad.clone() for n, m in (('enh', enh), ('asr', asr), ('gan', gan)) for k, p in m.named_parameters()}
     for k, ref in grads[False].items():
         rel(k, grads[True][k], ref.cpu().numpy(), tol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('overlap', [True, False])
+def test_joint_step_without_gan_vs_oracle(golden_dir, overlap):
+    """isGAN=False (the reference's default for --isGAN) with a CORAL weight: the clean branch's conv stack is reached ONLY
+    through CORAL and the shared BLSTMP.  With the multi-stream schedule that stack runs on the side stream behind a graph
+    cut; its gradients must still arrive (they were dropped on this path once), in both schedules, against the oracle."""
+    import __graft_entry__ as g
+    from oracle import joint as oj
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    fx = _fx(golden_dir, 'joint_tiny.npz')
+    W = torch.from_numpy(_fx(golden_dir, 'fbank_tiny.npz')['W'])
+    opt = g._tiny_opt()
+    opt.isGAN, opt.coral_loss_lambda = False, 20.0
+    t = lambda k: torch.from_numpy(fx[k])
+    lens, tls = fx['lens'].tolist(), fx['tlens'].tolist()
+    cfg = dict(enhance_layers=2, elayers=2, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=20.0, gan_loss_lambda=1.0, grad_clip=5.0,
+               eps=1e-8, isGAN=False, enhance_loss_type='L2')
+    sub = lambda pre: {k[len(pre):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith(pre)}
+    st = oj.JointState(sub('enh.'), sub('asr.'), sub('gan.'), W, cfg)
+    ref = oj.joint_step(st, (t('clean'), t('mix'), t('mix_log'), t('targets'), lens, tls), t('cmvn'))
+    # the oracle itself must see the clean-only path: CORAL-only gradient of the conv stack is not negligible
+    cfg0 = dict(cfg, coral_loss_lambda=0.0)
+    ref0 = oj.joint_step(oj.JointState(sub('enh.'), sub('asr.'), sub('gan.'), W, cfg0),
+                         (t('clean'), t('mix'), t('mix_log'), t('targets'), lens, tls), t('cmvn'))
+    k0 = 'enc.enc1.conv1_1.weight'
+    assert (ref['g_asr'][k0] - ref0['g_asr'][k0]).abs().max() > 1e-2 * ref['g_asr'][k0].abs().max()
+    enh, asr = _load(EnhanceModel(opt), fx, 'enh.'), _load(ShareE2E(opt), fx, 'asr.')
+    fb = FbankModel(opt)
+    fb.load_state_dict({'fc': W})
+    tr = JointTrainer(opt, enh, fb.to(DEV).train(), asr, None)
+    tr.overlap_dstep = overlap
+    data = (None, None, t('clean'), None, t('mix'), t('mix_log'), None, t('targets'), torch.IntTensor(lens), torch.IntTensor(tls))
+    out = JointTrainer.to_floats(tr.step(data, 0.0, t('cmvn')))
+    assert getattr(asr, 'clean_cut', None) is None           # no stale graph kept alive
+    assert 'train/loss_D' not in out and 'train/gan_loss' not in out
+    for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss'):
+        a, b = out['train/' + k], float(ref[k])
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (k, a, b)
+    assert abs(out['grad_norm'] - ref['grad_norm_asr']) <= 2e-3 * ref['grad_norm_asr']
+    for pre, m, gd in (('enh', enh, ref['g_enh']), ('asr', asr, ref['g_asr'])):
+        for k, p in m.named_parameters():
+            if k in gd:
+                rel(pre + '.' + k, p.grad, gd[k].numpy(), tol=3e-3, atol=1e-7)
 
 
 @pytest.mark.parametrize('lens,tls', [([33], [1]), ([37, 6], [2, 1]), ([33, 33, 32, 17, 5], [4, 1, 3, 2, 1]), ([64, 8], [7, 1])])
