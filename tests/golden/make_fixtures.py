@@ -16,8 +16,7 @@ Fixtures
   e2e_tiny.npz      E2E (vggblstmp + CTC + AttLoc + decoder) fwd/bwd         (F5-F10)
   gan_tiny.npz      GANModel 'basic' + GANLoss fwd/bwd, BN running stats     (F11, F12)
   joint_tiny.npz    one composed joint_train step with S1-S3 semantics       (F13)
-  collate_tiny.npz  hand-built ragged batch for _collate_fn (restated; the
-                    reference loader module cannot be imported: librosa etc.) (F1)
+  (collate_tiny.npz, F1, is written by make_fixtures_collate.py from the reference's own _collate_fn)
 """
 import argparse
 import os
@@ -291,28 +290,7 @@ def main():
     fx.update(sd_np('gan_after.', gan))
     np.savez_compressed(os.path.join(HERE, 'joint_tiny.npz'), **fx)
 
-    # ---------------- collate (restated from mix_data_loader.py:264-302) ---------------
-    g = torch.Generator().manual_seed(9)
-    slens = [4, 7, 5]
-    samples = []
-    for i, l in enumerate(slens):
-        s = [torch.rand(l, 6, generator=g) for _ in range(5)]
-        samples.append((s, list(range(i + 1, i + 1 + (i + 2)))))
-    order = sorted(range(3), key=lambda i: slens[i], reverse=True)
-    Tm = max(slens)
-    exp = np.zeros((5, 3, Tm, 6), np.float32)
-    for x, i in enumerate(order):
-        for k in range(5):
-            exp[k, x, :slens[i]] = samples[i][0][k].numpy()
-    fx = dict(order=np.array(order), expected=exp,
-              input_sizes=np.array([slens[i] for i in order], np.int32),
-              target_sizes=np.array([len(samples[i][1]) for i in order], np.int32),
-              targets=np.array(sum([samples[i][1] for i in order], []), np.int64))
-    for i in range(3):
-        for k in range(5):
-            fx['s%d_%d' % (i, k)] = samples[i][0][k].numpy()
-        fx['t%d' % i] = np.array(samples[i][1], np.int64)
-    np.savez_compressed(os.path.join(HERE, 'collate_tiny.npz'), **fx)
+    # collate_tiny.npz (F1) comes from the reference's own _collate_fn: make_fixtures_collate.py
     print('fixtures written to', HERE)
 
 

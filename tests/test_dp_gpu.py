@@ -52,7 +52,7 @@ def test_dp_branches_equal_single_process_step(golden_dir, one_rank_group, monke
     for dp in (False, True):
         opt = g._tiny_opt()
         opt.etype, opt.isGAN = etype, isgan
-        opt.coral_loss_lambda = 5.0
+        opt.coral_loss_lambda = 2e6
         enh, fb, asr, gan = _nets(opt, fx, W)
         tr = JointTrainer(opt, enh, fb, asr, gan if isgan else None)
         with monkeypatch.context() as mp:

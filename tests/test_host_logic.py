@@ -10,28 +10,38 @@ def _fx(golden_dir, name):
     return dict(np.load(os.path.join(golden_dir, name)))
 
 
-def test_collate_matches_golden(golden_dir):
+def test_collate_matches_reference_output(golden_dir):
+    """F1: ``_collate_fn`` against the OUTPUT of the reference's own function (tests/golden/make_fixtures_collate.py imports
+    data/mix_data_loader.py:264-302): a tie in lengths (stable order), an empty target list, a one-frame sample."""
     from robust_e2e_gan_amd.data.mix_data_loader import _collate_fn
     fx = _fx(golden_dir, 'collate_tiny.npz')
     batch = []
-    for i in range(3):
+    for i in range(int(fx['n'])):
         s = [torch.from_numpy(fx['s%d_%d' % (i, k)]) for k in range(5)]
-        batch.append(('utt%d' % i, 'spk%d' % i, s[0], s[1], s[2], s[3], s[4], fx['t%d' % i].tolist()))
+        batch.append(('utt%d' % i, 'spk%d' % (i % 2), s[0], s[1], s[2], s[3], s[4], fx['t%d' % i].tolist()))
     out = _collate_fn(batch)
     assert out[0] == ['utt%d' % i for i in fx['order']]
+    assert out[1] == ['spk%d' % i for i in fx['spk']]
     for k in range(5):
-        assert np.array_equal(out[2 + k].numpy(), fx['expected'][k])
+        assert out[2 + k].dtype == torch.float32 and np.array_equal(out[2 + k].numpy(), fx['expected'][k])
     assert out[8].dtype == torch.int32 and np.array_equal(out[8].numpy(), fx['input_sizes'])
-    assert np.array_equal(out[9].numpy(), fx['target_sizes'])
+    assert out[9].dtype == torch.int32 and np.array_equal(out[9].numpy(), fx['target_sizes'])
     assert out[7].dtype == torch.int64 and np.array_equal(out[7].numpy(), fx['targets'])
+    assert 0 in fx['target_sizes'].tolist() and len(set(fx['input_sizes'].tolist())) < int(fx['n'])      # the edge cases are in
 
 
-def test_asr_collate():
+def test_asr_collate_matches_reference_output(golden_dir):
+    """the ASR twin, data/data_loader.py:236-265"""
     from robust_e2e_gan_amd.data.data_loader import _collate_fn
-    b = [('a', 's', torch.ones(3, 4), torch.ones(3, 4) * 2, [1, 2]), ('b', 's', torch.ones(5, 4), torch.ones(5, 4) * 2, [3])]
-    out = _collate_fn(b)
-    assert out[0] == ['b', 'a'] and out[2].shape == (2, 5, 4) and out[2][1, 3:].sum() == 0
-    assert out[5].tolist() == [5, 3] and out[6].tolist() == [1, 2] and out[4].tolist() == [3, 1, 2]
+    fx = _fx(golden_dir, 'collate_tiny.npz')
+    batch = [('a%d' % i, 's', torch.from_numpy(fx['asr.s%d_0' % i]), torch.from_numpy(fx['asr.s%d_1' % i]), fx['asr.t%d' % i].tolist())
+             for i in range(int(fx['asr.n']))]
+    out = _collate_fn(batch)
+    assert out[0] == ['a%d' % i for i in fx['asr.order']]
+    assert np.array_equal(out[2].numpy(), fx['asr.expected'][0]) and np.array_equal(out[3].numpy(), fx['asr.expected'][1])
+    assert out[4].dtype == torch.int64 and np.array_equal(out[4].numpy(), fx['asr.targets'])
+    assert out[5].dtype == torch.int32 and np.array_equal(out[5].numpy(), fx['asr.input_sizes'])
+    assert np.array_equal(out[6].numpy(), fx['asr.target_sizes'])
 
 
 def test_options_surface():

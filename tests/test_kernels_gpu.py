@@ -442,6 +442,25 @@ def test_misc_layout_kernels():
     close('pack_pad', padded, ref, tol=0, atol=0)
 
 
+def test_collate_device_matches_reference_output(golden_dir):
+    """K1/F1: the device-side collate (one H2D copy per stream + pad kernel) against the OUTPUT of the reference's
+    ``_collate_fn`` (tests/golden/make_fixtures_collate.py): bit-exact, ties in length and an empty target included."""
+    import os
+    import numpy as np
+    from robust_e2e_gan_amd.data.mix_data_loader import collate_device
+    fx = dict(np.load(os.path.join(golden_dir, 'collate_tiny.npz')))
+    batch = []
+    for i in range(int(fx['n'])):
+        s5 = [torch.from_numpy(fx['s%d_%d' % (i, k)]) for k in range(5)]
+        batch.append(('utt%d' % i, 'spk%d' % (i % 2), s5[0], s5[1], s5[2], s5[3], s5[4], fx['t%d' % i].tolist()))
+    out = collate_device(batch, DEV, streams=(2, 3, 4, 5, 6))
+    assert out[0] == ['utt%d' % i for i in fx['order']]
+    for k in range(5):
+        assert out[2 + k].is_cuda and np.array_equal(out[2 + k].cpu().numpy(), fx['expected'][k]), k
+    assert np.array_equal(out[7].numpy(), fx['targets']) and np.array_equal(out[8].numpy(), fx['input_sizes'])
+    assert np.array_equal(out[9].numpy(), fx['target_sizes'])
+
+
 @pytest.mark.parametrize('M,N', [(1000, 64), (517, 2048), (300, 1200), (77, 4233), (5000, 8), (9, 128), (40000, 256)])
 def test_colsum_and_fused_act_bwd(M, N):
     """re2e_colsum / re2e_act_bwd_colsum: vectorised tiles (N/4 a power of two, or N % 1024 == 0) and the scalar

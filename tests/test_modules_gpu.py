@@ -216,7 +216,8 @@ def test_joint_step_overlap_equals_single_stream(golden_dir):
     grads = {}
     for overlap in (False, True):
         opt = g._tiny_opt()
-        opt.coral_loss_lambda = 50.0            # makes the clean branch's (CORAL-only) contribution to the gradients large
+        opt.coral_loss_lambda = 2e6             # raw CORAL is ~4e-9 at initialisation: at this weight the clean branch's (CORAL-only)
+                                                # contribution is ~15 % of the conv-stack gradients (a dropped one cannot hide in the tolerance)
         enh, asr, gan = _load(EnhanceModel(opt), fx, 'enh.'), _load(ShareE2E(opt), fx, 'asr.'), _load(GANModel(opt), fx, 'gan.')
         fb = FbankModel(opt)
         fb.load_state_dict({'fc': torch.from_numpy(W)})
@@ -246,10 +247,10 @@ def test_joint_step_without_gan_vs_oracle(golden_dir, overlap):
     fx = _fx(golden_dir, 'joint_tiny.npz')
     W = torch.from_numpy(_fx(golden_dir, 'fbank_tiny.npz')['W'])
     opt = g._tiny_opt()
-    opt.isGAN, opt.coral_loss_lambda = False, 20.0
+    opt.isGAN, opt.coral_loss_lambda = False, 2e6       # raw CORAL is ~4e-9 at initialisation: the weight that makes it matter
     t = lambda k: torch.from_numpy(fx[k])
     lens, tls = fx['lens'].tolist(), fx['tlens'].tolist()
-    cfg = dict(enhance_layers=2, elayers=2, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=20.0, gan_loss_lambda=1.0, grad_clip=5.0,
+    cfg = dict(enhance_layers=2, elayers=2, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=2e6, gan_loss_lambda=1.0, grad_clip=5.0,
                eps=1e-8, isGAN=False, enhance_loss_type='L2')
     sub = lambda pre: {k[len(pre):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith(pre)}
     st = oj.JointState(sub('enh.'), sub('asr.'), sub('gan.'), W, cfg)
@@ -259,7 +260,7 @@ def test_joint_step_without_gan_vs_oracle(golden_dir, overlap):
     ref0 = oj.joint_step(oj.JointState(sub('enh.'), sub('asr.'), sub('gan.'), W, cfg0),
                          (t('clean'), t('mix'), t('mix_log'), t('targets'), lens, tls), t('cmvn'))
     k0 = 'enc.enc1.conv1_1.weight'
-    assert (ref['g_asr'][k0] - ref0['g_asr'][k0]).abs().max() > 1e-2 * ref['g_asr'][k0].abs().max()
+    assert (ref['g_asr'][k0] - ref0['g_asr'][k0]).abs().max() > 5e-2 * ref['g_asr'][k0].abs().max()
     enh, asr = _load(EnhanceModel(opt), fx, 'enh.'), _load(ShareE2E(opt), fx, 'asr.')
     fb = FbankModel(opt)
     fb.load_state_dict({'fc': W})
