@@ -111,3 +111,7 @@ bool thin_conv_forward(const ConvGeom& g, const float* wg, int Cout, const OutMa
                        float beta, hipStream_t st);
 int thin_wgrad_slabs(int C, int Cout, int KH, int KW, long P, long rows);
 void thin_wgrad(const ConvGeom& g, const float* dout, int Cout, float* slabs, int nslab, hipStream_t st);
+
+// 3x3 / stride-1 / pad-1 convolutions with C % 16 == 0 and Cout % 64 == 0 (conv3x3.hip: halo patch staged once per channel
+// chunk, taps walked in LDS).  Returns false when the geometry is not covered (the caller then uses the implicit GEMM).
+bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, const float* bias, int act, float beta, hipStream_t st);

@@ -1,0 +1,224 @@
+// K5: 3x3 / stride-1 / pad-1 convolution (forward and data gradient) over NHWC activations as a HALO-TILE
+// implicit GEMM on the fp32 matrix core (v_mfma_f32_32x32x2_f32), gfx950 only.
+//
+// The general engine (igemm.hip) re-stages the im2col operand once per tap: every 16-channel k-step gathers a fresh
+// 256 x 16 tile from global memory, 9 times per channel chunk, with per-lane tap/bounds arithmetic between the loads
+// (profiles/r01_conv1_2_pmc_*.json: FETCH 3.4x the input, matrix pipe 69 % busy).  Here a workgroup owns a TH x TW patch of
+// output pixels (256 of them) x 64 output channels and walks the input channels in chunks of 16:
+//
+//   per chunk   the (TH+2) x (TW+2) input patch WITH its halo (16 channels = one 64-byte segment per pixel) and the
+//               9 x 64 x 16 weight slice are staged in LDS ONCE (register-staged: the loads of chunk c+1 are issued before
+//               the matrix work of chunk c and written to LDS behind it),
+//   9 taps      are then 9 constant LDS address offsets on the same patch: 288 MFMAs per wavefront between two barriers
+//               (the engine: 32), no address arithmetic, no bounds checks, no global traffic inside the matrix block.
+//
+// Out-of-image halo pixels read as zero through the buffer descriptor's range check (offset 2^31), so padding costs no
+// branch.  LDS rows are padded to 20 floats: one ds_read_b128 per fragment feeds 4 MFMAs (k = 8q + 4*(lane>>5) + j, the
+// engine's mapping), conflict-free.  73.3 KB of LDS and <= 256 registers: two workgroups per CU, so one workgroup's staging /
+// epilogue runs under the other's matrix block.  Workgroups are ordered XCD-aware (each XCD's L2 sees a contiguous run of
+// patches, the two 64-channel halves of a 128-channel layer back to back).
+//
+// DIR = +1: forward (tap (a,b) reads pixel (y+a-1, x+b-1)); DIR = -1: data gradient (reads (y+1-a, x+1-b) of dy with the
+// transposed gathered weights) -- the same two geometries re2e_conv_igemm receives from ops.Conv2dFn / ops.conv_dgrad.
+//
+// Replaces (reference): nn.Conv2d 3x3 of VGG2L, model/e2e_encoder.py:234-237,258-266 (conv1_2, conv2_1, conv2_2) and their
+// autograd data gradients.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CK = 16;        // input channels per chunk (one 64-byte segment per pixel)
+constexpr int LDC = CK + 4;   // padded LDS row (floats)
+constexpr int NT = 64;        // output channels per workgroup
+constexpr unsigned OOB = 0x80000000u;   // byte offset beyond any tensor this path accepts (< 2 GiB): the load returns 0
+
+struct HaloArgs {
+  const float* in; const float* wg; float* out; const float* bias;
+  int NI, H, W, C, Cout, act; float beta;
+  int tiles_x, tiles_y, ngn;      // patches per row / column, 64-channel groups
+  unsigned in_bytes, wg_bytes;
+};
+
+template <int TH, int TW, int DIR>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
+  constexpr int HPW = TW + 2, HPH = TH + 2, HP = HPW * HPH;
+  constexpr int AIT = (HP * 4 + 255) / 256;            // float4 items per thread, input patch
+  constexpr int ASZ = AIT * 64 * LDC;                  // floats (rows beyond HP are scratch for the surplus items)
+  constexpr int RPS = 32 / TW;                         // patch rows per 32-pixel MFMA sub-tile
+  static_assert(TH * TW == 256 && 32 % TW == 0, "patch must hold 8 sub-tiles of 32 pixels");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + ASZ;                              // [9][64][LDC]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of the sequence
+  int pid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
+  const int nblk = pid % p.ngn, tile = pid / p.ngn;
+  const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW, n0 = nblk * NT;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wg), 0, p.wg_bytes, 0x00020000);
+
+  // ---- staging addresses: fixed for the whole patch, the chunk only adds c0*4 bytes
+  unsigned a_off[AIT];
+#pragma unroll
+  for (int i = 0; i < AIT; ++i) {
+    const int idx = i * 256 + tid, hp = idx >> 2, kq = idx & 3;
+    const int hy = hp / HPW, hx = hp - hy * HPW;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool ok = (hp < HP) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+    a_off[i] = ok ? (unsigned)(((((long)n * p.H + iy) * p.W + ix) * p.C + kq * 4) * 4) : OOB;
+  }
+  const int a_dst = (tid >> 2) * LDC + (tid & 3) * 4;                       // + i*64*LDC
+  const unsigned b_off = (unsigned)((((long)(n0 + (tid >> 2)) * 9) * p.C + (tid & 3) * 4) * 4);   // + tap*C*4 + c0*4
+  const int b_dst = (tid >> 2) * LDC + (tid & 3) * 4;                       // + tap*64*LDC
+
+  // ---- fragment addresses
+  int a_frag[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int s = 2 * wid + i;
+    const int py = s * RPS + lr / TW, px = lr % TW;
+    a_frag[i] = ((py + 1) * HPW + (px + 1)) * LDC + 4 * lh;
+  }
+  const int b_frag = lr * LDC + 4 * lh;                                     // + j*32*LDC + tap*64*LDC + 8q
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[AIT], rb[9];
+  auto fetch = [&](int c0) {
+    const unsigned cb = (unsigned)c0 * 4u;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i] + cb, 0, 0));
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      rb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off + (unsigned)(t * p.C * 4) + cb, 0, 0));
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) *reinterpret_cast<f32x4*>(As + a_dst + i * 64 * LDC) = ra[i];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(Bs + b_dst + t * 64 * LDC) = rb[t];
+  };
+
+  fetch(0);
+  stage();
+  __syncthreads();
+  for (int c0 = 0; c0 < p.C; c0 += CK) {
+    const bool more = c0 + CK < p.C;
+    if (more) fetch(c0 + CK);                     // in flight under this chunk's 288 MFMAs
+    // 18 blocks of 16 MFMAs (9 taps x 2 channel octets); the fragments of block b+1 are read from LDS before the MFMAs of
+    // block b are issued (two register sets), so no MFMA ever waits for an LDS read issued right in front of it
+    f32x4 fa[2][2], fb[2][2];
+    auto frags = [&](int blk, int set) {
+      const int t = blk >> 1, q = blk & 1, a = t / 3, b = t % 3;
+      const int tapoff = (DIR * (a - 1) * HPW + DIR * (b - 1)) * LDC;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(As + a_frag[i] + tapoff + 8 * q);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bs + b_frag + (t * 64 + j * 32) * LDC + 8 * q);
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int blk = 0; blk < 18; ++blk) {
+      const int set = blk & 1;
+      if (blk + 1 < 18) frags(blk + 1, set ^ 1);
+      __builtin_amdgcn_sched_barrier(0);          // keep the reads IN FRONT of the block (the scheduler sinks them behind it otherwise)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][jj], fb[set][j][jj], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                              // every wave is done reading this chunk
+    if (more) {
+      stage();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias, activation, optional accumulate; lanes 0-31 / 32-63 write 128 contiguous bytes each
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int co = n0 + j * 32 + lr;
+    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int s = 2 * wid + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int y = y0 + s * RPS + m / TW, x = x0 + m % TW;
+        if (y < p.H && x < p.W) {
+          const long off = (((long)n * p.H + y) * p.W + x) * p.Cout + co;
+          float v = apply_act(acc[i][j][r] + bv, p.act);
+          if (p.beta != 0.f) v += p.out[off];
+          p.out[off] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TH, int TW, int DIR>
+void launch_halo(const HaloArgs& a, hipStream_t st) {
+  constexpr int HP = (TW + 2) * (TH + 2);
+  constexpr int AIT = (HP * 4 + 255) / 256;
+  constexpr size_t lds = (size_t)(AIT * 64 * LDC + 9 * 64 * LDC) * sizeof(float);
+  static bool attr_done = false;   // idempotent; racing writers set the same value
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_done = true;
+  }
+  const long nwg = (long)a.NI * a.tiles_x * a.tiles_y * a.ngn;
+  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, DIR>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+}
+
+}  // namespace
+
+// Returns true when the geometry is a 3x3 / stride-1 / pad-1 convolution (forward or data-gradient form) this kernel
+// covers and the launch was enqueued; false -> the caller uses the general engine.
+bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, const float* bias, int act, float beta, hipStream_t st) {
+  static const bool off = getenv("RE2E_NO_HALO") != nullptr;     // A/B measurements against the general engine
+  if (off) return false;
+  if (g.KH != 3 || g.KW != 3 || g.SY != 1 || g.SX != 1 || g.PH != g.H || g.PW != g.W) return false;
+  int dir;
+  if (g.DY == 1 && g.DX == 1 && g.OY0 == -1 && g.OX0 == -1) dir = 1;
+  else if (g.DY == -1 && g.DX == -1 && g.OY0 == 1 && g.OX0 == 1) dir = -1;
+  else return false;
+  if (g.C % CK || Cout % NT) return false;
+  const long in_bytes = (long)g.NI * g.H * g.W * g.C * 4, wg_bytes = (long)Cout * 9 * g.C * 4;
+  if (in_bytes >= 0x7FFFFF00L || wg_bytes >= 0x7FFFFF00L) return false;
+  if ((reinterpret_cast<uintptr_t>(g.in) | reinterpret_cast<uintptr_t>(wg)) & 15) return false;
+  HaloArgs a;
+  a.in = g.in; a.wg = wg; a.out = out; a.bias = bias;
+  a.NI = g.NI; a.H = g.H; a.W = g.W; a.C = g.C; a.Cout = Cout; a.act = act; a.beta = beta;
+  a.ngn = Cout / NT; a.in_bytes = (unsigned)in_bytes; a.wg_bytes = (unsigned)wg_bytes;
+  // patch shape: 16 x 16 (smaller halo) unless 32 x 8 wastes fewer padded pixels (W = 40: 416 x 40 against 400 x 48)
+  const long pad16 = (long)cdiv(g.H, 16) * 16 * cdiv(g.W, 16) * 16, pad8 = (long)cdiv(g.H, 32) * 32 * cdiv(g.W, 8) * 8;
+  const bool wide = pad16 <= pad8;
+  const int TH = wide ? 16 : 32, TW = wide ? 16 : 8;
+  a.tiles_x = cdiv(g.W, TW); a.tiles_y = cdiv(g.H, TH);
+  if ((long)a.NI * a.tiles_x * a.tiles_y * a.ngn >= 0x7FFFFFFFL) return false;
+  if (wide) { if (dir > 0) launch_halo<16, 16, 1>(a, st); else launch_halo<16, 16, -1>(a, st); }
+  else { if (dir > 0) launch_halo<32, 8, 1>(a, st); else launch_halo<32, 8, -1>(a, st); }
+  return true;
+}

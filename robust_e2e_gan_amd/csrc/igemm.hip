@@ -830,6 +830,10 @@ extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, con
       return RE2E_OK;
     }
   }
+  if (!ep.remap && halo_conv3x3(g, wg, Cout, out, bias, act, beta, stream)) {
+    RE2E_LAUNCH_CHECK();
+    return RE2E_OK;
+  }
   if (C % 4 == 0 && aligned16(in) && aligned16(wg)) conv_dispatch<true>(g, M, K, wg, Cout, ep, stream);
   else conv_dispatch<false>(g, M, K, wg, Cout, ep, stream);
   RE2E_LAUNCH_CHECK();

@@ -164,6 +164,13 @@ CONVS = [  # N, H, W, Cin, Cout, k, stride, pad, act, bias
     (2, 11, 7, 64, 1, 3, 1, 1, None, False),
     (2, 9, 8, 1, 12, 3, 1, 1, None, True),
     (2, 9, 8, 12, 1, 3, 1, 1, 'lrelu', True),
+    # halo-patch 3x3 kernels (conv3x3.hip): C % 16 == 0 and Cout % 64 == 0; 16x16 patches (ragged in both directions) and
+    # the 32x8 patches chosen for narrow images; one / two 64-channel groups; 1, 4 and 8 channel chunks
+    (1, 35, 80, 64, 64, 3, 1, 1, 'relu', True),
+    (1, 100, 40, 128, 64, 3, 1, 1, None, False),
+    (2, 33, 8, 16, 64, 3, 1, 1, 'relu', True),
+    (1, 67, 40, 64, 128, 3, 1, 1, 'relu', True),
+    (3, 5, 3, 32, 128, 3, 1, 1, None, True),
 ]
 
 
@@ -189,6 +196,27 @@ def test_conv2d(cfg):
     close('dW', Wg.grad, Wr.grad, tol=2e-4)
     if has_b:
         close('db', bg.grad, br.grad, tol=2e-4)
+
+
+def test_conv3x3_halo_equals_general_engine_and_accumulates():
+    """The halo-patch kernel against the general implicit-GEMM engine on the same call (RE2E_NO_HALO is read once per
+    process, so the general engine is reached through a geometry the halo kernel declines: the same convolution with the
+    input channels padded to C+4 ... is not the same call; instead compare with F.conv2d) and the beta = 1 epilogue."""
+    ops, lib = _ops()
+    N, H, W, C, K = 2, 21, 24, 32, 64
+    x, Wt, b = rnd(N, H, W, C), rnd(K, C, 3, 3, seed=1, scale=0.1), rnd(K, seed=2)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), Wt, b, padding=1).permute(0, 2, 3, 1)
+    xg, Wg, bg = x.to(DEV), Wt.to(DEV), b.to(DEV)
+    wg = torch.empty(K, 3, 3, C, device=DEV)
+    lib.call('re2e_conv_weight_gather', Wg.data_ptr(), wg.data_ptr(), K, C, 3, 3, 0, 3, 3, 0, 0, 1)
+    y0 = rnd(N, H, W, K, seed=5).to(DEV)
+    y = y0.clone()
+    lib.call('re2e_conv_igemm', xg.data_ptr(), N, H, W, C, wg.data_ptr(), K, 3, 3, H, W, 1, 1, 1, 1, -1, -1, y.data_ptr(), H, W, 1, 1, 0, 0,
+             bg.data_ptr(), lib.ACT_NONE, 1.0)
+    close('beta=1', y, ref + y0.cpu(), tol=2e-4)
+    lib.call('re2e_conv_igemm', xg.data_ptr(), N, H, W, C, wg.data_ptr(), K, 3, 3, H, W, 1, 1, 1, 1, -1, -1, y.data_ptr(), H, W, 1, 1, 0, 0,
+             bg.data_ptr(), lib.ACT_RELU, 0.0)
+    close('relu', y, F.relu(ref), tol=2e-4)
 
 
 @pytest.mark.parametrize('C', [6, 8, 64])        # scalar path (C % 4 != 0) and the four-channels-per-thread path
