@@ -37,49 +37,72 @@ constexpr unsigned OOB = 0x80000000u;   // byte offset beyond any tensor this pa
 struct HaloArgs {
   const float* in; const float* wg; float* out; const float* bias;
   int NI, H, W, C, Cout, act; float beta;
-  int tiles_x, tiles_y, ngn;      // patches per row / column, 64-channel groups
+  int tiles_x, tiles_y, ngn, nitems;      // patches per row / column, 64-channel groups, work items = patches x groups
   unsigned in_bytes, wg_bytes;
+#ifdef RE2E_HALO_STAMPS
+  unsigned long long* stamps;     // diagnostic build only (tools/micro/conv3x3_probe.hip): 16 s_memtime stamps per workgroup
+#endif
 };
 
-template <int TH, int TW, int DIR>
+#ifdef RE2E_HALO_STAMPS
+#define HALO_STAMP(k) do { if (tid == 0 && (k) < 16) { p.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    if ((k) == 0 || (k) == 15) p.stamps[(size_t)gridDim.x * 16 + (size_t)blockIdx.x * 2 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define HALO_STAMP(k) do { } while (0)
+#endif
+
+template <int TH, int TW, int DIR, bool RELU>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
   constexpr int HPW = TW + 2, HPH = TH + 2, HP = HPW * HPH;
   constexpr int AIT = (HP * 4 + 255) / 256;            // float4 items per thread, input patch
   constexpr int ASZ = AIT * 64 * LDC;                  // floats (rows beyond HP are scratch for the surplus items)
   constexpr int RPS = 32 / TW;                         // patch rows per 32-pixel MFMA sub-tile
+  constexpr int LDO = NT + 4;                          // row stride of the epilogue's turn-around buffer
   static_assert(TH * TW == 256 && 32 % TW == 0, "patch must hold 8 sub-tiles of 32 pixels");
+  static_assert(4 * 64 * LDO <= ASZ + 9 * 64 * LDC, "the epilogue buffer reuses the staging buffers");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + ASZ;                              // [9][64][LDC]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of the sequence
-  int pid;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  }
-  const int nblk = pid % p.ngn, tile = pid / p.ngn;
-  const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / (p.tiles_x * p.tiles_y);
-  const int y0 = ty * TH, x0 = tx * TW, n0 = nblk * NT;
+  // PERSISTENT workgroups (2 per CU): work item = (patch, 64-channel group).  Workgroups are dealt round-robin over the 8
+  // XCDs, so XCD x owns the contiguous item range [x*per, (x+1)*per) and its j-th workgroup takes items j, j + nj, ... of it:
+  // at any time one XCD's L2 serves a run of neighbouring patches (shared halos; the two channel groups of a patch adjacent).
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, nj = (gridDim.x + 7 - xcd) >> 3;
+  const int per = (p.nitems + 7) >> 3;
+  const int item_end = min(p.nitems, (xcd + 1) * per);
+  int item = xcd * per + jx;
 
+#ifdef RE2E_HALO_NOLOAD        // diagnostic builds only: zero-record descriptors, every load returns 0 without memory traffic
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
+#else
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+#endif
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wg), 0, p.wg_bytes, 0x00020000);
 
-  // ---- staging addresses: fixed for the whole patch, the chunk only adds c0*4 bytes
-  unsigned a_off[AIT];
+  // ---- staging: a wave-instruction moves 16 rows (pixels / output channels) x 64 bytes, 4 lanes per row.  (Measured and
+  // rejected, same GPU session: a lane order that makes the ds_write_b128 of the 20-float rows bank-conflict-free -- 8
+  // contiguous lanes = the same 16-byte piece of 8 rows -- shortens the staging by 0.5k cycles per item but its global
+  // loads touch 4 lines per lane quad instead of 1 and the matrix block they fly under grows by 4k cycles.)
+  const int srow = tid >> 2, skq = tid & 3;
+  // addresses of the item being FETCHED (one item ahead of the one being computed during its last chunk)
+  unsigned a_off[AIT], b_off;
+  auto set_item = [&](int it) {
+    const int nblk = it % p.ngn, tile = it / p.ngn;
+    const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
 #pragma unroll
-  for (int i = 0; i < AIT; ++i) {
-    const int idx = i * 256 + tid, hp = idx >> 2, kq = idx & 3;
-    const int hy = hp / HPW, hx = hp - hy * HPW;
-    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    const bool ok = (hp < HP) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-    a_off[i] = ok ? (unsigned)(((((long)n * p.H + iy) * p.W + ix) * p.C + kq * 4) * 4) : OOB;
-  }
-  const int a_dst = (tid >> 2) * LDC + (tid & 3) * 4;                       // + i*64*LDC
-  const unsigned b_off = (unsigned)((((long)(n0 + (tid >> 2)) * 9) * p.C + (tid & 3) * 4) * 4);   // + tap*C*4 + c0*4
-  const int b_dst = (tid >> 2) * LDC + (tid & 3) * 4;                       // + tap*64*LDC
+    for (int i = 0; i < AIT; ++i) {
+      const int hp = i * 64 + srow, kq = skq;
+      const int hy = hp / HPW, hx = hp - hy * HPW;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = (hp < HP) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      a_off[i] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.C + kq * 4) * 4) : OOB;     // < 2^31: checked by the launcher
+    }
+    b_off = (unsigned)((((nblk * NT + srow) * 9) * p.C + skq * 4) * 4);   // + tap*C*4 + c0*4
+  };
+  const int a_dst = srow * LDC + skq * 4;                                   // + i*64*LDC
+  const int b_dst = srow * LDC + skq * 4;                                   // + tap*64*LDC
 
   // ---- fragment addresses
   int a_frag[2];
@@ -90,14 +113,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
     a_frag[i] = ((py + 1) * HPW + (px + 1)) * LDC + 4 * lh;
   }
   const int b_frag = lr * LDC + 4 * lh;                                     // + j*32*LDC + tap*64*LDC + 8q
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[AIT], rb[9];
   auto fetch = [&](int c0) {
@@ -115,81 +130,130 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
     for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(Bs + b_dst + t * 64 * LDC) = rb[t];
   };
 
-  fetch(0);
-  stage();
-  __syncthreads();
-  for (int c0 = 0; c0 < p.C; c0 += CK) {
-    const bool more = c0 + CK < p.C;
-    if (more) fetch(c0 + CK);                     // in flight under this chunk's 288 MFMAs
-    // 18 blocks of 16 MFMAs (9 taps x 2 channel octets); the fragments of block b+1 are read from LDS before the MFMAs of
-    // block b are issued (two register sets), so no MFMA ever waits for an LDS read issued right in front of it
-    f32x4 fa[2][2], fb[2][2];
-    auto frags = [&](int blk, int set) {
-      const int t = blk >> 1, q = blk & 1, a = t / 3, b = t % 3;
-      const int tapoff = (DIR * (a - 1) * HPW + DIR * (b - 1)) * LDC;
+  HALO_STAMP(0);
+  if (item < item_end) { set_item(item); fetch(0); }
+  int nstamp = 1;
+  (void)nstamp;
+  while (item < item_end) {
+    const int nblk = item % p.ngn, tile = item / p.ngn;
+    const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nblk * NT;
+    const int next = item + nj;
+    // the bias is folded into the accumulators' initial value (a column of the tile = one output channel = one lane)
+    f32x16 acc[2][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(As + a_frag[i] + tapoff + 8 * q);
+    for (int j = 0; j < 2; ++j) {
+      const float bv = p.bias ? p.bias[n0 + j * 32 + lr] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bs + b_frag + (t * 64 + j * 32) * LDC + 8 * q);
-    };
-    frags(0, 0);
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int blk = 0; blk < 18; ++blk) {
-      const int set = blk & 1;
-      if (blk + 1 < 18) frags(blk + 1, set ^ 1);
-      __builtin_amdgcn_sched_barrier(0);          // keep the reads IN FRONT of the block (the scheduler sinks them behind it otherwise)
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
+    stage();                                        // chunk 0 of this item (fetched under the previous item's last chunk)
+    __syncthreads();
+    HALO_STAMP(1);
+    for (int c0 = 0; c0 < p.C; c0 += CK) {
+      const bool more = c0 + CK < p.C;
+      // the next chunk -- or chunk 0 of the NEXT item -- is in flight under this chunk's 288 MFMAs
+      if (more) fetch(c0 + CK);
+      else if (next < item_end) { set_item(next); fetch(0); }
+      // 18 blocks of 16 MFMAs (9 taps x 2 channel octets); the fragments of block b+1 are read from LDS before the MFMAs of
+      // block b are issued (two register sets), so no MFMA ever waits for an LDS read issued right in front of it
+      f32x4 fa[2][2], fb[2][2];
+      auto frags = [&](int blk, int set) {
+        const int t = blk >> 1, q = blk & 1, a = t / 3, b = t % 3;
+        const int tapoff = (DIR * (a - 1) * HPW + DIR * (b - 1)) * LDC;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+        for (int i = 0; i < 2; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(As + a_frag[i] + tapoff + 8 * q);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bs + b_frag + (t * 64 + j * 32) * LDC + 8 * q);
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int blk = 0; blk < 18; ++blk) {
+        const int set = blk & 1;
+        if (blk + 1 < 18) frags(blk + 1, set ^ 1);
+        __builtin_amdgcn_sched_barrier(0);          // keep the reads IN FRONT of the block (the scheduler sinks them behind it otherwise)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][jj], fb[set][j][jj], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      HALO_STAMP(2 + 3 * (c0 / CK));
+      __syncthreads();                              // every wave is done reading this chunk
+      HALO_STAMP(3 + 3 * (c0 / CK));
+      if (more) {
+        stage();
+        __syncthreads();
+      }
+      HALO_STAMP(4 + 3 * (c0 / CK));
+    }
+
+    // ---- epilogue.  The accumulators hold, per register, 32 consecutive output channels of ONE pixel (lanes 0-31) and of
+    // the pixel 4 rows of the sub-tile further (lanes 32-63); stored from there a wave-instruction moves 2 x 128 bytes.  Each
+    // wavefront turns its 64 pixel x 64 channel block around in LDS instead (the staging buffers are free behind the last
+    // barrier; row stride 68 floats) and stores whole 256-byte channel rows, 16 bytes per lane, 4 pixels per instruction.
+    {
+      float* Os = smem + wid * (64 * LDO);               // 17 KB per wavefront
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][jj], fb[set][j][jj], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();                              // every wave is done reading this chunk
-    if (more) {
-      stage();
+          for (int r = 0; r < 16; ++r) {
+            const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;       // pixel of this wavefront's 64
+            Os[m * LDO + j * 32 + lr] = RELU ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
+          }
       __syncthreads();
-    }
-  }
-
-  // ---- epilogue: bias, activation, optional accumulate; lanes 0-31 / 32-63 write 128 contiguous bytes each
+      const int c4 = (lane & 15) * 4, prow = lane >> 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int co = n0 + j * 32 + lr;
-    const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int s = 2 * wid + i;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int y = y0 + s * RPS + m / TW, x = x0 + m % TW;
+      for (int it = 0; it < 16; ++it) {
+        const int m = it * 4 + prow;                                     // 0..63: sub-tile m>>5, pixel m&31 of it
+        const int s = 2 * wid + (m >> 5), q = m & 31;
+        const int y = y0 + s * RPS + q / TW, x = x0 + q % TW;
         if (y < p.H && x < p.W) {
-          const long off = (((long)n * p.H + y) * p.W + x) * p.Cout + co;
-          float v = apply_act(acc[i][j][r] + bv, p.act);
-          if (p.beta != 0.f) v += p.out[off];
-          p.out[off] = v;
+          f32x4 v = *reinterpret_cast<const f32x4*>(Os + m * LDO + c4);
+          float* dst = p.out + ((((long)n * p.H + y) * p.W + x) * p.Cout + n0 + c4);
+          if (p.beta != 0.f) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+            v += o;
+          }
+#ifndef RE2E_HALO_NOSTORE      // diagnostic builds only (tools/micro/conv3x3_probe.hip)
+          *reinterpret_cast<f32x4*>(dst) = v;
+#else
+          if (v[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(dst) = v;
+#endif
         }
       }
+      __syncthreads();                                  // the turn-around buffer is the next item's staging buffer
     }
+    HALO_STAMP(15);
+    item = next;
   }
 }
 
-template <int TH, int TW, int DIR>
+template <int TH, int TW, int DIR, bool RELU>
 void launch_halo(const HaloArgs& a, hipStream_t st) {
   constexpr int HP = (TW + 2) * (TH + 2);
   constexpr int AIT = (HP * 4 + 255) / 256;
   constexpr size_t lds = (size_t)(AIT * 64 * LDC + 9 * 64 * LDC) * sizeof(float);
   static bool attr_done = false;   // idempotent; racing writers set the same value
+  static int slots = 512;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, DIR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, DIR, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = 2 * cus;                     // two workgroups per CU (LDS and registers both allow exactly two)
+    if (getenv("RE2E_HALO_SLOTS")) slots = atoi(getenv("RE2E_HALO_SLOTS"));   // occupancy experiments
     attr_done = true;
   }
-  const long nwg = (long)a.NI * a.tiles_x * a.tiles_y * a.ngn;
-  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, DIR>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+  const int nwg = a.nitems < slots ? a.nitems : slots;
+  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, DIR, RELU>), dim3((unsigned)nwg), dim3(256), lds, st, a);
 }
 
 }  // namespace
@@ -205,6 +269,8 @@ bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, cons
   else if (g.DY == -1 && g.DX == -1 && g.OY0 == 1 && g.OX0 == 1) dir = -1;
   else return false;
   if (g.C % CK || Cout % NT) return false;
+  if (act != RE2E_ACT_NONE && act != RE2E_ACT_RELU) return false;
+  if (reinterpret_cast<uintptr_t>(out) & 15) return false;
   const long in_bytes = (long)g.NI * g.H * g.W * g.C * 4, wg_bytes = (long)Cout * 9 * g.C * 4;
   if (in_bytes >= 0x7FFFFF00L || wg_bytes >= 0x7FFFFF00L) return false;
   if ((reinterpret_cast<uintptr_t>(g.in) | reinterpret_cast<uintptr_t>(wg)) & 15) return false;
@@ -217,8 +283,14 @@ bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, cons
   const bool wide = pad16 <= pad8;
   const int TH = wide ? 16 : 32, TW = wide ? 16 : 8;
   a.tiles_x = cdiv(g.W, TW); a.tiles_y = cdiv(g.H, TH);
-  if ((long)a.NI * a.tiles_x * a.tiles_y * a.ngn >= 0x7FFFFFFFL) return false;
-  if (wide) { if (dir > 0) launch_halo<16, 16, 1>(a, st); else launch_halo<16, 16, -1>(a, st); }
-  else { if (dir > 0) launch_halo<32, 8, 1>(a, st); else launch_halo<32, 8, -1>(a, st); }
+  const long nitems = (long)a.NI * a.tiles_x * a.tiles_y * a.ngn;
+  if (nitems >= 0x7FFFFFF0L) return false;
+  a.nitems = (int)nitems;
+  const bool relu = act == RE2E_ACT_RELU;
+#define HALO_GO(TH_, TW_) do { \
+    if (dir > 0) { if (relu) launch_halo<TH_, TW_, 1, true>(a, st); else launch_halo<TH_, TW_, 1, false>(a, st); } \
+    else { if (relu) launch_halo<TH_, TW_, -1, true>(a, st); else launch_halo<TH_, TW_, -1, false>(a, st); } } while (0)
+  if (wide) HALO_GO(16, 16); else HALO_GO(32, 8);
+#undef HALO_GO
   return true;
 }
