@@ -14,8 +14,8 @@ that is already resident in HBM.  Weak scaling: every rank processes its own B=3
 flat gradient buffers are averaged with RCCL.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     -- the dominant kernel (fp32-MFMA implicit-GEMM convolution at the VGG conv1_2 shape
-                  of this workload) timed live with HIP events on the launch stream
+  roofline     -- the dominant kernel (fp32-MFMA 3x3 convolution at the VGG conv1_2 shape of this
+                  workload) timed live with HIP events on the launch stream
   cpu_baseline -- the CPU oracle (oracle/joint.py, "port") timed on this box's host cores on a
                   bounded sample of the same workload (rank 0, N=1 only): 1 warm-up + 3 timed steps, median
   parity       -- the FIRST GPU step against the oracle's step on the SAME full batch, initial weights and cmvn
@@ -81,9 +81,10 @@ def synthetic_cmvn(enh, fb, batches, dev):
 
 
 def conv_roofline(dev, iters=20):
-    """Average launch duration of the dominant kernel -- the implicit-GEMM conv at the VGG conv1_2
-    shape of this workload (2B=64 images, 800x80, 64->64, 3x3) -- measured with HIP events on the
-    stream the kernel is launched on.  Algorithmic FLOPs = 2*9*64*64 per output pixel."""
+    """Average launch duration of the dominant kernel -- the 3x3 convolution at the VGG conv1_2 shape of this workload
+    (2B=64 images, 800x80, 64->64; csrc/conv3x3.hip behind re2e_conv_igemm) -- measured with HIP events on the stream
+    the kernel is launched on.  Algorithmic FLOPs = 2*9*64*64 per output pixel; algorithmic bytes = input + output +
+    weights (2.10 GB)."""
     from robust_e2e_gan_amd import lib
     N, H, W, C, K = 64, 800, 80, 64, 64
     x = torch.randn(N, H, W, C, device=dev)
@@ -108,11 +109,11 @@ def conv_roofline(dev, iters=20):
     # kernel and shape, tools/roofline_conv.py); a counter pass cannot run inside this process.
     traffic, tsrc = None, None
     try:
-        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_conv1_2_pmc_traffic.json')))
-        traffic, tsrc = pj['traffic_bytes_per_launch'], 'profiles/r01_conv1_2_pmc_traffic.json'
+        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r02_conv1_2_pmc_traffic.json')))
+        traffic, tsrc = pj['traffic_bytes_per_launch'], 'profiles/r02_conv1_2_pmc_traffic.json'
     except Exception:
         pass
-    return {'bound': 'mfma', 'kernel': 'igemm_kernel<ConvK,DenseK,256x64> (VGG conv1_2 fwd, 64x800x80, 64->64, 3x3)', 'achieved': round(ach, 2),
+    return {'bound': 'mfma', 'kernel': 'conv3x3_halo_kernel<16,16,1,true> (VGG conv1_2 fwd, 64x800x80, 64->64, 3x3)', 'achieved': round(ach, 2),
             'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
             'traffic_unit': 'bytes per launch (FETCH_SIZE + WRITE_SIZE)', 'traffic_source': tsrc,
             'algorithmic_bytes_per_launch': 4.0 * (N * H * W * C + N * H * W * K + K * 9 * C),

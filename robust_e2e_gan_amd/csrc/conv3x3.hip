@@ -253,6 +253,10 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int nwg = a.nitems < slots ? a.nitems : slots;
+  static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
+  if (log_calls)
+    fprintf(stderr, "[igemm] A=Halo%s B=DenseK tile=%dx%dx%d vec=1 M=%d N=%d K=%d splits=1\n", DIR > 0 ? "F" : "D", TH * TW, NT, CK,
+            a.NI * a.H * a.W, a.Cout, 9 * a.C);
   hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, DIR, RELU>), dim3((unsigned)nwg), dim3(256), lds, st, a);
 }
 

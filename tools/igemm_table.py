@@ -22,7 +22,7 @@ def main(log_path, trace_path):
             calls.append((a, b) + tuple(int(x) for x in m.groups()[2:]))
     kern = []
     for r in csv.DictReader(open(trace_path)):
-        if "igemm_kernel" in r["Kernel_Name"]:
+        if "igemm_kernel" in r["Kernel_Name"] or "conv3x3_halo_kernel" in r["Kernel_Name"] or "conv3x3_wgrad_kernel" in r["Kernel_Name"]:
             kern.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     kern.sort()
     if len(kern) != len(calls):
