@@ -172,7 +172,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
 #pragma unroll
       for (int blk = 0; blk < 18; ++blk) {
         const int set = blk & 1;
+#ifdef RE2E_HALO_NOFRAG        // diagnostic builds only: one fragment read per chunk instead of 18
+        if (blk == 0) frags(1, 1);
+#else
         if (blk + 1 < 18) frags(blk + 1, set ^ 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);          // keep the reads IN FRONT of the block (the scheduler sinks them behind it otherwise)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
