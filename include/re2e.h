@@ -40,6 +40,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 #define RE2E_LOSS_L2 0
 #define RE2E_LOSS_L1 1
 #define RE2E_LOSS_SMOOTH_L1 2
+#define RE2E_LOSS_BCE 3 /* nn.BCELoss on probabilities, logs clamped at -100 (model/gan_model.py:157-160, --no_lsgan) */
 
 int re2e_version(void);
 const char* re2e_last_error(void);
@@ -106,6 +107,11 @@ int re2e_mul(const float* a, const float* b, float* out, long n, re2e_stream_t s
 /* CMVN: out[r][j] = (x[r][j] + c0[j]) * c1[j]; c0==NULL gives x*c1 (its backward)  (feat_model.py:132-134) */
 int re2e_affine_cols(const float* x, const float* c0, const float* c1, float* out, long rows, int N,
                      re2e_stream_t stream);
+/* Dropout with a counter-based mask (F.dropout model/e2e_ctc.py:51 -- always on, its default training=True --,
+ * nn.LSTM(dropout=) between the layers of BLSTM model/e2e_encoder.py:156-157, nn.Dropout of the U-Net blocks
+ * model/enhance_model.py:298): y_i = x_i / (1-p) when word (i&3) of Philox4x32-10(counter {i>>2, i>>34, call, 0}, key = seed)
+ * is >= floor(p * 2^32), else 0.  The backward pass is the same call on dy with the same (seed, call): no mask is stored. */
+int re2e_dropout(const float* x, float* y, long n, float p, unsigned long long seed, unsigned call, re2e_stream_t stream);
 /* y = a*x + b*y elementwise (gradient accumulation) */
 int re2e_axpby(float a, const float* x, float b, float* y, long n, re2e_stream_t stream);
 /* dst[i][:] = src[idx[i]][:] (rows of width W); scatter is the inverse (dst[idx[i]][:] = src[i][:]) */
@@ -138,6 +144,11 @@ int re2e_fbank_fwd(const float* x, long rows, int F, int NF, const int* band_off
 int re2e_fbank_bwd(const float* x, long rows, int F, int NF, const int* band_off, const int* band_len,
                    const float* band_w, int maxw, const float* dy_raw, const float* dy_norm, const float* cmvn,
                    float* dx, re2e_stream_t stream);
+/* Dense trainable filterbank (fbank_opti_type 'train', feat_model.py:105-109): x^2 W and its gradients are re2e_gemm calls;
+ * these are the element-wise tail of feat_model.py:127-134: y = log(max(z,1e-7)) [-> (y + cmvn[0]) * cmvn[1]] and
+ * dz = dy * cmvn[1] / z, zero where the clamp fired (cmvn (2,N) optional). */
+int re2e_logclamp_fwd(const float* z, const float* cmvn, long rows, int N, float* y, re2e_stream_t stream);
+int re2e_logclamp_bwd(const float* z, const float* cmvn, long rows, int N, const float* dy, float* dz, re2e_stream_t stream);
 /* per-column sum and sum of squares over valid frames of y (B,T,NF): feat_model.py:62-80 on device */
 int re2e_cmvn_stats(const float* y, const int* lens_dev, int B, int T, int NF, float* sum_out, float* sumsq_out,
                     re2e_stream_t stream);

@@ -64,12 +64,31 @@ def _bilstm(x, lens, w, prefix, layer):
 # --------------------------------------------------------------------------------------
 # F2  EnhanceModel (blstm)   model/enhance_model.py:125-174, e2e_encoder.py:153-177
 # --------------------------------------------------------------------------------------
-def enhance_forward(p, mix, mix_log, lens, layers, clean=None, cos=None):
+def tm_mask(mask_flat, B, T, W):
+    """A dropout mask drawn over the TIME-MAJOR (T,B,W) tensor (the product's layout, oracle/philox.py) as a batch-first
+    (B,T,W) tensor."""
+    return torch.as_tensor(mask_flat).view(T, B, W).transpose(0, 1)
+
+
+def enhance_forward(p, mix, mix_log, lens, layers, clean=None, cos=None, inter_masks=None, kind='blstm'):
+    """``inter_masks[l]``: dropout mask (already scaled by 1/(1-p), batch-first) applied to the output of LSTM layer l < layers-1
+    -- nn.LSTM(dropout=p) in training mode (e2e_encoder.py:156-157).  ``kind='blstmp'``: the BLSTMP enhancer
+    (enhance_model.py:90-93: per-layer projection, no l_last)."""
+    if kind == 'blstmp':
+        proj3, _ = blstmp_forward(p, mix_log, lens, layers, pre='enc1.')
+        B, T, _ = proj3.shape
+        return _enhance_head(p, proj3.reshape(B * T, -1), B, T, mix, lens, clean, cos)
     x = mix_log
     for l in range(layers):
         x = _bilstm(x, lens, {k.replace('enc1.nblstm.', ''): v for k, v in p.items()}, '', l)
+        if inter_masks is not None and l + 1 < layers:
+            x = x * inter_masks[l]
     B, T, _ = x.shape
     proj = torch.tanh(F.linear(x.reshape(B * T, -1), p['enc1.l_last.weight'], p['enc1.l_last.bias']))
+    return _enhance_head(p, proj, B, T, mix, lens, clean, cos)
+
+
+def _enhance_head(p, proj, B, T, mix, lens, clean, cos):
     lin = F.linear(proj, p['fc.0.module.0.weight']).view(B, T, -1)
     out = torch.sigmoid(lin)
     valid = (torch.arange(T).unsqueeze(0) < torch.as_tensor(lens).view(-1, 1)).unsqueeze(-1)
@@ -173,7 +192,10 @@ def encoder_forward(p, x, lens, elayers):
 # --------------------------------------------------------------------------------------
 # F7  CTC   model/e2e_ctc.py:33-66  (warp-ctc restated: softmax inside, blank 0, sum/B)
 # --------------------------------------------------------------------------------------
-def ctc_forward(p, hpad, hlens, ys):
+def ctc_forward(p, hpad, hlens, ys, dropout_mask=None):
+    """``dropout_mask``: (B,T',E) mask scaled by 1/(1-p) -- F.dropout(hs_pad, p) of e2e_ctc.py:51 (always on)."""
+    if dropout_mask is not None:
+        hpad = hpad * dropout_mask
     logits = F.linear(hpad, p['ctc.ctc_lo.weight'], p['ctc.ctc_lo.bias']).transpose(0, 1)
     olens = torch.tensor([len(y) for y in ys], dtype=torch.long)
     nll = F.ctc_loss(logits.log_softmax(2), torch.cat(ys).long(), torch.as_tensor(hlens).long(),
@@ -248,12 +270,18 @@ def split_targets(targets, target_sizes):
     return ys
 
 
-def e2e_forward(p, feats, targets, lens, tlens, elayers, mtlalpha=0.5, sample_steps=None):
-    """E2E.forward   model/e2e_model.py:169-202"""
+def e2e_forward(p, feats, targets, lens, tlens, elayers, mtlalpha=0.5, sample_steps=None, ctc_dropout=None):
+    """E2E.forward   model/e2e_model.py:169-202.  ``ctc_dropout`` = (p, seed, call): the CTC head's input dropout with the
+    product's counter-based mask (oracle/philox.py)."""
     ys = split_targets(targets, tlens)
     V = p['dec.output.weight'].size(0)
     hpad, hlens = encoder_forward(p, feats, lens, elayers)
-    loss_ctc = ctc_forward(p, hpad, hlens, ys) if mtlalpha != 0 else None
+    cmask = None
+    if ctc_dropout is not None:
+        from .philox import dropout_mask
+        B, T, E = hpad.shape
+        cmask = tm_mask(dropout_mask(B * T * E, *ctc_dropout), B, T, E)
+    loss_ctc = ctc_forward(p, hpad, hlens, ys, cmask) if mtlalpha != 0 else None
     loss_att, acc = decoder_forward(p, hpad, hlens, ys, V - 1, sample_steps=sample_steps) if mtlalpha != 1 else (None, None)
     return loss_ctc, loss_att, acc, hpad, hlens
 
@@ -287,8 +315,9 @@ def coral(src, tgt):
 # --------------------------------------------------------------------------------------
 # F11/F12  GANModel 'basic' + GANLoss   model/gan_model.py:55-95,141-145,152-171
 # --------------------------------------------------------------------------------------
-def discriminator_forward(p, buf, x, cmvn=None, train=True, momentum=0.1, eps=1e-5):
-    """``buf`` holds running_mean/var/num_batches_tracked and is updated in place (train)."""
+def discriminator_forward(p, buf, x, cmvn=None, train=True, momentum=0.1, eps=1e-5, use_sigmoid=False):
+    """``buf`` holds running_mean/var/num_batches_tracked and is updated in place (train).  ``use_sigmoid``: the
+    --no_lsgan discriminator ends in nn.Sigmoid (gan_model.py:90-91,126)."""
     if cmvn is not None:                                 # S3
         x = (x + cmvn[0, :]) * cmvn[1, :]
     h = x.unsqueeze(1) if x.dim() == 3 else x
@@ -300,8 +329,13 @@ def discriminator_forward(p, buf, x, cmvn=None, train=True, momentum=0.1, eps=1e
         if train:
             buf[bn + '.num_batches_tracked'] += 1
         h = F.leaky_relu(h, 0.2)
-    return F.conv2d(h, p['model.11.weight'], p['model.11.bias'], stride=1, padding=1)
+    h = F.conv2d(h, p['model.11.weight'], p['model.11.bias'], stride=1, padding=1)
+    return torch.sigmoid(h) if use_sigmoid else h
 
 
-def gan_loss(d_out, target_is_real):
-    return ((d_out - (1.0 if target_is_real else 0.0)) ** 2).mean()
+def gan_loss(d_out, target_is_real, use_lsgan=True):
+    """GANLoss (gan_model.py:152-171): MSE to the broadcast label, or nn.BCELoss on probabilities with --no_lsgan."""
+    t = 1.0 if target_is_real else 0.0
+    if use_lsgan:
+        return ((d_out - t) ** 2).mean()
+    return F.binary_cross_entropy(d_out, torch.full_like(d_out, t))

@@ -212,6 +212,44 @@ extern "C" int re2e_axpby(float a, const float* x, float b, float* y, long n, hi
   return RE2E_OK;
 }
 
+// ---- dropout (F.dropout / nn.LSTM(dropout=) / nn.Dropout: e2e_ctc.py:51, e2e_encoder.py:156-157, enhance_model.py:298) ----
+// Counter-based mask: element i keeps its value when word (i & 3) of Philox4x32-10(counter = {i >> 2 (lo), i >> 34 (hi), call, 0},
+// key = {seed lo, seed hi}) is >= threshold = floor(p * 2^32); kept values are scaled by 1 / (1 - p).  Nothing is stored:
+// the backward pass regenerates the mask from (seed, call).  oracle/philox.py is the same generator in numpy.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, unsigned thr, float scale, unsigned k0, unsigned k1,
+                               unsigned call) {
+  const long n4 = (n + 3) >> 2;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+    unsigned w[4];
+    philox4x32_10((unsigned)q, (unsigned)((unsigned long long)q >> 32), call, 0u, k0, k1, w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long i = q * 4 + j;
+      if (i < n) y[i] = w[j] >= thr ? x[i] * scale : 0.f;
+    }
+  }
+}
+extern "C" int re2e_dropout(const float* x, float* y, long n, float p, unsigned long long seed, unsigned call, hipStream_t stream) {
+  RE2E_CHECK_ARG(x && y && n > 0, "bad args");
+  RE2E_CHECK_ARG(p >= 0.f && p < 1.f, "dropout rate must be in [0, 1)");
+  const double t = (double)p * 4294967296.0;
+  const unsigned thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((n + 3) >> 2)), dim3(TPB), 0, stream, x, y, n, thr, 1.0f / (1.0f - p), (unsigned)seed,
+                     (unsigned)(seed >> 32), call);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
 __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
 }
@@ -306,6 +344,16 @@ __device__ __forceinline__ float loss_grad(float d, int kind) {
   if (kind == RE2E_LOSS_L1) return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
   return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
 }
+// RE2E_LOSS_BCE: nn.BCELoss on probabilities (gan_model.py:157-160 with --no_lsgan): -(t log a + (1-t) log(1-a)) with both
+// logarithms clamped at -100, gradient (a - t) / max(a (1-a), 1e-12) -- ATen's binary_cross_entropy forward / backward.
+__device__ __forceinline__ float loss_elem2(float a, float t, int kind) {
+  if (kind != RE2E_LOSS_BCE) return loss_elem(a - t, kind);
+  return -(t * fmaxf(logf(a), -100.f) + (1.f - t) * fmaxf(logf(1.f - a), -100.f));
+}
+__device__ __forceinline__ float loss_grad2(float a, float t, int kind) {
+  if (kind != RE2E_LOSS_BCE) return loss_grad(a - t, kind);
+  return (a - t) / fmaxf(a * (1.f - a), 1e-12f);
+}
 static inline int reduce_blocks(long n) { long g = (n + 4095) / 4096; return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g)); }
 extern "C" size_t re2e_reduce_workspace_bytes(long n) { return (size_t)reduce_blocks(n) * sizeof(float); }
 
@@ -314,7 +362,7 @@ __global__ void loss_partial_kernel(const float* __restrict__ a, const float* __
   __shared__ float red[16];
   float s = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    s += loss_elem(a[i] - (b ? b[i] : target), kind);
+    s += loss_elem2(a[i], b ? b[i] : target, kind);
   s = block_sum(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
@@ -339,7 +387,7 @@ __global__ void loss_bwd_kernel(const float* __restrict__ a, const float* __rest
                                 const float* __restrict__ gscale, float scale, float* da, float beta) {
   float g = (gscale ? gscale[0] : 1.f) * scale / (float)n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float v = g * loss_grad(a[i] - (b ? b[i] : target), kind);
+    float v = g * loss_grad2(a[i], b ? b[i] : target, kind);
     da[i] = (beta != 0.f ? beta * da[i] : 0.f) + v;
   }
 }

@@ -147,3 +147,43 @@ extern "C" int re2e_cmvn_stats(const float* y, const int* lens, int B, int T, in
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
+
+
+// ---- dense (trainable) filterbank, fbank_opti_type 'train' (model/feat_model.py:105-109): the matrix is a full (257,80)
+// parameter, so x^2 W and its two gradients run on the GEMM engine (re2e_gemm); these two kernels are the element-wise tail of
+// feat_model.py:127-134 around it: y = log(max(z, 1e-7)) [-> (y + cmvn0) * cmvn1], and dz = dy * cmvn1 / z, zero where the
+// in-place clamp of :130 fired (z <= 1e-7).
+__global__ void logclamp_fwd_kernel(const float* __restrict__ z, const float* __restrict__ cmvn, long rows, int N, float* __restrict__ y) {
+  const long tot = rows * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % N);
+    float v = logf(fmaxf(z[i], 1e-7f));
+    if (cmvn) v = (v + cmvn[j]) * cmvn[N + j];
+    y[i] = v;
+  }
+}
+__global__ void logclamp_bwd_kernel(const float* __restrict__ z, const float* __restrict__ cmvn, long rows, int N,
+                                    const float* __restrict__ dy, float* __restrict__ dz) {
+  const long tot = rows * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % N);
+    const float zz = z[i];
+    float g = dy[i];
+    if (cmvn) g *= cmvn[N + j];
+    dz[i] = zz > 1e-7f ? g / zz : 0.f;
+  }
+}
+extern "C" int re2e_logclamp_fwd(const float* z, const float* cmvn, long rows, int N, float* y, hipStream_t stream) {
+  RE2E_CHECK_ARG(z && y && rows > 0 && N > 0, "bad args");
+  const long tot = rows * N;
+  hipLaunchKernelGGL(logclamp_fwd_kernel, dim3((unsigned)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256)), dim3(256), 0, stream, z, cmvn, rows, N, y);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+extern "C" int re2e_logclamp_bwd(const float* z, const float* cmvn, long rows, int N, const float* dy, float* dz, hipStream_t stream) {
+  RE2E_CHECK_ARG(z && dy && dz && rows > 0 && N > 0, "bad args");
+  const long tot = rows * N;
+  hipLaunchKernelGGL(logclamp_bwd_kernel, dim3((unsigned)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256)), dim3(256), 0, stream, z, cmvn, rows, N, dy, dz);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}

@@ -7,7 +7,7 @@ on a CPU-only box for the build/ABI checks); the first kernel call needs a GPU.
 import atexit
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint, c_ulonglong, c_void_p
 
 import torch
 
@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
-LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1 = range(3)
+LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
 
 P, I, L, F, Z = c_void_p, c_int, c_long, c_float, c_size_t
 
@@ -40,6 +40,7 @@ SIGNATURES = {
     're2e_mask_mul_bwd': (I, [P, P, P, P, L, P]),
     're2e_mul': (I, [P, P, P, L, P]),
     're2e_affine_cols': (I, [P, P, P, P, L, I, P]),
+    're2e_dropout': (I, [P, P, L, F, c_ulonglong, c_uint, P]),
     're2e_axpby': (I, [F, P, F, P, L, P]),
     're2e_gather_rows': (I, [P, P, P, I, I, P]),
     're2e_scatter_rows': (I, [P, P, P, I, I, P]),
@@ -48,6 +49,8 @@ SIGNATURES = {
     're2e_kaldi_decode_pad': (I, [P, P, P, P, I, I, I, P, P, P, P]),
     're2e_fbank_fwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P]),
     're2e_fbank_bwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P, P]),
+    're2e_logclamp_fwd': (I, [P, P, L, I, P, P]),
+    're2e_logclamp_bwd': (I, [P, P, L, I, P, P, P]),
     're2e_cmvn_stats': (I, [P, P, I, I, I, P, P, P]),
     're2e_reduce_workspace_bytes': (Z, [L]),
     're2e_loss_fwd': (I, [P, P, F, L, I, P, P, Z, P]),

@@ -10,8 +10,6 @@ from .e2e_common import LinearParams, host_to_dev, lens_dev
 class CTC(torch.nn.Module):
     def __init__(self, odim, eprojs, dropout_rate):
         super(CTC, self).__init__()
-        if dropout_rate:
-            raise Re2eError('dropout > 0 is outside the round-1 hot path (Appendix A.8)')
         self.dropout_rate = dropout_rate
         self.loss = None
         self.ctc_lo = LinearParams(eprojs, odim)
@@ -24,6 +22,8 @@ class CTC(torch.nn.Module):
         ll = [len(y) for y in ylist]
         flat = host_to_dev(np.asarray(sum(ylist, []), np.int32), dev)
         off = host_to_dev(np.concatenate([[0], np.cumsum(ll)[:-1]]).astype(np.int32), dev)
+        # e2e_ctc.py:51: F.dropout(hs_pad, p) with its DEFAULT training=True -- applied in eval mode too (Appendix A.8)
+        hs_tm = ops.dropout(hs_tm, self.dropout_rate)
         logits = ops.linear(hs_tm, self.ctc_lo.weight, self.ctc_lo.bias)           # (T',B,V): warp-ctc's layout
         self.loss = ops.ctc_loss(logits, lens_dev(hlens, dev), flat, off, host_to_dev(np.asarray(ll, np.int32), dev), max(ll))
         return self.loss

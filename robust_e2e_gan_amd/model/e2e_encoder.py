@@ -18,8 +18,7 @@ class BLSTM(torch.nn.Module):
 
     def __init__(self, idim, elayers, cdim, hdim, dropout):
         super(BLSTM, self).__init__()
-        if dropout:
-            raise Re2eError('dropout > 0 is outside the round-1 hot path (Appendix A.8)')
+        self.dropout = float(dropout or 0.0)
         self.nblstm = LSTMParams(idim, cdim, elayers)
         self.l_last = LinearParams(cdim * 2, hdim)
         self.elayers = elayers
@@ -28,6 +27,11 @@ class BLSTM(torch.nn.Module):
         """time-major (T,B,I) -> (T,B,hdim)"""
         for l in range(self.elayers):
             x_tm = ops.bilstm(x_tm, lens_d, self.nblstm.layer_weights(l))
+            # nn.LSTM(dropout=p) (e2e_encoder.py:156-157): on the outputs of every layer but the last, training mode only.
+            # Upstream draws the mask over the packed (valid) frames; padded rows are zero here, so masking the padded
+            # tensor is the same arithmetic on the valid frames.
+            if self.dropout and self.training and l + 1 < self.elayers:
+                x_tm = ops.dropout(x_tm, self.dropout)
         return ops.linear(x_tm, self.l_last.weight, self.l_last.bias, 'tanh')
 
     def forward(self, xpad, ilens):
@@ -41,8 +45,8 @@ class BLSTM(torch.nn.Module):
 class BLSTMP(torch.nn.Module):
     def __init__(self, idim, elayers, cdim, hdim, subsample, subsample_type, dropout):
         super(BLSTMP, self).__init__()
-        if dropout:
-            raise Re2eError('dropout > 0 is outside the round-1 hot path (Appendix A.8)')
+        # every layer is its own nn.LSTM(num_layers=1, dropout=p) upstream (e2e_encoder.py:109): inter-layer dropout of a
+        # one-layer LSTM never fires, so ``dropout`` is accepted and has no effect here either.
         for i in range(elayers):
             setattr(self, 'bilstm%d' % i, LSTMParams(idim if i == 0 else hdim, cdim, 1))
             setattr(self, 'bt%d' % i, LinearParams(2 * cdim, hdim))

@@ -33,6 +33,9 @@ class EnhanceModel(ModelBase):
             ss = args.subsample.split('_')
             for j in range(min(args.enhance_layers + 1, len(ss))):
                 self.subsample[j] = int(ss[j])
+            if any(int(v) > 1 for v in self.subsample):
+                raise Re2eError('a mask enhancer cannot subsample frames: the mask has to cover every frame of mix_inputs '
+                                '(upstream fails on the shape mismatch at enhance_model.py:164)')
             self.enc1 = BLSTMP(idim, args.enhance_layers, args.enhance_units, args.enhance_projs, self.subsample, args.subsample_type,
                                args.dropout_rate)
         elif self.enhance_type in ('unet_128', 'unet_256', 'vggblstmp', 'vggblstm'):
@@ -82,8 +85,8 @@ class EnhanceModel(ModelBase):
             full = [mix_inputs.shape[1]] * len(lens)
             out, _ = self._mask_net(mix_inputs, to_cuda(self, mix_log_inputs), input_sizes)
             # frames beyond each length: sigmoid(fc(tanh(l_last.bias))) * mix, recomputed without the mask
-            proj_pad = ops.linear(torch.zeros(1, self.enc1.l_last.weight.shape[1], device=out.device), self.enc1.l_last.weight,
-                                  self.enc1.l_last.bias, 'tanh')
+            last = self.enc1.l_last if self.enhance_type == 'blstm' else getattr(self.enc1, 'bt%d' % (self.enc1.elayers - 1))
+            proj_pad = ops.linear(torch.zeros(1, last.weight.shape[1], device=out.device), last.weight, last.bias, 'tanh')
             padrow = ops.linear(proj_pad, self.fc[0].module[0].weight, None, 'sigmoid')      # (1, F)
             out = out.clone()
             for b, l in enumerate(lens):

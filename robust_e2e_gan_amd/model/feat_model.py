@@ -58,10 +58,11 @@ class FbankModel(ModelBase):
             raise Re2eError('nfilt must = 80, but get {}'.format(odim))     # feat_model.py:23-33
         self.fc = torch.nn.Parameter(torch.from_numpy(mel_matrix(odim)).clone())
         assert self.fc.shape[0] == idim, 'idim must be 257'
-        if getattr(args, 'fbank_opti_type', 'frozen') == 'frozen':
+        # 'frozen': the fixed mel matrix is banded (501 non-zeros) -> gather kernel; otherwise ('train', feat_model.py:108-109)
+        # it is a trainable dense (257,80) parameter -> GEMM path with dW (ops.fbank_dense)
+        self.trainable = getattr(args, 'fbank_opti_type', 'frozen') != 'frozen'
+        if not self.trainable:
             self.fc.requires_grad_(False)
-        else:
-            raise Re2eError('--fbank-opti-type train (dense trainable filterbank) is outside the round-1 hot path')
         self.sum = np.zeros([1, odim], np.float32)
         self.sum_sq = np.zeros([1, odim], np.float32)
         self.fbank_cmvn = np.zeros([2, odim], np.float32)
@@ -86,6 +87,8 @@ class FbankModel(ModelBase):
     def forward(self, xs, fbank_cmvn=None):
         """log(max((x^2) W, 1e-7)) [-> (y + cmvn[0]) * cmvn[1]]   (feat_model.py:118-135)"""
         xs = to_cuda(self, xs)
+        if self.trainable:
+            return ops.fbank_dense(xs, self.fc, to_cuda(self, fbank_cmvn).float().contiguous() if fbank_cmvn is not None else None)
         if fbank_cmvn is None:
             return ops.fbank(xs, self.band(), None, True, False)[0]
         fbank_cmvn = to_cuda(self, fbank_cmvn).float().contiguous()
@@ -94,6 +97,8 @@ class FbankModel(ModelBase):
     def forward_both(self, xs, fbank_cmvn):
         """One pass producing (raw, normalised) features -- used by the fused joint step."""
         xs = to_cuda(self, xs)
+        if self.trainable:
+            return self.forward(xs), self.forward(xs, fbank_cmvn)
         return ops.fbank(xs, self.band(), to_cuda(self, fbank_cmvn).float().contiguous(), True, True)
 
     def compute_cmvn(self, inputs, input_sizes):

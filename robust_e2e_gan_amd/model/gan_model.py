@@ -23,7 +23,11 @@ class _Act(torch.nn.Module):
     """placeholder that keeps nn.Sequential's numbering (LeakyReLU is fused into the conv / BN kernels)."""
 
 
-def init_NLayerDiscriminator(input_nc, ndf=64, n_layers=3):
+class _Sigmoid(torch.nn.Module):
+    """nn.Sigmoid() appended by ``use_sigmoid`` (--no_lsgan): fused into the last convolution's epilogue."""
+
+
+def init_NLayerDiscriminator(input_nc, ndf=64, n_layers=3, use_sigmoid=False):
     """gan_model.py:55-95 with norm_layer = BatchNorm2d (use_bias False on the normalised convs)."""
     seq = [ConvParams(input_nc, ndf, 4, stride=2, padding=1), _Act()]
     nf_mult = 1
@@ -33,14 +37,19 @@ def init_NLayerDiscriminator(input_nc, ndf=64, n_layers=3):
     nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
     seq += [ConvParams(ndf * nf_prev, ndf * nf_mult, 4, bias=False, stride=1, padding=1), BatchNormParams(ndf * nf_mult), _Act()]
     seq += [ConvParams(ndf * nf_mult, 1, 4, stride=1, padding=1)]
+    if use_sigmoid:
+        seq += [_Sigmoid()]
     return torch.nn.Sequential(*seq)
 
 
-def init_PixelDiscriminator(input_nc, ndf=64):
+def init_PixelDiscriminator(input_nc, ndf=64, use_sigmoid=False):
     """gan_model.py:98-116 (1x1 PatchGAN) with norm_layer = BatchNorm2d: only the first conv has a bias."""
-    return torch.nn.Sequential(ConvParams(input_nc, ndf, 1, stride=1, padding=0), _Act(),
-                               ConvParams(ndf, ndf * 2, 1, bias=False, stride=1, padding=0), BatchNormParams(ndf * 2), _Act(),
-                               ConvParams(ndf * 2, 1, 1, bias=False, stride=1, padding=0))
+    seq = [ConvParams(input_nc, ndf, 1, stride=1, padding=0), _Act(),
+           ConvParams(ndf, ndf * 2, 1, bias=False, stride=1, padding=0), BatchNormParams(ndf * 2), _Act(),
+           ConvParams(ndf * 2, 1, 1, bias=False, stride=1, padding=0)]
+    if use_sigmoid:
+        seq += [_Sigmoid()]
+    return torch.nn.Sequential(*seq)
 
 
 def init_net(net, gain=0.02):
@@ -61,16 +70,15 @@ class GANModel(ModelBase):
         self.opt = args
         if args.norm_D != 'batch':
             raise Re2eError('norm_D=%s: only BatchNorm discriminators are on the hot path' % args.norm_D)
-        if args.no_lsgan:
-            raise Re2eError('--no_lsgan (sigmoid + BCE) is outside the round-1 hot path')
+        use_sigmoid = bool(args.no_lsgan)                   # gan_model.py:126: the plain-GAN discriminator ends in a Sigmoid
         if args.netD_type == 'basic':
-            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, n_layers=3)
+            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, n_layers=3, use_sigmoid=use_sigmoid)
         elif args.netD_type == 'n_layers':
-            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, args.n_layers_D)
+            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, args.n_layers_D, use_sigmoid=use_sigmoid)
         elif args.netD_type == 'pixel':
             # the module itself is built; upstream's joint loop cannot drive it (joint_train.py:178 reads an undefined
             # mix_feat at train time and applies the 80-wide CMVN to the 160-wide concatenation)
-            self.model = init_PixelDiscriminator(args.input_nc, args.ndf)
+            self.model = init_PixelDiscriminator(args.input_nc, args.ndf, use_sigmoid=use_sigmoid)
         else:
             raise NotImplementedError('Discriminator model name [%s] is not recognized' % args.netD_type)
         init_net(self.model, 0.02)
@@ -103,7 +111,7 @@ class GANModel(ModelBase):
                         self._bn_layers_last.append(nxt)
                     i += 3
                 else:
-                    h = ops.conv2d(h, m.weight, m.bias, m.stride, m.padding, None)
+                    h = ops.conv2d(h, m.weight, m.bias, m.stride, m.padding, 'sigmoid' if isinstance(nxt, _Sigmoid) else None)
                     i += 1
             else:
                 i += 1
@@ -124,18 +132,18 @@ def replay_running_stats(stats):
 
 
 class GANLoss(torch.nn.Module):
-    """LSGAN: MSE(D(x), 1.0 or 0.0 broadcast)   (gan_model.py:152-171)"""
+    """LSGAN: MSE(D(x), 1.0 or 0.0 broadcast); ``use_lsgan=False`` (--no_lsgan): nn.BCELoss on the discriminator's
+    sigmoid outputs against the same broadcast constants (gan_model.py:152-171)."""
 
     def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0):
         super(GANLoss, self).__init__()
-        if not use_lsgan:
-            raise Re2eError('--no_lsgan (BCE) is outside the round-1 hot path')
         self.register_buffer('real_label', torch.tensor(target_real_label))
         self.register_buffer('fake_label', torch.tensor(target_fake_label))
         self._real, self._fake = float(target_real_label), float(target_fake_label)
+        self._kind = lib.LOSS_L2 if use_lsgan else lib.LOSS_BCE
 
     def __call__(self, input, target_is_real):
-        return ops.mean_loss(input, None, self._real if target_is_real else self._fake, lib.LOSS_L2)
+        return ops.mean_loss(input, None, self._real if target_is_real else self._fake, self._kind)
 
 
 def CORAL(source, target):

@@ -289,6 +289,54 @@ def fbank(x, band, cmvn=None, want_raw=True, want_norm=False):
     return (raw if want_raw else None), (nrm if want_norm else None)
 
 
+class FbankDenseFn(torch.autograd.Function):
+    """Trainable dense filterbank (fbank_opti_type 'train', feat_model.py:105-109,118-135): y = log(max((x^2) W, 1e-7))
+    [-> (y + cmvn0) * cmvn1] with W a (F, NF) Parameter: GEMM engine for x^2 W, dz W^T and (x^2)^T dz."""
+
+    @staticmethod
+    def forward(ctx, x, W, cmvn):
+        _need_gpu(x)
+        x = _f32(x)
+        F_, NF = W.shape
+        rows = x.numel() // F_
+        x2 = x.reshape(rows, F_)
+        sq = empty((rows, F_), x)
+        call('re2e_mul', x2.data_ptr(), x2.data_ptr(), sq.data_ptr(), sq.numel())
+        z = empty((rows, NF), x)
+        gemm(sq, W, z, rows, NF, F_)                               # (x^2) W, W stored (K=F, N=NF)
+        y = empty(x.shape[:-1] + (NF,), x)
+        call('re2e_logclamp_fwd', z.data_ptr(), ptr(cmvn), rows, NF, y.data_ptr())
+        ctx.W, ctx.cmvn = W, cmvn
+        ctx.save_for_backward(x2, sq, z)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, sq, z = ctx.saved_tensors
+        W, cmvn = ctx.W, ctx.cmvn
+        rows, F_ = x2.shape
+        NF = W.shape[1]
+        dy = _f32(dy)
+        dz = empty((rows, NF), dy)
+        call('re2e_logclamp_bwd', z.data_ptr(), ptr(cmvn), rows, NF, dy.data_ptr(), dz.data_ptr())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            ds = empty((rows, F_), dy)
+            gemm(dz, W, ds, rows, F_, NF, transb=True)            # dz W^T
+            dx = empty((rows, F_), dy)
+            call('re2e_mul', x2.data_ptr(), ds.data_ptr(), dx.data_ptr(), dx.numel())
+            call('re2e_axpby', 2.0, dx.data_ptr(), 0.0, dx.data_ptr(), dx.numel())      # d(x^2) = 2 x
+            dx = dx.view(dy.shape[:-1] + (F_,))
+        if _wants(ctx, 1, W):
+            with param_grads(dz, sq), accumulate(W) as (gw, beta):
+                gemm(sq, dz, gw, F_, NF, rows, transa=True, beta=beta)       # (x^2)^T dz
+        return dx, None, None
+
+
+def fbank_dense(x, W, cmvn=None):
+    return FbankDenseFn.apply(x, W, cmvn)
+
+
 # ---------------------------------------------------------------------------------------------
 # enhancer mask epilogue: out = sigmoid(proj W^T) * [t < len] * mix
 # ---------------------------------------------------------------------------------------------
@@ -913,6 +961,50 @@ class MulConstFn(torch.autograd.Function):
 
 
 mul_const = MulConstFn.apply
+
+
+# ---------------------------------------------------------------------------------------------
+# Dropout (F.dropout e2e_ctc.py:51, nn.LSTM(dropout=) e2e_encoder.py:156-157, nn.Dropout enhance_model.py:298)
+# ---------------------------------------------------------------------------------------------
+_DROPOUT = {'seed': 0x5EED5EED5EED, 'call': 0}
+
+
+def dropout_seed(seed, call=0):
+    """Seed of the counter-based dropout masks (re2e_dropout) and the index of the next mask: every ``dropout`` call draws
+    mask number ``call`` of the stream ``seed`` and advances it, so a run is reproducible from (seed, call)."""
+    _DROPOUT['seed'], _DROPOUT['call'] = int(seed) & 0xFFFFFFFFFFFFFFFF, int(call)
+
+
+def dropout_state():
+    return _DROPOUT['seed'], _DROPOUT['call']
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, call_idx):
+        _need_gpu(x)
+        x = _f32(x)
+        y = empty(x.shape, x)
+        call('re2e_dropout', x.data_ptr(), y.data_ptr(), x.numel(), float(p), seed, call_idx)
+        ctx.cfg = (float(p), seed, call_idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, call_idx = ctx.cfg
+        dy = _f32(dy)
+        dx = empty(dy.shape, dy)
+        call('re2e_dropout', dy.data_ptr(), dx.data_ptr(), dy.numel(), p, seed, call_idx)      # same mask, regenerated
+        return dx, None, None, None
+
+
+def dropout(x, p):
+    """x * mask / (1 - p) with the next mask of the module-level stream (``dropout_seed``); p == 0 returns x."""
+    if not p:
+        return x
+    seed, idx = _DROPOUT['seed'], _DROPOUT['call']
+    _DROPOUT['call'] = (idx + 1) & 0xFFFFFFFF
+    return DropoutFn.apply(x, p, seed, idx)
 
 
 class DecoderLoopFn(torch.autograd.Function):

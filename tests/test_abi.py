@@ -16,7 +16,8 @@ def _ctype_of(decl):
         return ctypes.c_void_p
     base = re.sub(r'\s+\w+$', '', d).strip() if re.search(r'\s\w+$', d) else d          # drop the parameter name
     table = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t,
-             're2e_stream_t': ctypes.c_void_p, 'unsigned': ctypes.c_uint, 'double': ctypes.c_double}
+             're2e_stream_t': ctypes.c_void_p, 'unsigned': ctypes.c_uint, 'double': ctypes.c_double,
+             'unsigned long long': ctypes.c_ulonglong}
     assert base in table, 'include/re2e.h: unhandled parameter type %r' % decl
     return table[base]
 

@@ -373,3 +373,78 @@ def test_fp32_sides_within_1e3_of_fp64(golden_dir):
                 ref32[d][k[len(pre):]] = torch.from_numpy(v)
     dev, name = _grad_dev(ref32, f64)
     assert dev < 1e-3, ('reference fp32', dev, name)
+
+
+# ---- SURVEY 8(f) N4, round 2 (tests/golden/make_fixtures_n4b.py): --no_lsgan, blstmp enhancer, trainable fbank, dropout ----
+def test_philox_known_answers():
+    """Random123's published known-answer vectors for philox4x32-10: pins the generator the dropout masks are built on."""
+    from oracle.philox import philox4x32_10, dropout_mask
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kat:
+        got = philox4x32_10(np.array([c], np.uint32), np.array(k, np.uint32))[0]
+        assert tuple(int(x) for x in got) == want
+    m = dropout_mask(200001, 0.3, 99, 4)
+    assert m.shape == (200001,) and set(np.unique(m).tolist()) == {0.0, float(np.float32(1.0) / (np.float32(1.0) - np.float32(0.3)))}
+    assert abs((m > 0).mean() - 0.7) < 5e-3
+    assert not np.array_equal(m, dropout_mask(200001, 0.3, 99, 5))            # another mask index, another mask
+
+
+def test_bce_gan_loss(golden_dir):
+    fx = _load(golden_dir, 'n4b_tiny.npz')
+    full = _sub(fx, 'bce.p.')
+    p = {k: v.clone().requires_grad_(True) for k, v in full.items() if v.dtype.is_floating_point and 'running' not in k}
+    buf = {k: v.clone() for k, v in full.items() if 'running' in k or 'num_batches' in k}
+    x = torch.from_numpy(fx['feats']).requires_grad_(True)
+    d = nets.discriminator_forward(p, buf, x, use_sigmoid=True)
+    np.testing.assert_allclose(d.detach().numpy(), fx['bce.d_out'], **TOL)
+    lr = nets.gan_loss(d, True, use_lsgan=False)
+    lf = nets.gan_loss(nets.discriminator_forward(p, buf, x * 0.9 + 0.1, use_sigmoid=True), False, use_lsgan=False)
+    np.testing.assert_allclose(lr.detach().numpy().reshape(-1), fx['bce.l_real'], rtol=1e-4)
+    np.testing.assert_allclose(lf.detach().numpy().reshape(-1), fx['bce.l_fake'], rtol=1e-4)
+    ((lr + lf) * 0.5).backward()
+    np.testing.assert_allclose(x.grad.numpy(), fx['bce.dx'], rtol=2e-3, atol=1e-7)
+    for k, v in p.items():
+        ref = fx['bce.g.' + k]
+        assert np.abs(v.grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, k
+
+
+def test_blstmp_enhancer(golden_dir):
+    fx = _load(golden_dir, 'n4b_tiny.npz')
+    p = {k: v.clone().requires_grad_(True) for k, v in _sub(fx, 'enhb.p.').items()}
+    t = lambda k: torch.from_numpy(fx[k])
+    lens = fx['lens'].tolist()
+    out = nets.enhance_forward(p, t('mix'), t('mix_log'), lens, 2, kind='blstmp')
+    np.testing.assert_allclose(out.detach().numpy(), fx['enhb.enhance_out'], **TOL)
+    loss, out2 = nets.enhance_forward(p, t('mix'), t('mix_log'), lens, 2, t('clean'), t('cos'), kind='blstmp')
+    np.testing.assert_allclose(loss.detach().numpy().reshape(-1), fx['enhb.l1_loss'], rtol=1e-4)
+    (loss + (out2 * torch.linspace(0.5, 1.5, 257)).mean()).backward()
+    for k, v in p.items():
+        ref = fx['enhb.g.' + k]
+        assert np.abs(v.grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, k
+
+
+def test_trainable_fbank(golden_dir):
+    fx = _load(golden_dir, 'n4b_tiny.npz')
+    W = torch.from_numpy(fx['fbt.W']).requires_grad_(True)
+    x = torch.from_numpy(fx['fbt.x']).requires_grad_(True)
+    cm = torch.from_numpy(fx['cmvn'])
+    np.testing.assert_allclose(nets.fbank_forward(x, W).detach().numpy(), fx['fbt.y_nocmvn'], rtol=1e-5, atol=1e-5)
+    y1 = nets.fbank_forward(x, W, cm)
+    np.testing.assert_allclose(y1.detach().numpy(), fx['fbt.y_cmvn'], rtol=1e-5, atol=1e-5)
+    (y1 * torch.linspace(-1, 1, 80)).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), fx['fbt.dx'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(W.grad.numpy(), fx['fbt.dW'], rtol=1e-4, atol=1e-3 * np.abs(fx['fbt.dW']).max())
+
+
+def test_ctc_dropout_matches_reference_run(golden_dir):
+    """The reference's CTC head with F.dropout replaced by the recorded counter-based mask (make_fixtures_n4b.py)."""
+    fx = _load(golden_dir, 'n4b_tiny.npz')
+    p = {k: v.clone().requires_grad_(True) for k, v in _sub(fx, 'drop.p.').items() if v.dtype.is_floating_point and not k.startswith('dec.att.')}
+    lc, la, acc, _, _ = nets.e2e_forward(p, torch.from_numpy(fx['feats']), torch.from_numpy(fx['drop.targets']), fx['lens'].tolist(),
+                                         fx['drop.tlens'].tolist(), 2, ctc_dropout=(0.3, int(fx['drop.seed']), 0))
+    np.testing.assert_allclose(lc.detach().numpy().reshape(-1), fx['drop.loss_ctc'], rtol=3e-4)
+    np.testing.assert_allclose(la.detach().numpy().reshape(-1), fx['drop.loss_att'], rtol=3e-4)
+    (0.5 * lc + 0.5 * la).backward()
+    _e2e_grads_close(p, fx, 'drop.', ['ctc.ctc_lo.weight', 'ctc.ctc_lo.bias', 'enc.enc2.bt1.weight', 'enc.enc1.conv1_1.weight'])

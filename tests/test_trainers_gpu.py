@@ -297,3 +297,148 @@ def test_pixel_discriminator(golden_dir):
     for k, v in gan.state_dict().items():
         if 'running' in k or 'num_batches' in k:
             rel('pix.after.' + k, v, fx['pix.after.' + k], tol=1e-4)
+
+
+# ---- SURVEY 8(f) N4, round 2 (tests/golden/make_fixtures_n4b.py): --no_lsgan, blstmp enhancer, trainable fbank, dropout ----
+def test_bce_gan_loss_no_lsgan(golden_dir):
+    """--no_lsgan: Sigmoid-headed discriminator (gan_model.py:90-91,126) + nn.BCELoss (gan_model.py:157-160) against the
+    reference: probabilities, both losses, every gradient, BatchNorm running statistics."""
+    import argparse
+    from robust_e2e_gan_amd.model.gan_model import GANModel, GANLoss
+    fx = _fx(golden_dir, 'n4b_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), 'no_lsgan': True})
+    gan = _load(GANModel(opt), fx, 'bce.p.')
+    crit = GANLoss(use_lsgan=False)
+    x = torch.from_numpy(fx['feats']).to(DEV).requires_grad_(True)
+    d = gan(x)
+    rel('bce.d_out', d, fx['bce.d_out'])
+    lr = crit(d, True)
+    lf = crit(gan(x * 0.9 + 0.1), False)
+    rel('bce.l_real', lr.view(1), fx['bce.l_real'])
+    rel('bce.l_fake', lf.view(1), fx['bce.l_fake'])
+    ((lr + lf) * 0.5).backward()
+    rel('bce.dx', x.grad, fx['bce.dx'], tol=3e-3)
+    for k, p in gan.named_parameters():
+        rel('bce.g.' + k, p.grad, fx['bce.g.' + k], tol=3e-3)
+    for k, v in gan.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            rel('bce.after.' + k, v, fx['bce.after.' + k], tol=1e-4)
+
+
+def test_blstmp_enhancer(golden_dir):
+    """EnhanceModel(enhance_type='blstmp') (enhance_model.py:90-93) against the reference: mask product, mask-L1 loss, grads."""
+    import argparse
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    fx = _fx(golden_dir, 'n4b_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), 'enhance_type': 'blstmp', 'enhance_layers': 2, 'subsample': '1_1_1'})
+    enh = _load(EnhanceModel(opt), fx, 'enhb.p.')
+    t = lambda k: torch.from_numpy(fx[k])
+    lens = torch.IntTensor(fx['lens'])
+    out = enh(t('mix'), t('mix_log'), lens)
+    rel('enhb.enhance_out', out, fx['enhb.enhance_out'])
+    for b, l in enumerate(fx['lens']):
+        assert (out[b, l:] == 0).all()
+    loss, out2 = enh(t('mix'), t('mix_log'), lens, t('clean'), t('cos'))
+    rel('enhb.l1_loss', loss.view(1), fx['enhb.l1_loss'])
+    (loss + (out2 * torch.linspace(0.5, 1.5, 257).to(DEV)).mean()).backward()
+    for k, p in enh.named_parameters():
+        rel('enhb.g.' + k, p.grad, fx['enhb.g.' + k], tol=2e-3)
+    spec = enh.calculate_all_specgram(t('mix'), t('mix_log'), lens)           # no length mask: padded rows = sigmoid(fc(tanh(bias)))
+    assert spec.shape == out.shape and torch.isfinite(spec).all()
+    assert torch.equal(spec[0, :int(fx['lens'][0])], out.detach()[0, :int(fx['lens'][0])])
+
+
+def test_trainable_fbank(golden_dir):
+    """FbankModel(fbank_opti_type='train') (feat_model.py:105-109): dense (257,80) parameter -- features, dx and dW."""
+    import argparse
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    fx = _fx(golden_dir, 'n4b_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), 'fbank_opti_type': 'train'})
+    fb = FbankModel(opt)
+    assert fb.fc.requires_grad
+    fb.load_state_dict({'fc': torch.from_numpy(fx['fbt.W'])})
+    fb = fb.to(DEV)
+    x = torch.from_numpy(fx['fbt.x']).to(DEV).requires_grad_(True)
+    cm = torch.from_numpy(fx['cmvn'])
+    rel('fbt.y_nocmvn', fb(x), fx['fbt.y_nocmvn'], tol=1e-5)
+    y1 = fb(x, cm)
+    rel('fbt.y_cmvn', y1, fx['fbt.y_cmvn'], tol=1e-5)
+    (y1 * torch.linspace(-1, 1, 80).to(DEV)).sum().backward()
+    rel('fbt.dx', x.grad, fx['fbt.dx'], tol=1e-4)
+    rel('fbt.dW', fb.fc.grad, fx['fbt.dW'], tol=1e-4)
+
+
+def test_dropout_kernel_is_the_recorded_mask():
+    """re2e_dropout against oracle/philox.py bit for bit (odd sizes, several rates / seeds / mask indices), and its backward
+    (the same mask regenerated, nothing stored)."""
+    from oracle.philox import dropout_mask
+    from robust_e2e_gan_amd import ops
+    for n, p, seed, call in ((1, 0.5, 1, 0), (7, 0.1, 0xFFFFFFFFFFFF, 3), (100003, 0.3, 20261003, 0), (4096, 0.9, 42, 4000000000)):
+        x = torch.randn(n, generator=torch.Generator().manual_seed(n)).to(DEV).requires_grad_(True)
+        ops.dropout_seed(seed, call)
+        y = ops.dropout(x, p)
+        m = torch.from_numpy(dropout_mask(n, p, seed, call)).to(DEV)
+        assert torch.equal(y.detach(), x.detach() * m), (n, p)
+        g = torch.ones(n, device=DEV) * 3.0
+        y.backward(g)
+        assert torch.equal(x.grad, g * m)
+        assert ops.dropout_state() == (seed & 0xFFFFFFFFFFFFFFFF, (call + 1) & 0xFFFFFFFF)
+    assert ops.dropout(x, 0.0) is x
+
+
+def test_ctc_dropout_matches_reference_run(golden_dir):
+    """dropout_rate = 0.3 through E2E: the CTC head's always-on F.dropout (e2e_ctc.py:51) with the recorded mask -- losses and
+    gradients equal the reference's run with that mask; BLSTMP's per-layer nn.LSTM(dropout=) stays a no-op."""
+    import argparse
+    from robust_e2e_gan_amd import ops
+    from robust_e2e_gan_amd.model.e2e_model import E2E
+    fx = _fx(golden_dir, 'n4b_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), 'dropout_rate': 0.3})
+    asr = _load(E2E(opt), fx, 'drop.p.')
+    ops.dropout_seed(int(fx['drop.seed']), 0)
+    lc, la, acc = asr(torch.from_numpy(fx['feats']), torch.from_numpy(fx['drop.targets']), torch.IntTensor(fx['lens']),
+                      torch.IntTensor(fx['drop.tlens']), 0.0)
+    assert ops.dropout_state()[1] == 1                                  # exactly one mask was drawn
+    rel('drop.loss_ctc', lc.view(1), fx['drop.loss_ctc'])
+    rel('drop.loss_att', la.view(1), fx['drop.loss_att'])
+    (0.5 * lc.view(()) + 0.5 * la.view(())).backward()
+    named = dict(asr.named_parameters())
+    for n in ('ctc.ctc_lo.weight', 'ctc.ctc_lo.bias', 'enc.enc2.bt1.weight', 'enc.enc1.conv1_1.weight'):
+        rel('drop.g.' + n, named[n].grad, fx['drop.g.' + n], tol=3e-3)
+    asr.eval()                                                          # upstream's F.dropout ignores eval mode
+    ops.dropout_seed(int(fx['drop.seed']), 0)
+    with torch.no_grad():
+        lc2, _, _ = asr(torch.from_numpy(fx['feats']), torch.from_numpy(fx['drop.targets']), torch.IntTensor(fx['lens']),
+                        torch.IntTensor(fx['drop.tlens']), 0.0)
+    assert torch.equal(lc2.view(1), lc.detach().view(1))
+
+
+def test_blstm_interlayer_dropout_vs_oracle(golden_dir):
+    """nn.LSTM(num_layers=2, dropout=p) of the enhancer's BLSTM (e2e_encoder.py:156-157): the mask falls on layer 0's output in
+    training mode only.  torch's generator cannot be replayed inside nn.LSTM, so this site is pinned through the oracle with
+    the recorded mask; eval mode must equal the dropout-free reference output."""
+    import argparse
+    from oracle import nets as on
+    from oracle.philox import dropout_mask
+    from robust_e2e_gan_amd import ops
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    fx = _fx(golden_dir, 'enhance_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), 'dropout_rate': 0.25})
+    enh = _load(EnhanceModel(opt), fx, 'p.')
+    t = lambda k: torch.from_numpy(fx[k])
+    lens = fx['lens'].tolist()
+    B, T, H2 = len(lens), max(lens), 2 * opt.enhance_units
+    ops.dropout_seed(77, 5)
+    out = enh(t('mix'), t('mix_log'), torch.IntTensor(lens))
+    p = {k[2:]: torch.from_numpy(v).clone().requires_grad_(True) for k, v in fx.items() if k.startswith('p.')}
+    mask = on.tm_mask(dropout_mask(T * B * H2, 0.25, 77, 5), B, T, H2)
+    ref = on.enhance_forward(p, t('mix'), t('mix_log'), lens, 2, inter_masks=[mask])
+    rel('enhance_out (dropout)', out, ref.detach().numpy())
+    assert (out.detach().cpu() - t('enhance_out')).abs().max() > 1e-2 * t('enhance_out').abs().max()      # the mask did something
+    (out * torch.linspace(0.5, 1.5, 257).to(DEV)).mean().backward()
+    (ref * torch.linspace(0.5, 1.5, 257)).mean().backward()
+    for k, q in enh.named_parameters():
+        rel('g.' + k, q.grad, p[k].grad.numpy(), tol=2e-3)
+    enh.eval()
+    with torch.no_grad():
+        rel('eval: no dropout', enh(t('mix'), t('mix_log'), torch.IntTensor(lens)), fx['enhance_out'])
