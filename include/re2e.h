@@ -252,6 +252,16 @@ int re2e_ctc_bwd(const float* logits, int T, int B, int V, const int* hlens_dev,
                  const int* label_off_dev, const int* label_len_dev, int Lmax, const float* nll_per_utt,
                  const float* gscale_dev, float* dlogits, const void* workspace, re2e_stream_t stream);
 
+/* ---- N3 CTC prefix scores for joint CTC/attention beam search (CTCPrefixScore model/e2e_ctc.py:78-155 as called per
+ * hypothesis at model/e2e_decoder.py:231-263), all `nh` live hypotheses of one output position in one launch.
+ * lpz (T,V) CTC log posteriors; att_lsm (nh,V) attention log-probabilities; r_prev (nh,T,2) forward variables of each
+ * hypothesis; last_label / out_len (labels without <sos>) / prev_score (nh).  Per hypothesis: cand_out (ctc_beam) = its top
+ * labels in torch.topk order, ctc_score_out = log prefix probabilities, local_out = att_weight*att + ctc_weight*(ctc - prev), r_new
+ * (nh,ctc_beam,T,2) = the candidates' new forward variables.  ctc_beam <= 64 (RE2E_EUNSUPPORTED beyond). */
+int re2e_ctc_prefix_score(const float* lpz, int T, int V, const float* att_lsm, int nh, const float* r_prev, const int* last_label_dev,
+                          const int* out_len_dev, const float* prev_score_dev, int ctc_beam, float att_weight, float ctc_weight, int blank,
+                          int eos, int* cand_out, float* local_out, float* ctc_score_out, float* r_new, re2e_stream_t stream);
+
 /* ---- K7 location-aware attention step (model/e2e_attention.py:258-297) -------------------- */
 /* per utterance b: w = softmax_t(2*(gvec . tanh(W_att conv(att_prev) + pre[b,t] + W_dec z[b]) + gb)),
  * c[b] = sum_t w[t]*enc[b,t].  att_prev==NULL => uniform 1/hlen over valid frames.

@@ -224,3 +224,106 @@ extern "C" int re2e_ctc_bwd(const float* logits, int T, int B, int V, const int*
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
+
+
+// ============================================================================================
+// N3: CTC prefix scores for joint CTC / attention beam search (CTCPrefixScore, model/e2e_ctc.py:78-155, called per
+// hypothesis at model/e2e_decoder.py:231-263) -- one launch per output position for ALL live hypotheses.
+// One workgroup per hypothesis:
+//   1. the top `ctc_beam` labels of its attention log-probabilities (torch.topk order: descending, ties -> lower label),
+//      by `ctc_beam` rounds of a workgroup arg-max over the row held in LDS;
+//   2. one thread per candidate label runs Algorithm 2's recursion over the T frames: the hypothesis' previous forward
+//      variables r_prev (T,2) are staged in LDS (shared by all its candidates), the candidate's own r_t^n, r_t^b live in two
+//      registers and are streamed out as the candidate's new state;
+//   3. local score att_weight * att + ctc_weight * (ctc - ctc_prev) per candidate (e2e_decoder.py:246-248).
+// Only cand / local / ctc_score (ctc_beam values each per hypothesis) leave the GPU; the states stay in `r_new` and the
+// survivors are gathered by index for the next position.
+// ============================================================================================
+namespace {
+constexpr float CTC_LOGZERO = -10000000000.0f;
+__device__ __forceinline__ float logaddexp_(float x, float y) {      // numpy's float32 logaddexp
+  if (x == y) return x + 0.69314718055994530942f;
+  const float d = x - y;
+  return d > 0.f ? x + log1pf(expf(-d)) : y + log1pf(expf(d));
+}
+
+__global__ __launch_bounds__(256) void ctc_prefix_kernel(const float* __restrict__ lpz, int T, int V, const float* __restrict__ att, const float* __restrict__ r_prev,
+                                                         const int* __restrict__ last_label, const int* __restrict__ out_len,
+                                                         const float* __restrict__ prev_score, int ctc_beam, float att_weight, float ctc_weight, int blank, int eos,
+                                                         int* __restrict__ cand_out, float* __restrict__ local_out, float* __restrict__ ctc_out,
+                                                         float* __restrict__ r_new) {
+  extern __shared__ float sm[];
+  float* row = sm;                       // [V] attention log-probabilities, selected entries overwritten with -inf
+  float* rp = sm + V;                    // [T][2] previous forward variables
+  float* rsum = rp + 2 * T;              // [T]
+  __shared__ float red_v[4];
+  __shared__ int red_i[4];
+  __shared__ int cand[64];
+  __shared__ float cand_att[64];
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < V; i += 256) row[i] = att[(long)h * V + i];
+  for (int i = tid; i < 2 * T; i += 256) rp[i] = r_prev[(long)h * 2 * T + i];
+  __syncthreads();
+  for (int t = tid; t < T; t += 256) rsum[t] = logaddexp_(rp[2 * t], rp[2 * t + 1]);
+  for (int k = 0; k < ctc_beam; ++k) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) { const float v = row[i]; if (v > bv) { bv = v; bi = i; } }     // ascending i: first maximum wins
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { red_v[wid] = bv; red_i[wid] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w) if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
+      cand[k] = bi; cand_att[k] = bv; row[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+  if (tid < ctc_beam) {
+    const int c = cand[tid], n = out_len[h], last = last_label[h];
+    float* rn = r_new + ((long)h * ctc_beam + tid) * 2 * T;
+    const int start = n > 1 ? n : 1;
+    float rn_n, rn_b;                                   // r[t-1][0], r[t-1][1]
+    for (int t = 0; t < start - 1; ++t) { rn[2 * t] = CTC_LOGZERO; rn[2 * t + 1] = CTC_LOGZERO; }     // never read (numpy leaves them unset)
+    if (n == 0) { rn_n = lpz[c]; rn_b = CTC_LOGZERO; } else { rn_n = CTC_LOGZERO; rn_b = CTC_LOGZERO; }
+    rn[2 * (start - 1)] = rn_n; rn[2 * (start - 1) + 1] = rn_b;
+    const bool rep = n > 0 && c == last;                // a repeated label needs a blank in between
+    float log_psi = rn_n;
+    for (int t = start; t < T; ++t) {
+      const float phi = rep ? rp[2 * (t - 1) + 1] : rsum[t - 1];
+      const float xs = lpz[(long)t * V + c], xb = lpz[(long)t * V + blank];
+      const float nn = logaddexp_(rn_n, phi) + xs;
+      const float nb = logaddexp_(rn_n, rn_b) + xb;
+      log_psi = logaddexp_(log_psi, phi + xs);
+      rn_n = nn; rn_b = nb;
+      rn[2 * t] = nn; rn[2 * t + 1] = nb;
+    }
+    if (c == eos) log_psi = rsum[T - 1];
+    cand_out[(long)h * ctc_beam + tid] = c;
+    ctc_out[(long)h * ctc_beam + tid] = log_psi;
+    local_out[(long)h * ctc_beam + tid] = att_weight * cand_att[tid] + ctc_weight * (log_psi - prev_score[h]);
+  }
+}
+}  // namespace
+
+extern "C" int re2e_ctc_prefix_score(const float* lpz, int T, int V, const float* att_lsm, int nh, const float* r_prev, const int* last_label_dev,
+                                     const int* out_len_dev, const float* prev_score_dev, int ctc_beam, float att_weight, float ctc_weight, int blank,
+                                     int eos, int* cand_out, float* local_out, float* ctc_score_out, float* r_new, hipStream_t stream) {
+  RE2E_CHECK_ARG(lpz && att_lsm && r_prev && last_label_dev && out_len_dev && prev_score_dev && cand_out && local_out && ctc_score_out && r_new,
+                 "null operand");
+  RE2E_CHECK_ARG(T > 0 && V > 0 && nh > 0 && blank >= 0 && blank < V && eos >= 0 && eos < V, "bad geometry");
+  if (ctc_beam < 1 || ctc_beam > 64 || ctc_beam > V) { re2e_set_error("re2e_ctc_prefix_score: ctc_beam must be in [1, min(64, V)]"); return RE2E_EUNSUPPORTED; }
+  const size_t lds = ((size_t)V + 3 * (size_t)T) * sizeof(float);
+  if (lds > 150 * 1024) { re2e_set_error("re2e_ctc_prefix_score: V + 3T floats exceed the LDS"); return RE2E_EUNSUPPORTED; }
+  static bool attr_done = false;   // idempotent
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_prefix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(ctc_prefix_kernel, dim3(nh), dim3(256), lds, stream, lpz, T, V, att_lsm, r_prev, last_label_dev, out_len_dev, prev_score_dev,
+                     ctc_beam, att_weight, ctc_weight, blank, eos, cand_out, local_out, ctc_score_out, r_new);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}

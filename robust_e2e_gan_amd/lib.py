@@ -80,6 +80,7 @@ SIGNATURES = {
     're2e_ctc_workspace_bytes': (Z, [I, I, I]),
     're2e_ctc_fwd': (I, [P, I, I, I, P, P, P, P, I, P, P, P, Z, P]),
     're2e_ctc_bwd': (I, [P, I, I, I, P, P, P, P, I, P, P, P, P, P]),
+    're2e_ctc_prefix_score': (I, [P, I, I, P, I, P, P, P, P, I, F, F, I, I, P, P, P, P, P]),
     're2e_attloc_fwd': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, L, P, P, P, P]),
     're2e_attloc_partial_floats': (Z, [I, I, I]),
     're2e_attloc_workspace_bytes': (Z, [I, I, I, I]),

@@ -4,8 +4,15 @@ CTCPrefixScore (model/e2e_ctc.py:78-155) and end_detect (model/e2e_common.py:226
 The reference advances one hypothesis at a time (B = 1 attention / LSTMCell / output-layer calls, ``beam`` of them
 per output position).  Here all live hypotheses of a position form ONE batch on the GPU: a single AttLoc step,
 LSTMCell, output layer and row-wise log-softmax for the whole beam, one device->host copy of the (beam, V) local
-scores per position; the search bookkeeping (top-k, CTC prefix scores in numpy -- as upstream --, pruning, end
-detection) stays on the host and follows the reference line by line, so the n-best lists agree."""
+scores per position; the search bookkeeping (pruning, length penalties, end detection) stays on the host and follows the
+reference line by line, so the n-best lists agree.
+
+Joint CTC/attention decoding: the CTC prefix scores of ALL live hypotheses x their ``ctc_beam`` candidate labels are one
+launch per position (re2e_ctc_prefix_score: top-k pre-selection, Algorithm 2's recursion with the forward variables in
+LDS / registers, the combined local score); the hypotheses' CTC states never leave the GPU and only
+3 x nh x ctc_beam numbers (candidate labels, local scores, prefix scores) are copied to the host per position -- instead of
+the (nh, V) attention scores plus a numpy recursion per hypothesis.  ``ctc_beam`` > 64 (ctc_weight == 1.0 scores all V
+labels upstream, e2e_decoder.py:233-234) keeps the host scorer below, which is upstream's own numpy algorithm."""
 import numpy as np
 import torch
 
@@ -69,7 +76,10 @@ def _topk(row, k):
     return row[idx], idx
 
 
-def recognize_beam(p, h, lpz, recog_args, eos, prefix=''):
+DEVICE_CTC_MAX_BEAM = 64        # re2e_ctc_prefix_score: one thread per candidate label, <= 64 candidates per hypothesis
+
+
+def recognize_beam(p, h, lpz, recog_args, eos, prefix='', lpz_dev=None):
     """``p``: reference-named decoder / attention Parameters; ``h``: (T, eprojs) encoder states of ONE utterance on the
     GPU; ``lpz``: (T, V) CTC log posteriors (numpy) or None.  Returns the n-best list of {'yseq', 'score'}."""
     dev = h.device
@@ -94,10 +104,15 @@ def recognize_beam(p, h, lpz, recog_args, eos, prefix=''):
         maxlen = T if recog_args.maxlenratio == 0 else max(1, int(recog_args.maxlenratio * T))
         minlen = int(recog_args.minlenratio * T)
         hyps = [{'score': np.float32(0.0), 'yseq': [eos], 'parent': 0}]
+        dev_ctc = False
         if lpz is not None:
             ctc = CTCPrefixScore(lpz, 0, eos)
             hyps[0]['ctc_state'], hyps[0]['ctc_score'] = ctc.initial_state(), np.float32(0.0)
             ctc_beam = min(V, int(beam * CTC_SCORING_RATIO)) if ctc_weight != 1.0 else V
+            dev_ctc = ctc_beam <= DEVICE_CTC_MAX_BEAM
+            if dev_ctc:
+                lpz_d = lpz_dev.float().contiguous() if lpz_dev is not None else torch.from_numpy(np.ascontiguousarray(lpz, np.float32)).to(dev)
+                r_prev = torch.from_numpy(hyps[0].pop('ctc_state')).to(dev).view(1, T, 2)      # states stay on the device from here on
         z, c, a_prev = torch.zeros(1, D, device=dev), torch.zeros(1, D, device=dev), None
         ended = []
         for i in range(maxlen):
@@ -119,9 +134,28 @@ def recognize_beam(p, h, lpz, recog_args, eos, prefix=''):
             logits, lsm = torch.empty(nh, V, device=dev), torch.empty(nh, V, device=dev)
             ops.gemm(z_new, out_w, logits, nh, V, D, transb=True, bias=out_b)
             call('re2e_log_softmax_rows', logits.data_ptr(), nh, V, V, lsm.data_ptr())
-            local_all = lsm.cpu().numpy()                                 # the one host round trip of this position
+            if dev_ctc:
+                last = host_to_dev(np.asarray([hp['yseq'][-1] for hp in hyps], np.int32), dev)
+                olen = host_to_dev(np.asarray([len(hp['yseq']) - 1 for hp in hyps], np.int32), dev)
+                prev = host_to_dev(np.asarray([hp['ctc_score'] for hp in hyps], np.float32), dev, torch.float32)
+                cand_d = torch.empty(nh, ctc_beam, dtype=torch.int32, device=dev)
+                out_d = torch.empty(2, nh, ctc_beam, device=dev)                  # [0] local scores, [1] prefix scores
+                r_new = torch.empty(nh * ctc_beam, 2 * T, device=dev)
+                call('re2e_ctc_prefix_score', lpz_d.data_ptr(), T, V, lsm.data_ptr(), nh, r_prev.data_ptr(), last.data_ptr(), olen.data_ptr(),
+                     prev.data_ptr(), ctc_beam, float(np.float32(1.0 - ctc_weight)), float(np.float32(ctc_weight)), 0, eos, cand_d.data_ptr(),
+                     out_d[0].data_ptr(), out_d[1].data_ptr(), r_new.data_ptr())
+                cand_all, out_all = cand_d.cpu().numpy(), out_d.cpu().numpy()      # 3 x nh x ctc_beam numbers: this position's host round trip
+            else:
+                local_all = lsm.cpu().numpy()                             # host scorer: the (nh, V) local scores cross once per position
             kept = []
             for k, hyp in enumerate(hyps):
+                if dev_ctc:
+                    best_scores, joint = _topk(out_all[0, k], beam)
+                    for j in range(len(joint)):
+                        kept.append({'score': np.float32(hyp['score'] + best_scores[j]), 'yseq': hyp['yseq'] + [int(cand_all[k, joint[j]])],
+                                     'parent': k, 'ctc_row': k * ctc_beam + int(joint[j]), 'ctc_score': out_all[1, k, joint[j]]})
+                    kept = sorted(kept, key=lambda x: x['score'], reverse=True)[:beam]
+                    continue
                 local_att = local_all[k]
                 if lpz is not None:
                     _, cand = _topk(local_att, ctc_beam)
@@ -157,5 +191,8 @@ def recognize_beam(p, h, lpz, recog_args, eos, prefix=''):
                 break
             parents = host_to_dev(np.asarray([hp['parent'] for hp in hyps], np.int64), dev, torch.int64)
             z, c, a_prev = z_new.index_select(0, parents), c_new.index_select(0, parents), w_new.index_select(0, parents)
+            if dev_ctc:                                                   # the survivors' CTC states, gathered on the device
+                rows = host_to_dev(np.asarray([hp['ctc_row'] for hp in hyps], np.int64), dev, torch.int64)
+                r_prev = r_new.index_select(0, rows)
         best = sorted(ended, key=lambda x: x['score'], reverse=True)[:min(len(ended), recog_args.nbest)]
         return [{'yseq': b['yseq'], 'score': float(b['score'])} for b in best]

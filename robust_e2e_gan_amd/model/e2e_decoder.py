@@ -110,7 +110,7 @@ class Decoder(torch.nn.Module):
         p = {'dec.' + k: v for k, v in self.named_parameters() if not k.startswith('att.')}
         p.update({'att.' + k: v for k, v in self.att.named_parameters()})
         lp = lpz.detach().cpu().numpy() if isinstance(lpz, torch.Tensor) else lpz
-        return recognize_beam(p, h, lp, recog_args, self.eos)
+        return recognize_beam(p, h, lp, recog_args, self.eos, lpz_dev=lpz if isinstance(lpz, torch.Tensor) and lpz.is_cuda else None)
 
     def calculate_all_attentions(self, hpad, hlen, ys):
         """e2e_decoder.py:371-461 -- attention weights (B, Lmax+1, T').  NB the reference's pass is GREEDY: for i > 0 it
