@@ -89,6 +89,9 @@ int re2e_conv_weight_gather(const float* W, float* dst, int Cout, int Cin, int K
 /* ---- elementwise / layout helpers ------------------------------------------------------- */
 /* out[d1][d0][:] = in[d0][d1][:]  (batch-first <-> time-major) */
 int re2e_transpose01(const float* in, float* out, int D0, int D1, int W, re2e_stream_t stream);
+/* y = act(x): stand-alone tanh / relu / lrelu(0.2) / sigmoid (the U-Net blocks' nn.LeakyReLU / nn.ReLU / nn.Sigmoid
+ * modules, enhance_model.py:277-291; everywhere else the activation is a GEMM / conv epilogue) */
+int re2e_act_fwd(const float* x, float* y, long n, int act, re2e_stream_t stream);
 /* dz = dy * act'(y), y = activation OUTPUT (tanh / relu / lrelu / sigmoid); dz may alias dy */
 int re2e_act_bwd(const float* dy, const float* y, float* dz, long n, int act, re2e_stream_t stream);
 /* out[n] = beta*out[n] + sum_m A[m*lda+n]; workspace >= re2e_colsum_workspace_bytes */
@@ -178,14 +181,16 @@ int re2e_vgg_pack_fwd(const float* in, const int* lens_dev, int NI, int T, int F
 int re2e_vgg_pack_bwd(const float* dout, const int* lens_dev, int NI, int T, int Fq, int C, float* din, int NI_total,
                       int n_off, re2e_stream_t stream);
 
-/* ---- K9 BatchNorm2d (train mode) + LeakyReLU(0.2) over NHWC rows [P][C] (gan_model.py:76-88) */
+/* ---- K9 BatchNorm2d (train mode) + LeakyReLU(slope) over NHWC rows [P][C]: slope 0.2 = the discriminator's
+ * BatchNorm2d + LeakyReLU(0.2) pairs (gan_model.py:76-88), slope 1.0 = plain BatchNorm2d (U-Net blocks,
+ * enhance_model.py:281-296) */
 size_t re2e_bn_workspace_bytes(long P, int C);
 int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gamma, const float* beta, float* running_mean,
-                      float* running_var, float momentum, float eps, int train, float* y, float* save_mean,
+                      float* running_var, float momentum, float eps, int train, float slope, float* y, float* save_mean,
                       float* save_invstd, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 /* dy is the gradient w.r.t. the LeakyReLU output; dgamma/dbeta may be NULL (frozen D) */
 int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C, const float* gamma, const float* beta,
-                      const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                      const float* save_mean, const float* save_invstd, float slope, float* dx, float* dgamma, float* dbeta,
                       float gbeta, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 
 /* ---- K4 bidirectional LSTM recurrence, packed-sequence semantics (nn.LSTM call sites

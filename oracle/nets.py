@@ -101,6 +101,47 @@ def _enhance_head(p, proj, B, T, mix, lens, clean, cos):
 
 
 # --------------------------------------------------------------------------------------
+# N4  U-Net enhancer   model/enhance_model.py:224-303 (UnetGenerator / UnetSkipConnectionBlock, BatchNorm)
+# --------------------------------------------------------------------------------------
+def _unet_block(p, buf, pre, x, depth, num_downs, train, drop_masks):
+    """One UnetSkipConnectionBlock (enhance_model.py:249-303); ``pre`` = its state_dict prefix ('enc1.model.' for the outermost)."""
+    outermost, innermost = depth == 0, depth == num_downs - 1
+    bn = lambda h, k: F.batch_norm(h, buf[pre + 'model.%d.running_mean' % k], buf[pre + 'model.%d.running_var' % k],
+                                   p[pre + 'model.%d.weight' % k], p[pre + 'model.%d.bias' % k], train, 0.1, 1e-5)
+    if outermost:
+        h = F.conv2d(x, p[pre + 'model.0.weight'], None, stride=2, padding=1)
+        h = _unet_block(p, buf, pre + 'model.1.', h, depth + 1, num_downs, train, drop_masks)
+        h = F.conv_transpose2d(F.relu(h), p[pre + 'model.3.weight'], p[pre + 'model.3.bias'], stride=2, padding=1)
+        return torch.sigmoid(h)
+    h = F.conv2d(F.leaky_relu(x, 0.2), p[pre + 'model.1.weight'], None, stride=2, padding=1)
+    if innermost:
+        h = F.conv_transpose2d(F.relu(h), p[pre + 'model.3.weight'], None, stride=2, padding=1)
+        h = bn(h, 4)
+    else:
+        h = bn(h, 2)
+        h = _unet_block(p, buf, pre + 'model.3.', h, depth + 1, num_downs, train, drop_masks)
+        h = F.conv_transpose2d(F.relu(h), p[pre + 'model.5.weight'], None, stride=2, padding=1)
+        h = bn(h, 6)
+        if drop_masks is not None and (pre + 'model.7') in drop_masks:
+            h = h * drop_masks[pre + 'model.7']
+    return torch.cat([x, h], 1)
+
+
+def unet_enhance_forward(p, buf, mix, mix_log, lens, num_downs=5, clean=None, cos=None, train=True, drop_masks=None):
+    """EnhanceModel.forward for enhance_type unet_128 / unet_256 (enhance_model.py:139-142,152-172): the U-Net output (already
+    through the outermost nn.Sigmoid) is squeezed and passed through sigmoid AGAIN, masked by length and multiplied with mix."""
+    y = _unet_block(p, buf, 'enc1.model.', mix_log.unsqueeze(1), 0, num_downs, train, drop_masks)
+    out = torch.sigmoid(y.squeeze(1))
+    B, T, _ = out.shape
+    valid = (torch.arange(T).unsqueeze(0) < torch.as_tensor(lens).view(-1, 1)).unsqueeze(-1)
+    enhance_out = out * valid.to(out.dtype) * mix
+    if clean is not None:
+        loss = (enhance_out - clean * cos).abs().sum() / float(sum(int(l) for l in lens))
+        return loss, enhance_out
+    return enhance_out
+
+
+# --------------------------------------------------------------------------------------
 # F3/F4  FbankModel   model/feat_model.py:118-135, :62-90
 # --------------------------------------------------------------------------------------
 def fbank_forward(x, W, cmvn=None):

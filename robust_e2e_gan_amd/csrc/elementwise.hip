@@ -212,6 +212,18 @@ extern "C" int re2e_axpby(float a, const float* x, float b, float* y, long n, hi
   return RE2E_OK;
 }
 
+// ---- stand-alone activation (the U-Net blocks apply LeakyReLU / ReLU / Sigmoid as separate modules: enhance_model.py:277-291)
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = apply_act(x[i], act);
+}
+extern "C" int re2e_act_fwd(const float* x, float* y, long n, int act, hipStream_t stream) {
+  RE2E_CHECK_ARG(x && y && n > 0, "bad args");
+  RE2E_CHECK_ARG(act > RE2E_ACT_NONE && act <= RE2E_ACT_SIGMOID, "bad activation");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, stream, x, y, n, act);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
 // ---- dropout (F.dropout / nn.LSTM(dropout=) / nn.Dropout: e2e_ctc.py:51, e2e_encoder.py:156-157, enhance_model.py:298) ----
 // Counter-based mask: element i keeps its value when word (i & 3) of Philox4x32-10(counter = {i >> 2 (lo), i >> 34 (hi), call, 0},
 // key = {seed lo, seed hi}) is >= threshold = floor(p * 2^32); kept values are scaled by 1 / (1 - p).  Nothing is stored:
@@ -581,7 +593,8 @@ extern "C" int re2e_vgg_pack_bwd(const float* dout, const int* lens, int NI, int
   return RE2E_OK;
 }
 
-// ---- K9 BatchNorm2d (train) + LeakyReLU(0.2) over rows [P][C] ---------------------------------
+// ---- K9 BatchNorm2d (train) + LeakyReLU(slope) over rows [P][C]; slope = 0.2 in the discriminator (gan_model.py:76-88),
+// 1.0 = plain BatchNorm2d (the U-Net blocks: the next block applies its own pre-activation, enhance_model.py:281-296)
 // partial sums over row chunks: mode 0: sum(x - center) ; mode 1: sum((x-center)^2)
 // mode 2 (backward): s0 = sum dz, s1 = sum dz*xhat with dz = dy * lrelu'(bn(x))
 static inline int bn_chunks(long P) { long c = (P + 255) / 256; return (int)(c > 512 ? 512 : (c < 1 ? 1 : c)); }
@@ -589,7 +602,7 @@ extern "C" size_t re2e_bn_workspace_bytes(long P, int C) { return (size_t)bn_chu
 
 __global__ void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, long P, int C, long rows_per_chunk,
                                   int mode, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ part) {
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ part, float slope) {
   __shared__ float r0[4][64], r1[4][64];
   int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   int c = blockIdx.x * 64 + cx;
@@ -603,7 +616,7 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, const float* __re
       if (mode == 0) s0 += v;
       else if (mode == 1) s0 += v * v;
       else {
-        float xh = v * is; float y = xh * ga + be; float dz = dy[p * C + c]; dz = y > 0.f ? dz : 0.2f * dz;
+        float xh = v * is; float y = xh * ga + be; float dz = dy[p * C + c]; dz = y > 0.f ? dz : slope * dz;
         s0 += dz; s1 += dz * xh;
       }
     }
@@ -619,7 +632,7 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, const float* __re
 __global__ __launch_bounds__(256) void bn_partial_vec_kernel(const float* __restrict__ x, const float* __restrict__ dy, long P, int C,
                                                              long rows_per_chunk, int mode, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float* __restrict__ part) {
+                                                             const float* __restrict__ beta, float* __restrict__ part, float slope) {
   __shared__ __attribute__((aligned(16))) float r0[16][64], r1[16][64];
   const int c4 = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
@@ -640,8 +653,8 @@ __global__ __launch_bounds__(256) void bn_partial_vec_kernel(const float* __rest
       const f32x4 xh_ = v_ * is;                                                              \
       const f32x4 y_ = xh_ * ga + be;                                                         \
       f32x4 dz_;                                                                              \
-      dz_[0] = y_[0] > 0.f ? (dv)[0] : 0.2f * (dv)[0]; dz_[1] = y_[1] > 0.f ? (dv)[1] : 0.2f * (dv)[1]; \
-      dz_[2] = y_[2] > 0.f ? (dv)[2] : 0.2f * (dv)[2]; dz_[3] = y_[3] > 0.f ? (dv)[3] : 0.2f * (dv)[3]; \
+      dz_[0] = y_[0] > 0.f ? (dv)[0] : slope * (dv)[0]; dz_[1] = y_[1] > 0.f ? (dv)[1] : slope * (dv)[1]; \
+      dz_[2] = y_[2] > 0.f ? (dv)[2] : slope * (dv)[2]; dz_[3] = y_[3] > 0.f ? (dv)[3] : slope * (dv)[3]; \
       s0 += dz_; s1 += dz_ * xh_;                                                             \
     }                                                                                         \
   } while (0)
@@ -721,18 +734,18 @@ __global__ void bn_eval_stats_kernel(const float* rm, const float* rv, int C, fl
 }
 __global__ void bn_apply_kernel(const float* __restrict__ x, long P, int C, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                float* __restrict__ y) {
+                                float* __restrict__ y, float slope) {
   long tot = P * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % C);
     float v = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
-    y[i] = v > 0.f ? v : 0.2f * v;
+    y[i] = v > 0.f ? v : slope * v;
   }
 }
 // float4 forms of the two apply kernels (C % 4 == 0): the channel vectors are loaded once per thread iteration
 __global__ void bn_apply_vec_kernel(const float* __restrict__ x, long P, int C4, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    float* __restrict__ y) {
+                                    float* __restrict__ y, float slope) {
   const long tot = P * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4);
@@ -740,14 +753,14 @@ __global__ void bn_apply_vec_kernel(const float* __restrict__ x, long P, int C4,
     const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c], be = reinterpret_cast<const f32x4*>(beta)[c];
     f32x4 v = (reinterpret_cast<const f32x4*>(x)[i] - m) * is * ga + be;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.2f * v[k];
+    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : slope * v[k];
     reinterpret_cast<f32x4*>(y)[i] = v;
   }
 }
 __global__ void bn_bwd_apply_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x, long P, int C4,
                                         const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                         const float* __restrict__ beta, const float* __restrict__ sdz, const float* __restrict__ sdzx,
-                                        float* __restrict__ dx) {
+                                        float* __restrict__ dx, float slope) {
   const long tot = P * C4;
   const float invP = 1.0f / (float)P;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
@@ -759,14 +772,14 @@ __global__ void bn_bwd_apply_vec_kernel(const float* __restrict__ dy, const floa
     const f32x4 yv = xh * ga + be;
     f32x4 dz = reinterpret_cast<const f32x4*>(dy)[i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dz[k] = yv[k] > 0.f ? dz[k] : 0.2f * dz[k];
+    for (int k = 0; k < 4; ++k) dz[k] = yv[k] > 0.f ? dz[k] : slope * dz[k];
     reinterpret_cast<f32x4*>(dx)[i] = ga * is * (dz - a * invP - xh * bq * invP);
   }
 }
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gamma, const float* beta, float* running_mean,
-                                 float* running_var, float momentum, float eps, int train, float* y, float* save_mean,
+                                 float* running_var, float momentum, float eps, int train, float slope, float* y, float* save_mean,
                                  float* save_invstd, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   RE2E_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && save_mean && save_invstd && workspace, "null arg");
   RE2E_CHECK_ARG(P > 0 && C > 0, "bad shape");
@@ -779,15 +792,15 @@ extern "C" int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gam
   if (train) {
     const bool vec = bn_vec_ok(x, nullptr, C);
     if (vec) hipLaunchKernelGGL(bn_partial_vec_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 0, (const float*)nullptr,
-                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
+                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, slope);
     else hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 0, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, slope);
     hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
                        0.f, tmp, (float*)nullptr);
     if (vec) hipLaunchKernelGGL(bn_partial_vec_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 1, (const float*)tmp,
-                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
+                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, slope);
     else hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, 1, (const float*)tmp,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, slope);
     hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f / (float)P,
                        0.f, tmp + C, (float*)nullptr);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)tmp, (const float*)(tmp + C), P, C,
@@ -798,24 +811,24 @@ extern "C" int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gam
   }
   if (C % 4 == 0 && al16(x) && al16(y) && al16(save_mean) && al16(save_invstd) && al16(gamma) && al16(beta))
     hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(grid_for(P * C / 4)), dim3(TPB), 0, stream, x, P, C / 4, (const float*)save_mean,
-                       (const float*)save_invstd, gamma, beta, y);
+                       (const float*)save_invstd, gamma, beta, y, slope);
   else
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, x, P, C, (const float*)save_mean,
-                       (const float*)save_invstd, gamma, beta, y);
+                       (const float*)save_invstd, gamma, beta, y, slope);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, long P, int C,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ sdz, const float* __restrict__ sdzx,
-                                    float* __restrict__ dx) {
+                                    float* __restrict__ dx, float slope) {
   long tot = P * C;
   float invP = 1.0f / (float)P;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % C);
     float xh = (x[i] - mean[c]) * invstd[c];
     float yv = xh * gamma[c] + beta[c];
-    float dz = dy[i]; dz = yv > 0.f ? dz : 0.2f * dz;
+    float dz = dy[i]; dz = yv > 0.f ? dz : slope * dz;
     dx[i] = gamma[c] * invstd[c] * (dz - sdz[c] * invP - xh * sdzx[c] * invP);
   }
 }
@@ -826,7 +839,7 @@ __global__ void bn_param_grad_kernel(const float* sdz, const float* sdzx, int C,
   dbeta[c] = (gbeta != 0.f ? gbeta * dbeta[c] : 0.f) + sdz[c];
 }
 extern "C" int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C, const float* gamma, const float* beta,
-                                 const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                                 const float* save_mean, const float* save_invstd, float slope, float* dx, float* dgamma, float* dbeta,
                                  float gbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   RE2E_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && dx && workspace, "null arg");
   RE2E_CHECK_ARG(workspace_bytes >= re2e_bn_workspace_bytes(P, C), "workspace too small");
@@ -835,15 +848,15 @@ extern "C" int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C,
   float* part = (float*)workspace;
   float* tmp = part + (size_t)chunks * 2 * C;
   dim3 g(cdiv(C, 64), chunks);
-  if (bn_vec_ok(x, dy, C)) hipLaunchKernelGGL(bn_partial_vec_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part);
-  else hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part);
+  if (bn_vec_ok(x, dy, C)) hipLaunchKernelGGL(bn_partial_vec_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part, slope);
+  else hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part, slope);
   hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f, 1.0f, tmp, tmp + C);
   if (C % 4 == 0 && al16(dy) && al16(x) && al16(dx) && al16(save_mean) && al16(save_invstd) && al16(gamma) && al16(beta) && al16(tmp))
     hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(grid_for(P * C / 4)), dim3(TPB), 0, stream, dy, x, P, C / 4, save_mean, save_invstd,
-                       gamma, beta, (const float*)tmp, (const float*)(tmp + C), dx);
+                       gamma, beta, (const float*)tmp, (const float*)(tmp + C), dx, slope);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, dy, x, P, C, save_mean, save_invstd, gamma,
-                       beta, (const float*)tmp, (const float*)(tmp + C), dx);
+                       beta, (const float*)tmp, (const float*)(tmp + C), dx, slope);
   if (dgamma && dbeta)
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, (const float*)tmp, (const float*)(tmp + C), C,
                        dgamma, dbeta, gbeta);

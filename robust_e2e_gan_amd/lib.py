@@ -33,6 +33,7 @@ SIGNATURES = {
     're2e_conv_dgrad_s2': (I, [P, I, I, I, I, P, I, I, I, I, I, I, P, P, P]),
     're2e_conv_weight_gather': (I, [P, P, I, I, I, I, I, I, I, I, I, I, P]),
     're2e_transpose01': (I, [P, P, I, I, I, P]),
+    're2e_act_fwd': (I, [P, P, L, I, P]),
     're2e_act_bwd': (I, [P, P, P, L, I, P]),
     're2e_act_bwd_colsum': (I, [P, P, P, I, I, I, P, F, P, Z, P]),
     're2e_colsum_workspace_bytes': (Z, [I, I]),
@@ -61,8 +62,8 @@ SIGNATURES = {
     're2e_vgg_pack_fwd': (I, [P, P, I, I, I, I, P, I, I, P]),
     're2e_vgg_pack_bwd': (I, [P, P, I, I, I, I, P, I, I, P]),
     're2e_bn_workspace_bytes': (Z, [L, I]),
-    're2e_bn_lrelu_fwd': (I, [P, L, I, P, P, P, P, F, F, I, P, P, P, P, Z, P]),
-    're2e_bn_lrelu_bwd': (I, [P, P, L, I, P, P, P, P, P, P, P, F, P, Z, P]),
+    're2e_bn_lrelu_fwd': (I, [P, L, I, P, P, P, P, F, F, I, F, P, P, P, P, Z, P]),
+    're2e_bn_lrelu_bwd': (I, [P, P, L, I, P, P, P, P, F, P, P, P, F, P, Z, P]),
     're2e_lstm_workspace_bytes': (Z, [I, I]),
     're2e_lstm_abort_count': (I, []),
     're2e_lstm_seq_fwd': (I, [P, P, P, P, P, P, P, I, I, I, P, Z, P]),

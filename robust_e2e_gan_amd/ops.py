@@ -504,6 +504,91 @@ def conv2d(x, W, b=None, stride=1, pad=1, act=None):
     return Conv2dFn.apply(x, W, b, stride, pad, ACT[act])
 
 
+class ConvTranspose2dFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(C1, C2, k, stride 2, padding p) over NHWC (U-Net up-convolutions, enhance_model.py:266-283).
+    x: (N,H,W,C1); Wt: (C1,C2,KH,KW) (ConvTranspose2d's own layout = a Conv2d weight with Cout=C1, Cin=C2); returns
+    (N,2H,2W,C2).  A transposed convolution IS the data gradient of the convolution with that weight, so the three passes are
+    the convolution's three kernels with their roles rotated: forward = stride-2 data gradient (re2e_conv_dgrad_s2),
+    input gradient = stride-2 forward convolution of dy, weight gradient = re2e_conv_wgrad with (input, output-gradient) =
+    (dy, x)."""
+
+    @staticmethod
+    def forward(ctx, x, Wt, b, stride, pad):
+        _need_gpu(x)
+        x = _f32(x)
+        N, H, Wd, C1 = x.shape
+        _, C2, KH, KW = Wt.shape
+        if stride != 2 or KH % 2 or KW % 2 or KH != 2 * pad + 2:
+            raise lib.Re2eError('conv_transpose2d is built for kernel 2p+2, stride 2 (output exactly 2x the input)')
+        OH, OW = 2 * H, 2 * Wd
+        y = conv_dgrad(x, Wt, (N, OH, OW, C2), stride, pad)
+        if b is not None:
+            ones, yb = torch.ones(C2, device=x.device), empty(y.shape, y)
+            call('re2e_affine_cols', y.data_ptr(), b.data_ptr(), ones.data_ptr(), yb.data_ptr(), N * OH * OW, C2)      # (y + b) * 1
+            y = yb
+        ctx.Wt, ctx.b, ctx.cfg = Wt, b, (stride, pad)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        Wt, b = ctx.Wt, ctx.b
+        stride, pad = ctx.cfg
+        N, H, Wd, C1 = x.shape
+        _, C2, KH, KW = Wt.shape
+        OH, OW = 2 * H, 2 * Wd
+        dy = _f32(dy).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wg = empty((C1, KH, KW, C2), dy)
+            call('re2e_conv_weight_gather', Wt.data_ptr(), wg.data_ptr(), C1, C2, KH, KW, 0, KH, KW, 0, 0, 1)
+            dx = empty((N, H, Wd, C1), dy)
+            call('re2e_conv_igemm', dy.data_ptr(), N, OH, OW, C2, wg.data_ptr(), C1, KH, KW, H, Wd, stride, stride, 1, 1, -pad, -pad,
+                 dx.data_ptr(), H, Wd, 1, 1, 0, 0, None, lib.ACT_NONE, 0.0)
+        with param_grads(dy, x):
+            if _wants(ctx, 1, Wt):
+                wsb = query('re2e_conv_wgrad_workspace_bytes', N, H, Wd, C2, C1, KH, KW)
+                ws = workspace(wsb, x.device, 'wgrad')
+                with accumulate(Wt) as (gw, beta):
+                    call('re2e_conv_wgrad', dy.data_ptr(), N, OH, OW, C2, x.data_ptr(), C1, KH, KW, H, Wd, stride, stride, -pad, -pad,
+                         gw.data_ptr(), beta, ws.data_ptr(), wsb)
+            if b is not None and _wants(ctx, 2, b):
+                with accumulate(b) as (gb, beta):
+                    colsum_into(dy.view(N * OH * OW, C2), N * OH * OW, C2, gb, beta)
+        return dx, None, None, None, None
+
+
+def conv_transpose2d(x, Wt, b=None, stride=2, pad=1):
+    return ConvTranspose2dFn.apply(x, Wt, b, stride, pad)
+
+
+class ActFn(torch.autograd.Function):
+    """Stand-alone activation module (nn.LeakyReLU(0.2) / nn.ReLU / nn.Sigmoid of the U-Net blocks)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        _need_gpu(x)
+        x = _f32(x).contiguous()
+        y = empty(x.shape, x)
+        call('re2e_act_fwd', x.data_ptr(), y.data_ptr(), x.numel(), act)
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _f32(dy).contiguous()
+        dz = empty(dy.shape, dy)
+        call('re2e_act_bwd', dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), ctx.act)
+        return dz, None
+
+
+def activation(x, act):
+    return ActFn.apply(x, ACT[act])
+
+
 class MaxPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -575,7 +660,7 @@ class BnLreluFn(torch.autograd.Function):
     """BatchNorm2d (train-mode statistics, running-stat update) + LeakyReLU(0.2) over NHWC."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, train, momentum, eps):
+    def forward(ctx, x, gamma, beta, rm, rv, train, momentum, eps, slope=0.2):
         _need_gpu(x)
         x = _f32(x)
         C = x.shape[-1]
@@ -586,8 +671,8 @@ class BnLreluFn(torch.autograd.Function):
         ws = workspace(wsb, x.device, 'bn')
         defer = BN_DEFER_RUNNING and BN_STATS_SINK is not None and train      # momentum 0 keeps running_mean / running_var bit-identical
         call('re2e_bn_lrelu_fwd', x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
-             0.0 if defer else float(momentum), float(eps), int(train), y.data_ptr(), sm.data_ptr(), si.data_ptr(), ws.data_ptr(), wsb)
-        ctx.gamma, ctx.beta, ctx.train = gamma, beta, train
+             0.0 if defer else float(momentum), float(eps), int(train), float(slope), y.data_ptr(), sm.data_ptr(), si.data_ptr(), ws.data_ptr(), wsb)
+        ctx.gamma, ctx.beta, ctx.train, ctx.slope = gamma, beta, train, float(slope)
         ctx.save_for_backward(x, sm, si)
         if BN_STATS_SINK is not None and train:
             BN_STATS_SINK.append((rm, rv, sm, si, Pn, float(momentum), float(eps)))
@@ -608,15 +693,16 @@ class BnLreluFn(torch.autograd.Function):
         if _wants(ctx, 1, gamma):
             with accumulate(gamma) as (dg, gbeta), accumulate(beta) as (db, _):
                 call('re2e_bn_lrelu_bwd', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
-                     dx.data_ptr(), dg.data_ptr(), db.data_ptr(), gbeta, ws.data_ptr(), wsb)
+                     ctx.slope, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), gbeta, ws.data_ptr(), wsb)
         else:
             call('re2e_bn_lrelu_bwd', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
-                 dx.data_ptr(), None, None, 0.0, ws.data_ptr(), wsb)
-        return dx, None, None, None, None, None, None, None
+                 ctx.slope, dx.data_ptr(), None, None, 0.0, ws.data_ptr(), wsb)
+        return dx, None, None, None, None, None, None, None, None
 
 
-def bn_lrelu(x, gamma, beta, rm, rv, train=True, momentum=0.1, eps=1e-5):
-    return BnLreluFn.apply(x, gamma, beta, rm, rv, train, momentum, eps)
+def bn_lrelu(x, gamma, beta, rm, rv, train=True, momentum=0.1, eps=1e-5, slope=0.2):
+    """BatchNorm2d + LeakyReLU(slope); slope=1.0 is plain BatchNorm2d."""
+    return BnLreluFn.apply(x, gamma, beta, rm, rv, train, momentum, eps, slope)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -9,6 +9,10 @@
           (e2e_ctc.py:51; BLSTMP's per-layer nn.LSTM(num_layers=1, dropout=p) never drops).  torch's own generator cannot be
           reproduced on the GPU, so F.dropout is replaced FOR THIS RUN by the product's counter-based mask (oracle/philox.py,
           seed 20261003, mask 0, drawn over the time-major tensor): everything else is the reference's arithmetic.
+  unet.*  EnhanceModel with enhance_type 'unet_128' (pix2pix U-Net, enhance_model.py:224-303; ngf 4, a (64, 32) image): mask
+          product (upstream's double sigmoid included), mask-L1 loss, all gradients, BatchNorm running statistics.
+          lecun_normal_init_parameters zeroes every 1-d parameter -- BatchNorm gains included (enhance_model.py:183) --, so
+          the gains / shifts are set to non-trivial values before the run.
 Build container only (needs /root/reference); writes n4b_tiny.npz."""
 import argparse
 import os
@@ -117,6 +121,29 @@ def main():
     named = dict(asr.named_parameters())
     for n in ('ctc.ctc_lo.weight', 'ctc.ctc_lo.bias', 'enc.enc2.bt1.weight', 'enc.enc1.conv1_1.weight'):
         fx['drop.g.' + n] = named[n].grad.numpy().copy()
+    # ---- U-Net enhancer
+    u_opt = argparse.Namespace(**{**vars(opt), 'enhance_type': 'unet_128', 'idim': 32, 'enhance_input_nc': 1, 'enhance_output_nc': 1,
+                                  'enhance_ngf': 4, 'enhance_norm': 'batch'})
+    torch.manual_seed(815)
+    unet = EnhanceModel(u_opt)
+    unet.train()
+    gq = torch.Generator().manual_seed(816)
+    with torch.no_grad():
+        for k, v in unet.named_parameters():
+            if v.dim() == 1:
+                v.copy_((1.0 if k.endswith('weight') else 0.0) + 0.2 * torch.randn(v.shape, generator=gq))
+    fx.update(mf.sd_np('unet.p.', unet))
+    ulens = [64, 40]
+    uc, um, uml, ucos = mf.synth_batch(2, ulens, F_=32, seed=17)
+    ul = torch.IntTensor(ulens)
+    uout = unet(um, uml.unsqueeze(1), ul)
+    uloss, uout2 = unet(um, uml.unsqueeze(1), ul, uc, ucos)
+    unet.zero_grad()
+    (uloss + (uout2 * torch.linspace(0.5, 1.5, 32)).mean()).backward()
+    fx.update({'unet.lens': np.array(ulens, np.int32), 'unet.clean': uc.numpy(), 'unet.mix': um.numpy(), 'unet.mix_log': uml.numpy(),
+               'unet.cos': ucos.numpy(), 'unet.enhance_out': uout.detach().numpy(), 'unet.l1_loss': uloss.detach().numpy().reshape(-1)})
+    fx.update(mf.grads_np('unet.g.', unet))
+    fx.update(mf.sd_np('unet.after.', unet))
     np.savez_compressed(os.path.join(HERE, 'n4b_tiny.npz'), **fx)
     print('written n4b_tiny.npz; bce losses', fx['bce.l_real'], fx['bce.l_fake'], 'enhb l1', fx['enhb.l1_loss'])
 

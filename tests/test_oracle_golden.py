@@ -448,3 +448,23 @@ def test_ctc_dropout_matches_reference_run(golden_dir):
     np.testing.assert_allclose(la.detach().numpy().reshape(-1), fx['drop.loss_att'], rtol=3e-4)
     (0.5 * lc + 0.5 * la).backward()
     _e2e_grads_close(p, fx, 'drop.', ['ctc.ctc_lo.weight', 'ctc.ctc_lo.bias', 'enc.enc2.bt1.weight', 'enc.enc1.conv1_1.weight'])
+
+
+def test_unet_enhancer(golden_dir):
+    fx = _load(golden_dir, 'n4b_tiny.npz')
+    full = _sub(fx, 'unet.p.')
+    p = {k: v.clone().requires_grad_(True) for k, v in full.items() if v.dtype.is_floating_point and 'running' not in k}
+    buf = {k: v.clone() for k, v in full.items() if 'running' in k}
+    t = lambda k: torch.from_numpy(fx['unet.' + k])
+    lens = fx['unet.lens'].tolist()
+    out = nets.unet_enhance_forward(p, buf, t('mix'), t('mix_log'), lens)
+    np.testing.assert_allclose(out.detach().numpy(), fx['unet.enhance_out'], rtol=1e-4, atol=1e-4 * np.abs(fx['unet.enhance_out']).max())
+    loss, out2 = nets.unet_enhance_forward(p, buf, t('mix'), t('mix_log'), lens, clean=t('clean'), cos=t('cos'))
+    np.testing.assert_allclose(loss.detach().numpy().reshape(-1), fx['unet.l1_loss'], rtol=1e-4)
+    (loss + (out2 * torch.linspace(0.5, 1.5, 32)).mean()).backward()
+    for k, v in p.items():
+        if ('unet.g.' + k) in fx:
+            ref = fx['unet.g.' + k]
+            assert np.abs(v.grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, k
+    for k, v in buf.items():            # two train-mode forwards moved the running statistics
+        np.testing.assert_allclose(v.numpy(), fx['unet.after.' + k], rtol=1e-4, atol=1e-6, err_msg=k)

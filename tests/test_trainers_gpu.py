@@ -442,3 +442,33 @@ def test_blstm_interlayer_dropout_vs_oracle(golden_dir):
     enh.eval()
     with torch.no_grad():
         rel('eval: no dropout', enh(t('mix'), t('mix_log'), torch.IntTensor(lens)), fx['enhance_out'])
+
+
+def test_unet_enhancer(golden_dir):
+    """EnhanceModel(enhance_type='unet_128') (pix2pix U-Net, enhance_model.py:224-303): stride-2 convolutions, transposed
+    convolutions (fwd = the stride-2 data-gradient kernel, its gradients = the convolution's other two kernels), plain
+    BatchNorm, channel concatenation, the double sigmoid -- mask product, mask-L1 loss, every gradient and the BatchNorm
+    running statistics against the reference."""
+    import argparse
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    fx = _fx(golden_dir, 'n4b_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), 'enhance_type': 'unet_128', 'idim': 32, 'enhance_input_nc': 1, 'enhance_output_nc': 1,
+                                'enhance_ngf': 4, 'enhance_norm': 'batch'})
+    enh = _load(EnhanceModel(opt), fx, 'unet.p.')
+    t = lambda k: torch.from_numpy(fx['unet.' + k])
+    lens = torch.IntTensor(fx['unet.lens'])
+    out = enh(t('mix'), t('mix_log').unsqueeze(1), lens)                      # (B,1,T,F) as enhance_fbank_train.py:117 passes it
+    rel('unet.enhance_out', out, fx['unet.enhance_out'])
+    assert (out[1, int(fx['unet.lens'][1]):] == 0).all()
+    loss, out2 = enh(t('mix'), t('mix_log').unsqueeze(1), lens, t('clean'), t('cos'))
+    rel('unet.l1_loss', loss.view(1), fx['unet.l1_loss'])
+    (loss + (out2 * torch.linspace(0.5, 1.5, 32).to(DEV)).mean()).backward()
+    named = dict(enh.named_parameters())
+    for k in fx:
+        if k.startswith('unet.g.'):
+            rel(k, named[k[len('unet.g.'):]].grad, fx[k], tol=3e-3)
+    for k, v in enh.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            rel('unet.after.' + k, v, fx['unet.after.' + k], tol=1e-4)
+    with pytest.raises(Exception):
+        enh(t('mix')[:, :50], t('mix_log')[:, :50].unsqueeze(1), lens)        # T not a multiple of 32: refused, as upstream's cat would fail
