@@ -132,15 +132,28 @@ def main(filler='conv', which='fwd'):
                 t = (e[0].elapsed_time(e[1]) if mode != 'chain alone' else 0.0, e[2].elapsed_time(e[3]) if mode != 'filler alone' else 0.0)
                 best = t if best is None or sum(t) < sum(best) else best
             res[mode] = best
-        fl = 2.0 * 9 * C * K * N * H * W * nconv
+        # algorithmic FLOPs of ONE fill() -- per filler (round 1 priced every filler with the nconv-convolution formula and printed
+        # figures above the 157.3 TFLOP/s peak for the VGG filler); fillers with no defined FLOP count print n/a
+        if gan is not None:
+            fl = None                       # discriminator forward / backward variants: read the ms
+        elif filler.startswith('vgg'):
+            upto = int(filler[3:] or 4)
+            px1, px2 = 32 * 800 * 80, 32 * 400 * 40
+            per = [2.0 * 9 * 1 * 64 * px1, 2.0 * 9 * 64 * 64 * px1, 2.0 * 9 * 64 * 128 * px2, 2.0 * 9 * 128 * 128 * px2]
+            fl = 2 * sum(per[:upto])        # fill() runs the stack twice
+        elif filler == 'hbm':
+            fl = None
+        else:
+            fl = 2.0 * 9 * C * K * N * H * W * nconv
+        tf = lambda ms: ('%.1f TFLOP/s' % (fl / ms * 1e-9)) if fl else 'n/a'
         print('chain %s (persist=%s, %s priority), filler %s%s on a stream %s:' % (which, os.environ.get('RE2E_LSTM_PERSIST', '1'),
                                                                        'high' if os.environ.get('CHAIN_PRIO') else 'normal', filler,
                                                                        ' WITHOUT memory traffic' if os.environ.get('RE2E_IGEMM_NOMEM') else '',
                                                                        'CU-masked to %d' % masked if masked else 'unmasked'))
-        print('   filler alone %.2f ms (%.1f TFLOP/s) | chain alone %.2f ms (%.2f us/step)' % (res['filler alone'][0], fl / res['filler alone'][0] * 1e-9,
-                                                                                              res['chain alone'][1], res['chain alone'][1] * 1e3 / T))
-        print('   together: filler %.2f ms (%.1f TFLOP/s), chain %.2f ms (%.2f us/step)' % (res['both'][0], fl / res['both'][0] * 1e-9, res['both'][1],
-                                                                                            res['both'][1] * 1e3 / T))
+        print('   filler alone %.2f ms (%s) | chain alone %.2f ms (%.2f us/step)' % (res['filler alone'][0], tf(res['filler alone'][0]),
+                                                                                  res['chain alone'][1], res['chain alone'][1] * 1e3 / T))
+        print('   together: filler %.2f ms (%s), chain %.2f ms (%.2f us/step)' % (res['both'][0], tf(res['both'][0]), res['both'][1],
+                                                                                res['both'][1] * 1e3 / T))
 
 
 if __name__ == '__main__':
