@@ -1,6 +1,7 @@
 // Shared device/host helpers for the re2e HIP library (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -30,6 +31,20 @@ void re2e_set_error(const char* fmt, ...);
       return RE2E_EHIP;                                                            \
     }                                                                              \
   } while (0)
+
+// Dynamic-LDS limit of one kernel, raised on demand.  The library is re-entrant (include/re2e.h): the only process-wide state
+// are these idempotent attribute caches; the mutex keeps two host threads that ask for different sizes from leaving the smaller one set.
+struct LdsLimit {
+  std::mutex m;
+  size_t set = 0;
+  void ensure(const void* fn, size_t bytes) {
+    std::lock_guard<std::mutex> g(m);
+    if (bytes > set) {
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      set = bytes;
+    }
+  }
+};
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -245,17 +245,14 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
   constexpr int HP = (TW + 2) * (TH + 2);
   constexpr int AIT = (HP * 4 + 255) / 256;
   constexpr size_t lds = (size_t)(AIT * 64 * LDC + 9 * 64 * LDC) * sizeof(float);
-  static bool attr_done = false;   // idempotent; racing writers set the same value
-  static int slots = 512;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, DIR, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, DIR, RELU>), lds);
+  static const int slots = [] {          // two workgroups per CU (LDS and registers both allow exactly two)
+    if (getenv("RE2E_HALO_SLOTS")) return atoi(getenv("RE2E_HALO_SLOTS"));   // occupancy experiments
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots = 2 * cus;                     // two workgroups per CU (LDS and registers both allow exactly two)
-    if (getenv("RE2E_HALO_SLOTS")) slots = atoi(getenv("RE2E_HALO_SLOTS"));   // occupancy experiments
-    attr_done = true;
-  }
+    return 2 * cus;
+  }();
   const int nwg = a.nitems < slots ? a.nitems : slots;
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
   if (log_calls)

@@ -317,11 +317,8 @@ extern "C" int re2e_ctc_prefix_score(const float* lpz, int T, int V, const float
   if (ctc_beam < 1 || ctc_beam > 64 || ctc_beam > V) { re2e_set_error("re2e_ctc_prefix_score: ctc_beam must be in [1, min(64, V)]"); return RE2E_EUNSUPPORTED; }
   const size_t lds = ((size_t)V + 3 * (size_t)T) * sizeof(float);
   if (lds > 150 * 1024) { re2e_set_error("re2e_ctc_prefix_score: V + 3T floats exceed the LDS"); return RE2E_EUNSUPPORTED; }
-  static bool attr_done = false;   // idempotent
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_prefix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_done = true;
-  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&ctc_prefix_kernel), lds);
   hipLaunchKernelGGL(ctc_prefix_kernel, dim3(nh), dim3(256), lds, stream, lpz, T, V, att_lsm, r_prev, last_label_dev, out_len_dev, prev_score_dev,
                      ctc_beam, att_weight, ctc_weight, blank, eos, cand_out, local_out, ctc_score_out, r_new);
   RE2E_LAUNCH_CHECK();

@@ -413,58 +413,123 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   }
 
   // ---------------------------------- epilogue ----------------------------------
+  // A lane holds, per 32x32 tile, ONE output column (lr) and 16 rows ((r&3) + 8*(r>>2) + 4*lh).  The variants below are separate
+  // loop nests selected by wave-uniform branches OUTSIDE the loops: a per-element `if (beta) v += C[off]` next to the store of
+  // the same array made the compiler wait for every store before the next element's possible load (64 serialised global
+  // round trips per lane, the largest single cost of a short-K tile), and a per-element activation switch + row remap
+  // division tripled the code (20k lines of ISA per instance).  Row offsets are computed once per row, not per element.
   if (ep.nsplit > 1) {
     float* W = ep.ws + (long)zsplit * ep.M * ep.N;
 #pragma unroll
     for (int a = 0; a < CF::TM; ++a)
 #pragma unroll
-      for (int b = 0; b < CF::TN; ++b) {
-        int col = n0 + (wn * CF::TN + b) * 32 + lr;
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * CF::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* wr = W + (long)row * ep.N;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int row = m0 + (wm * CF::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < ep.M && col < ep.N) W[(long)row * ep.N + col] = acc[a][b][r];
+        for (int b = 0; b < CF::TN; ++b) {
+          const int col = n0 + (wn * CF::TN + b) * 32 + lr;
+          if (row < ep.M && col < ep.N) wr[col] = acc[a][b][r];
         }
       }
     return;
   }
+  float bv[CF::TN];
+  int colv[CF::TN];
 #pragma unroll
-  for (int a = 0; a < CF::TM; ++a)
+  for (int b = 0; b < CF::TN; ++b) {
+    colv[b] = n0 + (wn * CF::TN + b) * 32 + lr;
+    float v = 0.f;
+    if (colv[b] < ep.N) {
+      if (ep.bias) v += ep.bias[colv[b]];
+      if (ep.bias2) v += ep.bias2[colv[b]];
+    }
+    bv[b] = v;
+  }
+  // offset of a row's first element, or -1 when the row does not exist (ragged M; phantom row of a parity class)
+  auto row_base = [&](int row) -> long {
+    if (row >= ep.M) return -1;
+    if (!ep.remap) return (long)row * ep.ldc;
+    const int j = row % ep.PW; const int t = row / ep.PW; const int i = t % ep.PH; const int n = t / ep.PH;
+    const int oy = i * ep.osy + ooy, ox = j * ep.osx + oox;
+    if (oy >= ep.OHF || ox >= ep.OWF) return -1;
+    return (((long)n * ep.OHF + oy) * ep.OWF + ox) * ep.ldc;
+  };
+  if (ep.act == RE2E_ACT_SIGMOID_MASK_MUL) {            // enhancer fc epilogue (never split, never remapped, beta 0)
+    // three distinct tensors: without the no-alias promise every `mul` load waits for the two stores in front of it
+    const float* __restrict__ mulp = ep.mul;
+    float* __restrict__ maskp = ep.mask_out;
+    float* __restrict__ outp = ep.C;
 #pragma unroll
-    for (int b = 0; b < CF::TN; ++b) {
-      int col = n0 + (wn * CF::TN + b) * 32 + lr;
-      float bv = 0.f;
-      if (col < ep.N) {
-        if (ep.bias) bv += ep.bias[col];
-        if (ep.bias2) bv += ep.bias2[col];
-      }
+    for (int a = 0; a < CF::TM; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int row = m0 + (wm * CF::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < ep.M && col < ep.N) {
-          long off;
-          if (ep.remap) {
-            int j = row % ep.PW; int t = row / ep.PW; int i = t % ep.PH; int n = t / ep.PH;
-            const int oy = i * ep.osy + ooy, ox = j * ep.osx + oox;
-            if (oy >= ep.OHF || ox >= ep.OWF) continue;      // phantom row of a parity class (odd H or W)
-            off = (((long)n * ep.OHF + oy) * ep.OWF + ox) * ep.ldc + col;
-          } else {
-            off = (long)row * ep.ldc + col;
-          }
-          float v = acc[a][b][r] + bv;
-          if (ep.act == RE2E_ACT_SIGMOID_MASK_MUL) {
-            int bi = row / ep.T, t = row - bi * ep.T;
-            float s = (t < ep.lens[bi]) ? sigmoidf_(v) : 0.f;
-            ep.mask_out[off] = s;
-            v = s * ep.mul[off];
-          } else {
-            v = apply_act(v, ep.act);
-          }
-          if (ep.beta != 0.f) v += ep.C[off];
-          ep.C[off] = v;
+        const int row = m0 + (wm * CF::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= ep.M) continue;
+        const int bi = row / ep.T, t = row - bi * ep.T;
+        const bool live = t < ep.lens[bi];
+        const long rb = (long)row * ep.ldc;
+#pragma unroll
+        for (int b = 0; b < CF::TN; ++b) {
+          if (colv[b] >= ep.N) continue;
+          const float sg = live ? sigmoidf_(acc[a][b][r] + bv[b]) : 0.f;
+          maskp[rb + colv[b]] = sg;
+          outp[rb + colv[b]] = sg * mulp[rb + colv[b]];
         }
       }
-    }
+    return;
+  }
+  if (ep.beta != 0.f) {                                  // accumulate: the 16 old values of a tile row block are loaded before any store
+#pragma unroll
+    for (int a = 0; a < CF::TM; ++a)
+#pragma unroll
+      for (int b = 0; b < CF::TN; ++b) {
+        float old[16];
+        long offs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long rb = row_base(m0 + (wm * CF::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+          offs[r] = (rb >= 0 && colv[b] < ep.N) ? rb + colv[b] : -1;
+          old[r] = offs[r] >= 0 ? ep.C[offs[r]] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (offs[r] >= 0) ep.C[offs[r]] = apply_act(acc[a][b][r] + bv[b], ep.act) + old[r];
+      }
+    return;
+  }
+  if (ep.act == RE2E_ACT_TANH || ep.act == RE2E_ACT_SIGMOID) {
+    const bool th = ep.act == RE2E_ACT_TANH;
+#pragma unroll
+    for (int a = 0; a < CF::TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long rb = row_base(m0 + (wm * CF::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+        if (rb < 0) continue;
+#pragma unroll
+        for (int b = 0; b < CF::TN; ++b) {
+          const float v = acc[a][b][r] + bv[b];
+          if (colv[b] < ep.N) ep.C[rb + colv[b]] = th ? tanhf_(v) : sigmoidf_(v);
+        }
+      }
+    return;
+  }
+  {
+    // none / ReLU / LeakyReLU(0.2) in one branch-free form: max(v, slope * v) with slope 1 / 0 / 0.2
+    const float slope = ep.act == RE2E_ACT_RELU ? 0.f : (ep.act == RE2E_ACT_LRELU ? 0.2f : 1.f);
+#pragma unroll
+    for (int a = 0; a < CF::TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long rb = row_base(m0 + (wm * CF::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+        if (rb < 0) continue;
+#pragma unroll
+        for (int b = 0; b < CF::TN; ++b) {
+          const float v = acc[a][b][r] + bv[b];
+          if (colv[b] < ep.N) ep.C[rb + colv[b]] = fmaxf(v, slope * v);
+        }
+      }
+  }
 }
 
 // Deterministic split-K reduce: C[perm(m,n)] = act(sum_z ws[z][m][n] + bias) + beta*C.  perm: plain
@@ -520,12 +585,8 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
   size_t lds = (size_t)2 * (ASZ + BSZ) * sizeof(float);
   static const size_t lds_floor = getenv("RE2E_IGEMM_LDS_FLOOR") ? (size_t)atol(getenv("RE2E_IGEMM_LDS_FLOOR")) : 0;   // occupancy experiments
   if (lds < lds_floor) lds = lds_floor;
-  static bool attr_done = false;   // idempotent; racing writers set the same value
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<LA, LB, CF, VEC>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&igemm_kernel<LA, LB, CF, VEC>), lds);
   dim3 grid(cdiv(ep.M, CF::BM), cdiv(ep.N, CF::BN), ep.ncls ? ep.ncls : ep.nsplit);
   static const bool nomem = getenv("RE2E_IGEMM_NOMEM") != nullptr;
   ep.nomem = nomem ? 1 : 0;
@@ -549,8 +610,7 @@ using C256x64b = Cfg<4, 1, 2, 2, 32>;
 using C256x128 = Cfg<4, 2, 2, 2, 16>;
 
 inline int igemm_variant() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("RE2E_IGEMM_VARIANT"); v = e ? atoi(e) : 0; }
+  static const int v = getenv("RE2E_IGEMM_VARIANT") ? atoi(getenv("RE2E_IGEMM_VARIANT")) : 0;
   return v;
 }
 
@@ -790,9 +850,8 @@ __global__ void weight_gather_kernel(const float* W, float* dst, int Cout, int C
 
 // RE2E_NO_THIN=1 routes the Cin == 1 / Cout == 1 convolutions through the implicit GEMM (A/B measurements)
 static bool thin_enabled() {
-  static int v = -1;
-  if (v < 0) v = getenv("RE2E_NO_THIN") ? 0 : 1;
-  return v == 1;
+  static const bool v = getenv("RE2E_NO_THIN") == nullptr;
+  return v;
 }
 
 template <bool V>

@@ -614,8 +614,8 @@ template <int W>
 void launch_fwd(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, float* ybuf, float* cbuf, float* hfrag, const int* lens,
                 int T, int B, int H) {
   size_t lds = (size_t)W * 32 * 33 * sizeof(float);
-  static bool done = false;
-  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_step<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&lstm_fwd_step<W>), lds);
   dim3 grid(H / 8, cdiv(B, 32), 2);
   for (int s = 0; s < T; ++s)
     hipLaunchKernelGGL((lstm_fwd_step<W>), grid, dim3(W * 64), lds, st, xg_f, xg_r, wfrag, ybuf, cbuf, hfrag, lens, T, B, H, s);
@@ -629,8 +629,7 @@ void launch_bwd(hipStream_t st, float* g_f, float* g_r, const float* wb, const f
 }
 
 int cu_count() {
-  static int n = 0;
-  if (!n) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount; else n = 1; }
+  static const int n = [] { int dev = 0; hipDeviceProp_t p; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 1; }();
   return n;
 }
 
@@ -646,8 +645,8 @@ bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* w
   static const int hog = getenv("RE2E_LSTM_OWN_CU") ? atoi(getenv("RE2E_LSTM_OWN_CU")) : 160;
   static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 2;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
-  static size_t lds_set = 0;
-  if (lds > lds_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN>), lds);
   (void)hipMemsetAsync(hxmem, 0, hxbytes, st);                             // tags and the error word start at zero, every call
   unsigned* err = (unsigned*)hxmem;
   u64* hx = (u64*)((char*)hxmem + 16);
@@ -666,8 +665,8 @@ bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb,
   size_t lds = 0;
   static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 2;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)(hog - 16) * 1024;       // + ~13 KB static
-  static size_t lds_set = 0;
-  if (lds > lds_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_persist<TPW, UW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&lstm_bwd_persist<TPW, UW>), lds);
   hipLaunchKernelGGL((lstm_bwd_persist<TPW, UW>), grid, dim3(256), lds, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
   return true;
 }
