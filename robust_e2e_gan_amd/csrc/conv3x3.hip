@@ -38,6 +38,7 @@ struct HaloArgs {
   const float* in; const float* wg; float* out; const float* bias;
   int NI, H, W, C, Cout, act; float beta;
   int tiles_x, tiles_y, ngn, nitems;      // patches per row / column, 64-channel groups, work items = patches x groups
+  int ipw;                                // items per workgroup; 0 = persistent workgroups
   unsigned in_bytes, wg_bytes;
 #ifdef RE2E_HALO_STAMPS
   unsigned long long* stamps;     // diagnostic build only (tools/micro/conv3x3_probe.hip): 16 s_memtime stamps per workgroup
@@ -65,13 +66,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
   float* Bs = smem + ASZ;                              // [9][64][LDC]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
-  // PERSISTENT workgroups (2 per CU): work item = (patch, 64-channel group).  Workgroups are dealt round-robin over the 8
-  // XCDs, so XCD x owns the contiguous item range [x*per, (x+1)*per) and its j-th workgroup takes items j, j + nj, ... of it:
-  // at any time one XCD's L2 serves a run of neighbouring patches (shared halos; the two channel groups of a patch adjacent).
-  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, nj = (gridDim.x + 7 - xcd) >> 3;
-  const int per = (p.nitems + 7) >> 3;
-  const int item_end = min(p.nitems, (xcd + 1) * per);
-  int item = xcd * per + jx;
+  // Work item = (patch, 64-channel group).  A workgroup takes `ipw` CONSECUTIVE items (the first fetch of item k+1 flies under
+  // the last matrix block of item k).  ipw = 0: persistent workgroups, two per CU, XCD x owning the contiguous item range
+  // [x*per, (x+1)*per) -- the fastest form ALONE on the chip (no workgroup turn-over: 13 % of the slots were empty with one
+  // item per workgroup), but inside the training step its workgroups hold every CU for the whole launch and the recurrent
+  // chains on the high-priority stream cannot place theirs (enhancer forward 10.0 -> 11.2 ms, step +0.3 ms against the
+  // general engine, same GPU session).  Default ipw = 2: a workgroup lives ~140 us, as long as one of the engine's tiles, and
+  // CUs free up continuously; workgroups are ordered XCD-aware (each XCD's L2 sees a contiguous run of patches).
+  int item, item_end, nj;
+  if (p.ipw == 0) {
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int per = (p.nitems + 7) >> 3;
+    nj = (gridDim.x + 7 - xcd) >> 3;
+    item_end = min(p.nitems, (xcd + 1) * per);
+    item = xcd * per + jx;
+  } else {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    nj = 1;
+    item = pid * p.ipw;
+    item_end = min(p.nitems, item + p.ipw);
+  }
 
 #ifdef RE2E_HALO_NOLOAD        // diagnostic builds only: zero-record descriptors, every load returns 0 without memory traffic
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
@@ -253,12 +269,25 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return 2 * cus;
   }();
-  const int nwg = a.nitems < slots ? a.nitems : slots;
+  // items per workgroup: RE2E_HALO_IPW = 0 persistent, n > 0 fixed; default = the n in 1..3 that wastes the fewest slots in the
+  // last round of workgroups (conv1_2: 8000 items -> n = 2, 7.8 rounds of 512; conv2_2: 4160 items -> n = 3, 2.7 rounds; ties -> larger n)
+  static const int ipw_env = getenv("RE2E_HALO_IPW") ? atoi(getenv("RE2E_HALO_IPW")) : -1;
+  HaloArgs b = a;
+  if (ipw_env >= 0) b.ipw = ipw_env;
+  else {
+    double best = -1.0;
+    for (int n = 1; n <= 3; ++n) {
+      const long w = (a.nitems + n - 1) / n, rounds = (w + slots - 1) / slots;
+      const double eff = (double)a.nitems / ((double)rounds * slots * n);
+      if (eff >= best - 1e-9) { best = eff; b.ipw = n; }
+    }
+  }
+  const int nwg = b.ipw == 0 ? (a.nitems < slots ? a.nitems : slots) : (a.nitems + b.ipw - 1) / b.ipw;
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
   if (log_calls)
     fprintf(stderr, "[igemm] A=Halo%s B=DenseK tile=%dx%dx%d vec=1 M=%d N=%d K=%d splits=1\n", DIR > 0 ? "F" : "D", TH * TW, NT, CK,
             a.NI * a.H * a.W, a.Cout, 9 * a.C);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, DIR, RELU>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, DIR, RELU>), dim3((unsigned)nwg), dim3(256), lds, st, b);
 }
 
 }  // namespace

@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
   HaloArgs a;
   a.in = in; a.wg = wg; a.out = out; a.bias = bias; a.NI = N; a.H = H; a.W = W; a.C = C; a.Cout = K; a.act = RE2E_ACT_RELU; a.beta = 0.f;
   a.ngn = K / NT; a.in_bytes = (unsigned)(nin * 4); a.wg_bytes = (unsigned)(nw * 4); a.tiles_x = cdiv(W, 16); a.tiles_y = cdiv(H, 16);
-  a.nitems = N * a.tiles_x * a.tiles_y * a.ngn;
+  a.nitems = N * a.tiles_x * a.tiles_y * a.ngn; a.ipw = 0;
   const int slots = getenv("RE2E_HALO_SLOTS") ? atoi(getenv("RE2E_HALO_SLOTS")) : 512;
   const long nwg = a.nitems < slots ? a.nitems : slots;
   hipMalloc(&a.stamps, nwg * 18 * 8);
