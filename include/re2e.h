@@ -216,9 +216,19 @@ int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, const float* w
 /* gates [B,4H] pre-activation in -> activated out; c_prev [B,H] -> c_out, h_out */
 int re2e_lstm_cell_fwd(float* gates, const float* c_prev, float* c_out, float* h_out, int B, int H,
                        re2e_stream_t stream);
-/* gates: activated in -> dgates (pre-activation) out; dh,dc_in -> dc_prev_out */
-int re2e_lstm_cell_bwd(float* gates, const float* c_prev, const float* c_cur, const float* dh, const float* dc_in,
-                       float* dc_prev_out, int B, int H, re2e_stream_t stream);
+/* gates: activated in -> dgates (pre-activation) out; dh (+ dh2, optional: the decoder adds the direct gradient dZ[i] to
+ * the carried one), dc_in -> dc_prev_out */
+int re2e_lstm_cell_bwd(float* gates, const float* c_prev, const float* c_cur, const float* dh, const float* dh2,
+                       const float* dc_in, float* dc_prev_out, int B, int H, re2e_stream_t stream);
+/* One decoder step's LSTMCell (e2e_decoder.py:131) in one launch: gates [B,4D] (embedding half of the input projection + both
+ * biases on entry) += ctx [B,E] W_ih[:, Dd:]^T + z_prev [B,D] W_hh^T (w_ctx = &W_ih[0][Dd], row pitch ldw), then the cell:
+ * activated gates out, c_prev -> c_out, h_out.  E, D, ldw multiples of 4. */
+int re2e_dec_gates_cell_fwd(const float* cx, const float* z_prev, const float* w_ctx, long ldw, const float* w_hh, float* gates,
+                            const float* c_prev, float* c_out, float* h_out, int B, int E, int D, re2e_stream_t stream);
+/* Two skinny products that share A (M <= 32 rows) in one launch: C1 = A[M,K] B1[K,N1], C2 = A B2[K,N2] (B row-major (K,N));
+ * the decoder's backward step: d ctx = dgates W_ih[:, Dd:], d z = dgates W_hh. */
+int re2e_gemm_skinny2(int M, int K, const float* A, long lda, const float* B1, long ldb1, int N1, float* C1, long ldc1,
+                      const float* B2, long ldb2, int N2, float* C2, long ldc2, re2e_stream_t stream);
 int re2e_embedding_fwd(const float* table, const int* ids_dev, int n, int D, float* out, long ldo,
                        re2e_stream_t stream);
 /* dtable[v][:] = beta*dtable + sum_{i: ids[i]==v} dout[i][:] in index order (deterministic) */

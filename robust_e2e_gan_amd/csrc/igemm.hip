@@ -742,11 +742,78 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(const float* __restric
   }
 }
 
+// Two products that share the skinny left operand in ONE launch: C1[M,N1] = A[M,K] B1[K,N1] and C2[M,N2] = A B2[K,N2] (both B
+// row-major (K,N)).  The decoder's backward step needs d(ctx) = dgates W_ih[:, Dd:] and d(z) = dgates W_hh from the same
+// dgates (e2e_decoder.py:131 backward): two launches of 16 and 10 workgroups become one of 26.  Same in-workgroup K split and
+// fixed summation order as skinny_gemm_kernel.
+__global__ __launch_bounds__(512) void skinny_gemm2_kernel(const float* __restrict__ A, long lda, int M, int K, const float* __restrict__ B1, long ldb1,
+                                                           int N1, float* C1, long ldc1, const float* __restrict__ B2, long ldb2, int N2,
+                                                           float* C2, long ldc2) {
+  __shared__ float red[8][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int nt1 = (N1 + 31) / 32;
+  const bool second = (int)blockIdx.x >= nt1;
+  const float* B = second ? B2 : B1;
+  const long ldb = second ? ldb2 : ldb1;
+  const int N = second ? N2 : N1;
+  float* C = second ? C2 : C1;
+  const long ldc = second ? ldc2 : ldc1;
+  const int n0 = (second ? (int)blockIdx.x - nt1 : (int)blockIdx.x) * 32;
+  const int kq = (K + 7) / 8, per = (kq + 7) / 8;
+  const int q0 = wid * per, q1 = min(kq, q0 + per);
+  const int col = n0 + lr;
+  const bool rok = lr < M, cok = col < N;
+  const float* ap = A + (long)(rok ? lr : 0) * lda;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int qb = q0; qb < q1; qb += 4) {
+    float av[4][4], bv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 8 * (qb + u) + 4 * lh;
+      const bool qok = qb + u < q1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool kok = qok && k + j < K;
+        av[u][j] = (kok && rok) ? ap[k + j] : 0.f;
+        bv[u][j] = (kok && cok) ? B[(long)(k + j) * ldb + col] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], bv[u][j], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
+  __syncthreads();
+  for (int i = tid; i < 32 * 32; i += 512) {
+    const int m = i >> 5, n = n0 + (i & 31);
+    if (m < M && n < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[w][m][i & 31];
+      C[(long)m * ldc + n] = v;
+    }
+  }
+}
+
 }  // namespace
 
 // ============================================================================================
 // C ABI
 // ============================================================================================
+extern "C" int re2e_gemm_skinny2(int M, int K, const float* A, long lda, const float* B1, long ldb1, int N1, float* C1, long ldc1,
+                                 const float* B2, long ldb2, int N2, float* C2, long ldc2, hipStream_t stream) {
+  RE2E_CHECK_ARG(A && B1 && B2 && C1 && C2, "null operand");
+  RE2E_CHECK_ARG(M > 0 && M <= 32 && K > 0 && N1 > 0 && N2 > 0, "needs 1 <= M <= 32 rows");
+  hipLaunchKernelGGL(skinny_gemm2_kernel, dim3(cdiv(N1, 32) + cdiv(N2, 32)), dim3(512), 0, stream, A, lda, M, K, B1, ldb1, N1, C1, ldc1, B2, ldb2, N2,
+                     C2, ldc2);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
 extern "C" size_t re2e_gemm_workspace_bytes(int transa, int transb, int M, int N, int K) {
   if (transa && transb) return 0;
   int s = gemm_splits(transa, transb, M, N, K);

@@ -791,6 +791,84 @@ __global__ void lstm_cell_fwd_kernel(float* gates, const float* __restrict__ c_p
   c_out[i] = c;
   h_out[i] = go * tanhf_(c);
 }
+// Decoder step, fused: gates += [ctx | z_prev] [W_ih[:, Dd:] | W_hh]^T, then the LSTMCell non-linearity (e2e_decoder.py:131) in the
+// same launch -- three launches per decoder step (two skinny GEMMs + the cell kernel) become one.  A workgroup owns the four
+// gates of 8 hidden units (32 gate columns) for up to 32 utterances; its 8 wavefronts split K = E + D, the partial tiles
+// meet in LDS (fixed order: deterministic) and 256 threads apply the cell: activated gates back to `gates` (saved for the
+// backward), c and h out.  Operand fragments come straight from global memory as 16-byte loads (E, D, ldw multiples of 4).
+__global__ __launch_bounds__(512) void dec_gates_cell_kernel(const float* __restrict__ cx, const float* __restrict__ zp, const float* __restrict__ w_ctx,
+                                                             long ldw, const float* __restrict__ w_hh, float* gates,
+                                                             const float* __restrict__ c_prev, float* c_out, float* h_out, int B, int E, int D) {
+  __shared__ float red[8][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int u0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
+  const int g = lr >> 3, u = u0 + (lr & 7);                  // this lane's B-operand row: gate g of unit u
+  const bool cok = u < D, rok = b0 + lr < B;
+  const long wrow = (long)g * D + (cok ? u : 0);
+  const int brow = rok ? b0 + lr : 0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const int K = seg ? D : E;
+    const float* ap = (seg ? zp + (long)brow * D : cx + (long)brow * E);
+    const float* bp = (seg ? w_hh + wrow * D : w_ctx + wrow * ldw);
+    const int kq = (K + 7) / 8;
+    for (int qb = wid * 4; qb < kq; qb += 32) {             // wavefront w takes k-groups 4w .. 4w+3 of every 32
+      f32x4 av[4], bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = 8 * (qb + t) + 4 * lh;
+        const bool kok = qb + t < kq && k + 3 < K;
+        av[t] = (kok && rok) ? *reinterpret_cast<const f32x4*>(ap + k) : zero;
+        bv[t] = (kok && cok) ? *reinterpret_cast<const f32x4*>(bp + k) : zero;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][j], bv[t][j], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wid][(r & 3) + 8 * (r >> 2) + 4 * lh][lr] = acc[r];
+  __syncthreads();
+  if (tid < 256) {
+    const int bm = tid >> 3, jj = tid & 7, b = b0 + bm, uu = u0 + jj;
+    if (b < B && uu < D) {
+      float* gp = gates + (long)b * 4 * D + uu;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) a += red[w][bm][q * 8 + jj];
+        v[q] = a + gp[(long)q * D];
+      }
+      const float gi = sigmoidf_(v[0]), gf = sigmoidf_(v[1]), gg = tanhf_(v[2]), go = sigmoidf_(v[3]);
+      const float c = gf * c_prev[(long)b * D + uu] + gi * gg;
+      gp[0] = gi; gp[D] = gf; gp[2L * D] = gg; gp[3L * D] = go;
+      c_out[(long)b * D + uu] = c;
+      h_out[(long)b * D + uu] = go * tanhf_(c);
+    }
+  }
+}
+extern "C" int re2e_dec_gates_cell_fwd(const float* cx, const float* z_prev, const float* w_ctx, long ldw, const float* w_hh, float* gates,
+                                       const float* c_prev, float* c_out, float* h_out, int B, int E, int D, hipStream_t stream) {
+  RE2E_CHECK_ARG(cx && z_prev && w_ctx && w_hh && gates && c_prev && c_out && h_out, "null operand");
+  RE2E_CHECK_ARG(B > 0 && E > 0 && D > 0, "bad shape");
+  if (E % 4 || D % 4 || ldw % 4 || ((reinterpret_cast<uintptr_t>(cx) | reinterpret_cast<uintptr_t>(z_prev) | reinterpret_cast<uintptr_t>(w_ctx) |
+                                      reinterpret_cast<uintptr_t>(w_hh)) & 15)) {
+    re2e_set_error("re2e_dec_gates_cell_fwd: E, D, ldw must be multiples of 4 and the operands 16-byte aligned");
+    return RE2E_EUNSUPPORTED;
+  }
+  hipLaunchKernelGGL(dec_gates_cell_kernel, dim3(cdiv(D, 8), cdiv(B, 32)), dim3(512), 0, stream, cx, z_prev, w_ctx, ldw, w_hh, gates, c_prev, c_out,
+                     h_out, B, E, D);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
 extern "C" int re2e_lstm_cell_fwd(float* gates, const float* c_prev, float* c_out, float* h_out, int B, int H, hipStream_t stream) {
   RE2E_CHECK_ARG(gates && c_prev && c_out && h_out && B > 0 && H > 0, "bad args");
   hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)B * H, 256)), dim3(256), 0, stream, gates, c_prev, c_out, h_out, B, H);
@@ -798,14 +876,15 @@ extern "C" int re2e_lstm_cell_fwd(float* gates, const float* c_prev, float* c_ou
   return RE2E_OK;
 }
 __global__ void lstm_cell_bwd_kernel(float* gates, const float* __restrict__ c_prev, const float* __restrict__ c_cur,
-                                     const float* __restrict__ dh, const float* __restrict__ dc_in, float* dc_prev_out, int B, int H) {
+                                     const float* __restrict__ dh, const float* __restrict__ dh2, const float* __restrict__ dc_in,
+                                     float* dc_prev_out, int B, int H) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * H) return;
   int b = i / H, j = i % H;
   float* g = gates + (long)b * 4 * H + j;
   float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
   float tc = tanhf_(c_cur[i]);
-  float d = dh[i];
+  float d = dh[i] + (dh2 ? dh2[i] : 0.f);       // recurrent + direct gradient of h (the decoder adds dZ[i] to the carried dz)
   float dct = d * go * (1.f - tc * tc) + (dc_in ? dc_in[i] : 0.f);
   g[0] = dct * gg * gi * (1.f - gi);
   g[H] = dct * c_prev[i] * gf * (1.f - gf);
@@ -813,10 +892,10 @@ __global__ void lstm_cell_bwd_kernel(float* gates, const float* __restrict__ c_p
   g[3 * H] = d * tc * go * (1.f - go);
   dc_prev_out[i] = dct * gf;
 }
-extern "C" int re2e_lstm_cell_bwd(float* gates, const float* c_prev, const float* c_cur, const float* dh, const float* dc_in,
-                                  float* dc_prev_out, int B, int H, hipStream_t stream) {
+extern "C" int re2e_lstm_cell_bwd(float* gates, const float* c_prev, const float* c_cur, const float* dh, const float* dh2,
+                                  const float* dc_in, float* dc_prev_out, int B, int H, hipStream_t stream) {
   RE2E_CHECK_ARG(gates && c_prev && c_cur && dh && dc_prev_out && B > 0 && H > 0, "bad args");
-  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((long)B * H, 256)), dim3(256), 0, stream, gates, c_prev, c_cur, dh, dc_in,
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((long)B * H, 256)), dim3(256), 0, stream, gates, c_prev, c_cur, dh, dh2, dc_in,
                      dc_prev_out, B, H);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;

@@ -69,7 +69,9 @@ SIGNATURES = {
     're2e_lstm_seq_fwd': (I, [P, P, P, P, P, P, P, I, I, I, P, Z, P]),
     're2e_lstm_seq_bwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P]),
     're2e_lstm_cell_fwd': (I, [P, P, P, P, I, I, P]),
-    're2e_lstm_cell_bwd': (I, [P, P, P, P, P, P, I, I, P]),
+    're2e_lstm_cell_bwd': (I, [P, P, P, P, P, P, P, I, I, P]),
+    're2e_dec_gates_cell_fwd': (I, [P, P, P, L, P, P, P, P, P, I, I, I, P]),
+    're2e_gemm_skinny2': (I, [I, I, P, L, P, L, I, P, L, P, L, I, P, L, P]),
     're2e_embedding_fwd': (I, [P, P, I, I, P, L, P]),
     're2e_embedding_bwd': (I, [P, L, P, I, I, I, P, F, P]),
     're2e_lsm_fwd': (I, [P, P, I, I, I, P, P, Z, P]),

@@ -1093,6 +1093,9 @@ def dropout(x, p):
     return DropoutFn.apply(x, p, seed, idx)
 
 
+DECODER_FUSED = os.environ.get('RE2E_NO_DECODER_FUSION', '0') != '1'     # fused LSTMCell step kernels (A/B switch)
+
+
 class DecoderLoopFn(torch.autograd.Function):
     """hmask (B,T,E) masked encoder states, pre (B,T,A) = mlp_enc(hmask) -> decoder states (L1,B,D) step-major.
 
@@ -1135,6 +1138,7 @@ class DecoderLoopFn(torch.autograd.Function):
         conv = empty((L1, B, T, C), hmask)          # saved for the backward (no recomputation of the location conv)
         dpj = empty((L1, B, A), hmask)
         e_scr = empty((B, T), hmask)
+        fused = DECODER_FUSED and E % 4 == 0 and D % 4 == 0 and ldw % 4 == 0
         sampled = sample_steps is not None and any(sample_steps[1:])
         if sampled:
             ids_tm = ids_tm.clone()                 # becomes the list of tokens actually fed
@@ -1151,9 +1155,14 @@ class DecoderLoopFn(torch.autograd.Function):
                  hlens_dev.data_ptr(), w_decT.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(),
                  Pm['gvec_w'].data_ptr(), Pm['gvec_b'].data_ptr(), B, T, E, D, A, C, Fh, w[i].data_ptr(), cx[i].data_ptr(), E,
                  conv[i].data_ptr(), dpj[i].data_ptr(), e_scr.data_ptr())
-            gemm(cx[i], w_ctx, gates[i], B, 4 * D, E, transb=True, ldb=ldw, beta=1.0, dev=dev)
-            gemm(z[i], Pm['w_hh'], gates[i], B, 4 * D, D, transb=True, beta=1.0)
-            call('re2e_lstm_cell_fwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), z[i + 1].data_ptr(), B, D)
+            if fused:
+                # gates += [ctx | z] [W_ih[:, Dd:] | W_hh]^T and the cell in ONE launch (two skinny GEMMs + the cell kernel before)
+                call('re2e_dec_gates_cell_fwd', cx[i].data_ptr(), z[i].data_ptr(), w_ctx, ldw, Pm['w_hh'].data_ptr(), gates[i].data_ptr(),
+                     c[i].data_ptr(), c[i + 1].data_ptr(), z[i + 1].data_ptr(), B, E, D)
+            else:
+                gemm(cx[i], w_ctx, gates[i], B, 4 * D, E, transb=True, ldb=ldw, beta=1.0, dev=dev)
+                gemm(z[i], Pm['w_hh'], gates[i], B, 4 * D, D, transb=True, beta=1.0)
+                call('re2e_lstm_cell_fwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), z[i + 1].data_ptr(), B, D)
         ctx.Pm, ctx.ids, ctx.hlens = Pm, ids_tm, hlens_dev
         ctx.dims = (B, T, E, A, Dd, D, C, Fh, L1)
         ctx.save_for_backward(hmask, pre, emb, cx, z, c, w, gates, conv, dpj)
@@ -1183,14 +1192,23 @@ class DecoderLoopFn(torch.autograd.Function):
         dc_a, dc_b = zeros((B, D), hmask), empty((B, D), hmask)
         dw_a, dw_b = empty((B, T), hmask), empty((B, T), hmask)
         have_dw = False
+        fused = DECODER_FUSED and B <= 32
         for i in range(L1 - 1, -1, -1):
-            call('re2e_axpby', 1.0, dZ[i].data_ptr(), 1.0, dz_carry.data_ptr(), B * D)
-            call('re2e_lstm_cell_bwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), dz_carry.data_ptr(), dc_a.data_ptr(),
-                 dc_b.data_ptr(), B, D)
-            dc_a, dc_b = dc_b, dc_a
             d_cx = d_cx_all[i]
-            gemm(gates[i], w_ctx, d_cx, B, E, 4 * D, ldb=ldw, dev=dev)                     # d ctx = dgates W_ih[:, Dd:]
-            gemm(gates[i], Pm['w_hh'], dz_carry, B, D, 4 * D)                                # d z_{i-1} (recurrent path)
+            if fused:
+                # dh = carried dz + dZ[i] inside the cell kernel; d ctx and d z_{i-1} from the same dgates in one launch
+                call('re2e_lstm_cell_bwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), dz_carry.data_ptr(), dZ[i].data_ptr(),
+                     dc_a.data_ptr(), dc_b.data_ptr(), B, D)
+                dc_a, dc_b = dc_b, dc_a
+                call('re2e_gemm_skinny2', B, 4 * D, gates[i].data_ptr(), 4 * D, w_ctx, ldw, E, d_cx.data_ptr(), E, Pm['w_hh'].data_ptr(), D, D,
+                     dz_carry.data_ptr(), D)
+            else:
+                call('re2e_axpby', 1.0, dZ[i].data_ptr(), 1.0, dz_carry.data_ptr(), B * D)
+                call('re2e_lstm_cell_bwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), dz_carry.data_ptr(), None, dc_a.data_ptr(),
+                     dc_b.data_ptr(), B, D)
+                dc_a, dc_b = dc_b, dc_a
+                gemm(gates[i], w_ctx, d_cx, B, E, 4 * D, ldb=ldw, dev=dev)                     # d ctx = dgates W_ih[:, Dd:]
+                gemm(gates[i], Pm['w_hh'], dz_carry, B, D, 4 * D)                                # d z_{i-1} (recurrent path)
             call('re2e_attloc_bwd', pre.data_ptr(), hmask.data_ptr(), w[i - 1].data_ptr() if i > 0 else None, w[i].data_ptr(),
                  ctx.hlens.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['loc_conv'].data_ptr(), Pm['gvec_w'].data_ptr(), conv[i].data_ptr(),
                  dpj[i].data_ptr(), cx[i].data_ptr(), d_cx.data_ptr(), E, dw_a.data_ptr() if have_dw else None, B, T, E, A, C, Fh,

@@ -559,3 +559,50 @@ def test_ctc_prefix_score_device_vs_numpy():
     with pytest.raises(lib.Re2eError):
         lib.call('re2e_ctc_prefix_score', lpz_d.data_ptr(), T, V, lpz_d.data_ptr(), 1, lpz_d.data_ptr(), last.data_ptr(), olen.data_ptr(),
                  prev.data_ptr(), 65, 0.7, 0.3, 0, eos, cand.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), r_new.data_ptr())
+
+
+@pytest.mark.parametrize('B,E,D', [(32, 512, 300), (5, 20, 12), (32, 64, 8), (40, 128, 36)])
+def test_dec_gates_cell_fused_vs_unfused(B, E, D):
+    """re2e_dec_gates_cell_fwd (one launch) against the three launches it replaces (two skinny GEMMs with beta = 1 + the cell
+    kernel) and against torch: ragged last unit group (D = 300: 4 units in workgroup 37), K tails (D = 300 is 37.5 k-groups),
+    fewer than 32 and more than 32 utterances."""
+    ops, lib = _ops()
+    Dd = 16
+    ldw = Dd + E
+    cx, zp, cp = rnd(B, E, seed=1), rnd(B, D, seed=2), rnd(B, D, seed=3)
+    w_ih, w_hh = rnd(4 * D, ldw, seed=4, scale=0.2), rnd(4 * D, D, seed=5, scale=0.2)
+    g0 = rnd(B, 4 * D, seed=6)
+    pre = g0 + cx @ w_ih[:, Dd:].t() + zp @ w_hh.t()
+    gi, gf, gg, go = pre[:, :D].sigmoid(), pre[:, D:2 * D].sigmoid(), pre[:, 2 * D:3 * D].tanh(), pre[:, 3 * D:].sigmoid()
+    c_ref = gf * cp + gi * gg
+    h_ref = go * c_ref.tanh()
+    d = lambda t: t.to(DEV).contiguous()
+    cxd, zpd, cpd, wid, whd = d(cx), d(zp), d(cp), d(w_ih), d(w_hh)
+    gates, c_out, h_out = d(g0), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+    lib.call('re2e_dec_gates_cell_fwd', cxd.data_ptr(), zpd.data_ptr(), wid.data_ptr() + 4 * Dd, ldw, whd.data_ptr(), gates.data_ptr(), cpd.data_ptr(),
+             c_out.data_ptr(), h_out.data_ptr(), B, E, D)
+    close('c', c_out, c_ref, tol=2e-5)
+    close('h', h_out, h_ref, tol=2e-5)
+    close('gates', gates, torch.cat([gi, gf, gg, go], 1), tol=2e-5)
+    if B <= 32:                                           # the unfused path (skinny GEMMs need M <= 32 to take the same kernels)
+        g2, c2, h2 = d(g0), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+        ops.gemm(cxd, wid.data_ptr() + 4 * Dd, g2, B, 4 * D, E, transb=True, ldb=ldw, beta=1.0, dev=torch.device(DEV))
+        ops.gemm(zpd, whd, g2, B, 4 * D, D, transb=True, beta=1.0)
+        lib.call('re2e_lstm_cell_fwd', g2.data_ptr(), cpd.data_ptr(), c2.data_ptr(), h2.data_ptr(), B, D)
+        close('h vs unfused', h_out, h2.cpu(), tol=2e-5)
+
+
+@pytest.mark.parametrize('M,K,N1,N2', [(32, 1200, 512, 300), (3, 56, 20, 14), (17, 40, 33, 1)])
+def test_gemm_skinny2(M, K, N1, N2):
+    """re2e_gemm_skinny2: two products sharing the skinny left operand in one launch (decoder backward: d ctx and d z from
+    the same dgates), with leading dimensions larger than the widths."""
+    ops, lib = _ops()
+    A, B1, B2 = rnd(M, K, seed=1), rnd(K, N1 + 5, seed=2, scale=0.3), rnd(K, N2, seed=3, scale=0.3)
+    Ad, B1d, B2d = A.to(DEV), B1.to(DEV), B2.to(DEV)
+    C1, C2 = torch.full((M, N1), 7.0, device=DEV), torch.full((M, N2 + 2), 7.0, device=DEV)
+    lib.call('re2e_gemm_skinny2', M, K, Ad.data_ptr(), K, B1d.data_ptr(), N1 + 5, N1, C1.data_ptr(), N1, B2d.data_ptr(), N2, N2, C2.data_ptr(), N2 + 2)
+    close('C1', C1, A @ B1[:, :N1], tol=2e-5)
+    close('C2', C2[:, :N2], A @ B2, tol=2e-5)
+    assert (C2[:, N2:] == 7.0).all()                      # nothing written beyond the N2 columns
+    with pytest.raises(lib.Re2eError):
+        lib.call('re2e_gemm_skinny2', 33, K, Ad.data_ptr(), K, B1d.data_ptr(), N1 + 5, N1, C1.data_ptr(), N1, B2d.data_ptr(), N2, N2, C2.data_ptr(), N2 + 2)
