@@ -638,16 +638,37 @@ void launch_n64(const LA& la, const LB& lb, Epi& ep, int K, hipStream_t st) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Workgroups of one tile shape that are resident at once: (workgroups per CU the register file admits -- 146 VGPRs => 3 waves per
+// SIMD for the 8-wave 256x128 tile, i.e. ONE workgroup; 2 x 4 waves for 128x128 and 256x64; 3 x 4 for the 112-register
+// 192x64 and the 256x32 tiles: csrc/build/igemm.resources) x CUs.  A device query would be exact, but the split count must be
+// the same in re2e_*_workspace_bytes and in the launch, so it is this table.
+inline long tile_slots(int bm, int bn) {
+  static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int per_cu = (bm == 256 && bn == 128) ? 1 : ((bm == 192 && bn == 64) || (bm == 256 && bn == 32)) ? 3 : 2;
+  return (long)per_cu * cus;
+}
+
+// Split-K count of a product with few output tiles: the SMALLEST number of K slices (each >= 16 k-tiles) that fills the
+// resident slots to >= 92 % in its last round of workgroups -- not "about 768 workgroups": 9 tiles x 86 slices = 774
+// workgroups on 512 slots ran two rounds with the second 51 % empty (conv2_2 weight gradient), 160 x 5 = 800 on 256 slots
+// 3.1 rounds (BLSTMP layer-0 weight gradient).
 int pick_splits(int M, int N, int K, int bm, int bn) {
-  long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
-  int nkt = cdiv(K, BKD);
-  if (tiles >= 384 || nkt < 32) return 1;
-  long want = (768 + tiles - 1) / tiles;
+  const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
+  const int nkt = cdiv(K, BKD);
+  const long slots = tile_slots(bm, bn);
+  if (tiles >= slots * 3 / 4 || nkt < 32) return 1;
   long maxs = nkt / 16;          // >= 16 k-tiles (256 k) per split
-  long s = want < maxs ? want : maxs;
-  if (s < 1) s = 1;
-  if (s > 512) s = 512;
-  return (int)s;
+  if (maxs > 512) maxs = 512;
+  if (maxs < 1) maxs = 1;
+  long best_s = 1;
+  double best = 0.0;
+  for (long sp = 1; sp <= maxs; ++sp) {
+    const long w = tiles * sp, rounds = (w + slots - 1) / slots;
+    const double eff = (double)w / (double)(rounds * slots);
+    if (eff > best + 1e-9) { best = eff; best_s = sp; }
+    if (eff >= 0.92) { best_s = sp; break; }
+  }
+  return (int)best_s;
 }
 
 // skinny path (M <= 32): latency-bound, so spread K over many workgroups (>= 2 k-tiles of 32 each)
