@@ -648,10 +648,10 @@ inline long tile_slots(int bm, int bn) {
   return (long)per_cu * cus;
 }
 
-// Split-K count of a product with few output tiles: the SMALLEST number of K slices (each >= 16 k-tiles) that fills the
-// resident slots to >= 92 % in its last round of workgroups -- not "about 768 workgroups": 9 tiles x 86 slices = 774
-// workgroups on 512 slots ran two rounds with the second 51 % empty (conv2_2 weight gradient), 160 x 5 = 800 on 256 slots
-// 3.1 rounds (BLSTMP layer-0 weight gradient).
+// Split-K count of a product with few output tiles: the number of K slices (each >= 16 k-tiles) that minimises
+//   compute time / (fill of the resident slots over the rounds of workgroups)  +  slab traffic (one write + one read per slice)
+// -- not "about 768 workgroups": 9 tiles x 86 slices = 774 workgroups on 512 slots ran two rounds with the second 51 % empty
+// (conv2_2 weight gradient 3.0 -> 2.5 ms), 160 x 5 = 800 on 256 slots 3.1 rounds (BLSTMP layer-0 weight gradient 1.36 -> 1.14 ms).
 int pick_splits(int M, int N, int K, int bm, int bn) {
   const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
   const int nkt = cdiv(K, BKD);
@@ -660,13 +660,14 @@ int pick_splits(int M, int N, int K, int bm, int bn) {
   long maxs = nkt / 16;          // >= 16 k-tiles (256 k) per split
   if (maxs > 512) maxs = 512;
   if (maxs < 1) maxs = 1;
+  const double compute = 2.0 * M * N * (double)K / 110e12;            // seconds at the engine's typical rate
   long best_s = 1;
-  double best = 0.0;
+  double best = 1e30;
   for (long sp = 1; sp <= maxs; ++sp) {
     const long w = tiles * sp, rounds = (w + slots - 1) / slots;
     const double eff = (double)w / (double)(rounds * slots);
-    if (eff > best + 1e-9) { best = eff; best_s = sp; }
-    if (eff >= 0.92) { best_s = sp; break; }
+    const double t = compute / eff + (sp > 1 ? (double)sp * M * N * 8.0 / 3e12 : 0.0);
+    if (t < best - 1e-12) { best = t; best_s = sp; }
   }
   return (int)best_s;
 }
