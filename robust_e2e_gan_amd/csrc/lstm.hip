@@ -162,37 +162,44 @@ typedef __attribute__((address_space(1))) u64 gu64;
 __device__ unsigned g_persist_aborts = 0;      // sequences given up because a peer workgroup never published (re2e_lstm_abort_count)
 constexpr unsigned kSpinLimit = 1u << 18;      // polls (~1-2 us each, i.e. ~0.3-0.5 s) before a workgroup gives up on a peer
 
-template <int WAVES, int QN>
+// UW = 2: a workgroup owns 16 hidden units (two 32-column gate tiles): it sweeps the recurrent state ONCE for both, runs two MFMA
+// chains on it, and 512 of its threads apply the cell.  Half as many workgroups sweep (the swept traffic through the fabric
+// halves) and the 512-wide layers' grid fits half of the chip, so it can reserve its CUs like the narrower layers do (the
+// launcher's 160 KB LDS request): what slows a chain beside the filler streams is sharing SIMDs with their MFMA streams.
+template <int WAVES, int QN, int UW>
 __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, float* xg_r, const float* __restrict__ wfrag, float* ybuf,
                                                                float* cbuf, u64* hx_, unsigned* err, const int* __restrict__ lens,
                                                                int T, int B, int H) {
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [WAVES][32][33] | abort flag
-  static_assert(WAVES >= 4, "256 threads own the 32 x 8 cell updates");
-  const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y, NX = gridDim.x;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [UW][WAVES][32][33] | abort flag
+  static_assert(WAVES >= 4 * UW, "256 threads per 8 units own the 32 x 8 cell updates");
+  const int dir = blockIdx.z, mt = blockIdx.y, MT = gridDim.y, NX = gridDim.x * UW;     // NX = logical producers (8 units each)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int usub = (tid >> 8) < UW ? (tid >> 8) : 0;                 // which of the workgroup's 8-unit groups this thread's cell belongs to
+  const int x = blockIdx.x * UW + usub;
   float* xg = dir ? xg_r : xg_f;
   const int j0 = x * 8, b0 = mt * 32;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
-  constexpr int kAbort = WAVES * 32 * 33;            // red[kAbort] != 0: a sweep timed out
+  constexpr int kAbort = UW * WAVES * 32 * 33;            // red[kAbort] != 0: a sweep timed out
   if (tid == 0) red[kAbort] = 0.f;
   const long H2 = 2L * H;
   // recurrent weights of this wave's K range: registers for the whole sequence
-  f32x4 w[QN];
-  {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wfrag) + ((long)(dir * NX + x) * NX + wid * QN) * 64 + lane;
+  f32x4 w[UW][QN];
 #pragma unroll
-    for (int q = 0; q < QN; ++q) w[q] = wp[q * 64];
+  for (int u = 0; u < UW; ++u) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wfrag) + ((long)(dir * NX + blockIdx.x * UW + u) * NX + wid * QN) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < QN; ++q) w[u][q] = wp[q * 64];
   }
   // exchange buffer: [parity][dir][mt][producer x'][lh][b][i] granules; producer x' == k-group Q of the consumers
   gu64* hx = (gu64*)hx_;
-  const long par_sz = (long)2 * MT * NX * 256;
+  const int par_sz = 2 * MT * NX * 256;                 // granules per parity buffer (< 2^31: checked by the launcher's workspace size)
   const __amdgpu_buffer_rsrc_t hx_rs = __builtin_amdgcn_make_buffer_rsrc(hx_, 0, (int)(2 * par_sz * 8), 0x00020000);
-  const long grp = (long)(dir * MT + mt) * NX * 256;
-  const long rd_off = grp + (long)(wid * QN) * 256 + (lh * 32 + lr) * 4;
-  const bool pw = tid < 256;
+  const int grp = (dir * MT + mt) * NX * 256;
+  const int rd_off = grp + (wid * QN) * 256 + (lh * 32 + lr) * 4;
+  const bool pw = tid < 256 * UW;
   const int bm = (tid >> 3) & 31, jj = tid & 7, b = b0 + bm, j = j0 + jj;
   const bool ok = pw && b < B;
   const int ln = ok ? lens[b] : 0;
-  const long wr_off = grp + (long)x * 256 + ((jj >> 2) * 32 + bm) * 4 + (jj & 3);
+  const int wr_off = grp + x * 256 + ((jj >> 2) * 32 + bm) * 4 + (jj & 3);
   float c = 0.f, pre[4] = {0.f, 0.f, 0.f, 0.f};
   if (ok) {
     const float* gp = xg + ((long)(dir ? T - 1 : 0) * B + b) * 4 * H + j;
@@ -202,9 +209,11 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
   __syncthreads();
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
-    f32x16 acc;
+    f32x16 acc[UW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int u = 0; u < UW; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
     if (s > 0) {
       const gu64* src = hx + ((s & 1) ^ 1) * par_sz + rd_off;
       float hv[QN][4];
@@ -232,7 +241,9 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
 #pragma unroll
       for (int q = 0; q < QN; ++q)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[q][i], w[q][i], acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[q][i], w[u][q][i], acc[u], 0, 0, 0);
     }
     float nxt[4] = {0.f, 0.f, 0.f, 0.f};
     if (ok && s + 1 < T) {                       // next step's pre-activations: HBM latency hidden behind this step
@@ -240,7 +251,8 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
 #pragma unroll
       for (int g = 0; g < 4; ++g) nxt[g] = gp[g * H];
     }
-    store_acc(red + wid * (32 * 33), acc, lane);
+#pragma unroll
+    for (int u = 0; u < UW; ++u) store_acc(red + (u * WAVES + wid) * (32 * 33), acc[u], lane);
     __syncthreads();
     if (red[kAbort] != 0.f) break;
     if (pw) {
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
       for (int g = 0; g < 4; ++g) {
         float a = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < WAVES; ++wv) a += red[wv * (32 * 33) + bm * 33 + g * 8 + jj];
+        for (int wv = 0; wv < WAVES; ++wv) a += red[(usub * WAVES + wv) * (32 * 33) + bm * 33 + g * 8 + jj];
         v[g] = a + pre[g];
       }
       float gi = sigmoidf_(v[0]), gf = sigmoidf_(v[1]), gg = tanhf_(v[2]), go = sigmoidf_(v[3]);
@@ -633,11 +645,11 @@ int cu_count() {
   return n;
 }
 
-template <int W, int QN>
+template <int W, int QN, int UW = 1>
 bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, float* ybuf, float* cbuf, void* hxmem, size_t hxbytes,
                         const int* lens, int T, int B, int H) {
-  size_t lds = (size_t)W * 32 * 33 * sizeof(float) + 16;
-  dim3 grid(H / 8, cdiv(B, 32), 2);
+  size_t lds = (size_t)UW * W * 32 * 33 * sizeof(float) + 16;
+  dim3 grid(H / (8 * UW), cdiv(B, 32), 2);
   if ((long)grid.x * grid.y * grid.z > cu_count()) return false;          // every workgroup must be resident
   // A chain that fits half of the chip (RE2E_LSTM_OWN_CU_FRAC, quarter: 75.5, half: 75.1 ms) asks for (almost) a whole CU's LDS per workgroup: nothing else can then be
   // co-resident on its CUs, so its MFMA pipe and memory queue are its own while the filler streams keep the other CUs.
@@ -646,11 +658,11 @@ bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* w
   static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 2;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN>), lds);
+  lim.ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN, UW>), lds);
   (void)hipMemsetAsync(hxmem, 0, hxbytes, st);                             // tags and the error word start at zero, every call
   unsigned* err = (unsigned*)hxmem;
   u64* hx = (u64*)((char*)hxmem + 16);
-  hipLaunchKernelGGL((lstm_fwd_persist<W, QN>), grid, dim3(W * 64), lds, st, xg_f, xg_r, wfrag, ybuf, cbuf, hx, err, lens, T, B, H);
+  hipLaunchKernelGGL((lstm_fwd_persist<W, QN, UW>), grid, dim3(W * 64), lds, st, xg_f, xg_r, wfrag, ybuf, cbuf, hx, err, lens, T, B, H);
   return true;
 }
 
@@ -703,6 +715,10 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
   const char* v = getenv("RE2E_LSTM_PERSIST");
   if ((v && atoi(v) == 0) || T < 2) return false;
   const int NX = H / 8;
+  // 512-wide layers: RE2E_LSTM_FWD_UW=2 selects 16 units per workgroup (8 wavefronts x 8 k-groups: the 16-wavefront form of it
+  // needs 130 registers per lane, 2 more than 1024 threads leave)
+  static const int uw = getenv("RE2E_LSTM_FWD_UW") ? atoi(getenv("RE2E_LSTM_FWD_UW")) : 1;
+  if (NX == 64 && uw == 2) return launch_fwd_persist<8, 8, 2>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
 #define RE2E_TRY(W, Q) if (NX == (W) * (Q)) return launch_fwd_persist<W, Q>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H)
   RE2E_TRY(16, 4); RE2E_TRY(8, 5); RE2E_TRY(8, 4); RE2E_TRY(8, 3); RE2E_TRY(4, 4); RE2E_TRY(4, 2); RE2E_TRY(4, 1);
 #undef RE2E_TRY

@@ -19,7 +19,7 @@ def main(filler='conv', which='fwd'):
     wg = torch.randn(K, 3, 3, C, device=DEV) * 0.04
     y = torch.empty(N, H, W, K, device=DEV)
     conv_args = (x.data_ptr(), N, H, W, C, wg.data_ptr(), K, 3, 3, H, W, 1, 1, 1, 1, -1, -1, y.data_ptr(), H, W, 1, 1, 0, 0, None, lib.ACT_RELU, 0.0)
-    T, B, Hh = 800, 32, 256
+    T, B, Hh = int(os.environ.get('CHAIN_T', '800')), int(os.environ.get('CHAIN_B', '32')), int(os.environ.get('CHAIN_H', '256'))     # enhancer layer by default; 200 / 64 / 512 = BLSTMP
     xg = [torch.randn(T * B, 4 * Hh, device=DEV) * 0.1 for _ in range(2)]
     whh = [torch.randn(4 * Hh, Hh, device=DEV) * 0.05 for _ in range(2)]
     ybuf, cbuf = torch.zeros(T + 2, B, 2 * Hh, device=DEV), torch.zeros(T + 2, B, 2 * Hh, device=DEV)
