@@ -259,3 +259,66 @@ def test_config2_asr_full_size():
     _check_runs(runs)
     first = runs[0][0][0]
     assert 150.0 < first['train/loss_att'] < 260.0             # ~ L * ln(V) = 25 * 8.35 for a random-initialised model
+
+
+def test_recognize_full_width_device_ctc_vs_host_ctc():
+    """Joint CTC/attention beam search at the config-4 width (V = 4233, T' = 200, beam 10 -> 15 CTC candidates per hypothesis):
+    the device prefix scorer (re2e_ctc_prefix_score, states resident on the GPU) and the host scorer (upstream's numpy
+    algorithm, selected by an impossible device limit) must return the same n-best list."""
+    import argparse
+    from robust_e2e_gan_amd.joint_train import config4_opt
+    from robust_e2e_gan_amd.model import beam_search
+    from robust_e2e_gan_amd.model.e2e_model import E2E
+    opt = config4_opt()
+    torch.manual_seed(21)
+    asr = E2E(opt).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(1, 800, 80, generator=g)
+    args = argparse.Namespace(beam_size=10, penalty=0.0, ctc_weight=0.3, maxlenratio=0.08, minlenratio=0.0, nbest=5, lm_weight=0.0)
+    dev_nbest = asr.recognize(feats, args, opt.char_list)
+    saved = beam_search.DEVICE_CTC_MAX_BEAM
+    beam_search.DEVICE_CTC_MAX_BEAM = 0
+    try:
+        host_nbest = asr.recognize(feats, args, opt.char_list)
+    finally:
+        beam_search.DEVICE_CTC_MAX_BEAM = saved
+    assert len(dev_nbest) == len(host_nbest) == 5
+    for a, b in zip(dev_nbest, host_nbest):
+        assert a['yseq'] == b['yseq'], (a['yseq'], b['yseq'])
+        assert abs(a['score'] - b['score']) <= 2e-3 * max(1.0, abs(b['score']))
+
+
+def test_unet_enhancer_full_width_properties():
+    """unet_256 (8 stages, ngf 64, dropout 0.5 in the three middle blocks) on a (B=4, 1, 512, 256) log-spectrogram batch: finite
+    outputs and gradients, zero rows beyond each length, masks in [0, mix] (sigmoid of a sigmoid: 0.5 .. 0.73 of mix), bitwise
+    reproducible from the dropout seed, and a different mask with another seed."""
+    import argparse
+    from robust_e2e_gan_amd import ops
+    from robust_e2e_gan_amd.joint_train import config4_opt
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    opt = config4_opt(enhance_type='unet_256', idim=256, enhance_input_nc=1, enhance_output_nc=1, enhance_ngf=64, enhance_norm='batch',
+                      dropout_rate=0.5)
+    torch.manual_seed(5)
+    enh = EnhanceModel(opt).to(DEV).train()
+    with torch.no_grad():                               # lecun_normal_init zeroes the BatchNorm gains upstream: give them life
+        for k, v in enh.named_parameters():
+            if v.dim() == 1:
+                v.fill_(1.0 if k.endswith('weight') else 0.0)
+    g = torch.Generator().manual_seed(6)
+    lens = torch.IntTensor([512, 512, 384, 300])
+    mix = torch.rand(4, 512, 256, generator=g) * 100
+    mix_log = torch.randn(4, 1, 512, 256, generator=g)
+    outs = []
+    for seed in (11, 11, 12):
+        ops.dropout_seed(seed)
+        enh.zero_grad()
+        out = enh(mix, mix_log, lens)
+        out.mean().backward()
+        gsum = sum(float(p.grad.abs().sum()) for p in enh.parameters() if p.grad is not None)
+        assert torch.isfinite(out).all() and math.isfinite(gsum) and gsum > 0
+        outs.append(out.detach().clone())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    out = outs[0].cpu()
+    assert (out[2, 384:] == 0).all() and (out[3, 300:] == 0).all()
+    ratio = out[0] / mix[0].clamp_min(1e-3)
+    assert float(ratio.min()) >= 0.49 and float(ratio.max()) <= 0.74
