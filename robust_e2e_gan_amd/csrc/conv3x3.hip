@@ -29,6 +29,7 @@
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CK = 16;        // input channels per chunk (one 64-byte segment per pixel)
 constexpr int LDC = CK + 4;   // padded LDS row (floats)
 constexpr int NT = 64;        // output channels per workgroup
@@ -39,7 +40,7 @@ struct HaloArgs {
   int NI, H, W, C, Cout, act; float beta;
   int tiles_x, tiles_y, ngn, nitems;      // patches per row / column, 64-channel groups, work items = patches x groups
   int ipw;                                // items per workgroup; 0 = persistent workgroups
-  unsigned in_bytes, wg_bytes;
+  unsigned in_bytes, wg_bytes, out_bytes;
 #ifdef RE2E_HALO_STAMPS
   unsigned long long* stamps;     // diagnostic build only (tools/micro/conv3x3_probe.hip): 16 s_memtime stamps per workgroup
 #endif
@@ -95,27 +96,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
 #endif
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wg), 0, p.wg_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
   // ---- staging: a wave-instruction moves 16 rows (pixels / output channels) x 64 bytes, 4 lanes per row.  (Measured and
   // rejected, same GPU session: a lane order that makes the ds_write_b128 of the 20-float rows bank-conflict-free -- 8
   // contiguous lanes = the same 16-byte piece of 8 rows -- shortens the staging by 0.5k cycles per item but its global
   // loads touch 4 lines per lane quad instead of 1 and the matrix block they fly under grows by 4k cycles.)
   const int srow = tid >> 2, skq = tid & 3;
-  // addresses of the item being FETCHED (one item ahead of the one being computed during its last chunk)
-  unsigned a_off[AIT], b_off;
-  auto set_item = [&](int it) {
-    const int nblk = it % p.ngn, tile = it / p.ngn;
-    const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
+  // Addresses.  Everything that depends on the LANE is computed once per kernel; everything that depends on the ITEM is
+  // wave-uniform and goes through the buffer instructions' scalar offset, so an interior patch costs no vector instruction
+  // per load or store.  (A wavefront outside its matrix block shares its SIMD with the other workgroup's MFMA stream and
+  // gets about one VALU issue per MFMA: the kernel's matrix-pipe utilisation is set by how FEW vector instructions the
+  // prologue / epilogue need, not by their latency.)
+  //   a_rel[i]   byte offset of this lane's 16-byte piece of halo pixel hp = i*64 + srow relative to the halo's corner
+  //              pixel (y0-1, x0-1); OOB for the surplus rows of the last pass
+  //   a_off[i]   what the loads of the item being FETCHED use: a_rel (interior patch, scalar offset a_s = corner pixel) or
+  //              absolute offsets with OOB for out-of-image pixels (border patch, a_s = 0)
+  unsigned a_rel[AIT], a_off[AIT], a_s = 0, b_s = 0;
 #pragma unroll
-    for (int i = 0; i < AIT; ++i) {
-      const int hp = i * 64 + srow, kq = skq;
-      const int hy = hp / HPW, hx = hp - hy * HPW;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      const bool ok = (hp < HP) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-      a_off[i] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.C + kq * 4) * 4) : OOB;     // < 2^31: checked by the launcher
+  for (int i = 0; i < AIT; ++i) {
+    const int hp = i * 64 + srow, hy = hp / HPW, hx = hp - hy * HPW;
+    a_rel[i] = hp < HP ? (unsigned)(((hy * p.W + hx) * p.C + skq * 4) * 4) : OOB;
+  }
+  const unsigned b_rel = (unsigned)(((srow * 9) * p.C + skq * 4) * 4);      // + scalar (group*64*9*C + tap*C + c0)*4
+  // the item being fetched, decomposed; consecutive items advance it without divisions
+  struct Item { int nblk, tx, ty, n; };
+  auto decompose = [&](int it) {
+    Item r;
+    r.nblk = it % p.ngn;
+    const int tile = it / p.ngn, t2 = tile / p.tiles_x;
+    r.tx = tile - t2 * p.tiles_x;
+    r.n = t2 / p.tiles_y;
+    r.ty = t2 - r.n * p.tiles_y;
+    return r;
+  };
+  auto advance = [&](Item& r, int it) {
+    if (nj != 1) { r = decompose(it); return; }
+    if (++r.nblk < p.ngn) return;
+    r.nblk = 0;
+    if (++r.tx < p.tiles_x) return;
+    r.tx = 0;
+    if (++r.ty < p.tiles_y) return;
+    r.ty = 0; ++r.n;
+  };
+  auto set_item = [&](const Item& r) {
+    const int y0 = r.ty * TH, x0 = r.tx * TW;
+    b_s = (unsigned)(r.nblk * NT * 9 * p.C * 4);
+    if (y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= p.H && x0 + TW + 1 <= p.W) {
+      a_s = (unsigned)((((r.n * p.H + y0 - 1) * p.W + x0 - 1) * p.C) * 4);
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) a_off[i] = a_rel[i];
+    } else {
+      a_s = 0;
+#pragma unroll
+      for (int i = 0; i < AIT; ++i) {
+        const int hp = i * 64 + srow;
+        const int hy = hp / HPW, hx = hp - hy * HPW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = (hp < HP) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+        a_off[i] = ok ? (unsigned)((((r.n * p.H + iy) * p.W + ix) * p.C + skq * 4) * 4) : OOB;   // < 2^31: checked by the launcher
+      }
     }
-    b_off = (unsigned)((((nblk * NT + srow) * 9) * p.C + skq * 4) * 4);   // + tap*C*4 + c0*4
   };
   const int a_dst = srow * LDC + skq * 4;                                   // + i*64*LDC
   const int b_dst = srow * LDC + skq * 4;                                   // + tap*64*LDC
@@ -134,10 +175,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
   auto fetch = [&](int c0) {
     const unsigned cb = (unsigned)c0 * 4u;
 #pragma unroll
-    for (int i = 0; i < AIT; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i] + cb, 0, 0));
+    for (int i = 0; i < AIT; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i], a_s + cb, 0));
 #pragma unroll
     for (int t = 0; t < 9; ++t)
-      rb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off + (unsigned)(t * p.C * 4) + cb, 0, 0));
+      rb[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_rel, b_s + (unsigned)(t * p.C * 4) + cb, 0));
   };
   auto stage = [&]() {
 #pragma unroll
@@ -147,13 +188,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
   };
 
   HALO_STAMP(0);
-  if (item < item_end) { set_item(item); fetch(0); }
-  int nstamp = 1;
-  (void)nstamp;
+  Item fi = {0, 0, 0, 0};
+  if (item < item_end) { fi = decompose(item); set_item(fi); fetch(0); }
+  // output: this lane's 16 row-wide stores of the epilogue, relative to the patch's first pixel / the group's first channel
+  const int c4 = (lane & 15) * 4, prow = lane >> 4;
+  unsigned o_rel[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int m = it * 4 + prow, s = 2 * wid + (m >> 5), q = m & 31;
+    o_rel[it] = (unsigned)((((s * RPS + q / TW) * p.W + q % TW) * p.Cout + c4) * 4);
+  }
   while (item < item_end) {
-    const int nblk = item % p.ngn, tile = item / p.ngn;
-    const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x, ty = t2 % p.tiles_y, n = t2 / p.tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW, n0 = nblk * NT;
+    const int n = fi.n, y0 = fi.ty * TH, x0 = fi.tx * TW, n0 = fi.nblk * NT;
     const int next = item + nj;
     // the bias is folded into the accumulators' initial value (a column of the tile = one output channel = one lane)
     f32x16 acc[2][2];
@@ -172,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
       const bool more = c0 + CK < p.C;
       // the next chunk -- or chunk 0 of the NEXT item -- is in flight under this chunk's 288 MFMAs
       if (more) fetch(c0 + CK);
-      else if (next < item_end) { set_item(next); fetch(0); }
+      else if (next < item_end) { advance(fi, next); set_item(fi); fetch(0); }
       // 18 blocks of 16 MFMAs (9 taps x 2 channel octets); the fragments of block b+1 are read from LDS before the MFMAs of
       // block b are issued (two register sets), so no MFMA ever waits for an LDS read issued right in front of it
       f32x4 fa[2][2], fb[2][2];
@@ -228,25 +274,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
             const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;       // pixel of this wavefront's 64
             Os[m * LDO + j * 32 + lr] = RELU ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
           }
-      __syncthreads();
-      const int c4 = (lane & 15) * 4, prow = lane >> 4;
+      // (no barrier: a wavefront reads back only what it wrote itself, and one wavefront's LDS operations execute in order)
+      if (p.beta == 0.f && y0 + TH <= p.H && x0 + TW <= p.W) {
+        // whole patch inside the image, plain store: lane-constant offsets + one scalar offset per item
+        const unsigned o_s = (unsigned)(((((long)n * p.H + y0) * p.W + x0) * p.Cout + n0) * 4);
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int m = it * 4 + prow;                                     // 0..63: sub-tile m>>5, pixel m&31 of it
-        const int s = 2 * wid + (m >> 5), q = m & 31;
-        const int y = y0 + s * RPS + q / TW, x = x0 + q % TW;
-        if (y < p.H && x < p.W) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(Os + m * LDO + c4);
-          float* dst = p.out + ((((long)n * p.H + y) * p.W + x) * p.Cout + n0 + c4);
-          if (p.beta != 0.f) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
-            v += o;
-          }
+        for (int it = 0; it < 16; ++it) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Os + (it * 4 + prow) * LDO + c4);
 #ifndef RE2E_HALO_NOSTORE      // diagnostic builds only (tools/micro/conv3x3_probe.hip)
-          *reinterpret_cast<f32x4*>(dst) = v;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, o_rel[it], o_s, 0);
 #else
-          if (v[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(dst) = v;
+          if (v[0] == 1.2345e30f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, o_rel[it], o_s, 0);
 #endif
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int m = it * 4 + prow;                                     // 0..63: sub-tile m>>5, pixel m&31 of it
+          const int s = 2 * wid + (m >> 5), q = m & 31;
+          const int y = y0 + s * RPS + q / TW, x = x0 + q % TW;
+          if (y < p.H && x < p.W) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Os + m * LDO + c4);
+            float* dst = p.out + ((((long)n * p.H + y) * p.W + x) * p.Cout + n0 + c4);
+            if (p.beta != 0.f) {
+              const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+              v += o;
+            }
+#ifndef RE2E_HALO_NOSTORE
+            *reinterpret_cast<f32x4*>(dst) = v;
+#else
+            if (v[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(dst) = v;
+#endif
+          }
         }
       }
       __syncthreads();                                  // the turn-around buffer is the next item's staging buffer
@@ -306,12 +365,13 @@ bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, cons
   if (act != RE2E_ACT_NONE && act != RE2E_ACT_RELU) return false;
   if (reinterpret_cast<uintptr_t>(out) & 15) return false;
   const long in_bytes = (long)g.NI * g.H * g.W * g.C * 4, wg_bytes = (long)Cout * 9 * g.C * 4;
-  if (in_bytes >= 0x7FFFFF00L || wg_bytes >= 0x7FFFFF00L) return false;
+  const long out_bytes = (long)g.NI * g.H * g.W * Cout * 4;
+  if (in_bytes >= 0x7FFFFF00L || wg_bytes >= 0x7FFFFF00L || out_bytes >= 0x7FFFFF00L) return false;
   if ((reinterpret_cast<uintptr_t>(g.in) | reinterpret_cast<uintptr_t>(wg)) & 15) return false;
   HaloArgs a;
   a.in = g.in; a.wg = wg; a.out = out; a.bias = bias;
   a.NI = g.NI; a.H = g.H; a.W = g.W; a.C = g.C; a.Cout = Cout; a.act = act; a.beta = beta;
-  a.ngn = Cout / NT; a.in_bytes = (unsigned)in_bytes; a.wg_bytes = (unsigned)wg_bytes;
+  a.ngn = Cout / NT; a.in_bytes = (unsigned)in_bytes; a.wg_bytes = (unsigned)wg_bytes; a.out_bytes = (unsigned)out_bytes;
   // patch shape: 16 x 16 (smaller halo) unless 32 x 8 wastes fewer padded pixels (W = 40: 416 x 40 against 400 x 48)
   const long pad16 = (long)cdiv(g.H, 16) * 16 * cdiv(g.W, 16) * 16, pad8 = (long)cdiv(g.H, 32) * 32 * cdiv(g.W, 8) * 8;
   const bool wide = pad16 <= pad8;

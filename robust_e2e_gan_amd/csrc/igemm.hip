@@ -593,7 +593,7 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
   if (log_calls)
     fprintf(stderr, "[igemm] A=%s B=%s tile=%dx%dx%d vec=%d M=%d N=%d K=%d splits=%d\n", LA::NAME, LB::NAME, CF::BM, CF::BN,
-            CF::BK, (int)VEC, ep.M, ep.N, K, ep.nsplit);
+            CF::BK, (int)VEC, ep.ncls ? ep.M * ep.ncls : ep.M, ep.N, K, ep.nsplit);   // M = rows of ALL parity classes of the launch
   hipLaunchKernelGGL((igemm_kernel<LA, LB, CF, VEC>), grid, dim3(CF::THREADS), lds, st, la, lb, ep, K);
   return 0;
 }

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
   hipMemset(bias, 0, K * 4);
   HaloArgs a;
   a.in = in; a.wg = wg; a.out = out; a.bias = bias; a.NI = N; a.H = H; a.W = W; a.C = C; a.Cout = K; a.act = RE2E_ACT_RELU; a.beta = 0.f;
-  a.ngn = K / NT; a.in_bytes = (unsigned)(nin * 4); a.wg_bytes = (unsigned)(nw * 4); a.tiles_x = cdiv(W, 16); a.tiles_y = cdiv(H, 16);
+  a.ngn = K / NT; a.in_bytes = (unsigned)(nin * 4); a.wg_bytes = (unsigned)(nw * 4); a.out_bytes = (unsigned)(nout * 4); a.tiles_x = cdiv(W, 16); a.tiles_y = cdiv(H, 16);
   a.nitems = N * a.tiles_x * a.tiles_y * a.ngn; a.ipw = 0;
   const int slots = getenv("RE2E_HALO_SLOTS") ? atoi(getenv("RE2E_HALO_SLOTS")) : 512;
   const long nwg = a.nitems < slots ? a.nitems : slots;
@@ -66,8 +66,9 @@ int main(int argc, char** argv) {
     }
     printf("last launch: first start -> last end %.1f us; sum of workgroup lifetimes / that span = %.1f workgroups resident on average (512 slots)\n",
            (r1 - r0) / 100.0, sum / (double)(r1 - r0));
-    // resident workgroups sampled every 20 us
-    for (unsigned long long t = r0; t < r1; t += 2000) {
+    // resident workgroups sampled every 20 us (or 1/100 of the span)
+    const unsigned long long dt = std::max<unsigned long long>(2000, (r1 - r0) / 100);     // at most 100 samples
+    for (unsigned long long t = r0; t < r1; t += dt) {
       int c = 0;
       for (long w = 0; w < nwg; ++w) c += (st[nwg * 16 + w * 2] <= t && t < st[nwg * 16 + w * 2 + 1]);
       printf(" %d", c);
