@@ -15,6 +15,7 @@
 // model/e2e_decoder.py:131,150, model/enhance_model.py:108-114 and nn.Conv2d in
 // model/e2e_encoder.py:234-237 (VGG2L) and model/gan_model.py:63-90 (discriminator).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -371,43 +372,86 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   const int lr = lane & 31, lh = lane >> 5;
   // (measured and rejected: skipping the MFMA block of a wave whose slab lies outside a ragged matrix edge -- the
   //  per-iteration branch costs every kernel 10-20 %)
+  // PIPE (x W^T with 16-byte loads: both operands k-major): the loop body is ONE basic block -- tile kt+1 is staged and tile
+  // kt+2 fetched unconditionally (beyond K the loaders return the out-of-range offset: zeros, no traffic; the spare LDS buffer
+  // of the last iteration is never read) -- and its source order plus the scheduling directives at its end put the address
+  // arithmetic, the loads and the second k-group's fragment reads BETWEEN the MFMAs.  Left to itself the compiler emits all of
+  // them in front of the first MFMA, and with one 8-wave workgroup per CU both waves of a SIMD sit behind the same barrier:
+  // the matrix pipe idles for the prologue of every k-step.  Same GPU session, 256x128 tile: 12800x2048x2560 100.2 -> 104.1,
+  // 25600x1024x512 93.4 -> 96.1, 6400x4233x512 95.8 -> 99.7 TFLOP/s.  NOT for a row-major B (x W: 4 ds_read_b32 per fragment
+  // value, 112.8 -> 95.4), the transposing stage of the weight gradients (+-1 %) or the im2col A operand (its address arithmetic
+  // made branch-free for the purpose: D conv2 forward 116.7 -> 115.8, its data gradient 96.2 -> 93.3).
+  constexpr bool PIPE = VEC && BK == 16 && std::is_same<LA, DenseK>::value && std::is_same<LB, DenseK>::value;
   int cur = 0;
+  auto read_frags = [&](const float* Ac, const float* Bc, int q, f32x4 (&fa)[CF::TM], f32x4 (&fb)[CF::TN]) {
+#pragma unroll
+    for (int i = 0; i < CF::TM; ++i) {
+      int r = (wm * CF::TM + i) * 32 + lr;
+      if (AKL) fa[i] = *reinterpret_cast<const f32x4*>(Ac + r * LDK + q * 8 + lh * 4);
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[i][j] = Ac[(q * 8 + lh * 4 + j) * LDA_M + r];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CF::TN; ++i) {
+      int r = (wn * CF::TN + i) * 32 + lr;
+      if (BKL) fb[i] = *reinterpret_cast<const f32x4*>(Bc + r * LDK + q * 8 + lh * 4);
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[i][j] = Bc[(q * 8 + lh * 4 + j) * LDB_M + r];
+      }
+    }
+  };
+  auto mfma_group = [&](const f32x4 (&fa)[CF::TM], const f32x4 (&fb)[CF::TN]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < CF::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < CF::TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+  };
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     __syncthreads();                                   // tile kt is complete in buffer cur; buffer cur^1 is free
-    if (kt + 1 < kt_end) {
-      store_tile(cur ^ 1);
-      if (kt + 2 < kt_end) { advance_k(); fetch_tile(); }
-    }
     const float* Ac = As + cur * ASZ;
     const float* Bc = Bs + cur * BSZ;
+    if constexpr (PIPE) {
+      // source order = the issue order wanted (LDS accesses may alias for the compiler, so it keeps them in this order):
+      // fragments of the first k-group, THEN the staging of tile kt+1 / the address arithmetic / the loads of tile kt+2 and
+      // the later k-groups' fragment reads, all of which the directives below place between the MFMAs of the first k-group
+      static_assert(BK / 8 == 2, "two k-groups per tile");
+      f32x4 fa0[CF::TM], fb0[CF::TN], fa1[CF::TM], fb1[CF::TN];
+      read_frags(Ac, Bc, 0, fa0, fb0);
+      store_tile(cur ^ 1);
+      advance_k();
+      fetch_tile();
+      read_frags(Ac, Bc, 1, fa1, fb1);
+      mfma_group(fa0, fb0);
+      mfma_group(fa1, fb1);
+      constexpr int NM = CF::TM * CF::TN * (BK / 2);
+      constexpr int NDW = (AIT + BIT) * (TS ? 4 : 1), NVM = AIT + BIT;
+      constexpr int FR = (AKL ? CF::TM : 4 * CF::TM) + (BKL ? CF::TN : 4 * CF::TN);      // fragment reads per k-group
+      __builtin_amdgcn_sched_group_barrier(0x100, FR, 0);
 #pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      f32x4 fa[CF::TM], fb[CF::TN];
-#pragma unroll
-      for (int i = 0; i < CF::TM; ++i) {
-        int r = (wm * CF::TM + i) * 32 + lr;
-        if (AKL) fa[i] = *reinterpret_cast<const f32x4*>(Ac + r * LDK + q * 8 + lh * 4);
-        else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) fa[i][j] = Ac[(q * 8 + lh * 4 + j) * LDA_M + r];
-        }
+      for (int m = 0; m < NM; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m < NDW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (m >= 1 && m < 1 + 2 * NVM) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if (m >= 2 && m < 2 + 2 * NVM && (m & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (m >= NM / 4 && m < NM / 4 + FR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    } else {
+      if (kt + 1 < kt_end) {
+        store_tile(cur ^ 1);
+        if (kt + 2 < kt_end) { advance_k(); fetch_tile(); }
       }
 #pragma unroll
-      for (int i = 0; i < CF::TN; ++i) {
-        int r = (wn * CF::TN + i) * 32 + lr;
-        if (BKL) fb[i] = *reinterpret_cast<const f32x4*>(Bc + r * LDK + q * 8 + lh * 4);
-        else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) fb[i][j] = Bc[(q * 8 + lh * 4 + j) * LDB_M + r];
-        }
+      for (int q = 0; q < BK / 8; ++q) {
+        f32x4 fa[CF::TM], fb[CF::TN];
+        read_frags(Ac, Bc, q, fa, fb);
+        mfma_group(fa, fb);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int a = 0; a < CF::TM; ++a)
-#pragma unroll
-          for (int b = 0; b < CF::TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
     }
     cur ^= 1;
   }
@@ -608,6 +652,7 @@ using C32x128 = Cfg<1, 4, 1, 1, 32>;   // skinny (M<=32) GEMMs of the decoder lo
 using C128b = Cfg<2, 2, 2, 2, 32>;
 using C256x64b = Cfg<4, 1, 2, 2, 32>;
 using C256x128 = Cfg<4, 2, 2, 2, 16>;
+using C64 = Cfg<2, 2, 1, 1, BKD>;      // 64 x 64: the row tail of a Linear forward whose last round of 256x128 tiles would be mostly empty
 
 inline int igemm_variant() {
   static const int v = getenv("RE2E_IGEMM_VARIANT") ? atoi(getenv("RE2E_IGEMM_VARIANT")) : 0;
@@ -846,6 +891,20 @@ extern "C" size_t re2e_gemm_workspace_bytes(int transa, int transb, int M, int N
 static inline unsigned kbytes(long outer, long ld, long inner) { return (unsigned)(((outer - 1) * ld + inner) * 4); }
 static inline bool fits32(long outer, long ld, long inner) { return ((outer - 1) * ld + inner) * 4 < 0xFFFFFFF0L; }
 
+// Rows that stay with the 256x128 tiles of a Linear forward (see gemm_dispatch); M = no split.
+static int row_tail_split(int M, int N) {
+  if (M < 2048) return M;                                   // launch_big uses the wide tile from 2048 rows
+  const long tn = cdiv(N, 128), tm = cdiv(M, 256), slots = tile_slots(256, 128);
+  const long total = tm * tn, full = total / slots, rem = total % slots;
+  if (full < 1 || rem == 0 || rem * 2 >= slots) return M;
+  const long tm_main = full * slots / tn;                   // whole tile rows inside the full rounds
+  if (tm_main * 256 < 2048 || tm_main >= tm) return M;     // (launch_big keeps the wide tile from 2048 rows)
+  const long m1 = tm_main * 256, tail_wgs = (long)cdiv(M - (int)m1, 64) * cdiv(N, 64);
+  // a 64x64 workgroup does 1/8 of a big tile's work at about half its rate: a round of them costs ~0.25 big rounds
+  const double t_split = (double)cdiv((int)(tm_main * tn), (int)slots) + 0.25 * (double)cdiv((int)tail_wgs, 4 * (int)slots);   // >= 4 of them per CU
+  return t_split + 0.2 < (double)(full + 1) ? (int)m1 : M;
+}
+
 template <bool V>
 static void gemm_dispatch(int transa, int transb, int M, int N, int K, const float* A, long lda, const float* B, long ldb, Epi& ep,
                           hipStream_t st) {
@@ -854,7 +913,22 @@ static void gemm_dispatch(int transa, int transb, int M, int N, int K, const flo
     DenseK la{A, kbytes(M, lda, K), lda, M, K};
     DenseK lb{B, kbytes(N, ldb, K), ldb, N, K};
     if (skinny) launch_igemm<DenseK, DenseK, C32x128, V>(la, lb, ep, K, st);
-    else launch_big<DenseK, DenseK, V, true>(la, lb, ep, K, st);
+    else {
+      // Round-filling row split: 12800 x 2048 is 800 tiles of 256x128 on 256 resident workgroups -- 3.1 rounds, the 4th one
+      // 12 % full.  The rows of the last, mostly empty round go to a second launch of 64x64 tiles instead (256 small
+      // workgroups: every CU gets one), the launch of the big tiles ends on a full round.
+      static const bool no_tail = getenv("RE2E_NO_ROW_TAIL") != nullptr;
+      const int m1 = (V && !no_tail && igemm_variant() == 0 && ep.nsplit == 1 && ep.act != RE2E_ACT_SIGMOID_MASK_MUL) ? row_tail_split(M, N) : M;
+      if (m1 < M) {
+        Epi e1 = ep, e2 = ep;
+        e1.M = m1;
+        DenseK la1{A, kbytes(m1, lda, K), lda, m1, K};
+        launch_big<DenseK, DenseK, V, true>(la1, lb, e1, K, st);
+        e2.M = M - m1; e2.C = ep.C + (long)m1 * ep.ldc;
+        DenseK la2{A + (long)m1 * lda, kbytes(M - m1, lda, K), lda, M - m1, K};
+        launch_igemm<DenseK, DenseK, C64, V>(la2, lb, e2, K, st);
+      } else launch_big<DenseK, DenseK, V, true>(la, lb, ep, K, st);
+    }
   } else if (!transa && !transb) {  // C = A[M,K] * B[K,N]     (input gradient)
     DenseK la{A, kbytes(M, lda, K), lda, M, K};
     DenseM lb{B, kbytes(K, ldb, N), ldb, N, K};

@@ -52,6 +52,21 @@ def gemm(A, B, C, M, N, K, transa=False, transb=False, lda=None, ldb=None, ldc=N
     return C
 
 
+NT_INPUT_GRAD = os.environ.get('RE2E_NO_NT_INPUT_GRAD') is None
+
+
+def gemm_input_grad(dz, W, dx, M, K, N, beta=0.0):
+    """dx[M,K] = dz[M,N] W[N,K] (+ beta dx): the input gradient of y = x W^T.  For many rows the weight is transposed first (one
+    small gather, N*K elements) and the product runs as dz (W^T)^T on the engine's k-major path -- 256x128 tiles with the
+    interleaved k-step and the round-filling row tail -- instead of the row-major-B path (MI355X, 12800 x 2560 x 2048:
+    113 -> 128 TFLOP/s; RE2E_NO_NT_INPUT_GRAD=1 keeps the direct form)."""
+    if NT_INPUT_GRAD and M >= 2048 and K % 4 == 0 and N % 4 == 0 and W.is_contiguous():
+        wt = empty((K, N), dz)
+        call('re2e_conv_weight_gather', W.data_ptr(), wt.data_ptr(), N, K, 1, 1, 1, 1, 1, 0, 0, 1)       # wt[k][n] = W[n][k]
+        return gemm(dz, wt, dx, M, K, N, transb=True, beta=beta)
+    return gemm(dz, W, dx, M, K, N, beta=beta)
+
+
 def colsum_into(A2d, M, N, out, beta, lda=None):
     wsb = query('re2e_colsum_workspace_bytes', M, N)
     ws = workspace(wsb, A2d.device, 'colsum')
@@ -209,7 +224,7 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = empty((M, K), x2)
-            gemm(dz, W, dx, M, K, N)                       # dx = dz[M,N] * W[N,K]
+            gemm_input_grad(dz, W, dx, M, K, N)            # dx = dz[M,N] * W[N,K]
             dx = dx.view(ctx.xshape)
         with param_grads(dz, x2):
             if need_w:
@@ -368,7 +383,7 @@ class MaskFcFn(torch.autograd.Function):
         dp = None
         if ctx.needs_input_grad[0]:
             dp = empty((M, K), p2)
-            gemm(dlin, W, dp, M, K, N)
+            gemm_input_grad(dlin, W, dp, M, K, N)
             dp = dp.view(ctx.oshape[:-1] + (K,))
         if ctx.needs_input_grad[1]:
             with param_grads(dlin, p2), accumulate(W) as (gw, beta):
@@ -761,8 +776,8 @@ class BiLstmFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = empty((M, I), dy)
-            gemm(dG[0], w[0], dx, M, I, 4 * H)
-            gemm(dG[1], w[4], dx, M, I, 4 * H, beta=1.0)
+            gemm_input_grad(dG[0], w[0], dx, M, I, 4 * H)
+            gemm_input_grad(dG[1], w[4], dx, M, I, 4 * H, beta=1.0)
             dx = dx.view(T, B, I)
         yflat = ybuf.view((T + 2) * B, 2 * H)
         with param_grads(g_f, g_r, x2, ybuf):

@@ -38,7 +38,9 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('M,N,K', [(77, 257, 130), (256, 128, 64), (5, 3, 7), (300, 4233, 512), (130, 64, 257)])
+# the last two: 800 / 801 x 16 tiles of 256x128 on 256 workgroup slots -> the rows of the mostly empty 4th round run as 64x64 tiles
+@pytest.mark.parametrize('M,N,K', [(77, 257, 130), (256, 128, 64), (5, 3, 7), (300, 4233, 512), (130, 64, 257), (12800, 2048, 48),
+                                   (12803, 2040, 36)])
 def test_gemm_nt_nn(M, N, K):
     ops, lib = _ops()
     A, Bm, bias, C0 = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
@@ -85,6 +87,25 @@ def test_linear_autograd():
     y = ops.linear(xg, Wg, bg, 'tanh')
     (y * rnd(4, 9, 21, seed=5).to(DEV)).sum().backward()
     close('dW x2', Wg.grad, 2 * Wr.grad)
+
+
+def test_linear_input_grad_many_rows():
+    """M >= 2048 rows: the input gradient runs as dz (W^T)^T with a transposed copy of the weight (ops.gemm_input_grad)"""
+    ops, lib = _ops()
+    x, W, b = rnd(9, 260, 36), rnd(44, 36, seed=1), rnd(44, seed=2)
+    g = rnd(9, 260, 44, seed=5)
+    xr, Wr, br = [t.clone().requires_grad_(True) for t in (x, W, b)]
+    (F.linear(xr, Wr, br) * g).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    Wg, bg = torch.nn.Parameter(W.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    (ops.linear(xg, Wg, bg, None) * g.to(DEV)).sum().backward()
+    close('dx', xg.grad, xr.grad)
+    close('dW', Wg.grad, Wr.grad, tol=2e-4)
+    dz = g.view(-1, 44).to(DEV).contiguous()
+    dx0 = rnd(9 * 260, 36, seed=7)
+    dx = dx0.to(DEV).clone()
+    ops.gemm_input_grad(dz, Wg.data, dx, 9 * 260, 36, 44, beta=1.0)
+    close('dx beta', dx, dx0 + g.view(-1, 44) @ W)
 
 
 def test_mask_fc():
