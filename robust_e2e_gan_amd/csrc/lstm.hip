@@ -719,6 +719,13 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
   // needs 130 registers per lane, 2 more than 1024 threads leave)
   static const int uw = getenv("RE2E_LSTM_FWD_UW") ? atoi(getenv("RE2E_LSTM_FWD_UW")) : 1;
   if (NX == 64 && uw == 2) return launch_fwd_persist<8, 8, 2>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
+  // 512-wide layers, 8 units per workgroup: 8 wavefronts x 8 k-groups (140 registers, 2 waves per SIMD = 288 of a SIMD's 512) rather than
+  // 16 x 4 (94 registers, 4 waves per SIMD = 384).  Its 256 workgroups sit on every CU of the chip for the whole sequence, and what
+  // they leave free decides which filler workgroups can be co-resident: 224 registers per SIMD admit a 4-wave engine tile (152),
+  // 128 admit none of the engine's tiles.  Alone 7.4 instead of 7.0 us per step, in the training step 72.94 -> 72.69 ms (3 + 3 runs,
+  // one GPU session).  RE2E_LSTM_FWD_W8=0 selects the 16-wave form.
+  static const int w8 = getenv("RE2E_LSTM_FWD_W8") ? atoi(getenv("RE2E_LSTM_FWD_W8")) : 1;
+  if (NX == 64 && w8) return launch_fwd_persist<8, 8, 1>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
 #define RE2E_TRY(W, Q) if (NX == (W) * (Q)) return launch_fwd_persist<W, Q>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H)
   RE2E_TRY(16, 4); RE2E_TRY(8, 5); RE2E_TRY(8, 4); RE2E_TRY(8, 3); RE2E_TRY(4, 4); RE2E_TRY(4, 2); RE2E_TRY(4, 1);
 #undef RE2E_TRY
