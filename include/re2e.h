@@ -40,12 +40,20 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 #define RE2E_LOSS_L2 0
 #define RE2E_LOSS_L1 1
 #define RE2E_LOSS_SMOOTH_L1 2
+#define RE2E_STREAM_DEFAULT 0
+#define RE2E_STREAM_FILLER 1 /* bulk work overlapped with resident recurrences: see re2e_stream_role */
+
 #define RE2E_LOSS_BCE 3 /* nn.BCELoss on probabilities, logs clamped at -100 (model/gan_model.py:157-160, --no_lsgan) */
 
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
 int re2e_device_ok(void);
+/* Scheduling hint, no reference counterpart (the reference runs one stream).  role = RE2E_STREAM_FILLER marks a stream whose
+ * kernels run BESIDE the persistent recurrences of another stream (JointTrainer's side / weight-gradient streams,
+ * joint_train.py step): the MFMA engine then launches 4-wave tiles there, which fit the registers a resident recurrence
+ * leaves free on a CU; RE2E_STREAM_DEFAULT removes the mark.  Results do not depend on it.  At most 64 filler streams at a time. */
+int re2e_stream_role(re2e_stream_t stream, int role);
 
 /* ---- K3 dense GEMM (fp32 MFMA).  C[M,N] = act(op(A) op(B) + bias + bias2) + beta*C.
  * Row-major; transa=0: A stored [M,K], transa=1: A stored [K,M]; transb=0: B stored [K,N],

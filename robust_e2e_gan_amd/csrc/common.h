@@ -14,6 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define RE2E_WAVE 64
 
 void re2e_set_error(const char* fmt, ...);
+bool re2e_stream_is_filler(hipStream_t stream);     // core.hip: re2e_stream_role
 
 #define RE2E_CHECK_ARG(cond, msg)                     \
   do {                                                \

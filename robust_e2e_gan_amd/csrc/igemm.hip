@@ -662,13 +662,17 @@ inline int igemm_variant() {
 // big-tile launch.  WIDE = the 8-wave 256x128 tile is the measured default for this operand combination
 // (tools/bench_gemm.py on MI355X: +5..35 % for Linear-forward / weight-gradient GEMMs and conv forward /
 // data-gradient with Cout >= 128; the 4-wave 128x128 tile stays better for NN and conv weight-gradient).
-// RE2E_IGEMM_VARIANT = 1 (BK 32) / 2 (force wide) / 3 (force 128x128) override for tuning.
+// RE2E_IGEMM_VARIANT = 1 (BK 32) / 2 (force wide) / 3 (force 128x128) override for tuning.  On a FILLER stream the 4-wave tile is
+// used whatever its stand-alone rate: training step 72.61 -> 72.32 ms (3 + 3 runs, one GPU session).
+// the 8-wave tile everywhere but on streams marked as fillers (core.hip: re2e_stream_role)
+inline bool wide_allowed(hipStream_t st) { return !re2e_stream_is_filler(st); }
+
 template <class LA, class LB, bool V, bool WIDE>
 void launch_big(const LA& la, const LB& lb, Epi& ep, int K, hipStream_t st) {
   if constexpr (V) {
     int v = igemm_variant();
     if (v == 1) { launch_igemm<LA, LB, C128b, V>(la, lb, ep, K, st); return; }
-    bool wide = v == 2 ? true : (v == 3 ? false : (WIDE && ep.M >= 2048));
+    bool wide = v == 2 ? true : (v == 3 ? false : (WIDE && ep.M >= 2048 && wide_allowed(st)));
     if (wide) { launch_igemm<LA, LB, C256x128, V>(la, lb, ep, K, st); return; }
   }
   launch_igemm<LA, LB, C128, V>(la, lb, ep, K, st);
@@ -918,7 +922,7 @@ static void gemm_dispatch(int transa, int transb, int M, int N, int K, const flo
       // 12 % full.  The rows of the last, mostly empty round go to a second launch of 64x64 tiles instead (256 small
       // workgroups: every CU gets one), the launch of the big tiles ends on a full round.
       static const bool no_tail = getenv("RE2E_NO_ROW_TAIL") != nullptr;
-      const int m1 = (V && !no_tail && igemm_variant() == 0 && ep.nsplit == 1 && ep.act != RE2E_ACT_SIGMOID_MASK_MUL) ? row_tail_split(M, N) : M;
+      const int m1 = (V && !no_tail && igemm_variant() == 0 && ep.nsplit == 1 && ep.act != RE2E_ACT_SIGMOID_MASK_MUL && wide_allowed(st)) ? row_tail_split(M, N) : M;
       if (m1 < M) {
         Epi e1 = ep, e2 = ep;
         e1.M = m1;

@@ -90,6 +90,9 @@ class JointTrainer(object):
                 self.side_stream = torch.cuda.Stream()
             if self.wgrad_stream is None:
                 self.wgrad_stream = torch.cuda.Stream()
+            # both run beside the resident recurrences of the main stream: 4-wave engine tiles there (re2e_stream_role)
+            lib.set_stream_role(self.side_stream, True)
+            lib.set_stream_role(self.wgrad_stream, True)
             # NB: no further streams.  A process gets 4 hardware queues by default; a fifth stream (default + main + side
             # + wgrad + one more) is multiplexed onto an occupied queue and serialises against it (measured with a
             # dedicated D-step stream: 91 -> 155 ms/step).  Measured and rejected as well: running the D-step's

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
+STREAM_DEFAULT, STREAM_FILLER = 0, 1
 
 P, I, L, F, Z = c_void_p, c_int, c_long, c_float, c_size_t
 
@@ -25,6 +26,7 @@ SIGNATURES = {
     're2e_version': (I, []),
     're2e_last_error': (c_char_p, []),
     're2e_device_ok': (I, []),
+    're2e_stream_role': (I, [P, I]),
     're2e_gemm_workspace_bytes': (Z, [I, I, I, I, I]),
     're2e_gemm': (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, I, F, P, P, P, I, P, Z, P]),
     're2e_conv_igemm': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, I, F, P]),
@@ -140,6 +142,14 @@ def call(name, *args):
     rc = getattr(lib, name)(*args, stream())
     if rc != 0:
         raise Re2eError('%s failed (%d): %s' % (name, rc, lib.re2e_last_error().decode()))
+
+
+def set_stream_role(torch_stream, filler=True):
+    """Mark / unmark a torch stream as a FILLER stream (re2e_stream_role): bulk work that runs beside resident recurrences."""
+    lib = load()
+    rc = lib.re2e_stream_role(c_void_p(torch_stream.cuda_stream), STREAM_FILLER if filler else STREAM_DEFAULT)
+    if rc != 0:
+        raise Re2eError('re2e_stream_role failed (%d): %s' % (rc, lib.re2e_last_error().decode()))
 
 
 def query(name, *args):

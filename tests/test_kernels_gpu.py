@@ -89,6 +89,28 @@ def test_linear_autograd():
     close('dW x2', Wg.grad, 2 * Wr.grad)
 
 
+def test_stream_role_changes_tiles_not_results():
+    """re2e_stream_role: a FILLER stream gets the 4-wave engine tiles; the product is the same"""
+    ops, lib = _ops()
+    M, N, K = 4100, 300, 200
+    A, Bm = rnd(M, K).to(DEV), rnd(N, K, seed=1).to(DEV)
+    ref = torch.empty(M, N, device=DEV)
+    ops.gemm(A, Bm, ref, M, N, K, transb=True)
+    st = torch.cuda.Stream()
+    lib.set_stream_role(st, True)
+    lib.set_stream_role(st, True)                       # idempotent
+    got = torch.empty(M, N, device=DEV)
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        ops.gemm(A, Bm, got, M, N, K, transb=True)
+    st.synchronize()
+    lib.set_stream_role(st, False)
+    close('filler-stream gemm', got, ref, tol=1e-6)
+    with pytest.raises(lib.Re2eError):
+        if lib.load().re2e_stream_role(st.cuda_stream, 7) != 0:
+            raise lib.Re2eError(lib.load().re2e_last_error().decode())
+
+
 def test_linear_input_grad_many_rows():
     """M >= 2048 rows: the input gradient runs as dz (W^T)^T with a transposed copy of the weight (ops.gemm_input_grad)"""
     ops, lib = _ops()
