@@ -69,11 +69,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 31, lh = lane >> 5;
   // Work item = (patch, 64-channel group).  A workgroup takes `ipw` CONSECUTIVE items (the first fetch of item k+1 flies under
   // the last matrix block of item k).  ipw = 0: persistent workgroups, two per CU, XCD x owning the contiguous item range
-  // [x*per, (x+1)*per) -- the fastest form ALONE on the chip (no workgroup turn-over: 13 % of the slots were empty with one
-  // item per workgroup), but inside the training step its workgroups hold every CU for the whole launch and the recurrent
-  // chains on the high-priority stream cannot place theirs (enhancer forward 10.0 -> 11.2 ms, step +0.3 ms against the
-  // general engine, same GPU session).  Default ipw = 2: a workgroup lives ~140 us, as long as one of the engine's tiles, and
-  // CUs free up continuously; workgroups are ordered XCD-aware (each XCD's L2 sees a contiguous run of patches).
+  // [x*per, (x+1)*per).  Persistent workgroups were the fastest form alone on the chip while an item's set-up cost ~300 vector
+  // instructions (13 % of the slots were empty with one item per workgroup) but hold every CU for the whole launch, and the
+  // recurrent chains on the high-priority stream cannot place theirs (enhancer forward 10.0 -> 11.2 ms); with the set-up reduced
+  // to scalar arithmetic one item per workgroup is as fast (launch_halo) and is the default.  Workgroups are ordered XCD-aware
+  // (each XCD's L2 sees a contiguous run of patches).
   int item, item_end, nj;
   if (p.ipw == 0) {
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
@@ -328,19 +328,14 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return 2 * cus;
   }();
-  // items per workgroup: RE2E_HALO_IPW = 0 persistent, n > 0 fixed; default = the n in 1..3 that wastes the fewest slots in the
-  // last round of workgroups (conv1_2: 8000 items -> n = 2, 7.8 rounds of 512; conv2_2: 4160 items -> n = 3, 2.7 rounds; ties -> larger n)
+  // items per workgroup: RE2E_HALO_IPW = 0 persistent, n > 0 fixed.  Default 1: since an item's set-up is a handful of scalar
+  // instructions (lane-constant addresses), a fresh workgroup per item costs nothing measurable alone on the chip (conv1_2 0.851
+  // of peak against 0.838 / 0.852 / 0.850 with 2 / 3 / persistent, conv2_2 0.811 against 0.770 / 0.768 / 0.820: no half-empty
+  // last round) and its 70 us lifetime interleaves best with the other streams of the training step (72.41 -> 72.07 ms against
+  // the former 2-3 items; 3 + 3 runs, one GPU session).
   static const int ipw_env = getenv("RE2E_HALO_IPW") ? atoi(getenv("RE2E_HALO_IPW")) : -1;
   HaloArgs b = a;
-  if (ipw_env >= 0) b.ipw = ipw_env;
-  else {
-    double best = -1.0;
-    for (int n = 1; n <= 3; ++n) {
-      const long w = (a.nitems + n - 1) / n, rounds = (w + slots - 1) / slots;
-      const double eff = (double)a.nitems / ((double)rounds * slots * n);
-      if (eff >= best - 1e-9) { best = eff; b.ipw = n; }
-    }
-  }
+  b.ipw = ipw_env >= 0 ? ipw_env : 1;
   const int nwg = b.ipw == 0 ? (a.nitems < slots ? a.nitems : slots) : (a.nitems + b.ipw - 1) / b.ipw;
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
   if (log_calls)
