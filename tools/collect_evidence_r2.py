@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Copies the summaries of `bash tools/final_evidence_r2.sh` (gpurun_out/r2_final, gpurun_out/r2_pmc) into profiles/ and derives
+the two PMC evidence files of the roofline kernel from the counter summary.  Run in the repo after the GPU call."""
+import json
+import os
+import shutil
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F, P, O = os.path.join(R, 'gpurun_out', 'r2_final'), os.path.join(R, 'gpurun_out', 'r2_pmc'), os.path.join(R, 'profiles')
+for src, dst in (('bench_default.json', 'r02_bench_default.json'), ('bench_kernel_stats.csv', 'r02_bench_kernel_stats.csv'),
+                 ('bench_repeats.txt', 'r02_bench_repeats.txt'), ('bench_nooverlap_kernel_stats.csv', 'r02_bench_nooverlap_kernel_stats.csv'),
+                 ('igemm_calls_nooverlap.txt', 'r02_igemm_calls_nooverlap.txt'), ('hbm_kernels.md', 'r02_hbm_kernels.md'),
+                 ('step_timeline.txt', 'r02_step_timeline.txt'), ('bench_conv3x3.txt', 'r02_conv3x3_alone.txt'),
+                 ('bench_gemm.txt', 'r02_engine_shapes_alone.txt'), ('bench_lstm_persist.txt', 'r02_recurrence_rates_alone.txt')):
+    shutil.copyfile(os.path.join(F, src), os.path.join(O, dst))
+s = json.load(open(os.path.join(P, 'summary.json')))
+KERNEL = ('conv3x3_halo_kernel<16,16,1,true> at the VGG conv1_2 shape (64x800x80, 64->64, 3x3), tools/roofline_conv.py '
+          '(= bench.py conv_roofline: 3 + 20 launches)')
+json.dump({'what': 'FETCH_SIZE as reported by rocprofv3 for two kernels that read exactly 1 GiB (tools/micro/fetch_calib.hip): a streaming '
+                   'global_load_dwordx4 copy and the 64-byte-segment buffer_load_dwordx4 pattern of the conv kernels; KiB',
+           'expected_KiB': 1048576, 'stream_kernel': s['calib_stream_kernel'], 'segments_kernel': s['calib_segments_kernel'],
+           'conclusion': 'both patterns report 1/2 of the bytes read: the gfx950 x2 correction of MI355X_MICROARCH.md applies to the 64-byte-segment loads too'},
+          open(os.path.join(O, 'r02_fetch_size_calibration.json'), 'w'), indent=1)
+fe, wr = s['fetch']['FETCH_SIZE'], s['write']['WRITE_SIZE']
+inp = out = 64 * 800 * 80 * 64 * 4
+wts = 64 * 9 * 64 * 4
+fetch_b, write_b = fe['avg'] * 1024 * 2, wr['avg'] * 1024
+old = json.load(open(os.path.join(O, 'r02_conv1_2_pmc_traffic.json'))) if os.path.exists(os.path.join(O, 'r02_conv1_2_pmc_traffic.json')) else {}
+json.dump({'kernel': KERNEL,
+           'command': 'bash tools/pmc_conv_r2.sh  (rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes)',
+           'FETCH_SIZE': {'launches': fe['launches'], 'avg_KiB_as_reported': fe['avg'], 'min_KiB': fe['min'], 'max_KiB': fe['max'],
+                          'gfx950_correction': 'x2 (calibrated on this access pattern: profiles/r02_fetch_size_calibration.json)',
+                          'avg_bytes_corrected': fetch_b},
+           'WRITE_SIZE': {'launches': wr['launches'], 'avg_KiB': wr['avg'], 'avg_bytes': write_b},
+           'algorithmic_bytes': {'input': inp, 'output': out, 'weights': wts, 'total': inp + out + wts},
+           'traffic_bytes_per_launch': fetch_b + write_b, 'reads_over_input': fetch_b / inp,
+           'traffic_over_algorithmic': (fetch_b + write_b) / (inp + out + wts),
+           'earlier_this_round_2_to_3_patches_per_workgroup': {'reads_over_input': 1.4933},
+           'round1_same_shape_general_engine': old.get('round1_same_shape_general_engine'),
+           'notes': 'WRITE_SIZE equals the output tensor exactly.  One patch per workgroup, workgroups dealt XCD-aware: neighbouring patches '
+                    'run at the same time on the same XCD, so the 18x18 halo of a 16x16 patch (1.27x its interior) is served by that XCD\'s L2 '
+                    'and HBM reads are within 2 % of the input tensor (1.49x with 2-3 consecutive patches per workgroup earlier this round, '
+                    '6.8x for the general engine in round 1).'},
+          open(os.path.join(O, 'r02_conv1_2_pmc_traffic.json'), 'w'), indent=1)
+c = {k: v['avg'] for d in ('sq1', 'sq2') for k, v in s[d].items()}
+st = s['stats'][0]
+fl = 2.0 * 9 * 64 * 64 * 64 * 800 * 80
+avg_ms, min_ms, max_ms = float(st['AverageNs']) / 1e6, float(st['MinNs']) / 1e6, float(st['MaxNs']) / 1e6
+json.dump({'kernel': KERNEL,
+           'command': 'bash tools/pmc_conv_r2.sh (two SQ passes of 6 counters; averages over the 23 launches, summed over the chip)',
+           'counters': c,
+           'kernel_stats_same_script': {'calls': int(st['Calls']), 'avg_ms': avg_ms, 'min_ms': min_ms, 'max_ms': max_ms,
+                                        'avg_TFLOPs': fl / avg_ms / 1e9, 'avg_frac_of_157.3': fl / avg_ms / 1e9 / 157.3,
+                                        'min_frac': fl / min_ms / 1e9 / 157.3},
+           'derived': {'mfma_instructions_per_launch': c['SQ_VALU_MFMA_BUSY_CYCLES'] / 64,
+                       'wave_cycles_split': {k: c['SQ_' + k] / c['SQ_WAVE_CYCLES'] for k in ('WAIT_INST_ANY', 'WAIT_ANY', 'ACTIVE_INST_ANY')},
+                       'lds_bank_conflict_share_of_lds_active_cycles': c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'],
+                       'wait_inst_lds_share_of_wave_cycles': c['SQ_WAIT_INST_LDS'] / c['SQ_WAVE_CYCLES'],
+                       'valu_instructions_per_mfma': c['SQ_INSTS_VALU'] / (c['SQ_VALU_MFMA_BUSY_CYCLES'] / 64) / 2.0,
+                       'valu_instructions_earlier_this_round': 118912000.0},
+           'notes': 'SQ_VALU_MFMA_BUSY_CYCLES = 64 x the algorithmic MFMA count (no wasted matrix work).  SQ_INSTS_VALU fell from 118.9M to '
+                    '104.1M per launch with the lane-constant addressing (an interior patch issues no vector instruction per load / store; the '
+                    'rest are accumulator initialisation, ReLU and the border patches), SQ_WAIT_ANY from 265M to 135M quad-cycles.  See DESIGN.md '
+                    'section 4, "Round-2 findings on the f32 matrix pipe".'},
+          open(os.path.join(O, 'r02_conv1_2_pmc_sq.json'), 'w'), indent=1)
+stats_src = [f for f in os.listdir(os.path.join(P, 'stats', 'runc')) if f.endswith('kernel_stats.csv')] if os.path.isdir(os.path.join(P, 'stats', 'runc')) else []
+for f in stats_src:
+    shutil.copyfile(os.path.join(P, 'stats', 'runc', f), os.path.join(O, 'r02_roofline_conv_kernel_stats.csv'))
+print('profiles/ refreshed')
