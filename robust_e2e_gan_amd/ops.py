@@ -53,6 +53,7 @@ def gemm(A, B, C, M, N, K, transa=False, transb=False, lda=None, ldb=None, ldc=N
 
 
 NT_INPUT_GRAD = os.environ.get('RE2E_NO_NT_INPUT_GRAD') is None
+INLINE_LAST_WGRAD = os.environ.get('RE2E_NO_INLINE_LAST_WGRAD') is None
 
 
 def gemm_input_grad(dz, W, dx, M, K, N, beta=0.0):
@@ -108,15 +109,16 @@ class param_grads(object):
     MFMA work that fills the CUs left idle by the latency-bound parts of the step (recurrent chains, decoder).
     ``t*`` are the tensors the kernels read: they are kept alive for that stream.  Ordering of the accumulation
     into shared gradients is handled by ``accumulate``; the trainer joins the stream before the optimizer."""
-    __slots__ = ('ts', 'ctx')
+    __slots__ = ('ts', 'ctx', 'inline')
 
-    def __init__(self, *tensors):
+    def __init__(self, *tensors, inline=False):
         self.ts = tensors
         self.ctx = None
+        self.inline = inline        # keep the kernels on the current stream (see BiLstmFn.backward)
 
     def __enter__(self):
         ws = WGRAD_STREAM
-        if not MULTI_STREAM or ws is None:
+        if not MULTI_STREAM or ws is None or self.inline:
             return self
         cur = torch.cuda.current_stream()
         if cur == ws:
@@ -779,33 +781,45 @@ class BiLstmFn(torch.autograd.Function):
             gemm_input_grad(dG[0], w[0], dx, M, I, 4 * H)
             gemm_input_grad(dG[1], w[4], dx, M, I, 4 * H, beta=1.0)
             dx = dx.view(T, B, I)
+        # A layer whose input needs no gradient is the bottom of its network: its backward recurrence is the LAST link of the
+        # chain on this stream (the enhancer's first layer ends the training step's backward), so nothing waits behind its weight
+        # gradients here, while on the weight-gradient stream they would queue behind everything deferred so far: they stay on this
+        # stream and run beside that backlog: step 72.26 -> 71.71 ms (3 + 3 runs, one GPU session; RE2E_NO_INLINE_LAST_WGRAD=1:
+        # deferred like the others).  Handing the weight gradients of the layers ABOVE it to the trainer to run behind the chain as
+        # well was measured and changes nothing (71.63 against 71.55).
         yflat = ybuf.view((T + 2) * B, 2 * H)
-        with param_grads(g_f, g_r, x2, ybuf):
-            for d in range(2):
-                w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
-                n_ih, n_hh, n_bi, n_bh = ctx.needs_input_grad[2 + 4 * d:6 + 4 * d]
-                if n_ih and x2.shape[1] != I:              # padded input copy (see forward): full-width product, then the real columns
-                    tmp = empty((4 * H, x2.shape[1]), dy)
-                    gemm(dG[d], x2, tmp, 4 * H, x2.shape[1], M, transa=True)
-                    with accumulate(w_ih) as (gw, beta):
-                        if beta == 0.0:
-                            gw.copy_(tmp[:, :I])
-                        else:
-                            gw.add_(tmp[:, :I])
-                elif n_ih:
-                    with accumulate(w_ih) as (gw, beta):
-                        gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
-                if n_hh:
-                    # h_{t-1}: forward direction = ybuf block t (y[t-1]); reverse = ybuf block t+2 (y[t+1])
-                    hprev = yflat[(0 if d == 0 else 2 * B):, d * H:]
-                    with accumulate(w_hh) as (gw, beta):
-                        call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
-                if n_bi:
-                    with accumulate(b_ih) as (gb, beta):
-                        colsum_into(dG[d], M, 4 * H, gb, beta)
-                if n_bh:
-                    with accumulate(b_hh) as (gb, beta):
-                        colsum_into(dG[d], M, 4 * H, gb, beta)
+        last = INLINE_LAST_WGRAD and not ctx.needs_input_grad[0]
+        needs = ctx.needs_input_grad
+
+        def weight_grads(inline):
+            with param_grads(g_f, g_r, x2, ybuf, inline=inline):
+                for d in range(2):
+                    w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
+                    n_ih, n_hh, n_bi, n_bh = needs[2 + 4 * d:6 + 4 * d]
+                    if n_ih and x2.shape[1] != I:              # padded input copy (see forward): full-width product, then the real columns
+                        tmp = empty((4 * H, x2.shape[1]), dy)
+                        gemm(dG[d], x2, tmp, 4 * H, x2.shape[1], M, transa=True)
+                        with accumulate(w_ih) as (gw, beta):
+                            if beta == 0.0:
+                                gw.copy_(tmp[:, :I])
+                            else:
+                                gw.add_(tmp[:, :I])
+                    elif n_ih:
+                        with accumulate(w_ih) as (gw, beta):
+                            gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
+                    if n_hh:
+                        # h_{t-1}: forward direction = ybuf block t (y[t-1]); reverse = ybuf block t+2 (y[t+1])
+                        hprev = yflat[(0 if d == 0 else 2 * B):, d * H:]
+                        with accumulate(w_hh) as (gw, beta):
+                            call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
+                    if n_bi:
+                        with accumulate(b_ih) as (gb, beta):
+                            colsum_into(dG[d], M, 4 * H, gb, beta)
+                    if n_bh:
+                        with accumulate(b_hh) as (gb, beta):
+                            colsum_into(dG[d], M, 4 * H, gb, beta)
+
+        weight_grads(last)
         return (dx, None) + (None,) * len(w)
 
 
