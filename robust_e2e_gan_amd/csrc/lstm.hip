@@ -651,11 +651,14 @@ bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* w
   size_t lds = (size_t)UW * W * 32 * 33 * sizeof(float) + 16;
   dim3 grid(H / (8 * UW), cdiv(B, 32), 2);
   if ((long)grid.x * grid.y * grid.z > cu_count()) return false;          // every workgroup must be resident
-  // A chain that fits half of the chip (RE2E_LSTM_OWN_CU_FRAC, quarter: 75.5, half: 75.1 ms) asks for (almost) a whole CU's LDS per workgroup: nothing else can then be
+  // A chain (of any size up to the chip: RE2E_LSTM_OWN_CU_FRAC = 1; limited to a quarter of the chip the step was 75.5 ms, to half 75.1, and
+  // at the end of round 2 half 71.79 against whole 71.59 -- the 256-workgroup forward of the 512-wide layers then has the chip to itself)
+  // asks for (almost) a whole CU's LDS per workgroup: nothing else can then be
   // co-resident on its CUs, so its MFMA pipe and memory queue are its own while the filler streams keep the other CUs.
-  // (RE2E_LSTM_OWN_CU=0 turns it off, =n asks for n KB.  Step 77.9 -> 75.2 ms: enhancer forward 13.6 -> 9.6, backward 16.7 -> 13.0 ms.)
+  // (RE2E_LSTM_OWN_CU=0 turns it off, =n asks for n KB -- it has to be the whole CU: with 120 KB, which still admits a small filler
+  // workgroup, the step is 74.2 instead of 71.8 ms.  Step 77.9 -> 75.2 ms when introduced: enhancer forward 13.6 -> 9.6, backward 16.7 -> 13.0 ms.)
   static const int hog = getenv("RE2E_LSTM_OWN_CU") ? atoi(getenv("RE2E_LSTM_OWN_CU")) : 160;
-  static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 2;
+  static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 1;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN, UW>), lds);
@@ -675,7 +678,7 @@ bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb,
   unsigned* flags = (unsigned*)((char*)flagmem + 16);
   static const int hog = getenv("RE2E_LSTM_OWN_CU") ? atoi(getenv("RE2E_LSTM_OWN_CU")) : 160;      // see launch_fwd_persist
   size_t lds = 0;
-  static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 2;
+  static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 1;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)(hog - 16) * 1024;       // + ~13 KB static
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&lstm_bwd_persist<TPW, UW>), lds);
