@@ -726,7 +726,8 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
   // 16 x 4 (94 registers, 4 waves per SIMD = 384).  Its 256 workgroups sit on every CU of the chip for the whole sequence, and what
   // they leave free decides which filler workgroups can be co-resident: 224 registers per SIMD admit a 4-wave engine tile (152),
   // 128 admit none of the engine's tiles.  Alone 7.4 instead of 7.0 us per step, in the training step 72.94 -> 72.69 ms (3 + 3 runs,
-  // one GPU session).  RE2E_LSTM_FWD_W8=0 selects the 16-wave form.
+  // one GPU session; and again 71.73 against 71.97 with the chain owning its CUs, RE2E_LSTM_OWN_CU_FRAC = 1, where no engine workgroup
+  // is co-resident any more: half as many waves sweep and meet at the barrier).  RE2E_LSTM_FWD_W8=0 selects the 16-wave form.
   static const int w8 = getenv("RE2E_LSTM_FWD_W8") ? atoi(getenv("RE2E_LSTM_FWD_W8")) : 1;
   if (NX == 64 && w8) return launch_fwd_persist<8, 8, 1>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
 #define RE2E_TRY(W, Q) if (NX == (W) * (Q)) return launch_fwd_persist<W, Q>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H)
