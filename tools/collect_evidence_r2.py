@@ -56,8 +56,8 @@ json.dump({'kernel': KERNEL,
                        'wave_cycles_split': {k: c['SQ_' + k] / c['SQ_WAVE_CYCLES'] for k in ('WAIT_INST_ANY', 'WAIT_ANY', 'ACTIVE_INST_ANY')},
                        'lds_bank_conflict_share_of_lds_active_cycles': c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'],
                        'wait_inst_lds_share_of_wave_cycles': c['SQ_WAIT_INST_LDS'] / c['SQ_WAVE_CYCLES'],
-                       'valu_instructions_per_mfma': c['SQ_INSTS_VALU'] / (c['SQ_VALU_MFMA_BUSY_CYCLES'] / 64) / 2.0,
-                       'valu_instructions_earlier_this_round': 118912000.0},
+                       'other_vector_instructions_per_mfma': (c['SQ_INSTS_VALU'] - c['SQ_VALU_MFMA_BUSY_CYCLES'] / 64) / (c['SQ_VALU_MFMA_BUSY_CYCLES'] / 64),
+                       'other_vector_instructions_per_mfma_earlier_this_round': (118912000.0 - 73728000.0) / 73728000.0},
            'notes': 'SQ_VALU_MFMA_BUSY_CYCLES = 64 x the algorithmic MFMA count (no wasted matrix work).  SQ_INSTS_VALU fell from 118.9M to '
                     '104.1M per launch with the lane-constant addressing (an interior patch issues no vector instruction per load / store; the '
                     'rest are accumulator initialisation, ReLU and the border patches), SQ_WAIT_ANY from 265M to 135M quad-cycles.  See DESIGN.md '
