@@ -177,8 +177,10 @@ int re2e_loss_bwd(const float* a, const float* b, float target, long n, int kind
 int re2e_sumsq(const float* x, long n, float* out, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 
 /* ---- K5 pooling + VGG output packing (e2e_encoder.py:259-278) ------------------------------ */
-/* 2x2/2 ceil-mode max pool over NHWC; idx_u8 stores the argmax (0..3) for the backward */
-int re2e_maxpool2_fwd(const float* in, int NI, int H, int W, int C, float* out, unsigned char* idx_u8,
+/* 2x2/2 ceil-mode max pool over NHWC; idx_u8 stores the argmax (0..3) for the backward.  relu_in != 0: `in` is the output of the
+ * ReLU of the convolution in front (e2e_encoder.py:260-261,264-265) and the pool's backward is to return the gradient of that
+ * ReLU's INPUT: windows whose maximum is <= 0 get index 4, so re2e_maxpool2_bwd leaves their gradient out -- d(relu) costs no pass */
+int re2e_maxpool2_fwd(const float* in, int NI, int H, int W, int C, float* out, unsigned char* idx_u8, int relu_in,
                       re2e_stream_t stream);
 int re2e_maxpool2_bwd(const float* dout, const unsigned char* idx_u8, int NI, int H, int W, int C, float* din,
                       re2e_stream_t stream);

@@ -428,8 +428,10 @@ extern "C" int re2e_sumsq(const float* x, long n, float* out, void* workspace, s
 }
 
 // ---- K5 max pool 2x2 stride 2 ceil mode over NHWC -------------------------------------------
+// relu_in: the input is the output of a ReLU whose backward this pool's backward also performs -- a window whose maximum is <= 0 gets
+// index 4, which no position matches, so its gradient is dropped exactly as dy * (y > 0) would drop it
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ in, int NI, int H, int W, int C, float* __restrict__ out,
-                                    unsigned char* __restrict__ idx) {
+                                    unsigned char* __restrict__ idx, int relu_in) {
   int OH = (H + 1) / 2, OW = (W + 1) / 2;
   long tot = (long)NI * OH * OW * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
@@ -443,14 +445,14 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ in, int NI, int H,
         if (v > best) { best = v; bi = d; }     // first max wins (PyTorch order: row-major scan)
       }
     }
-    out[i] = best; idx[i] = (unsigned char)bi;
+    out[i] = best; idx[i] = (unsigned char)((relu_in && !(best > 0.f)) ? 4 : bi);
   }
 }
 // four channels per thread (C % 4 == 0, 16-byte aligned tensors): float4 loads / stores, one index word per thread,
 // a quarter of the index arithmetic -- these kernels move 0.7-1.2 GB per call at config 4
 typedef unsigned char uchar4v __attribute__((ext_vector_type(4)));
 __global__ void maxpool2_fwd_vec_kernel(const float* __restrict__ in, int NI, int H, int W, int C4, float* __restrict__ out,
-                                        unsigned char* __restrict__ idx) {
+                                        unsigned char* __restrict__ idx, int relu_in) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const long tot = (long)NI * OH * OW * C4;
   const f32x4* in4 = reinterpret_cast<const f32x4*>(in);
@@ -469,6 +471,10 @@ __global__ void maxpool2_fwd_vec_kernel(const float* __restrict__ in, int NI, in
       }
     }
     reinterpret_cast<f32x4*>(out)[i] = best;
+    if (relu_in) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bi[k] = best[k] > 0.f ? bi[k] : 4;
+    }
     uchar4v b = {(unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]};
     reinterpret_cast<uchar4v*>(idx)[i] = b;
   }
@@ -492,16 +498,16 @@ __global__ void maxpool2_bwd_vec_kernel(const float* __restrict__ dout, const un
 static inline bool pool_vec_ok(const void* a, const void* b, const void* c, int C) {
   return C % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && (reinterpret_cast<uintptr_t>(c) & 3) == 0;
 }
-extern "C" int re2e_maxpool2_fwd(const float* in, int NI, int H, int W, int C, float* out, unsigned char* idx,
+extern "C" int re2e_maxpool2_fwd(const float* in, int NI, int H, int W, int C, float* out, unsigned char* idx, int relu_in,
                                  hipStream_t stream) {
   RE2E_CHECK_ARG(in && out && idx && NI > 0 && H > 0 && W > 0 && C > 0, "bad args");
   long tot = (long)NI * ((H + 1) / 2) * ((W + 1) / 2) * C;
   if (pool_vec_ok(in, out, idx, C)) {
-    hipLaunchKernelGGL(maxpool2_fwd_vec_kernel, dim3(grid_for(tot / 4)), dim3(TPB), 0, stream, in, NI, H, W, C / 4, out, idx);
+    hipLaunchKernelGGL(maxpool2_fwd_vec_kernel, dim3(grid_for(tot / 4)), dim3(TPB), 0, stream, in, NI, H, W, C / 4, out, idx, relu_in);
     RE2E_LAUNCH_CHECK();
     return RE2E_OK;
   }
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(tot)), dim3(TPB), 0, stream, in, NI, H, W, C, out, idx);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(tot)), dim3(TPB), 0, stream, in, NI, H, W, C, out, idx, relu_in);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

@@ -59,7 +59,7 @@ SIGNATURES = {
     're2e_loss_fwd': (I, [P, P, F, L, I, P, P, Z, P]),
     're2e_loss_bwd': (I, [P, P, F, L, I, P, F, P, F, P]),
     're2e_sumsq': (I, [P, L, P, P, Z, P]),
-    're2e_maxpool2_fwd': (I, [P, I, I, I, I, P, P, P]),
+    're2e_maxpool2_fwd': (I, [P, I, I, I, I, P, P, I, P]),
     're2e_maxpool2_bwd': (I, [P, P, I, I, I, I, P, P]),
     're2e_vgg_pack_fwd': (I, [P, P, I, I, I, I, P, I, I, P]),
     're2e_vgg_pack_bwd': (I, [P, P, I, I, I, I, P, I, I, P]),

@@ -4,6 +4,7 @@ Internal layouts are MI355X-first: NHWC through the conv stack, time-major (T,B,
 recurrent stack; module boundaries stay batch-first (B,T,F) like the reference."""
 import logging
 import math
+import os
 import sys
 
 import torch
@@ -11,6 +12,8 @@ import torch
 from .. import ops
 from ..lib import Re2eError
 from .e2e_common import ConvParams, LinearParams, LSTMParams, _get_vgg2l_odim, lens_dev, lens_list
+
+FUSE_RELU_POOL_BWD = os.environ.get('RE2E_NO_RELU_POOL_FUSION') is None      # A/B switch (ops.conv2d relu_bwd_in_pool)
 
 
 class BLSTM(torch.nn.Module):
@@ -106,11 +109,12 @@ class VGG2L(torch.nn.Module):
         B, T, Fd = xs.shape
         h = xs.contiguous().view(B, T, Fd, 1)                                     # NCHW (B,1,T,F) == NHWC (B,T,F,1)
         h = ops.conv2d(h, self.conv1_1.weight, self.conv1_1.bias, 1, 1, 'relu')
-        h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu')
-        h = ops.maxpool2(h)
+        # conv -> ReLU -> pool: the pool's backward also performs the ReLU's (ops.maxpool2 relu_in)
+        h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu', relu_bwd_in_pool=FUSE_RELU_POOL_BWD)
+        h = ops.maxpool2(h, relu_in=FUSE_RELU_POOL_BWD)
         h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu')
-        h = ops.conv2d(h, self.conv2_2.weight, self.conv2_2.bias, 1, 1, 'relu')
-        return ops.maxpool2(h)
+        h = ops.conv2d(h, self.conv2_2.weight, self.conv2_2.bias, 1, 1, 'relu', relu_bwd_in_pool=FUSE_RELU_POOL_BWD)
+        return ops.maxpool2(h, relu_in=FUSE_RELU_POOL_BWD)
 
     @staticmethod
     def pooled_lens(ilens):

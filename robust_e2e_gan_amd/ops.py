@@ -438,19 +438,20 @@ class Conv2dFn(torch.autograd.Function):
     """x: (N,H,W,Cin) NHWC; W: (Cout,Cin,KH,KW) PyTorch layout; returns (N,OH,OW,Cout)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, stride, pad, act):
+    def forward(ctx, x, W, b, stride, pad, act, act_bwd_done=False):
         _need_gpu(x)
         x = _f32(x)
         N, H, Wd, Cin = x.shape
         Cout, _, KH, KW = W.shape
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(Wd, KW, stride, pad)
+        ctx.act_bwd_done = bool(act_bwd_done)          # the ONLY consumer (maxpool2(relu_in=True)) returns d(pre-activation)
         wg = empty((Cout, KH, KW, Cin), x)
         call('re2e_conv_weight_gather', W.data_ptr(), wg.data_ptr(), Cout, Cin, KH, KW, 0, KH, KW, 0, 0, 1)
         y = empty((N, OH, OW, Cout), x)
         call('re2e_conv_igemm', x.data_ptr(), N, H, Wd, Cin, wg.data_ptr(), Cout, KH, KW, OH, OW, stride, stride, 1, 1, -pad, -pad,
              y.data_ptr(), OH, OW, 1, 1, 0, 0, ptr(b), act, 0.0)
         ctx.W, ctx.b, ctx.cfg = W, b, (stride, pad, act)
-        ctx.save_for_backward(x, y if act != lib.ACT_NONE else None)
+        ctx.save_for_backward(x, y if (act != lib.ACT_NONE and not ctx.act_bwd_done) else None)
         return y
 
     @staticmethod
@@ -458,6 +459,9 @@ class Conv2dFn(torch.autograd.Function):
         x, y = ctx.saved_tensors
         W, b = ctx.W, ctx.b
         stride, pad, act = ctx.cfg
+        if ctx.act_bwd_done:
+            act = lib.ACT_NONE                       # dy already is d(pre-activation): no pass over dy and y, the bias gradient is a
+            #                                          plain column sum on the weight-gradient stream
         N, H, Wd, Cin = x.shape
         Cout, _, KH, KW = W.shape
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(Wd, KW, stride, pad)
@@ -477,7 +481,7 @@ class Conv2dFn(torch.autograd.Function):
             if b is not None and need_b and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, N * OH * OW, Cout, gb, beta)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 def conv_dgrad(dz, W, xshape, stride, pad):
@@ -517,8 +521,13 @@ def conv_dgrad(dz, W, xshape, stride, pad):
     return dx
 
 
-def conv2d(x, W, b=None, stride=1, pad=1, act=None):
-    return Conv2dFn.apply(x, W, b, stride, pad, ACT[act])
+def conv2d(x, W, b=None, stride=1, pad=1, act=None, relu_bwd_in_pool=False):
+    """``relu_bwd_in_pool``: act is 'relu' and the result goes ONLY into ``maxpool2(y, relu_in=True)``, whose backward applies the
+    ReLU's derivative (a pooled maximum <= 0 passes nothing back): this convolution's backward then skips the pass that would
+    read dy and y and write dz (1.6 GB for VGG conv1_2 at config 4) and takes its bias gradient as a column sum of dy."""
+    if relu_bwd_in_pool and act != 'relu':
+        raise lib.Re2eError('relu_bwd_in_pool needs act="relu"')
+    return Conv2dFn.apply(x, W, b, stride, pad, ACT[act], relu_bwd_in_pool)
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
@@ -607,14 +616,18 @@ def activation(x, act):
 
 
 class MaxPool2Fn(torch.autograd.Function):
+    """2x2 / stride-2 ceil-mode max pool over NHWC.  ``relu_in``: x is the output of ``conv2d(..., act='relu',
+    relu_bwd_in_pool=True)`` -- the pool's backward then returns the gradient of that ReLU's INPUT (windows with a maximum <= 0
+    pass nothing back) and the convolution's backward skips its own activation pass."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, relu_in):
         _need_gpu(x)
         x = _f32(x)
         N, H, W, C = x.shape
         y = empty((N, (H + 1) // 2, (W + 1) // 2, C), x)
         idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
-        call('re2e_maxpool2_fwd', x.data_ptr(), N, H, W, C, y.data_ptr(), idx.data_ptr())
+        call('re2e_maxpool2_fwd', x.data_ptr(), N, H, W, C, y.data_ptr(), idx.data_ptr(), 1 if relu_in else 0)
         ctx.save_for_backward(idx)
         ctx.xshape = x.shape
         return y
@@ -626,10 +639,11 @@ class MaxPool2Fn(torch.autograd.Function):
         dy = _f32(dy)
         dx = empty(ctx.xshape, dy)
         call('re2e_maxpool2_bwd', dy.data_ptr(), idx.data_ptr(), N, H, W, C, dx.data_ptr())
-        return dx
+        return dx, None
 
 
-maxpool2 = MaxPool2Fn.apply
+def maxpool2(x, relu_in=False):
+    return MaxPool2Fn.apply(x, relu_in)
 
 
 class VggPackFn(torch.autograd.Function):

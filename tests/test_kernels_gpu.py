@@ -284,6 +284,33 @@ def test_pool_and_pack(C):
     close('dx', xg.grad.permute(0, 3, 1, 2), xr.grad, tol=1e-6)
 
 
+@pytest.mark.parametrize('Cin,Cout', [(16, 64), (3, 6)])      # halo-patch conv + float4 pool / general engine + scalar pool
+def test_conv_relu_pool_backward_in_pool(Cin, Cout):
+    """conv2d(act=relu, relu_bwd_in_pool) -> maxpool2(relu_in): the pool's index byte carries the ReLU mask, the convolution's
+    backward skips its activation pass; every gradient equals conv -> relu -> max_pool2d(ceil_mode) of torch"""
+    ops, lib = _ops()
+    x, W, b = rnd(2, Cin, 21, 13), rnd(Cout, Cin, 3, 3, seed=1, scale=0.2), rnd(Cout, seed=2)
+    xr, Wr, br = [t.clone().requires_grad_(True) for t in (x, W, b)]
+    yr = F.max_pool2d(F.relu(F.conv2d(xr, Wr, br, padding=1)), 2, stride=2, ceil_mode=True)
+    go = rnd(*yr.shape, seed=3)
+    (yr * go).sum().backward()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    Wg, bg = torch.nn.Parameter(W.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    y = ops.maxpool2(ops.conv2d(xg, Wg, bg, 1, 1, 'relu', relu_bwd_in_pool=True), relu_in=True)
+    (y * go.permute(0, 2, 3, 1).contiguous().to(DEV)).sum().backward()
+    close('y', y.permute(0, 3, 1, 2), yr, tol=2e-5)
+    close('dx', xg.grad.permute(0, 3, 1, 2), xr.grad, tol=2e-5)
+    close('dW', Wg.grad, Wr.grad, tol=2e-5)
+    close('db', bg.grad, br.grad, tol=2e-5)
+    # the unfused composition gives the same numbers
+    xg2 = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    W2, b2 = torch.nn.Parameter(W.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    y2 = ops.maxpool2(ops.conv2d(xg2, W2, b2, 1, 1, 'relu'))
+    (y2 * go.permute(0, 2, 3, 1).contiguous().to(DEV)).sum().backward()
+    assert torch.equal(y, y2) and torch.equal(xg.grad, xg2.grad) and torch.equal(Wg.grad, W2.grad)
+    close('db vs unfused', bg.grad, b2.grad, tol=1e-6)
+
+
 @pytest.mark.parametrize('N,C,H,W', [(3, 16, 9, 5), (3, 6, 9, 5), (5, 128, 67, 31)])     # float4 path, scalar path, many rows per chunk
 def test_bn_lrelu(N, C, H, W):
     ops, lib = _ops()
