@@ -80,6 +80,13 @@ int re2e_gemm(int transa, int transb, int M, int N, int K, const float* A, long 
 int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW, int PH,
                     int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF, int OWF, int osy,
                     int osx, int ooy, int oox, const float* bias, int act, float beta, re2e_stream_t stream);
+/* The same product (no bias, no activation, dense output) followed by out = relu_out > 0 ? out : 0, `relu_out` an (NI,PH,PW,Cout)
+ * tensor: the data gradient of a convolution whose INPUT was the ReLU output `relu_out` of the layer in front, taken through that
+ * ReLU in the same launch (e2e_encoder.py:259-265: conv1_1 -> ReLU -> conv1_2, conv2_1 -> ReLU -> conv2_2), so the layer in front
+ * needs no activation-backward pass.  3x3 / stride-1 geometries apply the mask in the kernel's epilogue, others in a second pass. */
+int re2e_conv_igemm_masked(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW, int PH,
+                           int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF, int OWF, int osy,
+                           int osx, int ooy, int oox, const float* relu_out, re2e_stream_t stream);
 size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW);
 /* dW[Cout][C][KH][KW] = beta*dW + sum_pix dout[pix][co] * in[n][py*SY+kh+OY0][px*SX+kw+OX0][ci] */
 int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, int KH, int KW, int PH,

@@ -37,6 +37,7 @@ constexpr unsigned OOB = 0x80000000u;   // byte offset beyond any tensor this pa
 
 struct HaloArgs {
   const float* in; const float* wg; float* out; const float* bias;
+  const float* mask;                      // optional, shape of out: out = mask > 0 ? value : 0 (the ReLU derivative of the layer in front)
   int NI, H, W, C, Cout, act; float beta;
   int tiles_x, tiles_y, ngn, nitems;      // patches per row / column, 64-channel groups, work items = patches x groups
   int ipw;                                // items per workgroup; 0 = persistent workgroups
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
 #endif
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wg), 0, p.wg_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.out), 0, p.out_bytes, 0x00020000);
 
   // ---- staging: a wave-instruction moves 16 rows (pixels / output channels) x 64 bytes, 4 lanes per row.  (Measured and
   // rejected, same GPU session: a lane order that makes the ds_write_b128 of the 20-float rows bank-conflict-free -- 8
@@ -278,14 +280,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
       if (p.beta == 0.f && y0 + TH <= p.H && x0 + TW <= p.W) {
         // whole patch inside the image, plain store: lane-constant offsets + one scalar offset per item
         const unsigned o_s = (unsigned)(((((long)n * p.H + y0) * p.W + x0) * p.Cout + n0) * 4);
+        if (p.mask) {
+          // data gradient through the ReLU of the layer in front: four mask rows in flight at a time
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Os + (it * 4 + prow) * LDO + c4);
+          for (int i4 = 0; i4 < 16; i4 += 4) {
+            f32x4 mk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mk[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsM, o_rel[i4 + u], o_s, 0));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              f32x4 v = *reinterpret_cast<const f32x4*>(Os + ((i4 + u) * 4 + prow) * LDO + c4);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = mk[u][k] > 0.f ? v[k] : 0.f;
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, o_rel[i4 + u], o_s, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < 16; ++it) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Os + (it * 4 + prow) * LDO + c4);
 #ifndef RE2E_HALO_NOSTORE      // diagnostic builds only (tools/micro/conv3x3_probe.hip)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, o_rel[it], o_s, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, o_rel[it], o_s, 0);
 #else
-          if (v[0] == 1.2345e30f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, o_rel[it], o_s, 0);
+            if (v[0] == 1.2345e30f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, o_rel[it], o_s, 0);
 #endif
+          }
         }
       } else {
 #pragma unroll
@@ -296,6 +315,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
           if (y < p.H && x < p.W) {
             f32x4 v = *reinterpret_cast<const f32x4*>(Os + m * LDO + c4);
             float* dst = p.out + ((((long)n * p.H + y) * p.W + x) * p.Cout + n0 + c4);
+            if (p.mask) {
+              const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (dst - p.out));
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = mk[k] > 0.f ? v[k] : 0.f;
+            }
             if (p.beta != 0.f) {
               const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
               v += o;
@@ -348,7 +372,8 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
 
 // Returns true when the geometry is a 3x3 / stride-1 / pad-1 convolution (forward or data-gradient form) this kernel
 // covers and the launch was enqueued; false -> the caller uses the general engine.
-bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, const float* bias, int act, float beta, hipStream_t st) {
+bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, const float* bias, int act, float beta, const float* mask,
+                  hipStream_t st) {
   static const bool off = getenv("RE2E_NO_HALO") != nullptr;     // A/B measurements against the general engine
   if (off) return false;
   if (g.KH != 3 || g.KW != 3 || g.SY != 1 || g.SX != 1 || g.PH != g.H || g.PW != g.W) return false;
@@ -358,13 +383,13 @@ bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, cons
   else return false;
   if (g.C % CK || Cout % NT) return false;
   if (act != RE2E_ACT_NONE && act != RE2E_ACT_RELU) return false;
-  if (reinterpret_cast<uintptr_t>(out) & 15) return false;
+  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask)) & 15) return false;
   const long in_bytes = (long)g.NI * g.H * g.W * g.C * 4, wg_bytes = (long)Cout * 9 * g.C * 4;
   const long out_bytes = (long)g.NI * g.H * g.W * Cout * 4;
   if (in_bytes >= 0x7FFFFF00L || wg_bytes >= 0x7FFFFF00L || out_bytes >= 0x7FFFFF00L) return false;
   if ((reinterpret_cast<uintptr_t>(g.in) | reinterpret_cast<uintptr_t>(wg)) & 15) return false;
   HaloArgs a;
-  a.in = g.in; a.wg = wg; a.out = out; a.bias = bias;
+  a.in = g.in; a.wg = wg; a.out = out; a.bias = bias; a.mask = mask;
   a.NI = g.NI; a.H = g.H; a.W = g.W; a.C = g.C; a.Cout = Cout; a.act = act; a.beta = beta;
   a.ngn = Cout / NT; a.in_bytes = (unsigned)in_bytes; a.wg_bytes = (unsigned)wg_bytes; a.out_bytes = (unsigned)out_bytes;
   // patch shape: 16 x 16 (smaller halo) unless 32 x 8 wastes fewer padded pixels (W = 40: 416 x 40 against 400 x 48)

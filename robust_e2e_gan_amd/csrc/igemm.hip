@@ -1033,10 +1033,16 @@ static void conv_dispatch(const ConvGeom& g, int M, int K, const float* wg, int 
 // Forward / data-gradient implicit GEMM:
 //   out[pix(n,py,px)][co] = act( sum_{kh,kw,ci} in[n][py*SY+kh*DY+OY0][px*SX+kw*DX+OX0][ci] * w[co][kh][kw][ci] + bias[co] )
 // written at out[((n*OHF + py*osy+ooy)*OWF + px*osx+oox)*Cout + co].
-extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW,
-                               int PH, int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF,
-                               int OWF, int osy, int osx, int ooy, int oox, const float* bias, int act, float beta,
-                               hipStream_t stream) {
+// out = mask > 0 ? out : 0 (four channels per thread when the channel count allows): the separate pass of re2e_conv_igemm_masked
+// for geometries the halo-patch kernel does not cover
+__global__ void relu_mask_kernel(float* __restrict__ out, const float* __restrict__ mask, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = mask[i] > 0.f ? out[i] : 0.f;
+}
+
+static int conv_igemm_impl(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW,
+                           int PH, int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF,
+                           int OWF, int osy, int osx, int ooy, int oox, const float* bias, int act, float beta, const float* mask,
+                           hipStream_t stream) {
   RE2E_CHECK_ARG(in && wg && out, "null operand");
   RE2E_CHECK_ARG(NI > 0 && H > 0 && W > 0 && C > 0 && Cout > 0 && PH > 0 && PW > 0, "bad geometry");
   RE2E_CHECK_ARG(act >= 0 && act <= RE2E_ACT_SIGMOID, "bad activation");
@@ -1049,21 +1055,43 @@ extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, con
   ep.C = out; ep.ldc = Cout; ep.M = M; ep.N = Cout; ep.bias = bias; ep.act = act; ep.beta = beta; ep.nsplit = 1;
   ep.remap = 1; ep.PH = PH; ep.PW = PW; ep.OHF = OHF; ep.OWF = OWF; ep.osy = osy; ep.osx = osx; ep.ooy = ooy; ep.oox = oox;
   if (osy == 1 && osx == 1 && ooy == 0 && oox == 0 && OHF == PH && OWF == PW) ep.remap = 0;
-  if ((Cout == 1 || C == 1) && thin_enabled()) {
+  if ((Cout == 1 || C == 1) && thin_enabled() && !mask) {
     OutMap om{out, (long)Cout, ep.remap, PH, PW, OHF, OWF, osy, osx, ooy, oox};
     if (thin_conv_forward(g, wg, Cout, om, bias, act, beta, stream)) {
       RE2E_LAUNCH_CHECK();
       return RE2E_OK;
     }
   }
-  if (!ep.remap && halo_conv3x3(g, wg, Cout, out, bias, act, beta, stream)) {
+  if (!ep.remap && halo_conv3x3(g, wg, Cout, out, bias, act, beta, mask, stream)) {
     RE2E_LAUNCH_CHECK();
     return RE2E_OK;
   }
   if (C % 4 == 0 && aligned16(in) && aligned16(wg)) conv_dispatch<true>(g, M, K, wg, Cout, ep, stream);
   else conv_dispatch<false>(g, M, K, wg, Cout, ep, stream);
+  if (mask) {
+    const long n = (long)NI * OHF * OWF * Cout;
+    const long nb = (n + 255) / 256;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)(nb < 65535 * 8 ? nb : 65535 * 8)), dim3(256), 0, stream, out, mask, n);
+  }
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
+}
+
+extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW,
+                               int PH, int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF,
+                               int OWF, int osy, int osx, int ooy, int oox, const float* bias, int act, float beta,
+                               hipStream_t stream) {
+  return conv_igemm_impl(in, NI, H, W, C, wg, Cout, KH, KW, PH, PW, SY, SX, DY, DX, OY0, OX0, out, OHF, OWF, osy, osx, ooy, oox, bias, act,
+                         beta, nullptr, stream);
+}
+
+extern "C" int re2e_conv_igemm_masked(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW,
+                                      int PH, int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF,
+                                      int OWF, int osy, int osx, int ooy, int oox, const float* relu_out, hipStream_t stream) {
+  RE2E_CHECK_ARG(relu_out, "null mask");
+  RE2E_CHECK_ARG(osy == 1 && osx == 1 && ooy == 0 && oox == 0 && OHF == PH && OWF == PW, "the mask variant covers dense outputs only");
+  return conv_igemm_impl(in, NI, H, W, C, wg, Cout, KH, KW, PH, PW, SY, SX, DY, DX, OY0, OX0, out, OHF, OWF, osy, osx, ooy, oox, nullptr,
+                         RE2E_ACT_NONE, 0.f, relu_out, stream);
 }
 
 // Stride-2 data gradient (transposed convolution) in ONE launch: blockIdx.z walks the four output parity

@@ -13,7 +13,8 @@ from .. import ops
 from ..lib import Re2eError
 from .e2e_common import ConvParams, LinearParams, LSTMParams, _get_vgg2l_odim, lens_dev, lens_list
 
-FUSE_RELU_POOL_BWD = os.environ.get('RE2E_NO_RELU_POOL_FUSION') is None      # A/B switch (ops.conv2d relu_bwd_in_pool)
+FUSE_RELU_POOL_BWD = os.environ.get('RE2E_NO_RELU_POOL_FUSION') is None      # A/B switches (ops.conv2d relu_bwd_in_pool / relu_bwd_in_next)
+FUSE_RELU_CONV_BWD = os.environ.get('RE2E_NO_RELU_CONV_FUSION') is None
 
 
 class BLSTM(torch.nn.Module):
@@ -108,13 +109,16 @@ class VGG2L(torch.nn.Module):
             raise Re2eError('VGG2L with in_channel != 1 is not on the hot path')
         B, T, Fd = xs.shape
         h = xs.contiguous().view(B, T, Fd, 1)                                     # NCHW (B,1,T,F) == NHWC (B,T,F,1)
-        h = ops.conv2d(h, self.conv1_1.weight, self.conv1_1.bias, 1, 1, 'relu')
-        # conv -> ReLU -> pool: the pool's backward also performs the ReLU's (ops.maxpool2 relu_in)
-        h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu', relu_bwd_in_pool=FUSE_RELU_POOL_BWD)
-        h = ops.maxpool2(h, relu_in=FUSE_RELU_POOL_BWD)
-        h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu')
-        h = ops.conv2d(h, self.conv2_2.weight, self.conv2_2.bias, 1, 1, 'relu', relu_bwd_in_pool=FUSE_RELU_POOL_BWD)
-        return ops.maxpool2(h, relu_in=FUSE_RELU_POOL_BWD)
+        # No ReLU-backward pass anywhere in the stack: conv -> ReLU -> conv takes the data gradient of the second convolution through
+        # the ReLU in that kernel's epilogue (x_is_relu_out), conv -> ReLU -> pool folds the ReLU's mask into the pool's index
+        # byte (relu_in).  RE2E_NO_RELU_POOL_FUSION / RE2E_NO_RELU_CONV_FUSION restore the separate passes.
+        fp, fc = FUSE_RELU_POOL_BWD, FUSE_RELU_CONV_BWD
+        h = ops.conv2d(h, self.conv1_1.weight, self.conv1_1.bias, 1, 1, 'relu', relu_bwd_in_next=fc)
+        h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu', relu_bwd_in_pool=fp, x_is_relu_out=fc)
+        h = ops.maxpool2(h, relu_in=fp)
+        h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu', relu_bwd_in_next=fc)
+        h = ops.conv2d(h, self.conv2_2.weight, self.conv2_2.bias, 1, 1, 'relu', relu_bwd_in_pool=fp, x_is_relu_out=fc)
+        return ops.maxpool2(h, relu_in=fp)
 
     @staticmethod
     def pooled_lens(ilens):

@@ -438,13 +438,14 @@ class Conv2dFn(torch.autograd.Function):
     """x: (N,H,W,Cin) NHWC; W: (Cout,Cin,KH,KW) PyTorch layout; returns (N,OH,OW,Cout)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, stride, pad, act, act_bwd_done=False):
+    def forward(ctx, x, W, b, stride, pad, act, act_bwd_done=False, x_is_relu_out=False):
         _need_gpu(x)
         x = _f32(x)
         N, H, Wd, Cin = x.shape
         Cout, _, KH, KW = W.shape
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(Wd, KW, stride, pad)
-        ctx.act_bwd_done = bool(act_bwd_done)          # the ONLY consumer (maxpool2(relu_in=True)) returns d(pre-activation)
+        ctx.act_bwd_done = bool(act_bwd_done)          # the ONLY consumer (maxpool2(relu_in=True) / conv2d(x_is_relu_out=True)) returns d(pre-activation)
+        ctx.x_is_relu_out = bool(x_is_relu_out)        # x = ReLU output of the layer in front: dx is taken through that ReLU (dx = 0 where x <= 0)
         wg = empty((Cout, KH, KW, Cin), x)
         call('re2e_conv_weight_gather', W.data_ptr(), wg.data_ptr(), Cout, Cin, KH, KW, 0, KH, KW, 0, 0, 1)
         y = empty((N, OH, OW, Cout), x)
@@ -470,7 +471,7 @@ class Conv2dFn(torch.autograd.Function):
         dz = dz.view(N, OH, OW, Cout)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad)
+            dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad, relu_out=x if ctx.x_is_relu_out else None)
         with param_grads(dz, x):
             if need_w:
                 wsb = query('re2e_conv_wgrad_workspace_bytes', N, OH, OW, Cin, Cout, KH, KW)
@@ -481,11 +482,12 @@ class Conv2dFn(torch.autograd.Function):
             if b is not None and need_b and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, N * OH * OW, Cout, gb, beta)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
-def conv_dgrad(dz, W, xshape, stride, pad):
-    """Data gradient of an NHWC convolution (see re2e_conv_igemm)."""
+def conv_dgrad(dz, W, xshape, stride, pad, relu_out=None):
+    """Data gradient of an NHWC convolution (see re2e_conv_igemm).  ``relu_out`` (stride 1): the convolution's input, which was
+    the ReLU output of the layer in front -- the gradient is taken through that ReLU as well (re2e_conv_igemm_masked)."""
     N, H, Wd, Cin = xshape
     Cout, _, KH, KW = W.shape
     OH, OW = dz.shape[1], dz.shape[2]
@@ -493,9 +495,15 @@ def conv_dgrad(dz, W, xshape, stride, pad):
         wt = empty((Cin, KH, KW, Cout), dz)
         call('re2e_conv_weight_gather', W.data_ptr(), wt.data_ptr(), Cout, Cin, KH, KW, 1, KH, KW, 0, 0, 1)
         dx = empty((N, H, Wd, Cin), dz)
-        call('re2e_conv_igemm', dz.data_ptr(), N, OH, OW, Cout, wt.data_ptr(), Cin, KH, KW, H, Wd, 1, 1, -1, -1, pad, pad,
-             dx.data_ptr(), H, Wd, 1, 1, 0, 0, None, lib.ACT_NONE, 0.0)
+        if relu_out is not None:
+            call('re2e_conv_igemm_masked', dz.data_ptr(), N, OH, OW, Cout, wt.data_ptr(), Cin, KH, KW, H, Wd, 1, 1, -1, -1, pad, pad,
+                 dx.data_ptr(), H, Wd, 1, 1, 0, 0, relu_out.data_ptr())
+        else:
+            call('re2e_conv_igemm', dz.data_ptr(), N, OH, OW, Cout, wt.data_ptr(), Cin, KH, KW, H, Wd, 1, 1, -1, -1, pad, pad,
+                 dx.data_ptr(), H, Wd, 1, 1, 0, 0, None, lib.ACT_NONE, 0.0)
         return dx
+    if relu_out is not None:
+        raise lib.Re2eError('conv_dgrad: relu_out needs stride 1')
     if stride != 2 or KH % 2 or KW % 2:
         raise lib.Re2eError('conv data gradient supports stride 1, or stride 2 with even kernels')
     if Cin != 1:    # all four output parity classes in one launch
@@ -521,13 +529,17 @@ def conv_dgrad(dz, W, xshape, stride, pad):
     return dx
 
 
-def conv2d(x, W, b=None, stride=1, pad=1, act=None, relu_bwd_in_pool=False):
-    """``relu_bwd_in_pool``: act is 'relu' and the result goes ONLY into ``maxpool2(y, relu_in=True)``, whose backward applies the
-    ReLU's derivative (a pooled maximum <= 0 passes nothing back): this convolution's backward then skips the pass that would
-    read dy and y and write dz (1.6 GB for VGG conv1_2 at config 4) and takes its bias gradient as a column sum of dy."""
-    if relu_bwd_in_pool and act != 'relu':
-        raise lib.Re2eError('relu_bwd_in_pool needs act="relu"')
-    return Conv2dFn.apply(x, W, b, stride, pad, ACT[act], relu_bwd_in_pool)
+def conv2d(x, W, b=None, stride=1, pad=1, act=None, relu_bwd_in_pool=False, relu_bwd_in_next=False, x_is_relu_out=False):
+    """``relu_bwd_in_pool`` / ``relu_bwd_in_next``: act is 'relu' and the result goes ONLY into ``maxpool2(y, relu_in=True)`` /
+    ``conv2d(y, ..., x_is_relu_out=True)``, whose backward applies the ReLU's derivative (a pooled maximum <= 0 passes nothing back;
+    the next convolution's data gradient is masked by its input > 0 in the kernel's epilogue): this convolution's backward then
+    skips the pass that would read dy and y and write dz (1.6 GB for a 64-channel VGG layer at config 4) and takes its bias
+    gradient as a column sum of dy.  ``x_is_relu_out``: the counterpart flag on the consuming convolution (stride 1)."""
+    if (relu_bwd_in_pool or relu_bwd_in_next) and act != 'relu':
+        raise lib.Re2eError('relu_bwd_in_pool / relu_bwd_in_next need act="relu"')
+    if x_is_relu_out and stride != 1:
+        raise lib.Re2eError('x_is_relu_out needs stride 1')
+    return Conv2dFn.apply(x, W, b, stride, pad, ACT[act], relu_bwd_in_pool or relu_bwd_in_next, x_is_relu_out)
 
 
 class ConvTranspose2dFn(torch.autograd.Function):

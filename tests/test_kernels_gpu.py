@@ -311,6 +311,29 @@ def test_conv_relu_pool_backward_in_pool(Cin, Cout):
     close('db vs unfused', bg.grad, b2.grad, tol=1e-6)
 
 
+@pytest.mark.parametrize('C0,C1,C2', [(1, 64, 64), (16, 64, 128), (3, 6, 10)])   # VGG's first pair; halo epilogue mask; second-pass mask
+def test_conv_relu_conv_backward_through_relu(C0, C1, C2):
+    """conv2d(relu, relu_bwd_in_next) -> conv2d(relu, x_is_relu_out, relu_bwd_in_pool) -> maxpool2(relu_in): no activation-backward
+    pass anywhere; every gradient equals torch's conv -> relu -> conv -> relu -> max_pool2d"""
+    ops, lib = _ops()
+    x = rnd(2, C0, 37, 19)
+    W1, b1, W2, b2 = rnd(C1, C0, 3, 3, seed=1, scale=0.3), rnd(C1, seed=2, scale=0.3), rnd(C2, C1, 3, 3, seed=3, scale=0.1), rnd(C2, seed=4, scale=0.3)
+    ref = [t.clone().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+    yr = F.max_pool2d(F.relu(F.conv2d(F.relu(F.conv2d(ref[0], ref[1], ref[2], padding=1)), ref[3], ref[4], padding=1)), 2, stride=2, ceil_mode=True)
+    go = rnd(*yr.shape, seed=5)
+    (yr * go).sum().backward()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    P = [torch.nn.Parameter(t.to(DEV)) for t in (W1, b1, W2, b2)]
+    h = ops.conv2d(xg, P[0], P[1], 1, 1, 'relu', relu_bwd_in_next=True)
+    h = ops.conv2d(h, P[2], P[3], 1, 1, 'relu', relu_bwd_in_pool=True, x_is_relu_out=True)
+    y = ops.maxpool2(h, relu_in=True)
+    (y * go.permute(0, 2, 3, 1).contiguous().to(DEV)).sum().backward()
+    close('y', y.permute(0, 3, 1, 2), yr, tol=3e-5)
+    close('dx', xg.grad.permute(0, 3, 1, 2), ref[0].grad, tol=3e-5)
+    for name, g, r in zip(('dW1', 'db1', 'dW2', 'db2'), P, ref[1:]):
+        close(name, g.grad, r.grad, tol=3e-5)
+
+
 @pytest.mark.parametrize('N,C,H,W', [(3, 16, 9, 5), (3, 6, 9, 5), (5, 128, 67, 31)])     # float4 path, scalar path, many rows per chunk
 def test_bn_lrelu(N, C, H, W):
     ops, lib = _ops()
