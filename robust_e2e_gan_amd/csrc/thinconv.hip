@@ -11,6 +11,8 @@
 //   * wgrad_cout1_kernel: dW[tap][ci]  = sum_pix dout[pix] * in[pix+tap][ci]                  (Cout = 1)
 // Weight gradients are written as per-workgroup partial slabs [slab][tap*C+ci][co] and summed by the
 // implicit-GEMM engine's deterministic split-K reduce (fixed order => run-to-run bitwise stable).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -100,6 +102,64 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvGeom g, const float
       if (beta != 0.f) v += o.out[off];
       o.out[off] = v;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cout == 1, 64 channels, 3x3 / stride 1 / pad 1 (the data gradient of VGG conv1_1: 1 GB of dz at config 4 -> one value per pixel).
+// conv_cout1_kernel reads every pixel's 64 channels once per tap (9x, served by L2: ~1 TB/s of useful input).  Here the product is
+// split the other way round: a workgroup owns TH output rows of one image, FIRST projects every input pixel of its TH + 2 rows onto
+// the 9 tap vectors (each pixel's 256 bytes read ONCE by one thread, weights wave-uniform) into a
+// [row][column][9] table in LDS, THEN every output pixel adds its 9 table entries.  HBM traffic = (TH + 2) / TH of the input.
+// ---------------------------------------------------------------------------------------------
+template <int TH>
+__global__ __launch_bounds__(256) void conv_cout1_rows3x3_kernel(ConvGeom g, const float* __restrict__ wg, OutMap o, const float* __restrict__ bias,
+                                                                 int act, float beta) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* tab = sm;                                        // [(TH + 2)][W + 2][9], column 0 and W + 1 = outside the image (zero)
+  const int W2 = g.W + 2, tid = threadIdx.x;
+  const int tiles_y = (g.H + TH - 1) / TH;
+  const int n = blockIdx.x / tiles_y, y0 = (blockIdx.x - n * tiles_y) * TH;
+  for (int i = tid; i < (TH + 2) * W2 * 9; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  // projection: ONE thread per input pixel -- its 64 channels are 16 float4 loads (the four quarters of a 64-byte segment go to four
+  // consecutive instructions of the same thread), the weights are wave-uniform (scalar loads), no cross-lane reduction
+  const int npx = (TH + 2) * g.W;
+  const f32x4* in4 = reinterpret_cast<const f32x4*>(g.in) + (long)n * g.H * g.W * 16;
+  for (int q = tid; q < npx; q += 256) {
+    const int rr = q / g.W, xx = q - rr * g.W, iy = y0 - 1 + rr;
+    if (iy < 0 || iy >= g.H) continue;
+    const f32x4* px = in4 + ((long)iy * g.W + xx) * 16;
+    float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c4 = 0; c4 < 16; ++c4) {
+      const f32x4 v = px[c4];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float* wt = wg + t * 64 + c4 * 4;           // uniform address: scalar loads
+        s[t] = fmaf(v[0], wt[0], s[t]); s[t] = fmaf(v[1], wt[1], s[t]); s[t] = fmaf(v[2], wt[2], s[t]); s[t] = fmaf(v[3], wt[3], s[t]);
+      }
+    }
+    float* dst = tab + (rr * W2 + xx + 1) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dst[t] = s[t];
+  }
+  __syncthreads();
+  const float b = bias ? bias[0] : 0.f;
+  for (int q = tid; q < TH * g.W; q += 256) {
+    const int ry = q / g.W, x = q - ry * g.W, py = y0 + ry;
+    if (py >= g.H) break;
+    float acc = b;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int r = ry + 1 + kh * g.DY + g.OY0;           // table row of input row py + kh*DY + OY0
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) acc += tab[(r * W2 + x + 1 + kw * g.DX + g.OX0) * 9 + kh * 3 + kw];
+    }
+    const long off = ((long)n * g.H + py) * g.W + x;       // dense single-channel output
+    float val = apply_act(acc, act);
+    if (beta != 0.f) val += o.out[off];
+    o.out[off] = val;
   }
 }
 
@@ -298,6 +358,18 @@ bool thin_conv_forward(const ConvGeom& g, const float* wg, int Cout, const OutMa
     return true;
   }
   if (!(Cout == 1 && g.C % 4 == 0 && K <= 16384 && aligned16(g.in) && aligned16(wg))) return false;
+  // 64 channels, 3x3, stride 1, taps within one pixel of the output position, dense single-channel output: row-tile kernel
+  static const bool no_rows = getenv("RE2E_NO_COUT1_ROWS") != nullptr;
+  if (!no_rows && g.C == 64 && g.KH == 3 && g.KW == 3 && g.SY == 1 && g.SX == 1 && g.PH == g.H && g.PW == g.W && !o.remap && o.ldc == 1 &&
+      (g.DY == 1 || g.DY == -1) && (g.DX == 1 || g.DX == -1) && g.OY0 == -g.DY && g.OX0 == -g.DX && g.W <= 256) {
+    constexpr int TH = 8;
+    const size_t lds = (size_t)(TH + 2) * (g.W + 2) * 9 * sizeof(float);
+    auto kern = conv_cout1_rows3x3_kernel<TH>;
+    static LdsLimit lim;
+    lim.ensure(reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(g.NI * cdiv(g.H, TH))), dim3(256), lds, st, g, wg, o, bias, act, beta);
+    return true;
+  }
   const int c4n = g.C / 4;
   int L = 1;
   while (L < 64 && c4n % (L * 2) == 0) L *= 2;
