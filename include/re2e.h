@@ -87,6 +87,12 @@ int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, const float* w
 int re2e_conv_igemm_masked(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW, int PH,
                            int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF, int OWF, int osy,
                            int osx, int ooy, int oox, const float* relu_out, re2e_stream_t stream);
+/* 3x3 / stride-1 / pad-1 convolution -> ReLU -> 2x2 / stride-2 ceil-mode max pool in ONE launch (e2e_encoder.py:260-262, 264-266): only the
+ * pooled tensor (NI, ceil(H/2), ceil(W/2), Cout) and its index bytes (re2e_maxpool2_fwd's, with relu_in = 1) are written, the
+ * full-resolution activation never reaches memory.  RE2E_EUNSUPPORTED unless C % 16 == 0, Cout % 64 == 0 and the tensors are 16-byte
+ * aligned and < 2 GiB (the caller then runs re2e_conv_igemm + re2e_maxpool2_fwd). */
+int re2e_conv3x3_relu_pool(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, const float* bias, float* pooled,
+                           unsigned char* idx_u8, re2e_stream_t stream);
 size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW);
 /* dW[Cout][C][KH][KW] = beta*dW + sum_pix dout[pix][co] * in[n][py*SY+kh+OY0][px*SX+kw+OX0][ci] */
 int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, int KH, int KW, int PH,

@@ -38,6 +38,7 @@ constexpr unsigned OOB = 0x80000000u;   // byte offset beyond any tensor this pa
 struct HaloArgs {
   const float* in; const float* wg; float* out; const float* bias;
   const float* mask;                      // optional, shape of out: out = mask > 0 ? value : 0 (the ReLU derivative of the layer in front)
+  float* pool_out; unsigned char* pool_idx;   // optional: ONLY the 2x2 / stride-2 ceil-mode max pool of relu(out) is written (+ its index bytes)
   int NI, H, W, C, Cout, act; float beta;
   int tiles_x, tiles_y, ngn, nitems;      // patches per row / column, 64-channel groups, work items = patches x groups
   int ipw;                                // items per workgroup; 0 = persistent workgroups
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
 #endif
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wg), 0, p.wg_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.out), 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out ? p.out : p.pool_out, 0, p.out ? p.out_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.in), 0, p.mask ? p.out_bytes : 0, 0x00020000);
 
   // ---- staging: a wave-instruction moves 16 rows (pixels / output channels) x 64 bytes, 4 lanes per row.  (Measured and
   // rejected, same GPU session: a lane order that makes the ds_write_b128 of the 20-float rows bank-conflict-free -- 8
@@ -277,7 +278,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
             Os[m * LDO + j * 32 + lr] = RELU ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
           }
       // (no barrier: a wavefront reads back only what it wrote itself, and one wavefront's LDS operations execute in order)
-      if (p.beta == 0.f && y0 + TH <= p.H && x0 + TW <= p.W) {
+      if (p.pool_out) {
+        // conv -> ReLU -> 2x2 max pool: a wavefront's 64 pixels are 64 / TW full rows of the patch (TW = 16: 4 x 16, TW = 8: 8 x 8), i.e.
+        // 16 whole pooling windows; lane = (4 channels, window quarter), 4 passes.  The full-resolution output never reaches memory.
+        // Index byte: first maximum in row-major order, 4 when the maximum is <= 0 (maxpool2_fwd_kernel with relu_in).
+        constexpr int WR = 64 / TW, PC = TW / 2;
+        const int PH2 = (p.H + 1) >> 1, PW2 = (p.W + 1) >> 1;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int t = it * 4 + prow, pr = t / PC, pc = t - pr * PC;
+          const int yy = y0 + wid * WR + 2 * pr, xx = x0 + 2 * pc;
+          if (yy < p.H && xx < p.W) {
+            f32x4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+            int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              if (yy + (d >> 1) < p.H && xx + (d & 1) < p.W) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Os + ((2 * pr + (d >> 1)) * TW + 2 * pc + (d & 1)) * LDO + c4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  if (v[k] > best[k]) { best[k] = v[k]; bi[k] = d; }
+              }
+            }
+            const long po = ((((long)n * PH2 + (yy >> 1)) * PW2 + (xx >> 1)) * p.Cout + n0 + c4);
+            *reinterpret_cast<f32x4*>(p.pool_out + po) = best;
+            typedef unsigned char uchar4h __attribute__((ext_vector_type(4)));
+            uchar4h b4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b4[k] = (unsigned char)(best[k] > 0.f ? bi[k] : 4);
+            *reinterpret_cast<uchar4h*>(p.pool_idx + po) = b4;
+          }
+        }
+      } else if (p.beta == 0.f && y0 + TH <= p.H && x0 + TW <= p.W) {
         // whole patch inside the image, plain store: lane-constant offsets + one scalar offset per item
         const unsigned o_s = (unsigned)(((((long)n * p.H + y0) * p.W + x0) * p.Cout + n0) * 4);
         if (p.mask) {
@@ -373,7 +405,7 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
 // Returns true when the geometry is a 3x3 / stride-1 / pad-1 convolution (forward or data-gradient form) this kernel
 // covers and the launch was enqueued; false -> the caller uses the general engine.
 bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, const float* bias, int act, float beta, const float* mask,
-                  hipStream_t st) {
+                  hipStream_t st, float* pool_out, unsigned char* pool_idx) {
   static const bool off = getenv("RE2E_NO_HALO") != nullptr;     // A/B measurements against the general engine
   if (off) return false;
   if (g.KH != 3 || g.KW != 3 || g.SY != 1 || g.SX != 1 || g.PH != g.H || g.PW != g.W) return false;
@@ -383,13 +415,14 @@ bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, cons
   else return false;
   if (g.C % CK || Cout % NT) return false;
   if (act != RE2E_ACT_NONE && act != RE2E_ACT_RELU) return false;
-  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask)) & 15) return false;
+  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(pool_out)) & 15) return false;
+  if (pool_out && (act != RE2E_ACT_RELU || beta != 0.f || mask || dir != 1 || (reinterpret_cast<uintptr_t>(pool_idx) & 3))) return false;
   const long in_bytes = (long)g.NI * g.H * g.W * g.C * 4, wg_bytes = (long)Cout * 9 * g.C * 4;
   const long out_bytes = (long)g.NI * g.H * g.W * Cout * 4;
   if (in_bytes >= 0x7FFFFF00L || wg_bytes >= 0x7FFFFF00L || out_bytes >= 0x7FFFFF00L) return false;
   if ((reinterpret_cast<uintptr_t>(g.in) | reinterpret_cast<uintptr_t>(wg)) & 15) return false;
   HaloArgs a;
-  a.in = g.in; a.wg = wg; a.out = out; a.bias = bias; a.mask = mask;
+  a.in = g.in; a.wg = wg; a.out = pool_out ? nullptr : out; a.bias = bias; a.mask = mask; a.pool_out = pool_out; a.pool_idx = pool_idx;
   a.NI = g.NI; a.H = g.H; a.W = g.W; a.C = g.C; a.Cout = Cout; a.act = act; a.beta = beta;
   a.ngn = Cout / NT; a.in_bytes = (unsigned)in_bytes; a.wg_bytes = (unsigned)wg_bytes; a.out_bytes = (unsigned)out_bytes;
   // patch shape: 16 x 16 (smaller halo) unless 32 x 8 wastes fewer padded pixels (W = 40: 416 x 40 against 400 x 48)

@@ -1085,6 +1085,19 @@ extern "C" int re2e_conv_igemm(const float* in, int NI, int H, int W, int C, con
                          beta, nullptr, stream);
 }
 
+extern "C" int re2e_conv3x3_relu_pool(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, const float* bias,
+                                      float* pooled, unsigned char* idx_u8, hipStream_t stream) {
+  RE2E_CHECK_ARG(in && wg && pooled && idx_u8, "null operand");
+  RE2E_CHECK_ARG(NI > 0 && H > 0 && W > 0 && C > 0 && Cout > 0, "bad geometry");
+  ConvGeom g{in, NI, H, W, C, H, W, 3, 3, 1, 1, 1, 1, -1, -1};
+  if (!halo_conv3x3(g, wg, Cout, nullptr, bias, RE2E_ACT_RELU, 0.f, nullptr, stream, pooled, idx_u8)) {
+    re2e_set_error("re2e_conv3x3_relu_pool: needs C %% 16 == 0, Cout %% 64 == 0, 16-byte aligned tensors < 2 GiB");
+    return RE2E_EUNSUPPORTED;
+  }
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
 extern "C" int re2e_conv_igemm_masked(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, int KH, int KW,
                                       int PH, int PW, int SY, int SX, int DY, int DX, int OY0, int OX0, float* out, int OHF,
                                       int OWF, int osy, int osx, int ooy, int oox, const float* relu_out, hipStream_t stream) {

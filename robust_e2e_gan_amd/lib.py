@@ -30,6 +30,7 @@ SIGNATURES = {
     're2e_gemm_workspace_bytes': (Z, [I, I, I, I, I]),
     're2e_gemm': (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, I, F, P, P, P, I, P, Z, P]),
     're2e_conv_igemm': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, I, F, P]),
+    're2e_conv3x3_relu_pool': (I, [P, I, I, I, I, P, I, P, P, P, P]),
     're2e_conv_igemm_masked': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, P]),
     're2e_conv_wgrad_workspace_bytes': (Z, [I, I, I, I, I, I, I]),
     're2e_conv_wgrad': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, P, F, P, Z, P]),

@@ -15,6 +15,7 @@ from .e2e_common import ConvParams, LinearParams, LSTMParams, _get_vgg2l_odim, l
 
 FUSE_RELU_POOL_BWD = os.environ.get('RE2E_NO_RELU_POOL_FUSION') is None      # A/B switches (ops.conv2d relu_bwd_in_pool / relu_bwd_in_next)
 FUSE_RELU_CONV_BWD = os.environ.get('RE2E_NO_RELU_CONV_FUSION') is None
+FUSE_CONV_POOL = os.environ.get('RE2E_NO_CONV_POOL_FUSION') is None
 
 
 class BLSTM(torch.nn.Module):
@@ -114,6 +115,10 @@ class VGG2L(torch.nn.Module):
         # byte (relu_in).  RE2E_NO_RELU_POOL_FUSION / RE2E_NO_RELU_CONV_FUSION restore the separate passes.
         fp, fc = FUSE_RELU_POOL_BWD, FUSE_RELU_CONV_BWD
         h = ops.conv2d(h, self.conv1_1.weight, self.conv1_1.bias, 1, 1, 'relu', relu_bwd_in_next=fc)
+        if FUSE_CONV_POOL:          # conv -> ReLU -> pool in one launch: the full-resolution activation is never written
+            h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu', x_is_relu_out=fc, pool=True)
+            h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu', relu_bwd_in_next=fc)
+            return ops.conv2d(h, self.conv2_2.weight, self.conv2_2.bias, 1, 1, 'relu', x_is_relu_out=fc, pool=True)
         h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu', relu_bwd_in_pool=fp, x_is_relu_out=fc)
         h = ops.maxpool2(h, relu_in=fp)
         h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu', relu_bwd_in_next=fc)

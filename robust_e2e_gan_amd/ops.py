@@ -438,20 +438,37 @@ class Conv2dFn(torch.autograd.Function):
     """x: (N,H,W,Cin) NHWC; W: (Cout,Cin,KH,KW) PyTorch layout; returns (N,OH,OW,Cout)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, stride, pad, act, act_bwd_done=False, x_is_relu_out=False):
+    def forward(ctx, x, W, b, stride, pad, act, act_bwd_done=False, x_is_relu_out=False, pool=False):
         _need_gpu(x)
         x = _f32(x)
         N, H, Wd, Cin = x.shape
         Cout, _, KH, KW = W.shape
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(Wd, KW, stride, pad)
-        ctx.act_bwd_done = bool(act_bwd_done)          # the ONLY consumer (maxpool2(relu_in=True) / conv2d(x_is_relu_out=True)) returns d(pre-activation)
+        ctx.act_bwd_done = bool(act_bwd_done or pool)  # the ONLY consumer (maxpool2(relu_in=True) / conv2d(x_is_relu_out=True)) returns d(pre-activation)
         ctx.x_is_relu_out = bool(x_is_relu_out)        # x = ReLU output of the layer in front: dx is taken through that ReLU (dx = 0 where x <= 0)
+        ctx.pool = bool(pool)                          # the result is maxpool2(relu(conv)), 2x2 / stride 2 / ceil mode
         wg = empty((Cout, KH, KW, Cin), x)
         call('re2e_conv_weight_gather', W.data_ptr(), wg.data_ptr(), Cout, Cin, KH, KW, 0, KH, KW, 0, 0, 1)
+        ctx.W, ctx.b, ctx.cfg = W, b, (stride, pad, act)
+        if pool:
+            # one launch: only the pooled activation and its index bytes are written (re2e_conv3x3_relu_pool); geometries the fused
+            # kernel does not cover run the convolution and the pool (with the ReLU mask in its index byte) one after the other
+            yp = empty((N, (OH + 1) // 2, (OW + 1) // 2, Cout), x)
+            idx = torch.empty(yp.shape, dtype=torch.uint8, device=x.device)
+            fused = KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cin % 16 == 0 and Cout % 64 == 0 and x.numel() * 4 < 2 ** 31 - 256 \
+                and N * OH * OW * Cout * 4 < 2 ** 31 - 256
+            if fused:
+                call('re2e_conv3x3_relu_pool', x.data_ptr(), N, H, Wd, Cin, wg.data_ptr(), Cout, ptr(b), yp.data_ptr(), idx.data_ptr())
+            else:
+                y = empty((N, OH, OW, Cout), x)
+                call('re2e_conv_igemm', x.data_ptr(), N, H, Wd, Cin, wg.data_ptr(), Cout, KH, KW, OH, OW, stride, stride, 1, 1, -pad, -pad,
+                     y.data_ptr(), OH, OW, 1, 1, 0, 0, ptr(b), act, 0.0)
+                call('re2e_maxpool2_fwd', y.data_ptr(), N, OH, OW, Cout, yp.data_ptr(), idx.data_ptr(), 1)
+            ctx.save_for_backward(x, idx)
+            return yp
         y = empty((N, OH, OW, Cout), x)
         call('re2e_conv_igemm', x.data_ptr(), N, H, Wd, Cin, wg.data_ptr(), Cout, KH, KW, OH, OW, stride, stride, 1, 1, -pad, -pad,
              y.data_ptr(), OH, OW, 1, 1, 0, 0, ptr(b), act, 0.0)
-        ctx.W, ctx.b, ctx.cfg = W, b, (stride, pad, act)
         ctx.save_for_backward(x, y if (act != lib.ACT_NONE and not ctx.act_bwd_done) else None)
         return y
 
@@ -466,6 +483,10 @@ class Conv2dFn(torch.autograd.Function):
         N, H, Wd, Cin = x.shape
         Cout, _, KH, KW = W.shape
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(Wd, KW, stride, pad)
+        if ctx.pool:                                  # y holds the pool's index bytes: scatter the pooled gradient (ReLU mask included)
+            full = empty((N, OH, OW, Cout), x)
+            call('re2e_maxpool2_bwd', _f32(dy).contiguous().data_ptr(), y.data_ptr(), N, OH, OW, Cout, full.data_ptr())
+            dy, y = full, None
         need_w, need_b = _wants(ctx, 1, W), _wants(ctx, 2, b)      # fixed at graph construction (see LinearFn)
         dz, bias_done = act_bwd_bias(_f32(dy).reshape(N * OH * OW, Cout), y, act, b, need_b)
         dz = dz.view(N, OH, OW, Cout)
@@ -482,7 +503,7 @@ class Conv2dFn(torch.autograd.Function):
             if b is not None and need_b and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, N * OH * OW, Cout, gb, beta)
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 def conv_dgrad(dz, W, xshape, stride, pad, relu_out=None):
@@ -529,17 +550,21 @@ def conv_dgrad(dz, W, xshape, stride, pad, relu_out=None):
     return dx
 
 
-def conv2d(x, W, b=None, stride=1, pad=1, act=None, relu_bwd_in_pool=False, relu_bwd_in_next=False, x_is_relu_out=False):
+def conv2d(x, W, b=None, stride=1, pad=1, act=None, relu_bwd_in_pool=False, relu_bwd_in_next=False, x_is_relu_out=False, pool=False):
     """``relu_bwd_in_pool`` / ``relu_bwd_in_next``: act is 'relu' and the result goes ONLY into ``maxpool2(y, relu_in=True)`` /
     ``conv2d(y, ..., x_is_relu_out=True)``, whose backward applies the ReLU's derivative (a pooled maximum <= 0 passes nothing back;
     the next convolution's data gradient is masked by its input > 0 in the kernel's epilogue): this convolution's backward then
     skips the pass that would read dy and y and write dz (1.6 GB for a 64-channel VGG layer at config 4) and takes its bias
-    gradient as a column sum of dy.  ``x_is_relu_out``: the counterpart flag on the consuming convolution (stride 1)."""
+    gradient as a column sum of dy.  ``x_is_relu_out``: the counterpart flag on the consuming convolution (stride 1).
+    ``pool``: return maxpool2(relu(conv(x))) (2x2, stride 2, ceil mode) -- for 3x3 / stride-1 / pad-1 layers with C % 16 == 0 and
+    Cout % 64 == 0 in ONE launch that never writes the full-resolution activation (re2e_conv3x3_relu_pool)."""
     if (relu_bwd_in_pool or relu_bwd_in_next) and act != 'relu':
         raise lib.Re2eError('relu_bwd_in_pool / relu_bwd_in_next need act="relu"')
     if x_is_relu_out and stride != 1:
         raise lib.Re2eError('x_is_relu_out needs stride 1')
-    return Conv2dFn.apply(x, W, b, stride, pad, ACT[act], relu_bwd_in_pool or relu_bwd_in_next, x_is_relu_out)
+    if pool and act != 'relu':
+        raise lib.Re2eError('pool=True is conv -> ReLU -> maxpool2: act must be "relu"')
+    return Conv2dFn.apply(x, W, b, stride, pad, ACT[act], relu_bwd_in_pool or relu_bwd_in_next, x_is_relu_out, pool)
 
 
 class ConvTranspose2dFn(torch.autograd.Function):

@@ -311,6 +311,35 @@ def test_conv_relu_pool_backward_in_pool(Cin, Cout):
     close('db vs unfused', bg.grad, b2.grad, tol=1e-6)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 37, 19, 16, 64), (1, 40, 83, 64, 64), (2, 33, 8, 128, 128), (2, 9, 7, 6, 10)])
+def test_conv_relu_pool_one_launch(N, H, W, Cin, Cout):
+    """conv2d(..., act=relu, pool=True): re2e_conv3x3_relu_pool (16x16 and 32x8 patches, ragged / odd edges, two channel groups) or,
+    for the last shape, the unfused fallback -- output and index bytes identical to conv -> maxpool2(relu_in), gradients as torch's"""
+    ops, lib = _ops()
+    x, Wt, b = rnd(N, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=1, scale=0.15), rnd(Cout, seed=2, scale=0.3)
+    xr, Wr, br = [t.clone().requires_grad_(True) for t in (x, Wt, b)]
+    yr = F.max_pool2d(F.relu(F.conv2d(xr, Wr, br, padding=1)), 2, stride=2, ceil_mode=True)
+    go = rnd(*yr.shape, seed=3)
+    (yr * go).sum().backward()
+    outs = []
+    for fused in (True, False):
+        xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+        Wg, bg = torch.nn.Parameter(Wt.to(DEV)), torch.nn.Parameter(b.to(DEV))
+        if fused:
+            y = ops.conv2d(xg, Wg, bg, 1, 1, 'relu', pool=True)
+        else:
+            y = ops.maxpool2(ops.conv2d(xg, Wg, bg, 1, 1, 'relu', relu_bwd_in_pool=True), relu_in=True)
+        (y * go.permute(0, 2, 3, 1).contiguous().to(DEV)).sum().backward()
+        outs.append((y, xg.grad, Wg.grad, bg.grad))
+    y, dx, dW, db = outs[0]
+    close('y', y.permute(0, 3, 1, 2), yr, tol=3e-5)
+    close('dx', dx.permute(0, 3, 1, 2), xr.grad, tol=3e-5)
+    close('dW', dW, Wr.grad, tol=3e-5)
+    close('db', db, br.grad, tol=3e-5)
+    for a, bb in zip(outs[0], outs[1]):
+        assert torch.equal(a, bb), 'fused conv+pool must reproduce conv -> pool bit for bit'
+
+
 @pytest.mark.parametrize('C0,C1,C2', [(1, 64, 64), (16, 64, 128), (3, 6, 10)])   # VGG's first pair; halo epilogue mask; second-pass mask
 def test_conv_relu_conv_backward_through_relu(C0, C1, C2):
     """conv2d(relu, relu_bwd_in_next) -> conv2d(relu, x_is_relu_out, relu_bwd_in_pool) -> maxpool2(relu_in): no activation-backward

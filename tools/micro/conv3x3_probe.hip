@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
   hipMemcpy(wg, h.data(), nw * 4, hipMemcpyHostToDevice);
   hipMemset(bias, 0, K * 4);
   HaloArgs a;
-  a.in = in; a.wg = wg; a.out = out; a.bias = bias; a.mask = nullptr; a.NI = N; a.H = H; a.W = W; a.C = C; a.Cout = K; a.act = RE2E_ACT_RELU; a.beta = 0.f;
+  a.in = in; a.wg = wg; a.out = out; a.bias = bias; a.mask = nullptr; a.pool_out = nullptr; a.pool_idx = nullptr; a.NI = N; a.H = H; a.W = W; a.C = C; a.Cout = K; a.act = RE2E_ACT_RELU; a.beta = 0.f;
   a.ngn = K / NT; a.in_bytes = (unsigned)(nin * 4); a.wg_bytes = (unsigned)(nw * 4); a.out_bytes = (unsigned)(nout * 4); a.tiles_x = cdiv(W, 16); a.tiles_y = cdiv(H, 16);
   a.nitems = N * a.tiles_x * a.tiles_y * a.ngn; a.ipw = 0;
   const int slots = getenv("RE2E_HALO_SLOTS") ? atoi(getenv("RE2E_HALO_SLOTS")) : 512;
