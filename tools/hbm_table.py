@@ -25,15 +25,15 @@ KERNELS = [
      '2 calls x (read (B*T,257) + write (B*T,80))'),
     ('fbank_bwd_kernel', 'K2 fbank backward', (2 * rows_bt * F + rows_bt * NF) * f4, 'read x, dy; write dx'),
     ('conv_cin1_fwd_kernel<3, 3>', 'K5 VGG conv1_1 forward (Cin = 1 direct kernel)', (px1 + px1 * 64) * f4, 'read (2B,800,80,1), write (2B,800,80,64)'),
-    ('conv_cout1_kernel<16, 3, 3, 1>', 'K5 VGG conv1_1 data gradient (Cout = 1 direct kernel)', (px1 * 64 + px1) * f4, 'read dz (2B,800,80,64), write dx'),
+    ('conv_cout1_rows3x3_kernel', 'K5 VGG conv1_1 data gradient (Cout = 1 row-tile kernel; only the enhanced branch needs it)', (px1 * 64 + px1) / 2 * f4, 'read dz (B,800,80,64), write dx'),
     ('wgrad_cin1_kernel', 'K5/K9 Cin = 1 weight gradients (VGG conv1_1; D conv1 real + fake)',
      (px1 * 64 + px1) * f4 + 2 * (B * 400 * 40 * 64 + B * 800 * 80) * f4, 'read dout + input, three launches'),
-    ('maxpool2_fwd_vec_kernel', 'K5 2x2 max pooling forward (both pools)', (px1 * 64 + px2 * 64) * f4 + px2 * 64 + (px2 * 128 + px3 * 128) * f4 + px3 * 128,
-     'read in, write out + 1-byte argmax'),
+    ('maxpool2_fwd_vec_kernel', 'K5 2x2 max pooling forward (both pools; absent when the pools run in the convolutions\' epilogue)',
+     (px1 * 64 + px2 * 64) * f4 + px2 * 64 + (px2 * 128 + px3 * 128) * f4 + px3 * 128, 'read in, write out + 1-byte argmax'),
     ('maxpool2_bwd_vec_kernel', 'K5 2x2 max pooling backward (both pools)', (px1 * 64 + px2 * 64) * f4 + px2 * 64 + (px2 * 128 + px3 * 128) * f4 + px3 * 128,
      'read dy + argmax, write dx'),
-    ('colsum_vec_kernel<true>', 'K10 activation backward fused with the bias gradient (VGG ReLUs, D conv1 LeakyReLU)',
-     3 * (px1 * 64 * 2 + px2 * 128 * 2) * f4 + 3 * 2 * B * 400 * 40 * 64 * f4, 'read dy, y; write dz (+ partial column sums); VGG 4 convs + D conv1 x2'),
+    ('colsum_vec_kernel<true>', 'K10 activation backward fused with the bias gradient (D conv1 LeakyReLU; the VGG ReLUs need no pass any more)',
+     3 * 2 * B * 400 * 40 * 64 * f4, 'read dy, y; write dz (+ partial column sums); D conv1 x2'),
     ('bn_partial_vec_kernel', 'K9 BatchNorm statistics passes (forward: mean, variance; backward: sum dz, sum dz*xhat)',
      2 * (2 * dbn) + 2 * (2 * dbn) + 0.5 * 2 * dbn * 2, 'approx.: 2 D forwards x 2 passes x read x; 2 D backwards x read x, dy (+ G-step input-gradient pass)'),
     ('bn_apply_vec_kernel', 'K9 BatchNorm + LeakyReLU apply', 2 * 2 * dbn, '2 D forwards x (read x, write y)'),
