@@ -24,7 +24,7 @@ def main(path, a, b, rank=0, min_us=0.0):
         if e[3] != stream:
             continue
         s = (e[0] - t0) / 1e6
-        if a <= s < b and (e[1] - e[0]) / 1e3 >= min_us:
+        if a <= s < b and ((e[1] - e[0]) / 1e3 >= min_us or (prev and (e[0] - prev) / 1e3 >= 20.0)):       # long kernels and whatever follows an idle gap
             n = re.sub(r'\(anonymous namespace\)::', '', e[2])
             n = re.sub(r'^void ', '', n)[:64]
             print('%8.3f ms  %8.1f us  gap %7.1f us  grid %5d x%3d x%3d  %s' % (s, (e[1] - e[0]) / 1e3, (e[0] - prev) / 1e3 if prev else 0.0,

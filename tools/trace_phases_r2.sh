@@ -9,5 +9,6 @@ for w in "0 11.6" "11.6 16" "16 24.5" "24.5 28.2" "28.2 35.5" "35.5 47.6" "47.6 
 python3 tools/trace_list.py $DB 0 12 0 40 > $O/main_list_head.txt 2>&1
 python3 tools/trace_list.py $DB 0 12 1 40 > $O/side_list_head.txt 2>&1
 python3 tools/trace_list.py $DB 56 74 0 40 > $O/main_list_tail.txt 2>&1
+python3 tools/trace_list.py $DB 24 48 0 150 > $O/main_list_mid.txt 2>&1
 python3 tools/trace_bins.py $DB 2 > $O/bins.txt 2>&1
 rm -rf $O/t
