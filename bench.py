@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, 'Peak FP32 (matrix)'
-FLOP_PER_UTT = {'config4': 189.83e9}
+FLOP_PER_UTT = {2: 41.45e9, 3: 60.71e9, 4: 189.83e9, 5: 715.6e9}
 
 
 def log(msg):
@@ -80,44 +80,82 @@ def synthetic_cmvn(enh, fb, batches, dev):
     return torch.FloatTensor(out)
 
 
+def _time_launches(fn, iters):
+    """Average duration of ``iters`` back-to-back launches, HIP events on the launch stream."""
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def _profile_json(names):
+    for n in names:
+        try:
+            return json.load(open(os.path.join(ROOT, 'profiles', n))), 'profiles/' + n
+        except Exception:
+            pass
+    return None, None
+
+
+def engine_average():
+    """Average TFLOP/s of the fp32-MFMA engine over every GEMM / convolution call of one single-stream step: the 'total' line of the
+    committed per-call table (tools/igemm_table.py over a RE2E_NO_OVERLAP=1 rocprofv3 kernel trace of this script)."""
+    import re
+    for n in ('r03_igemm_calls_nooverlap.txt', 'r02_igemm_calls_nooverlap.txt'):
+        try:
+            last = open(os.path.join(ROOT, 'profiles', n)).read().strip().splitlines()[-1]
+            m = re.search(r'([\d.]+) TFLOP/s average', last)
+            if m:
+                return float(m.group(1)), 'profiles/' + n
+        except Exception:
+            pass
+    return None, None
+
+
 def conv_roofline(dev, iters=20):
-    """Average launch duration of the dominant kernel -- the 3x3 convolution at the VGG conv1_2 shape of this workload
-    (2B=64 images, 800x80, 64->64; csrc/conv3x3.hip behind re2e_conv_igemm) -- measured with HIP events on the stream
-    the kernel is launched on.  Algorithmic FLOPs = 2*9*64*64 per output pixel; algorithmic bytes = input + output +
-    weights (2.10 GB)."""
+    """Average launch duration of the dominant kernel, measured with HIP events on the stream the kernel is launched on: the 3x3
+    convolution at the VGG conv1_2 shape of this workload (2B=64 images, 800x80, 64->64).  The training step launches it as
+    conv -> ReLU -> 2x2 max pool in ONE kernel (``re2e_conv3x3_relu_pool``: only the pooled tensor and the index bytes are written);
+    that in-step variant is the figure on the line, the un-pooled ``re2e_conv_igemm`` launch of the same product is reported next
+    to it.  Algorithmic FLOPs = 2*9*64*64 per output pixel; algorithmic bytes = input + weights + what the variant writes."""
     from robust_e2e_gan_amd import lib
     N, H, W, C, K = 64, 800, 80, 64, 64
     x = torch.randn(N, H, W, C, device=dev)
     wg = torch.randn(K, 3, 3, C, device=dev) * 0.04
     b = torch.zeros(K, device=dev)
     y = torch.empty(N, H, W, K, device=dev)
+    pooled = torch.empty(N, (H + 1) // 2, (W + 1) // 2, K, device=dev)
+    idx = torch.empty(N, (H + 1) // 2, (W + 1) // 2, K, dtype=torch.uint8, device=dev)
     args = (x.data_ptr(), N, H, W, C, wg.data_ptr(), K, 3, 3, H, W, 1, 1, 1, 1, -1, -1, y.data_ptr(), H, W, 1, 1, 0, 0, b.data_ptr(),
             lib.ACT_RELU, 0.0)
-    for _ in range(3):
-        lib.call('re2e_conv_igemm', *args)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        lib.call('re2e_conv_igemm', *args)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    sec_plain = _time_launches(lambda: lib.call('re2e_conv_igemm', *args), iters)
+    sec_pool = _time_launches(lambda: lib.call('re2e_conv3x3_relu_pool', x.data_ptr(), N, H, W, C, wg.data_ptr(), K, b.data_ptr(),
+                                               pooled.data_ptr(), idx.data_ptr()), iters)
     flops = 2.0 * 9 * C * K * N * H * W
-    ach = flops / sec / 1e12
+    ach = flops / sec_pool / 1e12
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
     # kernel and shape, tools/roofline_conv.py); a counter pass cannot run inside this process.
-    traffic, tsrc = None, None
-    try:
-        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r02_conv1_2_pmc_traffic.json')))
-        traffic, tsrc = pj['traffic_bytes_per_launch'], 'profiles/r02_conv1_2_pmc_traffic.json'
-    except Exception:
-        pass
-    return {'bound': 'mfma', 'kernel': 'conv3x3_halo_kernel<16,16,1,true> (VGG conv1_2 fwd, 64x800x80, 64->64, 3x3)', 'achieved': round(ach, 2),
-            'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
-            'traffic_unit': 'bytes per launch (FETCH_SIZE + WRITE_SIZE)', 'traffic_source': tsrc,
-            'algorithmic_bytes_per_launch': 4.0 * (N * H * W * C + N * H * W * K + K * 9 * C),
-            'avg_launch_ms': round(sec * 1e3, 4), 'algorithmic_flop_per_launch': flops}
+    pj, tsrc = _profile_json(['r03_conv1_2_pool_pmc_traffic.json'])
+    pj2, tsrc2 = _profile_json(['r03_conv1_2_pmc_traffic.json', 'r02_conv1_2_pmc_traffic.json'])
+    eng, esrc = engine_average()
+    return {'bound': 'mfma', 'kernel': 'conv3x3_halo_kernel (VGG conv1_2 fwd as the step launches it: conv + ReLU + 2x2 max pool in one launch, '
+                                       '64x800x80, 64->64, 3x3)',
+            'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            'traffic': pj['traffic_bytes_per_launch'] if pj else None,
+            'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': tsrc,
+            'algorithmic_bytes_per_launch': 4.0 * (N * H * W * C + K * 9 * C) + 5.0 * pooled.numel(),
+            'avg_launch_ms': round(sec_pool * 1e3, 4), 'algorithmic_flop_per_launch': flops,
+            'unpooled_variant': {'entry': 're2e_conv_igemm (conv + bias + ReLU, full-resolution output)', 'avg_launch_ms': round(sec_plain * 1e3, 4),
+                                 'achieved': round(flops / sec_plain / 1e12, 2), 'frac': round(flops / sec_plain / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                 'traffic': pj2['traffic_bytes_per_launch'] if pj2 else None, 'traffic_source': tsrc2,
+                                 'algorithmic_bytes_per_launch': 4.0 * (N * H * W * C + N * H * W * K + K * 9 * C)},
+            'engine_avg_tflops': eng, 'engine_avg_frac': round(eng / PEAK_FP32_MFMA_TFLOPS, 4) if eng else None, 'engine_avg_source': esrc}
 
 
 PARITY_TOL = 1e-3
@@ -203,14 +241,61 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+CONFIG_SHAPES = {2: (16, 500, 25), 3: (32, 800, 40), 4: (32, 800, 40), 5: (8, 3000, 150)}     # (B per GPU, T, L)
+CONFIG_NAMES = {
+    2: 'config2: asr_train.py step (clean fbank features -> VGG+3xBLSTMP-512, CTC + loc-attention decoder 300, Adadelta)',
+    3: 'config3: enhance_gan_train.py step (2xBLSTM-256 mask enhancer + fbank + D basic ndf64, G-step and D-step, Adadelta)',
+    4: 'config4: joint_train.py full GAN+ASR step',
+    5: 'config5: joint_train.py full GAN+ASR step, long utterances',
+}
+
+
+def shard_batch(batch, idx, L):
+    """Rows ``idx`` of a synthetic batch (strong scaling: every rank builds the SAME global batch and keeps utterances r::N)."""
+    clean, mix, mix_log, targets, il, tl = batch
+    ii = torch.as_tensor(idx, dtype=torch.long)
+    tg = targets.view(-1, L)[ii].reshape(-1)
+    return clean[ii], mix[ii], mix_log[ii], tg, il[ii], tl[ii]
+
+
+def make_stepper(cfg_id, opt, nets, batch, cmvn_d, dev):
+    """-> (step(), trainer, flat optimizers): one training iteration of the configuration's trainer on a batch resident in HBM."""
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd import trainers
+    enh, fb, asr, gan = nets
+    clean, mix, mix_log, targets, il, tl = batch
+    if cfg_id in (4, 5):
+        tr = JointTrainer(opt, enh, fb, asr, gan)
+        data = (None, None, clean.to(dev), None, mix.to(dev), mix_log.to(dev), None, targets, il, tl)
+        return (lambda: tr.step(data, 0.0, cmvn_d)), tr, [tr.asr_optimizer, tr.enhance_optimizer, tr.gan_optimizer]
+    if cfg_id == 3:
+        tr = trainers.EnhanceGanTrainer(opt, enh, fb, gan)
+        g = torch.Generator().manual_seed(4321)
+        cos = torch.cos(torch.rand(clean.shape, generator=g) * 3.14159265).to(dev)          # cos of the clean/mix phase difference
+        data = (None, None, clean.to(dev), None, mix.to(dev), mix_log.to(dev), cos, targets, il, tl)
+        return (lambda: tr.step(data, cmvn_d)), tr, [tr.enhance_optimizer, tr.gan_optimizer]
+    if cfg_id == 2:
+        with torch.no_grad():                                                                 # pre-computed clean fbank features, CMVN applied
+            feats = ((fb(clean.to(dev)) + cmvn_d[0]) * cmvn_d[1]).contiguous()
+            for b, l in enumerate(il.tolist()):
+                feats[b, l:] = 0.0
+        tr = trainers.AsrTrainer(opt, asr)
+        data = (None, None, feats, targets, il, tl)
+        return (lambda: tr.step(data, 0.0)), tr, [tr.optimizer]
+    raise SystemExit('bench: --config must be 2, 3, 4 or 5 (config 1 is the CPU plumbing case of the tests)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--frames', type=int, default=800)
-    ap.add_argument('--labels', type=int, default=40)
+    ap.add_argument('--config', type=int, default=4, choices=(2, 3, 4, 5), help='BASELINE.json configuration (default 4 = the metric)')
+    ap.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
+                    help='weak: the configuration\'s batch per GPU; strong: that batch is the GLOBAL batch, rank r keeps utterances r::N')
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--frames', type=int, default=None)
+    ap.add_argument('--labels', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
@@ -231,16 +316,38 @@ def main():
 
     opt = config4_opt()
     log('building networks')
-    enh, fb, asr, gan = build(opt, dev)
-    B, T, L = a.batch, a.frames, a.labels
-    batch = make_batch(B, T, L, opt.odim, seed=1234 + rank)
-    log('synthetic batch ready; computing cmvn')
-    cmvn = synthetic_cmvn(enh, fb, [make_batch(B, T, L, opt.odim, seed=77 + i) for i in range(2)], dev)
-    tr = JointTrainer(opt, enh, fb, asr, gan)
-    clean, mix, mix_log, targets, il, tl = batch
-    data = (None, None, clean.to(dev), None, mix.to(dev), mix_log.to(dev), None, targets, il, tl)     # inputs resident in HBM
+    if a.config == 2:
+        from robust_e2e_gan_amd.model.e2e_model import E2E
+        from robust_e2e_gan_amd.model.feat_model import FbankModel
+        torch.manual_seed(1234)
+        enh, gan = None, None
+        fb, asr = FbankModel(opt).to(dev).train(), E2E(opt).to(dev).train()
+    else:
+        enh, fb, asr, gan = build(opt, dev)
+    cB, cT, cL = CONFIG_SHAPES[a.config]
+    B, T, L = a.batch or cB, a.frames or cT, a.labels or cL
+    if a.scaling == 'strong':
+        if B < world:
+            raise SystemExit('bench: strong scaling needs at least one utterance per rank (global batch %d, %d ranks)' % (B, world))
+        gbatch = make_batch(B, T, L, opt.odim, seed=1234)                       # the SAME global batch on every rank
+        batch = shard_batch(gbatch, rdist.shard_indices(B, rank, world), L)
+        global_b = B
+    else:
+        batch = make_batch(B, T, L, opt.odim, seed=1234 + rank)
+        global_b = B * world
+    local_b = int(batch[0].shape[0])
+    log('synthetic batch ready (%d utterances on this rank); computing cmvn' % local_b)
+    cmvn_batches = [make_batch(cB if a.batch is None else B, T, L, opt.odim, seed=77 + i) for i in range(2)]
+    if enh is not None:
+        cmvn = synthetic_cmvn(enh, fb, cmvn_batches, dev)
+    else:                                            # config 2: CMVN of the clean features themselves
+        with torch.no_grad():
+            f = torch.cat([fb(b[0].to(dev))[i, :l] for b in cmvn_batches for i, l in enumerate(b[4].tolist())], 0)
+            cmvn = torch.stack([-f.mean(0), 1.0 / f.std(0)]).cpu()
     cmvn_d = cmvn.to(dev)
-    want_cpu = world == 1 and not a.no_cpu_baseline
+    step, tr, optimizers = make_stepper(a.config, opt, (enh, fb, asr, gan), batch, cmvn_d, dev)
+    joint = a.config in (4, 5)
+    want_cpu = world == 1 and joint and not a.no_cpu_baseline
     sd0 = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in (enh, asr, gan)] if want_cpu else None
 
     log('warm-up (%d steps)' % a.warmup)
@@ -249,7 +356,7 @@ def main():
     for i in range(nwarm):
         torch.cuda.synchronize()
         h0 = time.perf_counter()
-        out = tr.step(data, 0.0, cmvn_d)
+        out = step()
         host_ms = (time.perf_counter() - h0) * 1e3       # enqueue time of ONE step issued into an idle GPU (no back-pressure)
         torch.cuda.synchronize()
         if i == 0 and want_cpu:                          # the step the parity gate compares: first update from the initial weights
@@ -261,19 +368,25 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = tr.step(data, 0.0, cmvn_d)
+        out = step()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / a.steps * 1e3]
     if world > 1:
-        tmax = torch.tensor([dt], device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        rank_ms = [float(t.item()) / a.steps * 1e3 for t in every]
+        dt = max(float(t.item()) for t in every)            # MAX over ranks
     log('timed region done: %.3fs for %d steps' % (dt, a.steps))
     losses = JointTrainer.to_floats(out)
-    from robust_e2e_gan_amd import lib as re2e_lib
-    aborts = re2e_lib.query('re2e_lstm_abort_count')
+    aborts = lib.query('re2e_lstm_abort_count')
+    if world > 1:                                            # every rank fails together (a lone SystemExit would hang the others' collectives)
+        flag = torch.tensor([float(aborts)], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        aborts = int(flag.item())
     if aborts != 0:        # a persistent recurrence gave up on a peer workgroup: its outputs are NaN, the numbers mean nothing
         raise SystemExit('bench: %d recurrent sequences were aborted by a persistent kernel (rank %d)' % (aborts, rank))
     if not all(v == v and abs(v) != float('inf') for v in losses.values()):
@@ -283,26 +396,33 @@ def main():
     if world > 1:
         # replicas must still be identical after the timed steps: the all-reduced gradients and the shared NaN gate give
         # every rank the same update (D's BatchNorm running statistics are per replica and not part of this check)
-        chk = torch.stack([tr.asr_optimizer.flat.double().sum(), tr.enhance_optimizer.flat.double().sum(), tr.gan_optimizer.flat.double().sum()])
+        chk = torch.stack([o.flat.double().sum() for o in optimizers])
         lo, hi = chk.clone(), chk.clone()
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi))
         if not replicas_identical:
-            log('WARNING: replicas differ after %d data-parallel steps: %r vs %r' % (a.steps, lo.tolist(), hi.tolist()))
+            raise SystemExit('bench: replicas differ after %d data-parallel steps: %r vs %r' % (a.steps, lo.tolist(), hi.tolist()))
     if rank != 0:
         return
-    value = B * world * a.steps / dt
+    value = global_b * a.steps / dt
+    default_shape = (B, T, L) == CONFIG_SHAPES[a.config]
+    metric = 'joint_train utterances/sec' if joint else {2: 'asr_train utterances/sec', 3: 'enhance_gan_train utterances/sec'}[a.config]
     line = {
-        'metric': 'joint_train utterances/sec', 'value': round(value, 3), 'unit': 'utterances/s', 'n_gpus': world, 'steps': a.steps,
-        'warmup': nwarm, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'metric': metric, 'value': round(value, 3), 'unit': 'utterances/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': nwarm, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'config4: joint_train.py full GAN+ASR step, B=%d per GPU, T=%d, F=257->80, L=%d, V=4233, enhancer 2xBLSTM-256, '
-                               'VGG+3xBLSTMP-512, loc-attention decoder 300, D basic ndf64, Adadelta' % (B, T, L),
-                   'global_batch': B * world, 'parallelism': 'dp%d' % world, 'coral_loss_lambda': opt.coral_loss_lambda},
-        'step_mfma_frac': round(value * FLOP_PER_UTT['config4'] / (world * PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if (B, T, L) == (32, 800, 40) else None,
+        'config': {'workload': '%s, B=%d %s, T=%d, F=257->80, L=%d, V=4233%s' % (
+                       CONFIG_NAMES[a.config], B, 'per GPU' if a.scaling == 'weak' else 'GLOBAL (rank r keeps utterances r::N)', T, L,
+                       ', enhancer 2xBLSTM-256, VGG+3xBLSTMP-512, loc-attention decoder 300, D basic ndf64, Adadelta' if joint else ''),
+                   'global_batch': global_b, 'per_rank_batch': local_b, 'parallelism': 'dp%d' % world, 'coral_loss_lambda': opt.coral_loss_lambda},
+        # whole-step fraction of the fp32-MFMA roofline: utterances/s x SURVEY 8(d) FLOP per utterance / (N x 157.3 TFLOP/s); the FLOP
+        # count holds for the configuration's own (T, L) whatever the batch, so it is given for weak and strong scaling alike
+        'step_mfma_frac': round(value * FLOP_PER_UTT[a.config] / (world * PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if (T, L) == CONFIG_SHAPES[a.config][1:] else None,
+        'default_shape': default_shape,
         'final_losses': {k: round(v, 5) for k, v in losses.items()}, 'persistent_kernel_aborts': aborts,
         'rccl_ranks': rccl_ranks, 'replicas_identical': replicas_identical, 'self_spawned': os.environ.get('RE2E_BENCH_SPAWNED') == '1',
+        'rank_ms_per_step': {'min': round(min(rank_ms), 3), 'max': round(max(rank_ms), 3)},
         'host_enqueue_ms_per_step': round(host_ms, 2) if host_ms is not None else None,
     }
     if not a.no_roofline:

@@ -45,10 +45,17 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 
 #define RE2E_LOSS_BCE 3 /* nn.BCELoss on probabilities, logs clamped at -100 (model/gan_model.py:157-160, --no_lsgan) */
 
+/* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
+ * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
+ * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
+#define RE2E_ABI_VERSION 300
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
 int re2e_device_ok(void);
+/* Optional, no reference counterpart: prepares every persistent-recurrence kernel (code object loaded, dynamic-LDS limit raised) so
+ * that the first sequence of a process is not a ~28 ms launch.  No stream, no device work, idempotent; needs a current HIP device. */
+int re2e_warmup(void);
 /* Scheduling hint, no reference counterpart (the reference runs one stream).  role = RE2E_STREAM_FILLER marks a stream whose
  * kernels run BESIDE the persistent recurrences of another stream (JointTrainer's side / weight-gradient streams,
  * joint_train.py step): the MFMA engine then launches 4-wave tiles there, which fit the registers a resident recurrence

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -32,6 +33,18 @@ bool re2e_stream_is_filler(hipStream_t stream);     // core.hip: re2e_stream_rol
       return RE2E_EHIP;                                                            \
     }                                                                              \
   } while (0)
+
+// Experiment switches.  The shipped library reads four environment variables, each covered by a parity test or result-neutral:
+//   RE2E_LSTM_PERSIST / RE2E_LSTM_PERSIST_BWD = 0  launch-per-step recurrences (tests/test_kernels_gpu.py: persistent vs stepwise)
+//   RE2E_LSTM_BWD_UW = 1 | 2                       hidden units per backward workgroup / 8 (same test, forced widths)
+//   RE2E_IGEMM_LOG                                 one stderr line per engine call (tools/igemm_table.py), no effect on results
+// Everything else -- tile variants, occupancy probes, rejected forms kept for A/B measurements -- is compiled in only with
+// -DRE2E_EXPERIMENTS (make EXPERIMENTS=1 -> libre2e_hip_exp.so, used by tools/ through RE2E_LIB) and answers "unset" otherwise.
+#ifdef RE2E_EXPERIMENTS
+static inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+static inline const char* exp_env(const char*) { return nullptr; }
+#endif
 
 // Dynamic-LDS limit of one kernel, raised on demand.  The library is re-entrant (include/re2e.h): the only process-wide state
 // are these idempotent attribute caches; the mutex keeps two host threads that ask for different sizes from leaving the smaller one set.

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;       // pixel of this wavefront's 64
-            Os[m * LDO + j * 32 + lr] = RELU ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
+            Os[m * LDO + j * 32 + lr] = RELU ? (acc[i][j][r] < 0.f ? 0.f : acc[i][j][r]) : acc[i][j][r];      // torch.relu: NaN stays NaN (fmaxf would drop it)
           }
       // (no barrier: a wavefront reads back only what it wrote itself, and one wavefront's LDS operations execute in order)
       if (p.pool_out) {
@@ -379,7 +379,7 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, DIR, RELU>), lds);
   static const int slots = [] {          // two workgroups per CU (LDS and registers both allow exactly two)
-    if (getenv("RE2E_HALO_SLOTS")) return atoi(getenv("RE2E_HALO_SLOTS"));   // occupancy experiments
+    if (exp_env("RE2E_HALO_SLOTS")) return atoi(exp_env("RE2E_HALO_SLOTS"));   // occupancy experiments
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     return 2 * cus;
@@ -389,7 +389,7 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
   // of peak against 0.838 / 0.852 / 0.850 with 2 / 3 / persistent, conv2_2 0.811 against 0.770 / 0.768 / 0.820: no half-empty
   // last round) and its 70 us lifetime interleaves best with the other streams of the training step (72.41 -> 72.07 ms against
   // the former 2-3 items; 3 + 3 runs, one GPU session).
-  static const int ipw_env = getenv("RE2E_HALO_IPW") ? atoi(getenv("RE2E_HALO_IPW")) : -1;
+  static const int ipw_env = exp_env("RE2E_HALO_IPW") ? atoi(exp_env("RE2E_HALO_IPW")) : -1;
   HaloArgs b = a;
   b.ipw = ipw_env >= 0 ? ipw_env : 1;
   const int nwg = b.ipw == 0 ? (a.nitems < slots ? a.nitems : slots) : (a.nitems + b.ipw - 1) / b.ipw;
@@ -406,7 +406,7 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
 // covers and the launch was enqueued; false -> the caller uses the general engine.
 bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, const float* bias, int act, float beta, const float* mask,
                   hipStream_t st, float* pool_out, unsigned char* pool_idx) {
-  static const bool off = getenv("RE2E_NO_HALO") != nullptr;     // A/B measurements against the general engine
+  static const bool off = exp_env("RE2E_NO_HALO") != nullptr;     // A/B measurements against the general engine
   if (off) return false;
   if (g.KH != 3 || g.KW != 3 || g.SY != 1 || g.SX != 1 || g.PH != g.H || g.PW != g.W) return false;
   int dir;
@@ -419,7 +419,17 @@ bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, cons
   if (pool_out && (act != RE2E_ACT_RELU || beta != 0.f || mask || dir != 1 || (reinterpret_cast<uintptr_t>(pool_idx) & 3))) return false;
   const long in_bytes = (long)g.NI * g.H * g.W * g.C * 4, wg_bytes = (long)Cout * 9 * g.C * 4;
   const long out_bytes = (long)g.NI * g.H * g.W * Cout * 4;
-  if (in_bytes >= 0x7FFFFF00L || wg_bytes >= 0x7FFFFF00L || out_bytes >= 0x7FFFFF00L) return false;
+  if (in_bytes >= 0x7FFFFF00L || wg_bytes >= 0x7FFFFF00L || out_bytes >= 0x7FFFFF00L) {
+    // the buffer descriptors address 2 GiB: a geometry this kernel would otherwise cover goes to the general engine (~15 % slower
+    // at the VGG shapes) -- say so once instead of losing the time silently (e.g. B = 64 per GPU at T = 800: 2.1 GB activations)
+    static std::once_flag warned;
+    std::call_once(warned, [&] {
+      fprintf(stderr, "[re2e] note: 3x3 convolution %dx%dx%d, %d->%d channels has a tensor of >= 2 GiB: the halo-patch kernel declines it, "
+                      "the general implicit-GEMM engine runs it (slower; split the batch to stay below 2 GiB per tensor)\n",
+              g.NI, g.H, g.W, g.C, Cout);
+    });
+    return false;
+  }
   if ((reinterpret_cast<uintptr_t>(g.in) | reinterpret_cast<uintptr_t>(wg)) & 15) return false;
   HaloArgs a;
   a.in = g.in; a.wg = wg; a.out = pool_out ? nullptr : out; a.bias = bias; a.mask = mask; a.pool_out = pool_out; a.pool_idx = pool_idx;

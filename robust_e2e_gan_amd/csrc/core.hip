@@ -14,7 +14,7 @@ void re2e_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int re2e_version(void) { return 100; }
+extern "C" int re2e_version(void) { return RE2E_ABI_VERSION; }
 
 extern "C" const char* re2e_last_error(void) { return g_err; }
 
@@ -57,7 +57,7 @@ extern "C" int re2e_stream_role(hipStream_t stream, int role) {
 }
 
 bool re2e_stream_is_filler(hipStream_t stream) {
-  static const bool ignore = getenv("RE2E_IGNORE_STREAM_ROLE") != nullptr;     // A/B measurements
+  static const bool ignore = exp_env("RE2E_IGNORE_STREAM_ROLE") != nullptr;     // A/B measurements
   if (ignore) return false;
   std::lock_guard<std::mutex> lock(g_role_mu);
   for (int i = 0; i < g_nfiller; ++i) if (g_filler[i] == stream) return true;

@@ -261,30 +261,36 @@ __global__ __launch_bounds__(256) void ctc_prefix_kernel(const float* __restrict
   __shared__ int cand[64];
   __shared__ float cand_att[64];
   const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int i = tid; i < V; i += 256) row[i] = att[(long)h * V + i];
+  // NaN scores are ranked as -inf (torch.topk would rank them first; a NaN row means the decoder has already diverged) and an
+  // entry that has been selected is marked with NaN and skipped afterwards, so the ctc_beam candidates are always ctc_beam
+  // DISTINCT, valid labels -- also for rows with fewer than ctc_beam entries above -inf (ties -> lower label, as torch.topk)
+  for (int i = tid; i < V; i += 256) { const float v = att[(long)h * V + i]; row[i] = v == v ? v : -INFINITY; }
   for (int i = tid; i < 2 * T; i += 256) rp[i] = r_prev[(long)h * 2 * T + i];
   __syncthreads();
   for (int t = tid; t < T; t += 256) rsum[t] = logaddexp_(rp[2 * t], rp[2 * t + 1]);
+  constexpr int NONE = 0x7fffffff;
   for (int k = 0; k < ctc_beam; ++k) {
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) { const float v = row[i]; if (v > bv) { bv = v; bi = i; } }     // ascending i: first maximum wins
+    float bv = -INFINITY; int bi = NONE;
+    for (int i = tid; i < V; i += 256) { const float v = row[i]; if (v == v && (bi == NONE || v > bv)) { bv = v; bi = i; } }   // ascending i: first maximum wins
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      if (oi != NONE && (bi == NONE || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
     }
     if (lane == 0) { red_v[wid] = bv; red_i[wid] = bi; }
     __syncthreads();
     if (tid == 0) {
-      for (int w = 1; w < 4; ++w) if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
-      cand[k] = bi; cand_att[k] = bv; row[bi] = -INFINITY;
+      for (int w = 1; w < 4; ++w) if (red_i[w] != NONE && (bi == NONE || red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi))) { bv = red_v[w]; bi = red_i[w]; }
+      cand[k] = bi; cand_att[k] = bv; row[bi] = __uint_as_float(0x7fc00000u);     // ctc_beam <= V: an unselected entry always exists
     }
     __syncthreads();
   }
   if (tid < ctc_beam) {
     const int c = cand[tid], n = out_len[h], last = last_label[h];
     float* rn = r_new + ((long)h * ctc_beam + tid) * 2 * T;
-    const int start = n > 1 ? n : 1;
+    // a hypothesis longer than the T frames (recog maxlenratio > 1): upstream's r[start - 1] raises IndexError there and the host
+    // caller raises it too (beam_search.py); here the state writes are clamped to the candidate's own (T, 2) block
+    const int start = min(n > 1 ? n : 1, T);
     float rn_n, rn_b;                                   // r[t-1][0], r[t-1][1]
     for (int t = 0; t < start - 1; ++t) { rn[2 * t] = CTC_LOGZERO; rn[2 * t + 1] = CTC_LOGZERO; }     // never read (numpy leaves them unset)
     if (n == 0) { rn_n = lpz[c]; rn_b = CTC_LOGZERO; } else { rn_n = CTC_LOGZERO; rn_b = CTC_LOGZERO; }

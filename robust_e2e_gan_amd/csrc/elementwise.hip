@@ -63,30 +63,38 @@ __global__ void colsum_partial_kernel(const float* __restrict__ A, int M, int N,
   __syncthreads();
   if (ry == 0 && col < N) part[(long)blockIdx.y * N + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
-// final stage: 64 columns x 16 chunk lanes per workgroup, lanes combined through LDS in a fixed order
+// final stage: CW columns x (1024 / CW) chunk lanes per workgroup, lanes combined through LDS in a fixed order.  CW = 64 for short
+// partial lists; CW = 16 for long ones (the 800-chunk bias gradients of the BLSTMP projections sit on the critical path of the
+// backward: 8 workgroups x 50 dependent passes took 215 us beside the weight-gradient stream's MFMA tiles, round 3 trace).
+template <int CW>
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int chunks, int N, float* out, float beta) {
-  __shared__ float red[16][64];
-  const int cx = threadIdx.x & 63, cl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cx;
+  constexpr int CL = 1024 / CW;
+  __shared__ float red[CL][CW];
+  const int cx = threadIdx.x % CW, cl = threadIdx.x / CW;
+  const int col = blockIdx.x * CW + cx;
   float s = 0.f;
   if (col < N) {
-    // 8 independent loads in flight per thread (a single workgroup reads up to 512 KB of partials: latency-bound otherwise)
+    // 8 independent loads in flight per thread (latency-bound otherwise)
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int c = cl;
-    for (; c + 7 * 16 < chunks; c += 8 * 16) {
+    for (; c + 7 * CL < chunks; c += 8 * CL) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += part[(long)(c + 16 * u) * N + col];
+      for (int u = 0; u < 8; ++u) a[u] += part[(long)(c + CL * u) * N + col];
     }
-    for (; c < chunks; c += 16) a[0] += part[(long)c * N + col];
+    for (; c < chunks; c += CL) a[0] += part[(long)c * N + col];
     s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   red[cl][cx] = s;
   __syncthreads();
   if (cl != 0 || col >= N) return;
   s = 0.f;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) s += red[q][cx];
+#pragma unroll 16
+  for (int q = 0; q < CL; ++q) s += red[q][cx];
   out[col] = (beta != 0.f ? beta * out[col] : 0.f) + s;
+}
+static void colsum_final_launch(const float* part, int chunks, int N, float* out, float beta, hipStream_t stream) {
+  if (chunks >= 128) hipLaunchKernelGGL(colsum_final_kernel<16>, dim3(cdiv(N, 16)), dim3(1024), 0, stream, part, chunks, N, out, beta);
+  else hipLaunchKernelGGL(colsum_final_kernel<64>, dim3(cdiv(N, 64)), dim3(1024), 0, stream, part, chunks, N, out, beta);
 }
 
 // Vectorised partial stage, optionally fused with the activation backward: dz = dy * act'(y) is written and
@@ -164,7 +172,7 @@ static void colsum_launch(const float* dy, const float* y, float* dz, int M, int
     }
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), chunks), dim3(256), 0, stream, dy, M, N, lda, rpc, part);
   }
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(1024), 0, stream, (const float*)part, chunks, N, out, beta);
+  colsum_final_launch(part, chunks, N, out, beta, stream);
 }
 
 extern "C" int re2e_colsum(const float* A, int M, int N, long lda, float* out, float beta, void* workspace,

@@ -559,8 +559,9 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
     return;
   }
   {
-    // none / ReLU / LeakyReLU(0.2) in one branch-free form: max(v, slope * v) with slope 1 / 0 / 0.2
+    // none / ReLU / LeakyReLU(0.2) as one select: v < 0 ? slope * v : v with slope 1 / 0 / 0.2
     const float slope = ep.act == RE2E_ACT_RELU ? 0.f : (ep.act == RE2E_ACT_LRELU ? 0.2f : 1.f);
+    const bool relu = ep.act == RE2E_ACT_RELU;
 #pragma unroll
     for (int a = 0; a < CF::TM; ++a)
 #pragma unroll
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
 #pragma unroll
         for (int b = 0; b < CF::TN; ++b) {
           const float v = acc[a][b][r] + bv[b];
-          if (colv[b] < ep.N) ep.C[rb + colv[b]] = fmaxf(v, slope * v);
+          if (colv[b] < ep.N) ep.C[rb + colv[b]] = v < 0.f ? (relu ? 0.f : slope * v) : v;      // torch semantics: NaN stays NaN, ReLU(-inf) = 0 (fmaxf(v, 0 * v) gave -inf)
         }
       }
   }
@@ -627,12 +628,12 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
   constexpr int ASZ = (LA::KMAJ || TS) ? CF::BM * CF::LDK : CF::BK * (CF::BM + 8);
   constexpr int BSZ = (LB::KMAJ || TS) ? CF::BN * CF::LDK : CF::BK * (CF::BN + 8);
   size_t lds = (size_t)2 * (ASZ + BSZ) * sizeof(float);
-  static const size_t lds_floor = getenv("RE2E_IGEMM_LDS_FLOOR") ? (size_t)atol(getenv("RE2E_IGEMM_LDS_FLOOR")) : 0;   // occupancy experiments
+  static const size_t lds_floor = exp_env("RE2E_IGEMM_LDS_FLOOR") ? (size_t)atol(exp_env("RE2E_IGEMM_LDS_FLOOR")) : 0;   // occupancy experiments
   if (lds < lds_floor) lds = lds_floor;
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&igemm_kernel<LA, LB, CF, VEC>), lds);
   dim3 grid(cdiv(ep.M, CF::BM), cdiv(ep.N, CF::BN), ep.ncls ? ep.ncls : ep.nsplit);
-  static const bool nomem = getenv("RE2E_IGEMM_NOMEM") != nullptr;
+  static const bool nomem = exp_env("RE2E_IGEMM_NOMEM") != nullptr;
   ep.nomem = nomem ? 1 : 0;
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
   if (log_calls)
@@ -655,7 +656,7 @@ using C256x128 = Cfg<4, 2, 2, 2, 16>;
 using C64 = Cfg<2, 2, 1, 1, BKD>;      // 64 x 64: the row tail of a Linear forward whose last round of 256x128 tiles would be mostly empty
 
 inline int igemm_variant() {
-  static const int v = getenv("RE2E_IGEMM_VARIANT") ? atoi(getenv("RE2E_IGEMM_VARIANT")) : 0;
+  static const int v = exp_env("RE2E_IGEMM_VARIANT") ? atoi(exp_env("RE2E_IGEMM_VARIANT")) : 0;
   return v;
 }
 
@@ -921,7 +922,7 @@ static void gemm_dispatch(int transa, int transb, int M, int N, int K, const flo
       // Round-filling row split: 12800 x 2048 is 800 tiles of 256x128 on 256 resident workgroups -- 3.1 rounds, the 4th one
       // 12 % full.  The rows of the last, mostly empty round go to a second launch of 64x64 tiles instead (256 small
       // workgroups: every CU gets one), the launch of the big tiles ends on a full round.
-      static const bool no_tail = getenv("RE2E_NO_ROW_TAIL") != nullptr;
+      static const bool no_tail = exp_env("RE2E_NO_ROW_TAIL") != nullptr;
       const int m1 = (V && !no_tail && igemm_variant() == 0 && ep.nsplit == 1 && ep.act != RE2E_ACT_SIGMOID_MASK_MUL && wide_allowed(st)) ? row_tail_split(M, N) : M;
       if (m1 < M) {
         Epi e1 = ep, e2 = ep;
@@ -959,7 +960,7 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
     return RE2E_EUNSUPPORTED;
   }
   RE2E_CHECK_ARG(fits32(transa ? K : M, lda, transa ? M : K) && fits32(transb ? N : K, ldb, transb ? K : N), "operand larger than 4 GiB");
-  static const bool no_skinny_kernel = getenv("RE2E_NO_SKINNY_GEMM") != nullptr;
+  static const bool no_skinny_kernel = exp_env("RE2E_NO_SKINNY_GEMM") != nullptr;
   if (!no_skinny_kernel && !transa && M <= 32 && K >= 64 && K <= 8192 && act == RE2E_ACT_NONE) {
     const bool v = K % 4 == 0 && aligned16(A) && lda % 4 == 0 && (!transb || (aligned16(B) && ldb % 4 == 0));
     const dim3 g(cdiv(N, 32)), t(512);
@@ -1017,7 +1018,7 @@ __global__ void weight_gather_kernel(const float* W, float* dst, int Cout, int C
 
 // RE2E_NO_THIN=1 routes the Cin == 1 / Cout == 1 convolutions through the implicit GEMM (A/B measurements)
 static bool thin_enabled() {
-  static const bool v = getenv("RE2E_NO_THIN") == nullptr;
+  static const bool v = exp_env("RE2E_NO_THIN") == nullptr;
   return v;
 }
 

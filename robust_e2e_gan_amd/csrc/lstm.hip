@@ -602,7 +602,7 @@ __global__ void zero_kernel(float* p, long n) {
 
 int pick_waves(int K, int min_kc, const char* env = nullptr) {
   if (env) {                       // tuning override (tools/bench_lstm.py): RE2E_LSTM_WAVES_{FWD,BWD}
-    const char* v = getenv(env);
+    const char* v = exp_env(env);
     if (v) { int w = atoi(v); if (w >= 1 && w <= 16 && (w & (w - 1)) == 0 && K % (8 * w) == 0) return w; }
   }
   for (int w = 16; w >= 1; w >>= 1)
@@ -645,6 +645,11 @@ int cu_count() {
   return n;
 }
 
+// dynamic-LDS limits of the persistent kernels, one per instantiation (raised on first use, or all at once by re2e_warmup)
+template <int W, int QN, int UW> LdsLimit& fwd_lim() { static LdsLimit l; return l; }
+template <int TPW, int UW> LdsLimit& bwd_lim() { static LdsLimit l; return l; }
+constexpr size_t kOwnCuLds = 160 * 1024;
+
 template <int W, int QN, int UW = 1>
 bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, float* ybuf, float* cbuf, void* hxmem, size_t hxbytes,
                         const int* lens, int T, int B, int H) {
@@ -657,11 +662,10 @@ bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* w
   // co-resident on its CUs, so its MFMA pipe and memory queue are its own while the filler streams keep the other CUs.
   // (RE2E_LSTM_OWN_CU=0 turns it off, =n asks for n KB -- it has to be the whole CU: with 120 KB, which still admits a small filler
   // workgroup, the step is 74.2 instead of 71.8 ms.  Step 77.9 -> 75.2 ms when introduced: enhancer forward 13.6 -> 9.6, backward 16.7 -> 13.0 ms.)
-  static const int hog = getenv("RE2E_LSTM_OWN_CU") ? atoi(getenv("RE2E_LSTM_OWN_CU")) : 160;
-  static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 1;
+  static const int hog = exp_env("RE2E_LSTM_OWN_CU") ? atoi(exp_env("RE2E_LSTM_OWN_CU")) : 160;
+  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 1;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
-  static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN, UW>), lds);
+  fwd_lim<W, QN, UW>().ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN, UW>), lds);
   (void)hipMemsetAsync(hxmem, 0, hxbytes, st);                             // tags and the error word start at zero, every call
   unsigned* err = (unsigned*)hxmem;
   u64* hx = (u64*)((char*)hxmem + 16);
@@ -676,12 +680,11 @@ bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb,
   (void)hipMemsetAsync(flagmem, 0, flagbytes, st);
   unsigned* err = (unsigned*)flagmem;
   unsigned* flags = (unsigned*)((char*)flagmem + 16);
-  static const int hog = getenv("RE2E_LSTM_OWN_CU") ? atoi(getenv("RE2E_LSTM_OWN_CU")) : 160;      // see launch_fwd_persist
+  static const int hog = exp_env("RE2E_LSTM_OWN_CU") ? atoi(exp_env("RE2E_LSTM_OWN_CU")) : 160;      // see launch_fwd_persist
   size_t lds = 0;
-  static const int frac = getenv("RE2E_LSTM_OWN_CU_FRAC") ? atoi(getenv("RE2E_LSTM_OWN_CU_FRAC")) : 1;
+  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 1;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)(hog - 16) * 1024;       // + ~13 KB static
-  static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&lstm_bwd_persist<TPW, UW>), lds);
+  bwd_lim<TPW, UW>().ensure(reinterpret_cast<const void*>(&lstm_bwd_persist<TPW, UW>), lds);
   hipLaunchKernelGGL((lstm_bwd_persist<TPW, UW>), grid, dim3(256), lds, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
   return true;
 }
@@ -689,7 +692,7 @@ bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb,
 // 0: launch per step; 1 / 2: persistent kernel with 8 / 16 hidden units per workgroup (the weights must be packed for that width)
 int bwd_persist_width(int T, int B, int H) {
   const char* v = getenv("RE2E_LSTM_PERSIST_BWD");
-  const char* mh = getenv("RE2E_LSTM_PERSIST_BWD_MAXH");
+  const char* mh = exp_env("RE2E_LSTM_PERSIST_BWD_MAXH");
   if ((v && atoi(v) == 0) || T < 2 || H > (mh ? atoi(mh) : 1024) || (H + 31) / 32 > 16) return 0;
   const char* wv = getenv("RE2E_LSTM_BWD_UW");      // tuning override
   int uw = wv ? atoi(wv) : (H >= 512 ? 2 : 1);     // wide layers are bound by the slab traffic: half as many, twice as wide workgroups
@@ -720,7 +723,7 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
   const int NX = H / 8;
   // 512-wide layers: RE2E_LSTM_FWD_UW=2 selects 16 units per workgroup (8 wavefronts x 8 k-groups: the 16-wavefront form of it
   // needs 130 registers per lane, 2 more than 1024 threads leave)
-  static const int uw = getenv("RE2E_LSTM_FWD_UW") ? atoi(getenv("RE2E_LSTM_FWD_UW")) : 1;
+  static const int uw = exp_env("RE2E_LSTM_FWD_UW") ? atoi(exp_env("RE2E_LSTM_FWD_UW")) : 1;
   if (NX == 64 && uw == 2) return launch_fwd_persist<8, 8, 2>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
   // 512-wide layers, 8 units per workgroup: 8 wavefronts x 8 k-groups (140 registers, 2 waves per SIMD = 288 of a SIMD's 512) rather than
   // 16 x 4 (94 registers, 4 waves per SIMD = 384).  Its 256 workgroups sit on every CU of the chip for the whole sequence, and what
@@ -728,7 +731,7 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
   // 128 admit none of the engine's tiles.  Alone 7.4 instead of 7.0 us per step, in the training step 72.94 -> 72.69 ms (3 + 3 runs,
   // one GPU session; and again 71.73 against 71.97 with the chain owning its CUs, RE2E_LSTM_OWN_CU_FRAC = 1, where no engine workgroup
   // is co-resident any more: half as many waves sweep and meet at the barrier).  RE2E_LSTM_FWD_W8=0 selects the 16-wave form.
-  static const int w8 = getenv("RE2E_LSTM_FWD_W8") ? atoi(getenv("RE2E_LSTM_FWD_W8")) : 1;
+  static const int w8 = exp_env("RE2E_LSTM_FWD_W8") ? atoi(exp_env("RE2E_LSTM_FWD_W8")) : 1;
   if (NX == 64 && w8) return launch_fwd_persist<8, 8, 1>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
 #define RE2E_TRY(W, Q) if (NX == (W) * (Q)) return launch_fwd_persist<W, Q>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H)
   RE2E_TRY(16, 4); RE2E_TRY(8, 5); RE2E_TRY(8, 4); RE2E_TRY(8, 3); RE2E_TRY(4, 4); RE2E_TRY(4, 2); RE2E_TRY(4, 1);
@@ -737,6 +740,24 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
 }
 
 }  // namespace
+
+// The first launch of a persistent recurrence used to take ~28 ms (rocprofv3: max 28.5 against min 2.69 ms for the enhancer's
+// forward layer): raising the kernel's dynamic-LDS limit loads its code object and reconfigures the function.  re2e_warmup does that
+// for every persistent instantiation up front (no launch, no stream, idempotent), so that the first sequence of a run -- smoke(),
+// short jobs -- runs at the speed of the thousandth.
+extern "C" int re2e_warmup(void) {
+#define RE2E_WF(W, Q, U) fwd_lim<W, Q, U>().ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, Q, U>), kOwnCuLds)
+  RE2E_WF(8, 8, 2); RE2E_WF(8, 8, 1); RE2E_WF(16, 4, 1); RE2E_WF(8, 5, 1); RE2E_WF(8, 4, 1); RE2E_WF(8, 3, 1); RE2E_WF(4, 4, 1); RE2E_WF(4, 2, 1);
+  RE2E_WF(4, 1, 1);
+#undef RE2E_WF
+#define RE2E_WB(T) bwd_lim<T, 1>().ensure(reinterpret_cast<const void*>(&lstm_bwd_persist<T, 1>), kOwnCuLds - 16 * 1024); \
+                   bwd_lim<T, 2>().ensure(reinterpret_cast<const void*>(&lstm_bwd_persist<T, 2>), kOwnCuLds - 16 * 1024)
+  RE2E_WB(1); RE2E_WB(2); RE2E_WB(3); RE2E_WB(4);
+#undef RE2E_WB
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { re2e_set_error("re2e_warmup: %s", hipGetErrorString(e)); return RE2E_EHIP; }
+  return RE2E_OK;
+}
 
 extern "C" size_t re2e_lstm_workspace_bytes(int B, int H) {
   size_t a = fwd_ws_floats(B, H) * sizeof(float) + fwd_hx_bytes(B, H), b = bwd_ws_floats(B, H) * sizeof(float) + bwd_flag_bytes(B, H);

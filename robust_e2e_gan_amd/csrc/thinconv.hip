@@ -359,7 +359,7 @@ bool thin_conv_forward(const ConvGeom& g, const float* wg, int Cout, const OutMa
   }
   if (!(Cout == 1 && g.C % 4 == 0 && K <= 16384 && aligned16(g.in) && aligned16(wg))) return false;
   // 64 channels, 3x3, stride 1, taps within one pixel of the output position, dense single-channel output: row-tile kernel
-  static const bool no_rows = getenv("RE2E_NO_COUT1_ROWS") != nullptr;
+  static const bool no_rows = exp_env("RE2E_NO_COUT1_ROWS") != nullptr;
   if (!no_rows && g.C == 64 && g.KH == 3 && g.KW == 3 && g.SY == 1 && g.SX == 1 && g.PH == g.H && g.PW == g.W && !o.remap && o.ldc == 1 &&
       (g.DY == 1 || g.DY == -1) && (g.DX == 1 || g.DX == -1) && g.OY0 == -g.DY && g.OX0 == -g.DX && g.W <= 256) {
     constexpr int TH = 8;

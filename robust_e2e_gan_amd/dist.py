@@ -49,6 +49,18 @@ def allreduce_mean_(flat, async_op=False):
     return None
 
 
+def any_rank(flag_value):
+    """max over ranks of a small non-negative host integer (an error count / flag).  Collective: EVERY rank must call it at the
+    same point.  Used so that a failure seen by one replica raises on all of them -- a lone raise would leave the others blocked
+    in their next collective."""
+    if world_size() == 1:
+        return int(flag_value)
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([float(flag_value)], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def rank():
     return dist.get_rank() if dist.is_initialized() else 0
 

@@ -40,8 +40,9 @@ def compute_cmvn_epoch(opt, train_loader, enhance_model, feat_model):
                 break
     enhance_model.train()
     feat_model.train()
-    if enhance_cmvn is None:
-        raise RuntimeError('train_loader exhausted before cmvn_num utterances were accumulated')
+    if rdist.any_rank(1 if enhance_cmvn is None else 0):        # every replica raises together (the broadcast below is a collective)
+        raise RuntimeError('train_loader exhausted before cmvn_num utterances were accumulated'
+                           + ('' if enhance_cmvn is None else ' (on another rank)'))
     # data parallel: every rank estimated the statistics on its own shard; all replicas use rank 0's (= the saved file)
     return rdist.broadcast_(torch.FloatTensor(enhance_cmvn), 0)
 
@@ -68,12 +69,20 @@ class JointTrainer(object):
                                                                                           gan_model if self.isGAN else None)
         self.criterionGAN = GANLoss(use_lsgan=not opt.no_lsgan) if self.isGAN else None
         self.asr_model.dec.return_acc_tensor = True
+        # Dropout masks (ops.dropout: counter-based Philox, nothing stored): one stream per process, keyed by (opt.seed, rank) so that
+        # data-parallel replicas draw DIFFERENT masks, as upstream's per-process RNG would; the (seed, next mask index) pair is part
+        # of ``state()`` and ``restore_dropout`` puts it back, so a resumed run continues the mask sequence instead of replaying
+        # it from index 0.  NB validation consumes mask indices too: upstream's CTC head calls F.dropout with training=True in
+        # eval mode as well (e2e_ctc.py:51), so the training masks after a validation pass depend on validate_freq -- upstream's
+        # global RNG has the same property.
+        if any(float(getattr(opt, k, 0.0) or 0.0) > 0.0 for k in ('dropout_rate', 'enhance_dropout_rate')):
+            ops.dropout_seed((int(getattr(opt, 'seed', 1234)) * 1000003 + rdist.rank()) & 0xFFFFFFFFFFFF)
         # run the D passes on a side HIP stream under the latency-bound recurrent chains (RE2E_NO_OVERLAP=1: profiling)
         self.overlap_dstep = os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
         self.marks = [] if os.environ.get('RE2E_TIMELINE') else None
         # the D-step's D(fake) forward equals the G-step's (same input, same weights): keep that graph and walk it twice
-        self.early_dreal = os.environ.get('RE2E_NO_EARLY_DREAL', '0') != '1'     # D-step real half under the enhancer's forward chain
-        self.reuse_dfake = os.environ.get('RE2E_NO_DFAKE_REUSE', '0') != '1' 
+        self.early_dreal = lib.exp_env('RE2E_NO_EARLY_DREAL', '0') != '1'     # D-step real half under the enhancer's forward chain
+        self.reuse_dfake = lib.exp_env('RE2E_NO_DFAKE_REUSE', '0') != '1' 
         self.side_stream = self.wgrad_stream = None
         if torch.cuda.is_available():
             # filler streams: optionally restricted to a subset of the CUs (RE2E_FILLER_CUS, default all) so that the
@@ -81,7 +90,7 @@ class JointTrainer(object):
             # MI355X sweeps (ms/step).  With launch-per-step recurrences: 128: 112.5, 160: 103.1, 192: 99.6, 224: 98.0, 256: 99.5.
             # With the persistent recurrences: 192: 90.6, 208: 91.2, 224: 89.0, 240: 90.1, 256 (no mask): 88.2 -- resident
             # chains no longer need CUs kept free for their launches, so the fillers get the whole chip.
-            ncu = int(os.environ.get('RE2E_FILLER_CUS', '256'))
+            ncu = int(lib.exp_env('RE2E_FILLER_CUS', '256'))
             dev = next(enhance_model.parameters()).device
             if 0 < ncu < 256:
                 self.side_stream = lib.cu_masked_stream(ncu, 256, dev)
@@ -112,7 +121,7 @@ class JointTrainer(object):
             # the persistent sequences (GPU_MAX_HW_QUEUES=8) changed nothing: what slows a resident chain beside the
             # fillers is two of its workgroups sharing a CU (tools/bench_fill_under_chain.py), not the queue it came from.
             try:
-                self.main_stream = torch.cuda.Stream(priority=int(os.environ.get('RE2E_MAIN_PRIORITY', '-1')))
+                self.main_stream = torch.cuda.Stream(priority=int(lib.exp_env('RE2E_MAIN_PRIORITY', '-1')))
             except Exception:
                 self.main_stream = None
 
@@ -160,7 +169,7 @@ class JointTrainer(object):
         overlap = self.overlap_dstep
         ops.MULTI_STREAM = bool(overlap)
         ops.WGRAD_STREAM = self.wgrad_stream if overlap else None
-        ops.AUX_STREAM = self.side_stream if (overlap and os.environ.get('RE2E_CTC_MAIN') != '1') else None
+        ops.AUX_STREAM = self.side_stream if (overlap and lib.exp_env('RE2E_CTC_MAIN') != '1') else None
         main = torch.cuda.current_stream()
         clean_branch, d_real_part = None, None
         if overlap and getattr(self.asr_model, 'etype', '').startswith('vgg'):
@@ -482,7 +491,7 @@ class JointTrainer(object):
             # a persistent recurrence that gave up on a peer workgroup poisons its outputs with NaN, the NaN gate then skips
             # every update: training would "run" without learning.  (The query synchronises the device: only called where
             # the loop reads the meters back anyway.)
-            n = lib.query('re2e_lstm_abort_count')
+            n = rdist.any_rank(lib.query('re2e_lstm_abort_count'))      # collective: all replicas fail together, none is left in an all-reduce
             if n != 0:
                 raise lib.Re2eError('%d recurrent sequences were aborted by a persistent LSTM kernel (a peer workgroup never '
                                     'arrived); their outputs are NaN and the updates were skipped' % n)
@@ -566,7 +575,15 @@ class JointTrainer(object):
               'eps': self.opt.eps, 'lr': self.opt.lr, 'best_loss': best_loss, 'best_acc': best_acc, 'acc_report': None, 'loss_report': None}
         if self.isGAN:
             st['gan_state_dict'] = self.gan_model.state_dict()
+        st['dropout_state'] = ops.dropout_state()          # (seed, index of the next mask); not an upstream key
         return st
+
+    @staticmethod
+    def restore_dropout(package):
+        """Continue the dropout mask stream of a checkpoint written by ``state()`` (no-op for checkpoints without the key)."""
+        ds = package.get('dropout_state') if isinstance(package, dict) else None
+        if ds is not None:
+            ops.dropout_seed(int(ds[0]), int(ds[1]))
 
 
 def config4_opt(**over):

@@ -14,6 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
+ABI_VERSION = 300      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
@@ -24,6 +25,7 @@ P, I, L, F, Z = c_void_p, c_int, c_long, c_float, c_size_t
 # name -> (restype, argtypes).  Must list every symbol of include/re2e.h (tests/test_abi.py).
 SIGNATURES = {
     're2e_version': (I, []),
+    're2e_warmup': (I, []),
     're2e_last_error': (c_char_p, []),
     're2e_device_ok': (I, []),
     're2e_stream_role': (I, [P, I]),
@@ -99,6 +101,14 @@ SIGNATURES = {
     're2e_adam_step': (I, [P, P, P, P, L, F, F, F, F, I, P, P]),
 }
 
+def exp_env(name, default=None):
+    """Host-side experiment / A-B switches (schedule variants, fusions turned off) are honoured only when RE2E_EXPERIMENTS=1 is set,
+    like the library's own (csrc/common.h exp_env): a stray variable must not change how the shipped path runs.  The documented
+    switches read directly are RE2E_LIB (another build of the same ABI), RE2E_NO_OVERLAP=1 (single-stream schedule, for per-kernel
+    profiles; tests run both schedules) and RE2E_TIMELINE=1 (phase marks for tools/step_timeline.py)."""
+    return os.environ.get(name, default) if os.environ.get('RE2E_EXPERIMENTS') == '1' else default
+
+
 _lib = None
 
 
@@ -115,11 +125,23 @@ def load():
         raise Re2eError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                         '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    lib.re2e_version.restype = ctypes.c_int
+    got = lib.re2e_version()
+    if got != ABI_VERSION:
+        # the arguments are positional: a stale library (RE2E_LIB override, a tree that was not rebuilt) would take shifted
+        # ints / floats / pointers without any error
+        raise Re2eError('%s was built for ABI version %d, this binding is written for %d (include/re2e.h RE2E_ABI_VERSION): rebuild it '
+                        'with `python -c "import __graft_entry__ as g; g.build()"`' % (LIB_PATH, got, ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    try:
+        if torch.cuda.is_available():
+            lib.re2e_warmup()        # persistent recurrences: first sequence at full speed (best effort; a failure shows up at the first call)
+    except Exception:
+        pass
     return lib
 
 

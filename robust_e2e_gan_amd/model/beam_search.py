@@ -136,6 +136,11 @@ def recognize_beam(p, h, lpz, recog_args, eos, prefix='', lpz_dev=None):
             call('re2e_log_softmax_rows', logits.data_ptr(), nh, V, V, lsm.data_ptr())
             if dev_ctc:
                 last = host_to_dev(np.asarray([hp['yseq'][-1] for hp in hyps], np.int32), dev)
+                if max(len(hp['yseq']) - 1 for hp in hyps) > T:
+                    # CTCPrefixScore indexes r[output_length - 1] over the T frames (e2e_ctc.py:128-133): a hypothesis longer than
+                    # the utterance has frames (maxlenratio > 1) is an IndexError upstream
+                    raise IndexError('CTC prefix score: hypothesis of %d labels on %d encoder frames (lower maxlenratio)'
+                                     % (max(len(hp['yseq']) - 1 for hp in hyps), T))
                 olen = host_to_dev(np.asarray([len(hp['yseq']) - 1 for hp in hyps], np.int32), dev)
                 prev = host_to_dev(np.asarray([hp['ctc_score'] for hp in hyps], np.float32), dev, torch.float32)
                 cand_d = torch.empty(nh, ctc_beam, dtype=torch.int32, device=dev)

@@ -10,12 +10,13 @@ import sys
 import torch
 
 from .. import ops
+from .. import lib
 from ..lib import Re2eError
 from .e2e_common import ConvParams, LinearParams, LSTMParams, _get_vgg2l_odim, lens_dev, lens_list
 
-FUSE_RELU_POOL_BWD = os.environ.get('RE2E_NO_RELU_POOL_FUSION') is None      # A/B switches (ops.conv2d relu_bwd_in_pool / relu_bwd_in_next)
-FUSE_RELU_CONV_BWD = os.environ.get('RE2E_NO_RELU_CONV_FUSION') is None
-FUSE_CONV_POOL = os.environ.get('RE2E_NO_CONV_POOL_FUSION') is None
+FUSE_RELU_POOL_BWD = lib.exp_env('RE2E_NO_RELU_POOL_FUSION') is None      # A/B switches (ops.conv2d relu_bwd_in_pool / relu_bwd_in_next)
+FUSE_RELU_CONV_BWD = lib.exp_env('RE2E_NO_RELU_CONV_FUSION') is None
+FUSE_CONV_POOL = lib.exp_env('RE2E_NO_CONV_POOL_FUSION') is None
 
 
 class BLSTM(torch.nn.Module):

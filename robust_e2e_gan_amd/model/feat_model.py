@@ -40,8 +40,9 @@ def band_from_matrix(W, device):
             lens.append(int(nz[-1] - nz[0] + 1))
     maxw = max(max(lens), 1)
     if maxw > 32:
-        raise Re2eError('filterbank is not banded (max %d taps per filter > 32): the dense trainable fbank '
-                        '(--fbank-opti-type train) is not on the round-1 hot path' % maxw)
+        raise Re2eError('filterbank is not banded (max %d taps per filter > 32): the banded gather kernel (re2e_fbank_fwd) covers the '
+                        'frozen mel matrix only; a dense matrix runs through the trainable path (--fbank-opti-type train: x^2 W on '
+                        'the GEMM engine)' % maxw)
     taps = np.zeros((NF, maxw), np.float32)
     for j in range(NF):
         taps[j, :lens[j]] = Wn[offs[j]:offs[j] + lens[j], j]

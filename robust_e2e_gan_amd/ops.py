@@ -52,8 +52,8 @@ def gemm(A, B, C, M, N, K, transa=False, transb=False, lda=None, ldb=None, ldc=N
     return C
 
 
-NT_INPUT_GRAD = os.environ.get('RE2E_NO_NT_INPUT_GRAD') is None
-INLINE_LAST_WGRAD = os.environ.get('RE2E_NO_INLINE_LAST_WGRAD') is None
+NT_INPUT_GRAD = lib.exp_env('RE2E_NO_NT_INPUT_GRAD') is None
+INLINE_LAST_WGRAD = lib.exp_env('RE2E_NO_INLINE_LAST_WGRAD') is None
 
 
 def gemm_input_grad(dz, W, dx, M, K, N, beta=0.0):
@@ -788,7 +788,7 @@ class BiLstmFn(torch.autograd.Function):
         x2 = x.view(T * B, I)
         xg = [empty((T * B, 4 * H), x), empty((T * B, 4 * H), x)]
         Ip = (I + 3) & ~3
-        if Ip != I and T * B >= 1024 and os.environ.get('RE2E_NO_PAD_INPUT') != '1':
+        if Ip != I and T * B >= 1024 and lib.exp_env('RE2E_NO_PAD_INPUT') != '1':
             # an input width that is not a multiple of 4 (the enhancer's 257 bins) would send three large GEMMs of this layer down
             # the scalar-load path of the engine: work on zero-padded copies of x and W_ih instead (exact: the extra products are 0)
             x2p = zeros((T * B, Ip), x)
@@ -1178,7 +1178,7 @@ def dropout(x, p):
     return DropoutFn.apply(x, p, seed, idx)
 
 
-DECODER_FUSED = os.environ.get('RE2E_NO_DECODER_FUSION', '0') != '1'     # fused LSTMCell step kernels (A/B switch)
+DECODER_FUSED = lib.exp_env('RE2E_NO_DECODER_FUSION', '0') != '1'     # fused LSTMCell step kernels (A/B switch)
 
 
 class DecoderLoopFn(torch.autograd.Function):

@@ -48,7 +48,8 @@ def test_library_exports_every_declared_symbol():
     assert len(decls) >= 50
     for name in decls:
         assert hasattr(so, name), 'symbol %s declared in include/re2e.h is not exported' % name
-    assert so.re2e_version() >= 100
+    abi_macro = int(re.search(r'#define\s+RE2E_ABI_VERSION\s+(\d+)', open(os.path.join(ROOT, 'include', 're2e.h')).read()).group(1))
+    assert so.re2e_version() == abi_macro == lib.ABI_VERSION, 'library, header and ctypes table must carry the same ABI version'
 
 
 def test_ctypes_table_matches_header():

@@ -26,7 +26,9 @@ def _worker(rank, world, port, q):
     sync.arm(y, early)
     (y * 3).sum().backward()
     sync.finish([late])
-    q.put((rank, g.tolist(), early.grad.tolist(), late.grad.tolist(), rdist.shard_indices(7, rank, world)))
+    # (c) a failure seen by ONE replica is seen by all (fit's abort check, compute_cmvn_epoch): max over ranks
+    flags = (rdist.any_rank(3 if rank == 1 else 0), rdist.any_rank(0))
+    q.put((rank, g.tolist(), early.grad.tolist(), late.grad.tolist(), rdist.shard_indices(7, rank, world), flags))
     torch.distributed.destroy_process_group()
 
 
@@ -41,7 +43,8 @@ def test_allreduce_mean_world2():
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    for rank, g, early, late, shard in res:
+    for rank, g, early, late, shard, flags in res:
+        assert flags == (3, 0)
         assert g == [1.5 * i for i in range(10)]
         assert early == [1.5] * 5 and late == [15.0] * 3
         assert shard == list(range(rank, 7, 2))
@@ -55,6 +58,7 @@ def test_world_size_one_needs_no_collective():
     x = torch.ones(2, requires_grad=True)
     s.arm(x * 1.0, _Opt(g))
     s.finish([_Opt(g)])
+    assert rdist.any_rank(2) == 2
 
 
 def _dp_worker(rank, world, port, q, golden):

@@ -69,3 +69,46 @@ def test_dp_branches_equal_single_process_step(golden_dir, one_rank_group, monke
         assert a == b, (a, b)                                        # bitwise: AVG over one rank is the identity
     for k, v in res[False][1].items():
         assert torch.equal(v, res[True][1][k]), k
+
+
+def test_allreduce_beside_persistent_recurrence(one_rank_group):
+    """The 0.4 s spin bound of the persistent recurrences must not be reachable by a co-resident RCCL kernel: the trainer issues
+    the 116 MB ASR all-reduce on RCCL's stream WHILE the enhancer's 800-step persistent backward owns its CUs.  Here: a T=800,
+    B=32, H=256 bidirectional layer (forward + BPTT, persistent kernels) alone, then again with all-reduces of a 116 MB buffer
+    issued back to back from a second stream for as long as the recurrence runs -- no sequence may be aborted and every output
+    and gradient must be bitwise equal to the undisturbed run."""
+    from robust_e2e_gan_amd import lib, ops
+    dist = one_rank_group
+    T, B, I, H = 800, 32, 64, 256
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(T, B, I, generator=g).to(DEV)
+    lens = torch.tensor([T - 7 * b for b in range(B)], dtype=torch.int32, device=DEV)
+    ws = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.05).to(DEV))
+          for s in ((4 * H, I), (4 * H, H), (4 * H,), (4 * H,), (4 * H, I), (4 * H, H), (4 * H,), (4 * H,))]
+    dy = torch.randn(T, B, 2 * H, generator=g).to(DEV)
+    flat = torch.randn(29_000_000, generator=g).to(DEV)            # 116 MB, the ASR net's flat gradient buffer
+    side = torch.cuda.Stream()
+    base = lib.query('re2e_lstm_abort_count')
+
+    def run(disturb):
+        for p in ws:
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        torch.cuda.synchronize()
+        works = []
+        if disturb:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(24):                                   # ~ the duration of the forward + backward chains
+                    works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True))
+        y = ops.bilstm(x, lens, ws)
+        (y * dy).sum().backward()
+        for w in works:
+            w.wait()
+        torch.cuda.synchronize()
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in ws]
+    ref = run(False)
+    got = run(True)
+    assert lib.query('re2e_lstm_abort_count') == base, 'a persistent recurrence gave up beside a co-resident RCCL kernel'
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)

@@ -110,3 +110,43 @@ def test_synthetic_batch_shapes():
     assert ilens.tolist() == lengths(4, 50) == [50, 45, 40, 35]
     assert clean.shape == (4, 50, 257) and (clean[3, 35:] == 0).all() and (mix_log[3, 35:] == 0).all()
     assert targets.min() >= 1 and targets.max() <= 28 and targets.numel() == 20
+
+
+def test_bench_strong_scaling_shards_cover_the_global_batch():
+    """bench.py --scaling strong: rank r keeps utterances r::N of the SAME global batch; the shards partition it (every utterance and
+    its labels exactly once) and keep the length-sorted order."""
+    import importlib
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module('bench')
+    from robust_e2e_gan_amd.data.synthetic import make_batch
+    from robust_e2e_gan_amd.dist import shard_indices
+    B, T, L, V = 8, 40, 5, 50
+    batch = make_batch(B, T, L, V, seed=3)
+    seen, rows = [], 0
+    for r in range(4):
+        idx = shard_indices(B, r, 4)
+        sh = bench.shard_batch(batch, idx, L)
+        assert sh[0].shape[0] == len(idx) == 2 and sh[3].numel() == len(idx) * L
+        for j, i in enumerate(idx):
+            assert torch.equal(sh[0][j], batch[0][i]) and torch.equal(sh[1][j], batch[1][i]) and int(sh[4][j]) == int(batch[4][i])
+            assert torch.equal(sh[3][j * L:(j + 1) * L], batch[3][i * L:(i + 1) * L])
+        assert sh[4].tolist() == sorted(sh[4].tolist(), reverse=True)
+        seen += idx
+        rows += sh[0].shape[0]
+    assert sorted(seen) == list(range(B)) and rows == B
+    assert set(bench.FLOP_PER_UTT) == set(bench.CONFIG_SHAPES) == {2, 3, 4, 5}
+
+
+def test_dropout_stream_is_checkpointed():
+    """JointTrainer.state() carries (seed, next mask index) of the dropout stream; restore_dropout continues it."""
+    from robust_e2e_gan_amd import ops
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    ops.dropout_seed(99, 17)
+    pkg = {'dropout_state': ops.dropout_state()}
+    ops.dropout_seed(1, 0)
+    JointTrainer.restore_dropout(pkg)
+    assert ops.dropout_state() == (99, 17)
+    JointTrainer.restore_dropout({})                   # checkpoints without the key: untouched
+    assert ops.dropout_state() == (99, 17)

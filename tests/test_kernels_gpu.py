@@ -728,3 +728,67 @@ def test_gemm_skinny2(M, K, N1, N2):
     assert (C2[:, N2:] == 7.0).all()                      # nothing written beyond the N2 columns
     with pytest.raises(lib.Re2eError):
         lib.call('re2e_gemm_skinny2', 33, K, Ad.data_ptr(), K, B1d.data_ptr(), N1 + 5, N1, C1.data_ptr(), N1, B2d.data_ptr(), N2, N2, C2.data_ptr(), N2 + 2)
+
+
+def test_ctc_prefix_score_degenerate_rows_and_long_hypotheses():
+    """Rows the top-k pre-selection cannot rank in the ordinary way must not fault (round-2 advisor finding): NaN attention scores
+    are ranked as -inf, a row with fewer than ctc_beam entries above -inf still yields ctc_beam DISTINCT valid labels (lowest
+    labels first among the ties, as torch.topk), and a hypothesis as long as the utterance has frames (out_len == T) keeps its
+    state writes inside its own (T, 2) block."""
+    import numpy as np
+    ops, lib = _ops()
+    rng = np.random.default_rng(11)
+    T, V, cb, eos = 9, 12, 5, 11
+    lpz = torch.log_softmax(torch.from_numpy(rng.normal(size=(T, V)).astype(np.float32)), 1)
+    lpz_d = lpz.to(DEV)
+    att = torch.full((3, V), float('-inf'))
+    att[0, 7], att[0, 3] = -0.5, -1.0                 # two finite entries, ten at -inf
+    att[1] = torch.log_softmax(torch.from_numpy(rng.normal(size=V).astype(np.float32)), 0)
+    att[1, 4] = float('nan')                          # one NaN among finite scores
+    att[2] = float('nan')                             # a diverged decoder row
+    nh = 3
+    r_prev = torch.full((nh, T, 2), -1e10).to(DEV)
+    last = torch.tensor([1, 2, 3], dtype=torch.int32, device=DEV)
+    olen = torch.tensor([1, T, T], dtype=torch.int32, device=DEV)             # two hypotheses as long as the utterance
+    prev = torch.zeros(nh, device=DEV)
+    cand = torch.full((nh, cb), -1, dtype=torch.int32, device=DEV)
+    out = torch.empty(2, nh, cb, device=DEV)
+    guard = torch.full((nh * cb + 1, 2 * T), 123.0, device=DEV)              # one spare state block behind the last candidate
+    lib.call('re2e_ctc_prefix_score', lpz_d.data_ptr(), T, V, att.to(DEV).data_ptr(), nh, r_prev.data_ptr(), last.data_ptr(), olen.data_ptr(),
+             prev.data_ptr(), cb, 0.7, 0.3, 0, eos, cand.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), guard.data_ptr())
+    torch.cuda.synchronize()
+    c = cand.cpu().numpy()
+    for k in range(nh):
+        assert len(set(c[k].tolist())) == cb and c[k].min() >= 0 and c[k].max() < V, c[k]
+    assert c[0].tolist() == [7, 3, 0, 1, 2]                                     # finite scores first, then the -inf ties by label
+    want1 = att[1].clone()
+    want1[4] = float('-inf')
+    assert c[1].tolist() == torch.topk(want1, cb).indices.tolist()
+    assert c[2].tolist() == [0, 1, 2, 3, 4]
+    assert bool((guard[nh * cb] == 123.0).all()), 'state writes ran past the last candidate block'
+
+
+@pytest.mark.parametrize('C,K', [(64, 64), (12, 24)])      # halo-patch kernel / general engine
+def test_conv_relu_propagates_nan_like_torch(C, K):
+    """ReLU epilogues follow torch.relu on non-finite pre-activations: NaN stays NaN (so that it reaches the grad-norm NaN gate of
+    joint_train.py:189-193 whichever kernel the geometry selected), +inf stays +inf, -inf becomes 0."""
+    ops, lib = _ops()
+    N, H, W = 1, 18, 16
+    x = rnd(N, H, W, C)
+    x[0, 3, 3, 0] = float('nan')
+    x[0, 12, 9, 1] = float('inf')
+    Wt, b = rnd(K, C, 3, 3, seed=1, scale=0.1), rnd(K, seed=2)
+    Wt[:, 1].abs_()                                   # +inf input x positive weights: +inf in some outputs, never inf - inf
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2), Wt, b, padding=1)).permute(0, 2, 3, 1)
+    y = ops.conv2d(x.to(DEV), torch.nn.Parameter(Wt.to(DEV)), torch.nn.Parameter(b.to(DEV)), 1, 1, 'relu').detach().cpu()
+    assert torch.equal(torch.isnan(y), torch.isnan(ref)) and bool(torch.isnan(ref).any())
+    assert torch.equal(torch.isinf(y), torch.isinf(ref)) and bool(torch.isinf(ref).any())
+    fin = torch.isfinite(ref)
+    assert (y[fin] - ref[fin]).abs().max() <= 2e-4 * ref[fin].abs().max()
+    # -inf pre-activation through the general engine's Linear epilogue
+    xl = rnd(40, 8)
+    xl[5, 2] = float('-inf')
+    Wl = rnd(6, 8, seed=3).abs_()
+    yl = ops.linear(xl.to(DEV), torch.nn.Parameter(Wl.to(DEV)), None, 'relu').detach().cpu()
+    refl = F.relu(xl @ Wl.t())
+    assert torch.equal(yl[5], refl[5]) and float(refl[5].abs().sum()) == 0.0

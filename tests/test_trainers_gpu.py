@@ -209,7 +209,7 @@ def test_fit_loop_cadence(golden_dir, tmp_path):
     assert os.path.isfile(os.path.join(str(tmp_path), 'latest')) and os.path.isfile(os.path.join(str(tmp_path), 'enhance_cmvn.npy'))
     st = torch.load(os.path.join(str(tmp_path), 'latest'), weights_only=False)
     assert set(st) == {'asr_state_dict', 'fbank_state_dict', 'enhance_state_dict', 'gan_state_dict', 'opt', 'epoch', 'iters', 'eps', 'lr',
-                       'best_loss', 'best_acc', 'acc_report', 'loss_report'}
+                       'best_loss', 'best_acc', 'acc_report', 'loss_report', 'dropout_state'}      # upstream's keys + the dropout mask stream
     assert st['iters'] == 6 and best_acc >= 0.0
     # either the first validation set the best accuracy (saved) or eps was decayed -- never both for one validation
     assert os.path.isfile(os.path.join(str(tmp_path), 'model.acc.best')) or tr.asr_optimizer.param_groups[0]['eps'] < eps0
