@@ -100,6 +100,19 @@ int re2e_conv_igemm_masked(const float* in, int NI, int H, int W, int C, const f
  * aligned and < 2 GiB (the caller then runs re2e_conv_igemm + re2e_maxpool2_fwd). */
 int re2e_conv3x3_relu_pool(const float* in, int NI, int H, int W, int C, const float* wg, int Cout, const float* bias, float* pooled,
                            unsigned char* idx_u8, re2e_stream_t stream);
+/* 3x3 / stride-1 / pad-1 convolution as a fused Winograd F(2x2,3x3) on the fp32 matrix core (2.25x fewer matrix instructions than the
+ * direct form; the transforms only add and halve, results agree with re2e_conv_igemm to a few ulp).  `w` is the layer's weight in
+ * PyTorch's (Cout_f, Cin_f, 3, 3) layout -- no gathered copy is needed.  dgrad = 0: forward, in (NI,H,W,C = Cin_f) -> out
+ * (NI,H,W,Cout = Cout_f), optional bias (Cout) and ReLU (relu = 1).  dgrad = 1: data gradient, in = dy (NI,H,W,C = Cout_f) -> out = dx
+ * (NI,H,W,Cout = Cin_f).  `mask` (optional, shape of out): out = mask > 0 ? value : 0 (re2e_conv_igemm_masked's epilogue).
+ * `pool_out` / `pool_idx` (optional, forward + relu): ONLY maxpool2(relu(conv)) (NI, ceil(H/2), ceil(W/2), Cout) and its index bytes are
+ * written (re2e_conv3x3_relu_pool's contract), `out` may then be NULL.  The workspace holds the transformed weights (prepared by the
+ * call itself).  RE2E_EUNSUPPORTED unless C % 8 == 0, Cout % 64 == 0, 16-byte aligned operands and tensors < 2 GiB: the caller then
+ * uses re2e_conv_igemm / re2e_conv_igemm_masked / re2e_conv3x3_relu_pool (e2e_encoder.py:234-237,258-266 and their autograd gradients). */
+size_t re2e_conv3x3_wino_workspace_bytes(int C, int Cout);
+int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int dgrad, const float* bias, int relu,
+                      const float* mask, float* out, float* pool_out, unsigned char* pool_idx, void* workspace, size_t workspace_bytes,
+                      re2e_stream_t stream);
 size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW);
 /* dW[Cout][C][KH][KW] = beta*dW + sum_pix dout[pix][co] * in[n][py*SY+kh+OY0][px*SX+kw+OX0][ci] */
 int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, int KH, int KW, int PH,

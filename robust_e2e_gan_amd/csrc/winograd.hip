@@ -1,0 +1,333 @@
+// K5: 3x3 / stride-1 / pad-1 convolution (forward and data gradient) over NHWC activations as a FUSED Winograd F(2x2, 3x3)
+// on the fp32 matrix core (v_mfma_f32_32x32x2_f32), gfx950 only.
+//
+// A 2x2 block of output pixels is  Y = A^T [ (G g G^T) . (B^T d B) ] A  with d the 4x4 input tile around it: 16 element-wise
+// products per (input channel, output channel) instead of 36 -- the convolution becomes 16 independent GEMMs (one per position
+// of the transformed tile) with 2.25x fewer matrix instructions than the direct form (conv3x3.hip).  The transforms only add
+// and halve (B and A hold 0 / +-1, G holds 0 / 1 / +-0.5), so in fp32 the result differs from the direct sum by a few ulp.
+//
+// Everything between the global loads and the output transform lives in REGISTERS, and the main loop has no barrier:
+//
+//   workgroup   = 32 tiles (a 16 x 8 or 8 x 16 pixel patch) x 64 output channels; wavefront i owns ROW i of the transformed
+//                 tile: positions (i, 0..3) = 4 GEMMs of 32 tiles x 64 channels (8 accumulator tiles, 128 registers);
+//   A operand   : lane (tile, k-half) loads the two input rows that B^T's row i touches (8 pixels x 4 channels, 16 bytes each),
+//                 transforms them in registers (8 packed adds per 4 channels) and feeds the MFMAs directly -- the im2col
+//                 operand never exists, neither in LDS nor in memory;
+//   B operand   : the transformed weights U[pos][cout][c] are prepared once per call in MFMA fragment order
+//                 ([group][chunk][pos][n-tile][lane][4], one contiguous KB per fragment) and stream L2 -> registers;
+//   pipeline    : input channels in chunks of 8 (32 MFMAs per wavefront and chunk); the loads of chunk c+1 are issued as soon
+//                 as the registers of chunk c are free (the raw pixels right after the transform, each position's weights right
+//                 after its MFMAs), so a load has a whole chunk (~2 000 cycles) to arrive;
+//   epilogue    : each wavefront applies the column half of A^T . A to its own accumulators (4 -> 2 values), the four rows meet
+//                 in LDS (68 KB) and are combined into the 2x2 outputs; bias, ReLU, the ReLU mask of the layer in front (data
+//                 gradient) or the 2x2 max pool -- a tile IS a pooling window -- are applied there and whole 256-byte channel
+//                 rows are stored.
+//
+// Out-of-image pixels read as zero through the buffer descriptor's range check.  <= 256 registers and 68 KB of LDS: two
+// workgroups per CU, one's epilogue / prologue runs under the other's matrix work.  Workgroups are ordered XCD-aware.
+//
+// Replaces (reference): nn.Conv2d 3x3 of VGG2L, model/e2e_encoder.py:234-237,258-266 (conv1_2, conv2_1, conv2_2) and their
+// autograd data gradients.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int WCK = 8;                  // input channels per chunk
+constexpr int WNT = 64;                 // output channels per workgroup
+constexpr int LDR = WNT + 4;            // row stride (floats) of the epilogue's exchange buffer
+constexpr unsigned WOOB = 0x80000000u;  // byte offset beyond any tensor this path accepts (< 2 GiB): the load returns 0
+
+struct WinoArgs {
+  const float* in; const float* ufrag; float* out; const float* bias;
+  const float* mask;                          // optional, shape of out: out = mask > 0 ? value : 0
+  float* pool_out; unsigned char* pool_idx;   // optional: only maxpool2(relu(out)) and its index bytes are written
+  int NI, H, W, C, Cout, relu;
+  int tiles_x, tiles_y, ngn, nitems;          // patches per row / column, 64-channel groups, work items
+  unsigned in_bytes, u_bytes, out_bytes;
+};
+
+// U[g][chunk][pos][nt][lane][e] = sum_{a,b} G[i][a] G[j][b] k[o][c][a][b],  pos = 4i + j, o = 64 g + 32 nt + (lane & 31),
+// c = 8 chunk + 4 (lane >> 5) + e.  k = the correlation kernel of THIS call: forward k[o][c][a][b] = w[o][c][a][b];
+// data gradient (in = dy, out = dx) k[o][c][a][b] = w[c][o][2-a][2-b]  (w in PyTorch's (Cout_f, Cin_f, 3, 3) layout).
+__global__ void wino_weights_kernel(const float* __restrict__ w, int Cout, int C, int dgrad, float* __restrict__ uf) {
+  const long total = (long)16 * Cout * C;
+  const int nch = C / WCK;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int e4 = (int)(e & 3), lane = (int)((e >> 2) & 63), nt = (int)((e >> 8) & 1), pos = (int)((e >> 9) & 15);
+    const long r = e >> 13;
+    const int chunk = (int)(r % nch), g = (int)(r / nch);
+    const int o = g * WNT + nt * 32 + (lane & 31), c = chunk * WCK + 4 * (lane >> 5) + e4;
+    float k[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        k[a][b] = dgrad ? w[(((long)c * Cout + o) * 3 + (2 - a)) * 3 + (2 - b)] : w[(((long)o * C + c) * 3 + a) * 3 + b];
+    const int i = pos >> 2, j = pos & 3;
+    // row transform with G row i, then column transform with G row j;  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+    float t[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      t[b] = i == 0 ? k[0][b] : (i == 1 ? 0.5f * (k[0][b] + k[1][b] + k[2][b]) : (i == 2 ? 0.5f * (k[0][b] - k[1][b] + k[2][b]) : k[2][b]));
+    const float u = j == 0 ? t[0] : (j == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (j == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
+    uf[e] = i == 2 ? -u : u;          // the kernel's row-2 input transform is d1 - d2 = -(B^T d)_2: the sign moves into the weights
+  }
+}
+
+template <int TXW>      // tiles per patch row: 8 (16 x 8 pixel patch) or 4 (8 x 16)
+__global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
+  constexpr int TYH = 32 / TXW;
+  constexpr int PW = 2 * TXW, PH = 2 * TYH;
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 rows i][2 b][32 tiles][LDR]
+
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and the compiler must know it (scalar offsets, scalar branches)
+  // ---- work item (XCD-aware order: each XCD's L2 sees a contiguous run of patches) ----
+  int item;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
+  if (item >= p.nitems) return;
+  // (the quotients are computed on the vector ALU: tell the compiler they are wave-uniform, or every buffer load that takes a
+  // scalar offset derived from them becomes a waterfall loop)
+  const int nblk = __builtin_amdgcn_readfirstlane(item % p.ngn);
+  const int tile_id = item / p.ngn, t2 = tile_id / p.tiles_x;
+  const int tx = __builtin_amdgcn_readfirstlane(tile_id - t2 * p.tiles_x), n = __builtin_amdgcn_readfirstlane(t2 / p.tiles_y);
+  const int ty = __builtin_amdgcn_readfirstlane(t2 - n * p.tiles_y);
+  const int y0 = ty * PH, x0 = tx * PW, n0 = nblk * WNT;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ufrag), 0, p.u_bytes, 0x00020000);
+
+  // ---- this lane's 8 input pixels: tile (tyi, txi) = lr, rows (ra, rb) of its 4x4 input tile, 4 columns, channels 4 lh .. 4 lh + 3
+  const int tyi = lr / TXW, txi = lr - tyi * TXW;
+  const int ra = wid == 0 ? 0 : 1, rb = wid == 3 ? 3 : 2;            // B^T row i touches input rows (0,2) (1,2) (1,2) (1,3)
+  unsigned a_off[8];
+  unsigned a_s;
+  if (y0 >= 1 && x0 >= 1 && y0 + PH + 1 <= p.H && x0 + PW + 1 <= p.W) {
+    a_s = (unsigned)((((n * p.H + y0 - 1) * p.W + x0 - 1) * p.C) * 4);     // the halo's corner pixel
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = k < 4 ? ra : rb, col = k & 3;
+      a_off[k] = (unsigned)((((2 * tyi + row) * p.W + 2 * txi + col) * p.C + 4 * lh) * 4);
+    }
+  } else {
+    a_s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = k < 4 ? ra : rb, col = k & 3;
+      const int iy = y0 - 1 + 2 * tyi + row, ix = x0 - 1 + 2 * txi + col;
+      const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      a_off[k] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.C + 4 * lh) * 4) : WOOB;      // < 2^31: checked by the launcher
+    }
+  }
+  a_s = (unsigned)__builtin_amdgcn_readfirstlane((int)a_s);
+  const int nch = p.C / WCK;
+  const unsigned u_lane = (unsigned)lane * 16u;
+  // fragment (chunk, position 4 wid + j, n-tile nt) of this group: ((((nblk * nch + chunk) * 16 + 4 wid + j) * 2 + nt) * 1024 bytes
+  const unsigned u_s0 = (unsigned)(((nblk * nch) * 16 + 4 * wid) * 2) * 1024u;
+
+  f32x4 raw[8], uf[4][2];
+  auto fetch_raw = [&](int chunk) {
+    const unsigned cb = a_s + (unsigned)(chunk * WCK * 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[k], cb, 0));
+  };
+  auto fetch_u = [&](int chunk, int j) {
+    const unsigned s = u_s0 + (unsigned)(chunk * 16 * 2 + j * 2) * 1024u;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) uf[j][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, u_lane, s + (unsigned)nt * 1024u, 0));
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+
+  // (same issue order as in the loop -- pixels first, then the weights position by position -- or the wait at the loop's head
+  // has to cover the prologue's order as well and degenerates to vmcnt(0))
+  __builtin_amdgcn_sched_barrier(0);
+  fetch_raw(0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    fetch_u(0, j);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // Row transform as ONE fused multiply-add per value: T[b] = d[ra][b] + tsign * d[rb][b] with tsign = -1, +1, -1, -1 for rows
+  // i = 0..3 of B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]; row 2 then carries the opposite sign (d1 - d2 instead of d2 - d1),
+  // which the weight transform compensates by negating U[2][.] (wino_weights_kernel).  The loop body has no branch -- the last
+  // chunk re-fetches itself instead of fetching nothing -- so the compiler's s_waitcnt counts stay exact: a wait only covers the
+  // loads it needs, never the ones issued a few instructions earlier.
+  const float tsign = wid == 1 ? 1.f : -1.f;
+  const f32x4 ts4 = {tsign, tsign, tsign, tsign};
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    f32x4 T[4], V[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) T[b] = raw[b] + ts4 * raw[4 + b];
+    V[0] = T[0] - T[2];
+    V[1] = T[1] + T[2];
+    V[2] = T[2] - T[1];
+    V[3] = T[1] - T[3];
+    const int nxt = chunk + 1 < nch ? chunk + 1 : chunk;
+    // (sched_barrier: the scheduler otherwise sinks every load to the end of the body, right in front of the wait that needs it)
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_raw(nxt);                                 // the raw registers are free: next chunk's pixels fly under this chunk's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j][jj], uf[j][nt][jj], acc[j][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_u(nxt, j);                              // ... and position j's weights of the next chunk behind its last use
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- output transform, column half, in registers: R[b] = sum_j M[i][j] A[j][b],  A^T = [1 1 1 0; 0 1 -1 -1]
+  float* Rs = smem + (wid * 2) * (32 * LDR);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;                  // tile of this wavefront's 32
+      Rs[m * LDR + nt * 32 + lr] = m0 + m1 + m2;
+      Rs[32 * LDR + m * LDR + nt * 32 + lr] = m1 - m2 - m3;
+    }
+  __syncthreads();
+  // ---- row half + bias / ReLU / mask / pool + store: wavefront w takes tiles 8w .. 8w+7, lane = (tile of 4, 4 channels), 2 passes
+  const int c4 = (lane & 15) * 4;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c4);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int tl = 8 * wid + 4 * it + (lane >> 4);
+    const int ty2 = tl / TXW, tx2 = tl - ty2 * TXW;
+    const int oy = y0 + 2 * ty2, ox = x0 + 2 * tx2;
+    f32x4 R[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) R[i][b] = *reinterpret_cast<const f32x4*>(smem + ((i * 2 + b) * 32 + tl) * LDR + c4);
+    f32x4 Y[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      Y[0][b] = R[0][b] + R[1][b] + R[2][b] + bv;
+      Y[1][b] = R[1][b] - R[2][b] - R[3][b] + bv;
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) Y[a][b][k] = Y[a][b][k] < 0.f ? 0.f : Y[a][b][k];       // torch.relu: NaN stays NaN
+    }
+    if (p.pool_out) {
+      // a tile is one 2x2 / stride-2 pooling window (y0, x0 even).  Index byte: first maximum in row-major order among the pixels
+      // inside the image (ceil mode), 4 when the maximum is <= 0 (re2e_maxpool2_fwd with relu_in)
+      if (oy < p.H && ox < p.W) {
+        const int PH2 = (p.H + 1) >> 1, PW2 = (p.W + 1) >> 1;
+        f32x4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          if (oy + (d >> 1) < p.H && ox + (d & 1) < p.W) {
+            const f32x4 v = Y[d >> 1][d & 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (v[k] > best[k]) { best[k] = v[k]; bi[k] = d; }
+          }
+        }
+        const long po = ((((long)n * PH2 + (oy >> 1)) * PW2 + (ox >> 1)) * p.Cout + n0 + c4);
+        *reinterpret_cast<f32x4*>(p.pool_out + po) = best;
+        typedef unsigned char uchar4h __attribute__((ext_vector_type(4)));
+        uchar4h b4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b4[k] = (unsigned char)(best[k] > 0.f ? bi[k] : 4);
+        *reinterpret_cast<uchar4h*>(p.pool_idx + po) = b4;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int y = oy + a, x = ox + b;
+          if (y < p.H && x < p.W) {
+            const long o = (((long)n * p.H + y) * p.W + x) * p.Cout + n0 + c4;
+            f32x4 v = Y[a][b];
+            if (p.mask) {
+              const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + o);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = mk[k] > 0.f ? v[k] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(p.out + o) = v;
+          }
+        }
+    }
+  }
+}
+
+template <int TXW>
+void launch_wino(const WinoArgs& a, hipStream_t st) {
+  constexpr size_t lds = (size_t)8 * 32 * LDR * sizeof(float);
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&wino_conv3x3_kernel<TXW>), lds);
+  hipLaunchKernelGGL((wino_conv3x3_kernel<TXW>), dim3((unsigned)a.nitems), dim3(256), lds, st, a);
+}
+
+}  // namespace
+
+extern "C" size_t re2e_conv3x3_wino_workspace_bytes(int C, int Cout) {
+  return C > 0 && Cout > 0 ? (size_t)16 * C * Cout * sizeof(float) : 0;
+}
+
+extern "C" int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int dgrad, const float* bias, int relu,
+                                 const float* mask, float* out, float* pool_out, unsigned char* pool_idx, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(in && w && workspace && (out || pool_out), "null operand");
+  RE2E_CHECK_ARG(NI > 0 && H > 0 && W > 0 && C > 0 && Cout > 0, "bad geometry");
+  RE2E_CHECK_ARG(!pool_out || (pool_idx && relu && !mask && !dgrad), "pool_out needs pool_idx, relu = 1, no mask, forward direction");
+  if (C % WCK || Cout % WNT) { re2e_set_error("re2e_conv3x3_wino: C must be a multiple of 8 and Cout of 64 (got %d, %d)", C, Cout); return RE2E_EUNSUPPORTED; }
+  const long in_bytes = (long)NI * H * W * C * 4, out_bytes = (long)NI * H * W * Cout * 4, u_bytes = (long)16 * C * Cout * 4;
+  if (in_bytes >= 0x7FFFFF00L || out_bytes >= 0x7FFFFF00L || u_bytes >= 0x7FFFFF00L) {
+    re2e_set_error("re2e_conv3x3_wino: tensors must be < 2 GiB");
+    return RE2E_EUNSUPPORTED;
+  }
+  const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask) |
+                       reinterpret_cast<uintptr_t>(pool_out) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(workspace);
+  if ((al & 15) || (reinterpret_cast<uintptr_t>(pool_idx) & 3)) { re2e_set_error("re2e_conv3x3_wino: operands must be 16-byte aligned"); return RE2E_EUNSUPPORTED; }
+  RE2E_CHECK_ARG(workspace_bytes >= (size_t)u_bytes, "workspace too small");
+  float* uf = (float*)workspace;
+  const long total = (long)16 * C * Cout;
+  hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256))), dim3(256), 0, stream, w, Cout, C, dgrad, uf);
+  WinoArgs a;
+  a.in = in; a.ufrag = uf; a.out = out; a.bias = bias; a.mask = mask; a.pool_out = pool_out; a.pool_idx = pool_idx;
+  a.NI = NI; a.H = H; a.W = W; a.C = C; a.Cout = Cout; a.relu = relu;
+  a.ngn = Cout / WNT; a.in_bytes = (unsigned)in_bytes; a.u_bytes = (unsigned)u_bytes; a.out_bytes = (unsigned)out_bytes;
+  // patch shape: 16 x 8 pixels (8 x 4 tiles) unless 8 x 16 wastes fewer padded pixels (W = 40: 8-wide patches fit exactly)
+  const long pad_w = (long)cdiv(H, 8) * 8 * cdiv(W, 16) * 16, pad_n = (long)cdiv(H, 16) * 16 * cdiv(W, 8) * 8;
+  const bool wide = pad_w <= pad_n;
+  const int PWp = wide ? 16 : 8, PHp = wide ? 8 : 16;
+  a.tiles_x = cdiv(W, PWp); a.tiles_y = cdiv(H, PHp);
+  const long nitems = (long)NI * a.tiles_x * a.tiles_y * a.ngn;
+  if (nitems >= 0x7FFFFFF0L) { re2e_set_error("re2e_conv3x3_wino: too many work items"); return RE2E_EUNSUPPORTED; }
+  a.nitems = (int)nitems;
+  if (wide) launch_wino<8>(a, stream); else launch_wino<4>(a, stream);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}

@@ -34,6 +34,8 @@ SIGNATURES = {
     're2e_conv_igemm': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, I, F, P]),
     're2e_conv3x3_relu_pool': (I, [P, I, I, I, I, P, I, P, P, P, P]),
     're2e_conv_igemm_masked': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, P]),
+    're2e_conv3x3_wino_workspace_bytes': (Z, [I, I]),
+    're2e_conv3x3_wino': (I, [P, I, I, I, I, P, I, I, P, I, P, P, P, P, P, Z, P]),
     're2e_conv_wgrad_workspace_bytes': (Z, [I, I, I, I, I, I, I]),
     're2e_conv_wgrad': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, P, F, P, Z, P]),
     're2e_conv_dgrad_s2': (I, [P, I, I, I, I, P, I, I, I, I, I, I, P, P, P]),

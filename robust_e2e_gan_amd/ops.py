@@ -434,6 +434,34 @@ def _conv_out(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
+WINOGRAD = lib.exp_env('RE2E_NO_WINOGRAD') is None      # A/B switch (RE2E_EXPERIMENTS=1): the direct halo-patch / engine kernels instead
+
+
+def _wino_ok(N, H, Wd, C, Cout, k, stride, pad):
+    """3x3 / stride-1 / pad-1 layers the fused Winograd F(2x2,3x3) kernel covers (re2e_conv3x3_wino: C % 8 == 0, Cout % 64 == 0,
+    tensors < 2 GiB)."""
+    return (WINOGRAD and k == (3, 3) and stride == 1 and pad == 1 and C % 8 == 0 and Cout % 64 == 0
+            and N * H * Wd * max(C, Cout) * 4 < 2 ** 31 - 256)
+
+
+def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool=False):
+    """re2e_conv3x3_wino on NHWC ``x`` with the layer's weight ``W`` in PyTorch layout: forward (dgrad=False: bias / ReLU / fused
+    2x2 max pool -> (pooled, index bytes)) or data gradient (dgrad=True: ``x`` is dy; ``mask``: the ReLU output in front)."""
+    N, H, Wd, C = x.shape
+    wsb = query('re2e_conv3x3_wino_workspace_bytes', C, Cout)
+    ws = workspace(wsb, x.device, 'wino')
+    if pool:
+        yp = empty((N, (H + 1) // 2, (Wd + 1) // 2, Cout), x)
+        idx = torch.empty(yp.shape, dtype=torch.uint8, device=x.device)
+        call('re2e_conv3x3_wino', x.data_ptr(), N, H, Wd, C, W.data_ptr(), Cout, 0, ptr(bias), 1, None, None, yp.data_ptr(), idx.data_ptr(),
+             ws.data_ptr(), wsb)
+        return yp, idx
+    y = empty((N, H, Wd, Cout), x)
+    call('re2e_conv3x3_wino', x.data_ptr(), N, H, Wd, C, W.data_ptr(), Cout, int(bool(dgrad)), ptr(bias), int(bool(relu)), ptr(mask), y.data_ptr(),
+         None, None, ws.data_ptr(), wsb)
+    return y
+
+
 class Conv2dFn(torch.autograd.Function):
     """x: (N,H,W,Cin) NHWC; W: (Cout,Cin,KH,KW) PyTorch layout; returns (N,OH,OW,Cout)."""
 
@@ -447,9 +475,18 @@ class Conv2dFn(torch.autograd.Function):
         ctx.act_bwd_done = bool(act_bwd_done or pool)  # the ONLY consumer (maxpool2(relu_in=True) / conv2d(x_is_relu_out=True)) returns d(pre-activation)
         ctx.x_is_relu_out = bool(x_is_relu_out)        # x = ReLU output of the layer in front: dx is taken through that ReLU (dx = 0 where x <= 0)
         ctx.pool = bool(pool)                          # the result is maxpool2(relu(conv)), 2x2 / stride 2 / ceil mode
+        ctx.W, ctx.b, ctx.cfg = W, b, (stride, pad, act)
+        if act in (lib.ACT_NONE, lib.ACT_RELU) and _wino_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and W.is_contiguous():
+            # 3x3 / stride-1 VGG layers: fused Winograd F(2x2,3x3), 2.25x fewer matrix instructions than the direct kernels below
+            if pool:
+                yp, idx = conv3x3_wino(x, W, Cout, bias=b, relu=True, pool=True)
+                ctx.save_for_backward(x, idx)
+                return yp
+            y = conv3x3_wino(x, W, Cout, bias=b, relu=act == lib.ACT_RELU)
+            ctx.save_for_backward(x, y if (act != lib.ACT_NONE and not ctx.act_bwd_done) else None)
+            return y
         wg = empty((Cout, KH, KW, Cin), x)
         call('re2e_conv_weight_gather', W.data_ptr(), wg.data_ptr(), Cout, Cin, KH, KW, 0, KH, KW, 0, 0, 1)
-        ctx.W, ctx.b, ctx.cfg = W, b, (stride, pad, act)
         if pool:
             # one launch: only the pooled activation and its index bytes are written (re2e_conv3x3_relu_pool); geometries the fused
             # kernel does not cover run the convolution and the pool (with the ReLU mask in its index byte) one after the other
@@ -512,6 +549,8 @@ def conv_dgrad(dz, W, xshape, stride, pad, relu_out=None):
     N, H, Wd, Cin = xshape
     Cout, _, KH, KW = W.shape
     OH, OW = dz.shape[1], dz.shape[2]
+    if stride == 1 and _wino_ok(N, H, Wd, Cout, Cin, (KH, KW), stride, pad) and (OH, OW) == (H, Wd) and W.is_contiguous():
+        return conv3x3_wino(_f32(dz), W, Cin, dgrad=True, mask=relu_out)
     if stride == 1:
         wt = empty((Cin, KH, KW, Cout), dz)
         call('re2e_conv_weight_gather', W.data_ptr(), wt.data_ptr(), Cout, Cin, KH, KW, 1, KH, KW, 0, 0, 1)

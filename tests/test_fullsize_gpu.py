@@ -160,7 +160,8 @@ def test_config4_full_size_vs_oracle():
     torch.cuda.synchronize()
     cfg = dict(enhance_layers=2, elayers=3, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=opt.coral_loss_lambda, gan_loss_lambda=1.0,
                grad_clip=5.0, eps=1e-8, isGAN=True, enhance_loss_type='L2')
-    torch.set_num_threads(max(1, min(64, len(__import__('os').sched_getaffinity(0)))))
+    from conftest import host_threads
+    torch.set_num_threads(host_threads())
     ref = oj.joint_step(oj.JointState(sd[0], sd[2], sd[3], sd[1]['fc'], cfg), (clean, mix, mix_log, targets, il.tolist(), tl.tolist()), cm,
                         update=False)
     for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'gan_loss', 'loss_D'):
@@ -222,7 +223,8 @@ def test_config5_full_step_vs_oracle():
     assert lib.query('re2e_lstm_abort_count') == 0
     cfg = dict(enhance_layers=2, elayers=3, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=opt.coral_loss_lambda, gan_loss_lambda=1.0,
                grad_clip=5.0, eps=1e-8, isGAN=True, enhance_loss_type='L2')
-    torch.set_num_threads(max(1, min(64, len(__import__('os').sched_getaffinity(0)))))
+    from conftest import host_threads
+    torch.set_num_threads(host_threads())
     ref = oj.joint_step(oj.JointState(sd[0], sd[2], sd[3], sd[1]['fc'], cfg), (clean, mix, mix_log, targets, il.tolist(), tl.tolist()), cm,
                         update=False)
     for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'gan_loss', 'loss_D'):
