@@ -109,8 +109,8 @@ def engine_average():
     import re
     for n in ('r03_igemm_calls_nooverlap.txt', 'r02_igemm_calls_nooverlap.txt'):
         try:
-            last = open(os.path.join(ROOT, 'profiles', n)).read().strip().splitlines()[-1]
-            m = re.search(r'([\d.]+) TFLOP/s average', last)
+            tail = [l for l in open(os.path.join(ROOT, 'profiles', n)).read().strip().splitlines() if l.startswith('total ')]
+            m = re.search(r'([\d.]+) TFLOP/s average', tail[-1]) if tail else None
             if m:
                 return float(m.group(1)), 'profiles/' + n
         except Exception:

@@ -38,7 +38,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int WCK = 8;                  // input channels per chunk
 constexpr int WNT = 64;                 // output channels per workgroup
-constexpr int LDR = WNT + 4;            // row stride (floats) of the epilogue's exchange buffer
+constexpr int LDR = WNT + 4;            // row stride (floats) of the epilogue's exchange buffer: [row i][b][32 tiles][64 channels + pad]
 constexpr unsigned WOOB = 0x80000000u;  // byte offset beyond any tensor this path accepts (< 2 GiB): the load returns 0
 
 struct WinoArgs {
@@ -46,8 +46,10 @@ struct WinoArgs {
   const float* mask;                          // optional, shape of out: out = mask > 0 ? value : 0
   float* pool_out; unsigned char* pool_idx;   // optional: only maxpool2(relu(out)) and its index bytes are written
   int NI, H, W, C, Cout, relu;
-  int tiles_x, tiles_y, ngn, nitems;          // patches per row / column, 64-channel groups, work items
-  unsigned in_bytes, u_bytes, out_bytes;
+  int tiles_x, tiles_y, ngn_shift, per_image; // patches per row / column, log2(64-channel groups), work items per image
+  unsigned long long* stamps;                 // RE2E_EXPERIMENTS builds only: 8 s_memtime stamps per wavefront of the first 4096 workgroups
+  int dbg;                                    // RE2E_EXPERIMENTS builds only: 1 = weight loads always hit the same 2 KB, 2 = pixel loads always read chunk 0
+  unsigned in_bytes, u_bytes, out_bytes, pool_bytes;
 };
 
 // U[g][chunk][pos][nt][lane][e] = sum_{a,b} G[i][a] G[j][b] k[o][c][a][b],  pos = 4i + j, o = 64 g + 32 nt + (lane & 31),
@@ -78,6 +80,13 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, int Cout, int C
   }
 }
 
+#ifdef RE2E_EXPERIMENTS
+#define WSTAMP(k) do { if (p.stamps && lane == 0 && blockIdx.y == 0 && blockIdx.x < 4096) \
+    p.stamps[((size_t)blockIdx.x * 4 + wid) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
+
 template <int TXW>      // tiles per patch row: 8 (16 x 8 pixel patch) or 4 (8 x 16)
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
   constexpr int TYH = 32 / TXW;
@@ -86,73 +95,93 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and the compiler must know it (scalar offsets, scalar branches)
-  // ---- work item (XCD-aware order: each XCD's L2 sees a contiguous run of patches) ----
+  // ---- work item: blockIdx.y = image, blockIdx.x = (patch, 64-channel group) of it in XCD-aware order (each XCD's L2 sees a
+  // contiguous run of patches).  Measured and rejected (round 3, same GPU session): 2-8 consecutive items per workgroup with the
+  // first loads of item k+1 issued under the last chunk and the epilogue of item k (the per-workgroup time per item fell 20 %, the
+  // kernel's did not move: what an item costs beyond its 256 MFMAs per wavefront is instruction issue beside the other workgroup's
+  // matrix stream, not latency); starting the second workgroup of every CU half an item late (no effect either way).
   int item;
   {
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   }
-  if (item >= p.nitems) return;
-  // (the quotients are computed on the vector ALU: tell the compiler they are wave-uniform, or every buffer load that takes a
-  // scalar offset derived from them becomes a waterfall loop)
-  const int nblk = __builtin_amdgcn_readfirstlane(item % p.ngn);
-  const int tile_id = item / p.ngn, t2 = tile_id / p.tiles_x;
-  const int tx = __builtin_amdgcn_readfirstlane(tile_id - t2 * p.tiles_x), n = __builtin_amdgcn_readfirstlane(t2 / p.tiles_y);
-  const int ty = __builtin_amdgcn_readfirstlane(t2 - n * p.tiles_y);
-  const int y0 = ty * PH, x0 = tx * PW, n0 = nblk * WNT;
+  const int n = blockIdx.y;
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ufrag), 0, p.u_bytes, 0x00020000);
+  // output side: 32-bit offsets through descriptors as well; a pixel outside the image gets the out-of-range offset and its store
+  // is dropped (its mask load returns 0) -- no branch, no 64-bit address arithmetic in the epilogue
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.pool_out ? p.pool_out : p.out, 0, p.pool_out ? p.pool_bytes : p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.in), 0, p.mask ? p.out_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(p.pool_idx ? (void*)p.pool_idx : (void*)p.in, 0, p.pool_idx ? p.pool_bytes / 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.in), 0, p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
 
-  // ---- this lane's 8 input pixels: tile (tyi, txi) = lr, rows (ra, rb) of its 4x4 input tile, 4 columns, channels 4 lh .. 4 lh + 3
+  // ---- a lane's 8 input pixels: tile (tyi, txi) = lr, rows (ra, rb) of its 4x4 input tile, 4 columns, channels 4 lh .. 4 lh + 3
   const int tyi = lr / TXW, txi = lr - tyi * TXW;
   const int ra = wid == 0 ? 0 : 1, rb = wid == 3 ? 3 : 2;            // B^T row i touches input rows (0,2) (1,2) (1,2) (1,3)
-  unsigned a_off[8];
-  unsigned a_s;
-  if (y0 >= 1 && x0 >= 1 && y0 + PH + 1 <= p.H && x0 + PW + 1 <= p.W) {
-    a_s = (unsigned)((((n * p.H + y0 - 1) * p.W + x0 - 1) * p.C) * 4);     // the halo's corner pixel
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int row = k < 4 ? ra : rb, col = k & 3;
-      a_off[k] = (unsigned)((((2 * tyi + row) * p.W + 2 * txi + col) * p.C + 4 * lh) * 4);
-    }
-  } else {
-    a_s = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int row = k < 4 ? ra : rb, col = k & 3;
-      const int iy = y0 - 1 + 2 * tyi + row, ix = x0 - 1 + 2 * txi + col;
-      const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-      a_off[k] = ok ? (unsigned)((((n * p.H + iy) * p.W + ix) * p.C + 4 * lh) * 4) : WOOB;      // < 2^31: checked by the launcher
-    }
-  }
-  a_s = (unsigned)__builtin_amdgcn_readfirstlane((int)a_s);
+  const int rowb = p.W * p.C * 4, colb = p.C * 4;
+  const unsigned a_s = (unsigned)(n * p.H * p.W * p.C * 4);          // the image; < 2^31: checked by the launcher
+  const int lane_base = (2 * tyi - 1) * rowb + (2 * txi - 1) * colb + 16 * lh;
   const int nch = p.C / WCK;
   const unsigned u_lane = (unsigned)lane * 16u;
-  // fragment (chunk, position 4 wid + j, n-tile nt) of this group: ((((nblk * nch + chunk) * 16 + 4 wid + j) * 2 + nt) * 1024 bytes
-  const unsigned u_s0 = (unsigned)(((nblk * nch) * 16 + 4 * wid) * 2) * 1024u;
+
+  struct Geo { int y0, x0, nblk; };
+  auto geo_of = [&](int it) {
+    Geo g;
+    g.nblk = it & ((1 << p.ngn_shift) - 1);
+    const int tile_id = it >> p.ngn_shift;
+    const int ty = __builtin_amdgcn_readfirstlane(tile_id / p.tiles_x);     // (vector-ALU quotient: tell the compiler it is uniform)
+    g.y0 = ty * PH;
+    g.x0 = (tile_id - ty * p.tiles_x) * PW;
+    return g;
+  };
+  unsigned a_off[8];
+  unsigned u_s0;         // fragment (chunk, position 4 wid + j, n-tile nt) of group nblk: ((((nblk nch + chunk) 16 + 4 wid + j) 2 + nt) KB
+  auto set_item = [&](const Geo& g) {
+    u_s0 = (unsigned)(((g.nblk * nch) * 16 + 4 * wid) * 2) * 1024u;
+    const int base = lane_base + g.y0 * rowb + g.x0 * colb;
+    if (g.y0 >= 1 && g.x0 >= 1 && g.y0 + PH + 1 <= p.H && g.x0 + PW + 1 <= p.W) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a_off[k] = (unsigned)(base + (k < 4 ? ra : rb) * rowb + (k & 3) * colb);
+    } else {
+      const int iy0 = g.y0 - 1 + 2 * tyi, ix0 = g.x0 - 1 + 2 * txi;
+      const bool rok0 = (unsigned)(iy0 + ra) < (unsigned)p.H, rok1 = (unsigned)(iy0 + rb) < (unsigned)p.H;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool ok = (k < 4 ? rok0 : rok1) & ((unsigned)(ix0 + (k & 3)) < (unsigned)p.W);
+        a_off[k] = ok ? (unsigned)(base + (k < 4 ? ra : rb) * rowb + (k & 3) * colb) : WOOB;
+      }
+    }
+  };
 
   f32x4 raw[8], uf[4][2];
   auto fetch_raw = [&](int chunk) {
-    const unsigned cb = a_s + (unsigned)(chunk * WCK * 4);
+    unsigned cb = a_s + (unsigned)(chunk * WCK * 4);
+#ifdef RE2E_EXPERIMENTS
+    if (p.dbg & 2) cb = a_s;                          // diagnostic: every chunk re-reads chunk 0 (cache hits): is the pixel traffic the limit?
+#endif
 #pragma unroll
     for (int k = 0; k < 8; ++k) raw[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[k], cb, 0));
   };
   auto fetch_u = [&](int chunk, int j) {
-    const unsigned s = u_s0 + (unsigned)(chunk * 16 * 2 + j * 2) * 1024u;
+    unsigned s = u_s0 + (unsigned)(chunk * 16 * 2 + j * 2) * 1024u;
+#ifdef RE2E_EXPERIMENTS
+    if (p.dbg & 1) s = 0;                             // diagnostic: every fragment load reads the same 2 KB: is the weight traffic the limit?
+#endif
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) uf[j][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, u_lane, s + (unsigned)nt * 1024u, 0));
   };
 
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+  // Row transform as ONE fused multiply-add per value: T[b] = d[ra][b] + tsign * d[rb][b] with tsign = -1, +1, -1, -1 for rows
+  // i = 0..3 of B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]; row 2 then carries the opposite sign (d1 - d2 instead of d2 - d1),
+  // which the weight transform compensates by negating U[2][.] (wino_weights_kernel).
+  const float tsign = wid == 1 ? 1.f : -1.f;
+  const float m1 = -1.f;
 
+  WSTAMP(0);
+  Geo cur = geo_of(item);
+  set_item(cur);
   // (same issue order as in the loop -- pixels first, then the weights position by position -- or the wait at the loop's head
   // has to cover the prologue's order as well and degenerates to vmcnt(0))
   __builtin_amdgcn_sched_barrier(0);
@@ -164,88 +193,115 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  // Row transform as ONE fused multiply-add per value: T[b] = d[ra][b] + tsign * d[rb][b] with tsign = -1, +1, -1, -1 for rows
-  // i = 0..3 of B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]; row 2 then carries the opposite sign (d1 - d2 instead of d2 - d1),
-  // which the weight transform compensates by negating U[2][.] (wino_weights_kernel).  The loop body has no branch -- the last
-  // chunk re-fetches itself instead of fetching nothing -- so the compiler's s_waitcnt counts stay exact: a wait only covers the
-  // loads it needs, never the ones issued a few instructions earlier.
-  const float tsign = wid == 1 ? 1.f : -1.f;
-  const f32x4 ts4 = {tsign, tsign, tsign, tsign};
-  for (int chunk = 0; chunk < nch; ++chunk) {
-    f32x4 T[4], V[4];
+  WSTAMP(1);
+  {
+    const int y0 = cur.y0, x0 = cur.x0, n0 = cur.nblk * WNT;
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) T[b] = raw[b] + ts4 * raw[4 + b];
-    V[0] = T[0] - T[2];
-    V[1] = T[1] + T[2];
-    V[2] = T[2] - T[1];
-    V[3] = T[1] - T[3];
-    const int nxt = chunk + 1 < nch ? chunk + 1 : chunk;
-    // (sched_barrier: the scheduler otherwise sinks every load to the end of the body, right in front of the wait that needs it)
-    __builtin_amdgcn_sched_barrier(0);
-    fetch_raw(nxt);                                 // the raw registers are free: next chunk's pixels fly under this chunk's MFMAs
-    __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j][jj], uf[j][nt][jj], acc[j][nt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      fetch_u(nxt, j);                              // ... and position j's weights of the next chunk behind its last use
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
+        for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
 
-  // ---- output transform, column half, in registers: R[b] = sum_j M[i][j] A[j][b],  A^T = [1 1 1 0; 0 1 -1 -1]
-  float* Rs = smem + (wid * 2) * (32 * LDR);
+    // The chunk loop has no branch -- the very last chunk of the workgroup re-fetches itself instead of fetching nothing -- so the
+    // compiler's s_waitcnt counts stay exact: a wait only covers the loads it needs, never the ones issued a few instructions
+    // earlier.  In the last chunk of an item the fetches already address chunk 0 of the NEXT item.
+    for (int chunk = 0; chunk < nch; ++chunk) {
+      f32x4 T[4], V[4];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+      for (int b = 0; b < 4; ++b) T[b] = raw[b] + tsign * raw[4 + b];
+      V[0] = T[0] + m1 * T[2];                        // subtractions as packed fused multiply-adds (there is no packed subtract)
+      V[1] = T[1] + T[2];
+      V[2] = T[2] + m1 * T[1];
+      V[3] = T[1] + m1 * T[3];
+      const int nxt = chunk + 1 < nch ? chunk + 1 : chunk;
+      // (sched_barrier: the scheduler otherwise sinks every load to the end of the body, right in front of the wait that needs it)
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_raw(nxt);                                 // the raw registers are free: next chunk's pixels fly under this chunk's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
-      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;                  // tile of this wavefront's 32
-      Rs[m * LDR + nt * 32 + lr] = m0 + m1 + m2;
-      Rs[32 * LDR + m * LDR + nt * 32 + lr] = m1 - m2 - m3;
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j][jj], uf[j][nt][jj], acc[j][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_u(nxt, j);                              // ... and position j's weights of the next chunk behind its last use
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  __syncthreads();
-  // ---- row half + bias / ReLU / mask / pool + store: wavefront w takes tiles 8w .. 8w+7, lane = (tile of 4, 4 channels), 2 passes
-  const int c4 = (lane & 15) * 4;
-  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + c4);
+
+    WSTAMP(2);
+    // ---- output transform, column half, in registers: R[b] = sum_j M[i][j] A[j][b],  A^T = [1 1 1 0; 0 1 -1 -1]
+    float* Rs = smem + (wid * 2) * (32 * LDR);
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int tl = 8 * wid + 4 * it + (lane >> 4);
-    const int ty2 = tl / TXW, tx2 = tl - ty2 * TXW;
-    const int oy = y0 + 2 * ty2, ox = x0 + 2 * tx2;
-    f32x4 R[4][2];
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0][nt][r], m1v = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;                  // tile of this wavefront's 32
+        Rs[m * LDR + nt * 32 + lr] = m0 + m1v + m2;
+        Rs[32 * LDR + m * LDR + nt * 32 + lr] = m1v - m2 - m3;
+      }
+    // Behind the LDS writes the accumulators are dead: the epilogue's own loads -- the bias of this item's channels and, for a data
+    // gradient, the ReLU mask of its output pixels -- are issued HERE, in front of the barrier, so that their latency hides behind
+    // the wait for the slowest wavefront and the LDS reads (fetched where they are used they would expose it whole: vmcnt counts
+    // in order and they would be the youngest loads).  Output offsets are 32-bit; a pixel outside the image gets the out-of-range
+    // offset: its mask reads 0, its store is dropped.
+    const int c4 = (lane & 15) * 4;
+    const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)((n0 + c4) * 4), 0, 0));
+    const int PH2 = (p.H + 1) >> 1, PW2 = (p.W + 1) >> 1;
+    unsigned o_off[2][4];
+    f32x4 mk[2][4];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) R[i][b] = *reinterpret_cast<const f32x4*>(smem + ((i * 2 + b) * 32 + tl) * LDR + c4);
-    f32x4 Y[2][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      Y[0][b] = R[0][b] + R[1][b] + R[2][b] + bv;
-      Y[1][b] = R[1][b] - R[2][b] - R[3][b] + bv;
-    }
-    if (p.relu) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) Y[a][b][k] = Y[a][b][k] < 0.f ? 0.f : Y[a][b][k];       // torch.relu: NaN stays NaN
-    }
-    if (p.pool_out) {
-      // a tile is one 2x2 / stride-2 pooling window (y0, x0 even).  Index byte: first maximum in row-major order among the pixels
-      // inside the image (ceil mode), 4 when the maximum is <= 0 (re2e_maxpool2_fwd with relu_in)
-      if (oy < p.H && ox < p.W) {
-        const int PH2 = (p.H + 1) >> 1, PW2 = (p.W + 1) >> 1;
-        f32x4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-        int bi[4] = {0, 0, 0, 0};
+    for (int it = 0; it < 2; ++it) {
+      const int tl = 8 * wid + 4 * it + (lane >> 4);
+      const int ty2 = tl / TXW, tx2 = tl - ty2 * TXW;
+      const int oy = y0 + 2 * ty2, ox = x0 + 2 * tx2;
+      if (p.pool_out) {
+        o_off[it][0] = (oy < p.H && ox < p.W) ? (unsigned)((((n * PH2 + (oy >> 1)) * PW2 + (ox >> 1)) * p.Cout + n0 + c4) * 4) : WOOB;
+      } else {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
+          const int y = oy + (d >> 1), x = ox + (d & 1);
+          o_off[it][d] = (y < p.H && x < p.W) ? (unsigned)((((n * p.H + y) * p.W + x) * p.Cout + n0 + c4) * 4) : WOOB;
+          if (p.mask) mk[it][d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsM, o_off[it][d], 0, 0));
+        }
+      }
+    }
+    WSTAMP(3);
+    __syncthreads();
+    WSTAMP(4);
+    // ---- row half + bias / ReLU / mask / pool + store: wavefront w takes tiles 8w .. 8w+7; lane = (tile of 4, 4 channels), 2 passes;
+    // a store instruction writes four pixels' 64 channels (4 x 256 contiguous bytes)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int tl = 8 * wid + 4 * it + (lane >> 4);
+      f32x4 R[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          R[i][b] = *reinterpret_cast<const f32x4*>(smem + ((i * 2 + b) * 32 + tl) * LDR + c4);
+      f32x4 Y[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const f32x4 s12 = R[1][b] + R[2][b], d12 = R[1][b] + m1 * R[2][b];
+        Y[0][b] = R[0][b] + s12 + bv;
+        Y[1][b] = d12 + m1 * R[3][b] + bv;
+      }
+      if (p.pool_out) {
+        // a tile is one 2x2 / stride-2 pooling window (y0, x0 even).  max and ReLU commute: the ReLU is applied to the pooled value.
+        // Index byte: first maximum in row-major order among the pixels inside the image (ceil mode), 4 when the maximum is <= 0
+        // (re2e_maxpool2_fwd with relu_in)
+        const int ty2 = tl / TXW, tx2 = tl - ty2 * TXW;
+        const int oy = y0 + 2 * ty2, ox = x0 + 2 * tx2;
+        f32x4 best = Y[0][0];
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
           if (oy + (d >> 1) < p.H && ox + (d & 1) < p.W) {
             const f32x4 v = Y[d >> 1][d & 1];
 #pragma unroll
@@ -253,32 +309,29 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
               if (v[k] > best[k]) { best[k] = v[k]; bi[k] = d; }
           }
         }
-        const long po = ((((long)n * PH2 + (oy >> 1)) * PW2 + (ox >> 1)) * p.Cout + n0 + c4);
-        *reinterpret_cast<f32x4*>(p.pool_out + po) = best;
-        typedef unsigned char uchar4h __attribute__((ext_vector_type(4)));
-        uchar4h b4;
+        unsigned b4 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) b4[k] = (unsigned char)(best[k] > 0.f ? bi[k] : 4);
-        *reinterpret_cast<uchar4h*>(p.pool_idx + po) = b4;
-      }
-    } else {
+        for (int k = 0; k < 4; ++k) { b4 |= (unsigned)(best[k] > 0.f ? bi[k] : 4) << (8 * k); best[k] = best[k] > 0.f ? best[k] : 0.f; }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, best), rsO, o_off[it][0], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(b4, rsI, o_off[it][0] == WOOB ? WOOB : o_off[it][0] >> 2, 0, 0);
+      } else {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int d = 0; d < 4; ++d) {
+          f32x4 v = Y[d >> 1][d & 1];
+          if (p.relu) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int y = oy + a, x = ox + b;
-          if (y < p.H && x < p.W) {
-            const long o = (((long)n * p.H + y) * p.W + x) * p.Cout + n0 + c4;
-            f32x4 v = Y[a][b];
-            if (p.mask) {
-              const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + o);
-#pragma unroll
-              for (int k = 0; k < 4; ++k) v[k] = mk[k] > 0.f ? v[k] : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(p.out + o) = v;
+            for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];       // torch.relu: NaN stays NaN
           }
+          if (p.mask) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = mk[it][d][k] > 0.f ? v[k] : 0.f;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, o_off[it][d], 0, 0);
         }
+      }
     }
+    WSTAMP(5);
+    WSTAMP(6);
   }
 }
 
@@ -287,7 +340,7 @@ void launch_wino(const WinoArgs& a, hipStream_t st) {
   constexpr size_t lds = (size_t)8 * 32 * LDR * sizeof(float);
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&wino_conv3x3_kernel<TXW>), lds);
-  hipLaunchKernelGGL((wino_conv3x3_kernel<TXW>), dim3((unsigned)a.nitems), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wino_conv3x3_kernel<TXW>), dim3((unsigned)a.per_image, (unsigned)a.NI), dim3(256), lds, st, a);
 }
 
 }  // namespace
@@ -318,15 +371,24 @@ extern "C" int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, c
   WinoArgs a;
   a.in = in; a.ufrag = uf; a.out = out; a.bias = bias; a.mask = mask; a.pool_out = pool_out; a.pool_idx = pool_idx;
   a.NI = NI; a.H = H; a.W = W; a.C = C; a.Cout = Cout; a.relu = relu;
-  a.ngn = Cout / WNT; a.in_bytes = (unsigned)in_bytes; a.u_bytes = (unsigned)u_bytes; a.out_bytes = (unsigned)out_bytes;
+  const int ngn = Cout / WNT;
+  if (ngn & (ngn - 1)) { re2e_set_error("re2e_conv3x3_wino: Cout / 64 must be a power of two (got Cout = %d)", Cout); return RE2E_EUNSUPPORTED; }
+  a.ngn_shift = 0;
+  while ((1 << a.ngn_shift) < ngn) ++a.ngn_shift;
+  a.in_bytes = (unsigned)in_bytes; a.u_bytes = (unsigned)u_bytes; a.out_bytes = (unsigned)out_bytes;
+  a.pool_bytes = (unsigned)((long)NI * ((H + 1) / 2) * ((W + 1) / 2) * Cout * 4);
   // patch shape: 16 x 8 pixels (8 x 4 tiles) unless 8 x 16 wastes fewer padded pixels (W = 40: 8-wide patches fit exactly)
   const long pad_w = (long)cdiv(H, 8) * 8 * cdiv(W, 16) * 16, pad_n = (long)cdiv(H, 16) * 16 * cdiv(W, 8) * 8;
   const bool wide = pad_w <= pad_n;
   const int PWp = wide ? 16 : 8, PHp = wide ? 8 : 16;
   a.tiles_x = cdiv(W, PWp); a.tiles_y = cdiv(H, PHp);
-  const long nitems = (long)NI * a.tiles_x * a.tiles_y * a.ngn;
-  if (nitems >= 0x7FFFFFF0L) { re2e_set_error("re2e_conv3x3_wino: too many work items"); return RE2E_EUNSUPPORTED; }
-  a.nitems = (int)nitems;
+  const long per_image = (long)a.tiles_x * a.tiles_y * ngn;
+  if (per_image >= 0x7FFFFFF0L || NI > 65535) { re2e_set_error("re2e_conv3x3_wino: too many work items"); return RE2E_EUNSUPPORTED; }
+  a.per_image = (int)per_image;
+  static const int dbg_env = exp_env("RE2E_WINO_DBG") ? atoi(exp_env("RE2E_WINO_DBG")) : 0;
+  a.dbg = dbg_env;
+  static const char* st_env = exp_env("RE2E_WINO_STAMPS");      // device address (hex) of a 4096 x 4 x 8 x 8-byte buffer
+  a.stamps = st_env ? (unsigned long long*)strtoull(st_env, nullptr, 16) : nullptr;
   if (wide) launch_wino<8>(a, stream); else launch_wino<4>(a, stream);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
