@@ -63,12 +63,14 @@ __global__ void colsum_partial_kernel(const float* __restrict__ A, int M, int N,
   __syncthreads();
   if (ry == 0 && col < N) part[(long)blockIdx.y * N + col] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
-// final stage: CW columns x (1024 / CW) chunk lanes per workgroup, lanes combined through LDS in a fixed order.  CW = 64 for short
-// partial lists; CW = 16 for long ones (the 800-chunk bias gradients of the BLSTMP projections sit on the critical path of the
-// backward: 8 workgroups x 50 dependent passes took 215 us beside the weight-gradient stream's MFMA tiles, round 3 trace).
+// final stage: CW columns x (256 / CW) chunk lanes per workgroup, lanes combined through LDS in a fixed order.  256-thread workgroups:
+// the 800-chunk bias gradients of the BLSTMP projections sit on the critical path of the backward, BESIDE the weight-gradient
+// stream's chip-filling tiles, and a 1024-thread workgroup has to wait for a CU with 16 free wave slots and their registers
+// (round-3 traces: 205-215 us for 1.6 MB of partials, with 8 as with 32 such workgroups); CW = 64 for short partial lists, 16 for
+// long ones (more workgroups, fewer dependent passes per thread).
 template <int CW>
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int chunks, int N, float* out, float beta) {
-  constexpr int CL = 1024 / CW;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int chunks, int N, float* out, float beta) {
+  constexpr int CL = 256 / CW;
   __shared__ float red[CL][CW];
   const int cx = threadIdx.x % CW, cl = threadIdx.x / CW;
   const int col = blockIdx.x * CW + cx;
@@ -88,13 +90,13 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
   __syncthreads();
   if (cl != 0 || col >= N) return;
   s = 0.f;
-#pragma unroll 16
+#pragma unroll
   for (int q = 0; q < CL; ++q) s += red[q][cx];
   out[col] = (beta != 0.f ? beta * out[col] : 0.f) + s;
 }
 static void colsum_final_launch(const float* part, int chunks, int N, float* out, float beta, hipStream_t stream) {
-  if (chunks >= 128) hipLaunchKernelGGL(colsum_final_kernel<16>, dim3(cdiv(N, 16)), dim3(1024), 0, stream, part, chunks, N, out, beta);
-  else hipLaunchKernelGGL(colsum_final_kernel<64>, dim3(cdiv(N, 64)), dim3(1024), 0, stream, part, chunks, N, out, beta);
+  if (chunks >= 128) hipLaunchKernelGGL(colsum_final_kernel<16>, dim3(cdiv(N, 16)), dim3(256), 0, stream, part, chunks, N, out, beta);
+  else hipLaunchKernelGGL(colsum_final_kernel<64>, dim3(cdiv(N, 64)), dim3(256), 0, stream, part, chunks, N, out, beta);
 }
 
 // Vectorised partial stage, optionally fused with the activation backward: dz = dy * act'(y) is written and
