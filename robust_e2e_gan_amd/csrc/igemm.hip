@@ -839,16 +839,26 @@ __global__ __launch_bounds__(512) void skinny_gemm2_kernel(const float* __restri
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // A's rows are one per lane: element-wise loads of it touch 32 cache lines per instruction for 4 useful bytes each (16 such
+  // instructions per pass; round-3 trace: 26 us per launch at K = 1200, a link of the decoder's backward chain).  With K and lda
+  // multiples of 4 the lane's four consecutive k are ONE 16-byte load.
+  const bool avec = (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
   for (int qb = q0; qb < q1; qb += 4) {
     float av[4][4], bv[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int k = 8 * (qb + u) + 4 * lh;
       const bool qok = qb + u < q1;
+      if (avec) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 a4 = (qok && k < K && rok) ? *reinterpret_cast<const f32x4*>(ap + k) : zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[u][j] = a4[j];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool kok = qok && k + j < K;
-        av[u][j] = (kok && rok) ? ap[k + j] : 0.f;
+        if (!avec) av[u][j] = (kok && rok) ? ap[k + j] : 0.f;
         bv[u][j] = (kok && cok) ? B[(long)(k + j) * ldb + col] : 0.f;
       }
     }

@@ -233,10 +233,11 @@ class JointTrainer(object):
                 d_fake, gan_loss = d_fake_forward()
             fake_bn_layers = list(self.gan_model._bn_layers_last)
         self._mark('fbank + G-step D fwd enqueued (side)')
-        loss_ctc, loss_att, acc, clean_context, mix_context = self.asr_model(clean_feat, enhance_feat, targets, input_sizes, target_sizes,
-                                                                              sche_samp_rate, enhance_cmvn, clean_branch=clean_branch)
+        loss_ctc, loss_att, acc, clean_context, mix_context = self.asr_model(
+            clean_feat, enhance_feat, targets, input_sizes, target_sizes, sche_samp_rate, enhance_cmvn, clean_branch=clean_branch,
+            context_loss=lambda cc, mc: opt.coral_loss_lambda * CORAL(cc, mc))      # on the filler stream, beside the decoder
         self._mark('ASR fwd')
-        coral_loss = opt.coral_loss_lambda * CORAL(clean_context, mix_context)
+        coral_loss = self.asr_model.last_context_loss
         asr_loss = opt.mtlalpha * loss_ctc.view(()) + (1 - opt.mtlalpha) * loss_att
         loss = asr_loss + enhance_loss + coral_loss
         if self.isGAN:
