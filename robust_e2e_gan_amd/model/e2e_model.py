@@ -158,6 +158,10 @@ class ShareE2E(E2E):
         # forward AND backward (autograd runs a node's backward on its forward stream) then run beside the decoder's latency-bound
         # loop instead of between its forward and backward on the critical stream (round 3: ~0.45 ms of small kernels).  The value is
         # left in ``self.last_context_loss``.
+        # (Measured and rejected, round 3: differentiating the two heads right here, behind their forward, and re-injecting their
+        # gradient at the encoder output -- the engine enqueues their backward only after the decoder's ~250 backward launches, so
+        # the critical stream waits ~0.9 ms for it -- removes that wait but puts the CTC / CORAL backward beside the decoder's
+        # FORWARD loop, which it slows by more: 65.0 against 64.7 ms per step.)
         def heads_on_aux():
             l_ctc = self.ctc.forward(hpad_enh, hlens, ys) if self.mtlalpha != 0 else None
             idx = host_to_dev(np.concatenate([b * Tq + np.arange(hlens[b], dtype=np.int32) for b in range(B)]).astype(np.int32), enh.device)
