@@ -169,6 +169,8 @@ class ShareE2E(E2E):
             cln_c = ops.gather_rows(hpad_cln.reshape(B * Tq, E), idx)
             l_ctx = context_loss(cln_c, mix_c) if context_loss is not None else None
             return l_ctc, cln_c, mix_c, l_ctx
+        # (... and so does enqueueing the heads BEHIND the decoder, which makes their backward nodes the first the engine enqueues:
+        # beside the decoder's backward loop they cost it more than the wait they remove, 65.3 against 64.75 ms.)
         if aux is not None:
             cur = torch.cuda.current_stream()
             aux.wait_stream(cur)
