@@ -460,13 +460,19 @@ class JointTrainer(object):
         return errors
 
     def fit(self, train_loader, val_loader, visualizer, train_sampler=None, start_epoch=0, iters=0, best_loss=float('inf'), best_acc=0.0,
-            max_iters=None):
+            max_iters=None, prefetch=False):
         """The reference's training loop (joint_train.py:145-329) around ``step`` / ``validate``: CMVN estimate before
         training and after every validation, scheduled-sampling rate updated only at validation time, ``print_freq``
         logging + 'latest' checkpoint, ``validate_freq`` validation + model selection (``opt.criterion`` 'acc' / 'loss';
         a worse score decays Adadelta's eps, a better one is saved as model.{acc,loss}.best) with the reference's
         checkpoint keys.  The per-step meters are read back one iteration late, after the next step has been enqueued,
-        so that logging never drains the GPU.  Returns (iters, best_loss, best_acc)."""
+        so that logging never drains the GPU.  Returns (iters, best_loss, best_acc).
+
+        ``prefetch``: ``train_loader`` yields UN-collated batches (lists of samples, or ``data.prefetch.Staged`` objects prepared by
+        loader workers) and they go through ``data.prefetch.DevicePrefetcher``: pinned staging, H2D and zero padding on a copy
+        stream two batches ahead of the step that consumes them (set GPU_MAX_HW_QUEUES=8: the step already runs on four
+        streams).  ``prefetch`` may also be a collate callable ``(batch, device, pool) -> 10-tuple`` (e.g. one that wraps
+        ``collate_kaldi_device`` for raw Kaldi records)."""
         from .utils import utils
         opt = self.opt
         enhance_cmvn = compute_cmvn_epoch(opt, train_loader, self.enhance_model, self.feat_model)
@@ -500,7 +506,12 @@ class JointTrainer(object):
         for epoch in range(start_epoch, opt.epochs):
             if train_sampler is not None and epoch > opt.shuffle_epoch:
                 train_sampler.shuffle(epoch)
-            for data in train_loader:
+            batches = train_loader
+            if prefetch:
+                from .data.prefetch import DevicePrefetcher, collate_device_pinned
+                batches = DevicePrefetcher(train_loader, next(self.enhance_model.parameters()).device,
+                                           collate=prefetch if callable(prefetch) else collate_device_pinned)
+            for data in batches:
                 errors = self.step(data, sche_samp_rate, enhance_cmvn)
                 flush()                                   # previous step's meters, now that this step is queued
                 pending = {k: v for k, v in errors.items() if k.startswith('train/') or k == 'grad_norm'}

@@ -844,3 +844,34 @@ def test_conv3x3_wino(N, H, W, C, K):
     else:
         with pytest.raises(lib.Re2eError):
             ops.conv3x3_wino(dy.to(DEV), Wg, C, dgrad=True)
+
+
+def test_device_prefetcher_equals_host_collate():
+    """data.prefetch.DevicePrefetcher (pinned staging slots reused every third batch, H2D + re2e_pack_pad on a copy stream, event
+    hand-off) against the host collate the reference defines (data/mix_data_loader.py:264-302), bit for bit, over more batches
+    than there are staging slots and with different batch shapes in turn -- while the consumer stream is kept busy, so that the
+    copy stream really runs ahead."""
+    from robust_e2e_gan_amd.data.mix_data_loader import _collate_fn
+    from robust_e2e_gan_amd.data.prefetch import DevicePrefetcher
+    g = torch.Generator().manual_seed(5)
+
+    def sample(i, T, F_=33, L=4):
+        mk = lambda: torch.randn(T, F_, generator=g)
+        return ('u%d' % i, 's', mk(), mk(), mk(), mk(), mk(), torch.randint(1, 9, (L,), generator=g))
+    batches = []
+    for k in range(8):
+        lens = [int(v) for v in torch.randint(5, 60 + 30 * (k % 3), (3 + k % 4,), generator=g)]
+        batches.append([sample(i, T) for i, T in enumerate(lens)])
+    busy = torch.randn(2048, 2048, device=DEV)
+    n = 0
+    for dev_b, host_list in zip(DevicePrefetcher(batches, DEV), batches):
+        for _ in range(3):
+            busy = busy @ busy * 1e-3                      # the consumer stream has work queued: the prefetcher is ahead of it
+        ref = _collate_fn(list(host_list))
+        assert dev_b[0] == ref[0]
+        for k in (2, 4, 5):
+            assert torch.equal(dev_b[k].cpu(), ref[k]), (n, k)
+        assert dev_b[3] is None and dev_b[6] is None
+        assert torch.equal(dev_b[7], ref[7]) and torch.equal(dev_b[8], ref[8]) and torch.equal(dev_b[9], ref[9])
+        n += 1
+    assert n == len(batches)
