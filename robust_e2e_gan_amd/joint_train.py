@@ -475,7 +475,13 @@ class JointTrainer(object):
         ``collate_kaldi_device`` for raw Kaldi records)."""
         from .utils import utils
         opt = self.opt
-        enhance_cmvn = compute_cmvn_epoch(opt, train_loader, self.enhance_model, self.feat_model)
+        def loader():
+            if not prefetch:
+                return train_loader
+            from .data.prefetch import DevicePrefetcher, collate_device_pinned
+            return DevicePrefetcher(train_loader, next(self.enhance_model.parameters()).device,
+                                    collate=prefetch if callable(prefetch) else collate_device_pinned)
+        enhance_cmvn = compute_cmvn_epoch(opt, loader(), self.enhance_model, self.feat_model)
         rampup = utils.ScheSampleRampup(opt.sche_samp_start_iter, opt.sche_samp_final_iter, opt.sche_samp_final_rate)
         sche_samp_rate = rampup.update(iters)
         acc_report = loss_report = None
@@ -506,12 +512,7 @@ class JointTrainer(object):
         for epoch in range(start_epoch, opt.epochs):
             if train_sampler is not None and epoch > opt.shuffle_epoch:
                 train_sampler.shuffle(epoch)
-            batches = train_loader
-            if prefetch:
-                from .data.prefetch import DevicePrefetcher, collate_device_pinned
-                batches = DevicePrefetcher(train_loader, next(self.enhance_model.parameters()).device,
-                                           collate=prefetch if callable(prefetch) else collate_device_pinned)
-            for data in batches:
+            for data in loader():
                 errors = self.step(data, sche_samp_rate, enhance_cmvn)
                 flush()                                   # previous step's meters, now that this step is queued
                 pending = {k: v for k, v in errors.items() if k.startswith('train/') or k == 'grad_norm'}
@@ -567,7 +568,7 @@ class JointTrainer(object):
                         st.update(acc_report=acc_report, loss_report=loss_report)
                         utils.save_checkpoint(st, opt.exp_path, filename=filename)
                     visualizer.reset()
-                    enhance_cmvn = compute_cmvn_epoch(opt, train_loader, self.enhance_model, self.feat_model)
+                    enhance_cmvn = compute_cmvn_epoch(opt, loader(), self.enhance_model, self.feat_model)
                 if max_iters is not None and iters >= max_iters:
                     flush()
                     return iters, best_loss, best_acc
