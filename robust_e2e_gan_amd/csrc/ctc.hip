@@ -51,6 +51,41 @@ __global__ __launch_bounds__(256) void ctc_lse_gather(const float* __restrict__ 
   }
 }
 
+// The same with the row held in registers (NV values per lane, V <= 64 NV): the logits are read from memory ONCE, every load of a
+// row is in flight before the first is used (the two-pass kernel above re-reads the 17 KB row from L2 and keeps one load in flight
+// per lane: 2.0 TB/s on the 108 MB of config 4).
+template <int NV>
+__global__ __launch_bounds__(256) void ctc_lse_gather_reg(const float* __restrict__ logits, int T, int B, int V,
+                                                          const int* __restrict__ hlens, const int* __restrict__ labels,
+                                                          const int* __restrict__ loff, const int* __restrict__ llen, int S,
+                                                          float* __restrict__ lse, float* __restrict__ lp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= T * B) return;
+  const int t = row / B, b = row % B;
+  if (t >= hlens[b]) return;
+  const float* x = logits + (long)row * V;
+  float v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { const int c = lane + 64 * i; v[i] = c < V ? x[c] : -3.0e38f; }
+  float m = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) m = fmaxf(m, v[i]);
+  m = wave_max(m);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (lane + 64 * i < V) ? expf(v[i] - m) : 0.f;
+  s = wave_sum(s);
+  const float l = m + logf(s);
+  if (lane == 0) lse[row] = l;
+  const int Sb = 2 * llen[b] + 1;
+  const int* lab = labels + loff[b];
+  for (int sidx = lane; sidx < Sb; sidx += 64) {
+    const int c = (sidx & 1) ? lab[sidx >> 1] : 0;
+    lp[(long)row * S + sidx] = x[c] - l;
+  }
+}
+
 __global__ void ctc_alpha_beta(int T, int B, const int* __restrict__ hlens, const int* __restrict__ labels,
                                const int* __restrict__ loff, const int* __restrict__ llen, int S,
                                const float* __restrict__ lp, float* __restrict__ alpha, float* __restrict__ beta,
@@ -199,8 +234,12 @@ extern "C" int re2e_ctc_fwd(const float* logits, int T, int B, int V, const int*
   float* lp = lse + (size_t)T * B;
   float* alpha = lp + (size_t)T * B * S;
   float* beta = alpha + (size_t)T * B * S;
-  hipLaunchKernelGGL(ctc_lse_gather, dim3(cdiv((long)T * B, 4)), dim3(256), 0, stream, logits, T, B, V, hlens, labels, loff, llen,
-                     S, lse, lp);
+  const dim3 lg(cdiv((long)T * B, 4)), lb(256);
+  const int nv = cdiv(V, 64);
+  if (nv <= 8) hipLaunchKernelGGL(ctc_lse_gather_reg<8>, lg, lb, 0, stream, logits, T, B, V, hlens, labels, loff, llen, S, lse, lp);
+  else if (nv <= 24) hipLaunchKernelGGL(ctc_lse_gather_reg<24>, lg, lb, 0, stream, logits, T, B, V, hlens, labels, loff, llen, S, lse, lp);
+  else if (nv <= 72) hipLaunchKernelGGL(ctc_lse_gather_reg<72>, lg, lb, 0, stream, logits, T, B, V, hlens, labels, loff, llen, S, lse, lp);
+  else hipLaunchKernelGGL(ctc_lse_gather, lg, lb, 0, stream, logits, T, B, V, hlens, labels, loff, llen, S, lse, lp);
   int threads = ((S + 63) / 64) * 64;
   hipLaunchKernelGGL(ctc_alpha_beta, dim3(B), dim3(threads), (size_t)2 * (S + 2) * sizeof(float), stream, T, B, hlens, labels, loff,
                      llen, S, (const float*)lp, alpha, beta, nll_per_utt);

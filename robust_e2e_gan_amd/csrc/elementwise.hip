@@ -420,10 +420,23 @@ extern "C" int re2e_loss_bwd(const float* a, const float* b, float target, long 
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
+// 16-byte loads, four of them in flight per thread (the 117 MB ASR gradient buffer: 21 us per launch = 2.2 TB/s with one
+// 4-byte load in flight, round 2); fixed grid and fixed per-thread order: deterministic
 __global__ void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
   __shared__ float red[16];
-  float s = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += x[i] * x[i];
+  const long n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n >> 2 : 0;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const f32x4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+    a0 += v0 * v0; a1 += v1 * v1; a2 += v2 * v2; a3 += v3 * v3;
+  }
+  for (; i < n4; i += stride) { const f32x4 v = x4[i]; a0 += v * v; }
+  const f32x4 a = (a0 + a1) + (a2 + a3);
+  float s = (a[0] + a[1]) + (a[2] + a[3]);
+  for (long j = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) s += x[j] * x[j];     // tail (or unaligned)
   s = block_sum(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }

@@ -1,99 +1,13 @@
 // K2: fused fbank feature extraction  y = log(max((x^2) . W, 1e-7)) [-> (y + cmvn0) * cmvn1]
 // (model/feat_model.py:118-135).  The reference multiplies by a dense (257,80) matrix of which
 // only 501 entries are non-zero (<=16 taps per filter); here the matrix is passed banded and the
-// op is a gather over an LDS-staged frequency tile: HBM-bound (read F, write NF floats per frame).
+// op is a banded gather, one thread per output element: HBM-bound (read F, write NF floats per frame).
 #include "common.h"
 
 namespace {
-constexpr int RB = 8;          // frames per block iteration
 constexpr int MAXF = 520;      // max spectrum width held in LDS
 constexpr int MAXNF = 128;
 constexpr int MAXW = 32;
-
-__global__ __launch_bounds__(256) void fbank_fwd_kernel(const float* __restrict__ x, long rows, int F, int NF,
-                                                        const int* __restrict__ boff, const int* __restrict__ blen,
-                                                        const float* __restrict__ bw, int maxw, float* __restrict__ y_raw,
-                                                        float* __restrict__ y_norm, const float* __restrict__ cmvn) {
-  __shared__ float xs[RB][MAXF];
-  __shared__ float ws[MAXNF * MAXW];
-  __shared__ int so[MAXNF], sl[MAXNF];
-  for (int i = threadIdx.x; i < NF * maxw; i += blockDim.x) ws[i] = bw[i];
-  for (int i = threadIdx.x; i < NF; i += blockDim.x) { so[i] = boff[i]; sl[i] = blen[i]; }
-  long ngroups = (rows + RB - 1) / RB;
-  for (long gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
-    long r0 = gi * RB;
-    int nr = (int)((rows - r0) < RB ? (rows - r0) : RB);
-    __syncthreads();
-    for (int i = threadIdx.x; i < nr * F; i += blockDim.x) {   // contiguous rows: fully coalesced
-      float v = x[r0 * F + i];
-      xs[i / F][i % F] = v * v;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nr * NF; i += blockDim.x) {
-      int r = i / NF, j = i % NF;
-      float s = 0.f;
-      int o = so[j], l = sl[j];
-      for (int t = 0; t < l; ++t) s += xs[r][o + t] * ws[j * maxw + t];
-      s = s > 1e-7f ? s : 1e-7f;
-      float lg = __logf(s);
-      long oidx = (r0 + r) * NF + j;
-      if (y_raw) y_raw[oidx] = lg;
-      if (y_norm) y_norm[oidx] = (lg + cmvn[j]) * cmvn[NF + j];
-    }
-  }
-}
-
-// Backward.  Small on purpose (128 threads, 4 frames per pass, ~14 KB of LDS, band weights read through the cache): it sits on the
-// critical path between two chip-filling phases and must find room beside the filler streams' workgroups.
-constexpr int RBB = 4;         // frames per pass of the backward kernel
-__global__ __launch_bounds__(128) void fbank_bwd_kernel(const float* __restrict__ x, long rows, int F, int NF,
-                                                        const int* __restrict__ boff, const int* __restrict__ blen,
-                                                        const float* __restrict__ bw, int maxw, const float* __restrict__ dy_raw,
-                                                        const float* __restrict__ dy_norm, const float* __restrict__ cmvn,
-                                                        float* __restrict__ dx) {
-  __shared__ float xs[RBB][MAXF];     // x (not squared)
-  __shared__ float gs[RBB][MAXNF];    // dL/dP_j = gy_j / P_j (0 where clamped)
-  __shared__ int so[MAXNF], sl[MAXNF];
-  __shared__ int jlo[MAXF], jhi[MAXF];
-  for (int i = threadIdx.x; i < NF; i += blockDim.x) { so[i] = boff[i]; sl[i] = blen[i]; }
-  for (int f = threadIdx.x; f < F; f += blockDim.x) { jlo[f] = NF; jhi[f] = -1; }
-  __syncthreads();
-  for (int j = threadIdx.x; j < NF; j += blockDim.x)          // filters covering bin f form a contiguous j range
-    for (int t = 0; t < sl[j]; ++t) { atomicMin(&jlo[so[j] + t], j); atomicMax(&jhi[so[j] + t], j); }
-  // thread = (row r of the pass, lane q of 32): no integer division anywhere, every global access a 128-byte row segment
-  const int r = threadIdx.x >> 5, q = threadIdx.x & 31;
-  long ngroups = (rows + RBB - 1) / RBB;
-  for (long gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
-    long r0 = gi * RBB;
-    int nr = (int)((rows - r0) < RBB ? (rows - r0) : RBB);
-    const bool on = r < nr;
-    __syncthreads();
-    if (on)
-      for (int f = q; f < F; f += 32) xs[r][f] = x[(r0 + r) * F + f];
-    __syncthreads();
-    if (on)
-      for (int j = q; j < NF; j += 32) {
-        float s = 0.f;
-        int o = so[j], l = sl[j];
-        for (int t = 0; t < l; ++t) { float v = xs[r][o + t]; s += v * v * bw[j * maxw + t]; }
-        long oidx = (r0 + r) * NF + j;
-        float gy = 0.f;
-        if (dy_raw) gy += dy_raw[oidx];
-        if (dy_norm) gy += dy_norm[oidx] * cmvn[NF + j];
-        gs[r][j] = s > 1e-7f ? gy / s : 0.f;     // in-place clamp => zero gradient (feat_model.py:130)
-      }
-    __syncthreads();
-    if (on)
-      for (int f = q; f < F; f += 32) {
-        float s = 0.f;
-        for (int j = jlo[f]; j <= jhi[f]; ++j) {
-          int t = f - so[j];
-          if (t >= 0 && t < sl[j]) s += bw[j * maxw + t] * gs[r][j];
-        }
-        dx[(r0 + r) * F + f] = 2.f * xs[r][f] * s;
-      }
-  }
-}
 
 // per-column sum / sum of squares over valid frames (B,T,NF): one block per (column tile, utterance chunk)
 __global__ void cmvn_stats_kernel(const float* __restrict__ y, const int* __restrict__ lens, int B, int T, int NF,
@@ -110,6 +24,68 @@ __global__ void cmvn_stats_kernel(const float* __restrict__ y, const int* __rest
   }
   sum_out[j] = s; sumsq_out[j] = q;
 }
+
+
+// ---- round 3: barrier-free forms.  One thread per OUTPUT element, no LDS staging, no workgroup barrier in the loop: the 1 KB
+// spectrum row of a frame is shared by the threads of its filters / bins through the L1, every thread is an independent chain of
+// <= 16 (forward) or <= 3 x 16 (backward: the <= 3 filters covering a bin recompute their band power) loads and FMAs.  The LDS-tiled
+// kernels above moved 34 / 61 MB at 0.8 / 1.0 TB/s alone (35 / 58 us) and, beside the filler streams on the critical path between the
+// VGG backward and the enhancer's backward chain, the backward took 1.1 ms (round-3 trace): 128-thread workgroups meeting at three
+// barriers per 4 frames make no progress when their waves are starved for issue slots.
+__global__ __launch_bounds__(256) void fbank_fwd_flat_kernel(const float* __restrict__ x, long rows, int F, int NF,
+                                                             const int* __restrict__ boff, const int* __restrict__ blen,
+                                                             const float* __restrict__ bw, int maxw, float* __restrict__ y_raw,
+                                                             float* __restrict__ y_norm, const float* __restrict__ cmvn) {
+  const long tot = rows * NF;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / NF;
+    const int j = (int)(i - r * NF);
+    const int o = boff[j], l = blen[j];
+    const float* xr = x + r * F + o;
+    const float* wr = bw + (long)j * maxw;
+    float s = 0.f;
+    for (int t = 0; t < l; ++t) { const float v = xr[t]; s += v * v * wr[t]; }
+    s = s > 1e-7f ? s : 1e-7f;
+    const float lg = __logf(s);
+    if (y_raw) y_raw[i] = lg;
+    if (y_norm) y_norm[i] = (lg + cmvn[j]) * cmvn[NF + j];
+  }
+}
+
+__global__ __launch_bounds__(256) void fbank_bwd_flat_kernel(const float* __restrict__ x, long rows, int F, int NF,
+                                                             const int* __restrict__ boff, const int* __restrict__ blen,
+                                                             const float* __restrict__ bw, int maxw, const float* __restrict__ dy_raw,
+                                                             const float* __restrict__ dy_norm, const float* __restrict__ cmvn,
+                                                             float* __restrict__ dx) {
+  __shared__ int jlo[MAXF], jhi[MAXF];                 // filters covering bin f: a contiguous range of j
+  __shared__ int so[MAXNF], sl[MAXNF];
+  for (int f = threadIdx.x; f < F; f += blockDim.x) { jlo[f] = NF; jhi[f] = -1; }
+  for (int j = threadIdx.x; j < NF; j += blockDim.x) { so[j] = boff[j]; sl[j] = blen[j]; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NF; j += blockDim.x)
+    for (int t = 0; t < sl[j]; ++t) { atomicMin(&jlo[so[j] + t], j); atomicMax(&jhi[so[j] + t], j); }
+  __syncthreads();
+  const long tot = rows * F;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / F;
+    const int f = (int)(i - r * F);
+    const float* xr = x + r * F;
+    float s = 0.f;
+    for (int j = jlo[f]; j <= jhi[f]; ++j) {
+      const int o = so[j], l = sl[j], t = f - o;
+      if (t < 0 || t >= l) continue;
+      const float* wr = bw + (long)j * maxw;
+      float pw = 0.f;
+      for (int u = 0; u < l; ++u) { const float v = xr[o + u]; pw += v * v * wr[u]; }
+      const long oidx = r * NF + j;
+      float gy = 0.f;
+      if (dy_raw) gy += dy_raw[oidx];
+      if (dy_norm) gy += dy_norm[oidx] * cmvn[NF + j];
+      s += wr[t] * (pw > 1e-7f ? gy / pw : 0.f);         // in-place clamp => zero gradient (feat_model.py:130)
+    }
+    dx[i] = 2.f * xr[f] * s;
+  }
+}
 }  // namespace
 
 extern "C" int re2e_fbank_fwd(const float* x, long rows, int F, int NF, const int* band_off, const int* band_len,
@@ -118,10 +94,9 @@ extern "C" int re2e_fbank_fwd(const float* x, long rows, int F, int NF, const in
   RE2E_CHECK_ARG(x && band_off && band_len && band_w && (y_raw || y_norm), "null arg");
   RE2E_CHECK_ARG(rows > 0 && F > 0 && F <= MAXF && NF > 0 && NF <= MAXNF && maxw > 0 && maxw <= MAXW, "shape out of range");
   RE2E_CHECK_ARG(!y_norm || cmvn, "y_norm requires cmvn");
-  long ngroups = (rows + RB - 1) / RB;
-  int grid = (int)(ngroups < 2048 ? ngroups : 2048);
-  hipLaunchKernelGGL(fbank_fwd_kernel, dim3(grid), dim3(256), 0, stream, x, rows, F, NF, band_off, band_len, band_w, maxw, y_raw,
-                     y_norm, cmvn);
+  const long nb = (rows * NF + 255) / 256;
+  hipLaunchKernelGGL(fbank_fwd_flat_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, x, rows, F, NF, band_off, band_len,
+                     band_w, maxw, y_raw, y_norm, cmvn);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
@@ -132,10 +107,9 @@ extern "C" int re2e_fbank_bwd(const float* x, long rows, int F, int NF, const in
   RE2E_CHECK_ARG(x && band_off && band_len && band_w && dx && (dy_raw || dy_norm), "null arg");
   RE2E_CHECK_ARG(rows > 0 && F > 0 && F <= MAXF && NF > 0 && NF <= MAXNF && maxw > 0 && maxw <= MAXW, "shape out of range");
   RE2E_CHECK_ARG(!dy_norm || cmvn, "dy_norm requires cmvn");
-  long ngroups = (rows + RBB - 1) / RBB;
-  int grid = (int)(ngroups < 2048 ? ngroups : 2048);
-  hipLaunchKernelGGL(fbank_bwd_kernel, dim3(grid), dim3(128), 0, stream, x, rows, F, NF, band_off, band_len, band_w, maxw, dy_raw,
-                     dy_norm, cmvn, dx);
+  const long nb = (rows * F + 255) / 256;
+  hipLaunchKernelGGL(fbank_bwd_flat_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, x, rows, F, NF, band_off, band_len,
+                     band_w, maxw, dy_raw, dy_norm, cmvn, dx);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
