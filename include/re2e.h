@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 300
+#define RE2E_ABI_VERSION 301
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -179,15 +179,16 @@ int re2e_kaldi_decode_pad(const unsigned char* blob, const long* rec_off_dev, co
                           int Tmax, int F, float* dst, float* dst_log, const float* cmvn, re2e_stream_t stream);
 
 /* ---- K2 fused fbank (model/feat_model.py:118-135): y = log(max((x^2) W, 1e-7)); optional
- * second output y_norm = (y + cmvn[0]) * cmvn[1].  W is given banded: for filter j the taps
- * band_w[j*maxw + i] apply to bins band_off[j]+i, i<band_len[j]. */
+ * second output y_norm = (y + cmvn[0]) * cmvn[1]; optional third output pw_out = (x^2) W itself, which re2e_fbank_bwd takes
+ * back.  W is given banded: for filter j the taps band_w[j*maxw + i] apply to bins band_off[j]+i, i<band_len[j]. */
 int re2e_fbank_fwd(const float* x, long rows, int F, int NF, const int* band_off, const int* band_len,
-                   const float* band_w, int maxw, float* y_raw, float* y_norm, const float* cmvn,
+                   const float* band_w, int maxw, float* y_raw, float* y_norm, const float* cmvn, float* pw_out,
                    re2e_stream_t stream);
-/* dx = 2x * sum_j W[f][j] * (dy_raw + dy_norm*cmvn1)[j] / P[j], zero where P<=1e-7 (clamp) */
-int re2e_fbank_bwd(const float* x, long rows, int F, int NF, const int* band_off, const int* band_len,
-                   const float* band_w, int maxw, const float* dy_raw, const float* dy_norm, const float* cmvn,
-                   float* dx, re2e_stream_t stream);
+/* dx = 2x * sum_j W[f][j] * (dy_raw + dy_norm*cmvn1)[j] / pw[j], zero where pw<=1e-7 (clamp).  pw (rows,NF) = the forward's pw_out.
+ * Here the matrix is banded the other way round (the filters covering a bin are a contiguous run as well): bin f is covered by
+ * filters bin_off[f] + i, i < bin_len[f], with weights bin_w[f*maxc + i]. */
+int re2e_fbank_bwd(const float* x, long rows, int F, int NF, const int* bin_off, const int* bin_len, const float* bin_w, int maxc,
+                   const float* pw, const float* dy_raw, const float* dy_norm, const float* cmvn, float* dx, re2e_stream_t stream);
 /* Dense trainable filterbank (fbank_opti_type 'train', feat_model.py:105-109): x^2 W and its gradients are re2e_gemm calls;
  * these are the element-wise tail of feat_model.py:127-134: y = log(max(z,1e-7)) [-> (y + cmvn[0]) * cmvn[1]] and
  * dz = dy * cmvn[1] / z, zero where the clamp fired (cmvn (2,N) optional). */

@@ -109,9 +109,13 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvGeom g, const float
 // Cout == 1, 64 channels, 3x3 / stride 1 / pad 1 (the data gradient of VGG conv1_1: 1 GB of dz at config 4 -> one value per pixel).
 // conv_cout1_kernel reads every pixel's 64 channels once per tap (9x, served by L2: ~1 TB/s of useful input).  Here the product is
 // split the other way round: a workgroup owns TH output rows of one image, FIRST projects every input pixel of its TH + 2 rows onto
-// the 9 tap vectors (each pixel's 256 bytes read ONCE by one thread, weights wave-uniform) into a
-// [row][column][9] table in LDS, THEN every output pixel adds its 9 table entries.  HBM traffic = (TH + 2) / TH of the input.
+// the 9 tap vectors into a [row][column][9] table in LDS, THEN every output pixel adds its 9 table entries.  HBM traffic =
+// (TH + 2) / TH of the input.  The projection reads the rows as the contiguous byte range they are: 16 consecutive lanes take the
+// 256 bytes of one pixel (a wave instruction = 1 KiB contiguous), every lane multiplies its 4 channels into 9 partial sums against
+// weights it keeps in registers, and a rotate-and-add over the 16-lane DPP row finishes the sums; lane t of the row stores tap t.
 // ---------------------------------------------------------------------------------------------
+#define RE2E_ROR_ADD(v, n) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x120 + (n), 0xf, 0xf, false)))
+
 template <int TH>
 __global__ __launch_bounds__(256) void conv_cout1_rows3x3_kernel(ConvGeom g, const float* __restrict__ wg, OutMap o, const float* __restrict__ bias,
                                                                  int act, float beta) {
@@ -120,29 +124,45 @@ __global__ __launch_bounds__(256) void conv_cout1_rows3x3_kernel(ConvGeom g, con
   const int W2 = g.W + 2, tid = threadIdx.x;
   const int tiles_y = (g.H + TH - 1) / TH;
   const int n = blockIdx.x / tiles_y, y0 = (blockIdx.x - n * tiles_y) * TH;
-  for (int i = tid; i < (TH + 2) * W2 * 9; i += 256) tab[i] = 0.f;
-  __syncthreads();
-  // projection: ONE thread per input pixel -- its 64 channels are 16 float4 loads (the four quarters of a 64-byte segment go to four
-  // consecutive instructions of the same thread), the weights are wave-uniform (scalar loads), no cross-lane reduction
-  const int npx = (TH + 2) * g.W;
-  const f32x4* in4 = reinterpret_cast<const f32x4*>(g.in) + (long)n * g.H * g.W * 16;
-  for (int q = tid; q < npx; q += 256) {
-    const int rr = q / g.W, xx = q - rr * g.W, iy = y0 - 1 + rr;
-    if (iy < 0 || iy >= g.H) continue;
-    const f32x4* px = in4 + ((long)iy * g.W + xx) * 16;
-    float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < (TH + 2) * 18; i += 256) {        // the two border columns; everything else is written by the projection
+    const int r = i / 18, j = i - r * 18;
+    tab[(r * W2 + (j < 9 ? 0 : g.W + 1)) * 9 + (j < 9 ? j : j - 9)] = 0.f;
+  }
+  const int lt = tid & 15, slot = tid >> 4;               // channel quad of the pixel, pixel slot of the 16 a workgroup pass covers
+  f32x4 w[9];
 #pragma unroll
-    for (int c4 = 0; c4 < 16; ++c4) {
-      const f32x4 v = px[c4];
+  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const f32x4*>(wg + t * 64 + lt * 4);
+  const unsigned img_bytes = (unsigned)g.H * g.W * 256u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.in) + (long)n * g.H * g.W * 64, 0, img_bytes, 0x00020000);
+  const int npx = (TH + 2) * g.W;
+  int rr = slot / g.W, xx = slot - rr * g.W;              // g.W >= 16: a pass never skips a row
+  constexpr int U = 3;
+  for (int q0 = slot; q0 < npx; q0 += 16 * U) {
+    f32x4 v[U];
+    int ti[U];
+    int r2 = rr, x2 = xx;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int iy = y0 - 1 + r2;
+      const bool ok = (q0 + 16 * u < npx) & ((unsigned)iy < (unsigned)g.H);
+      v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)((iy * g.W + x2) * 256 + lt * 16) : 0x80000000u, 0, 0));
+      ti[u] = (q0 + 16 * u < npx) ? (r2 * W2 + x2 + 1) * 9 + lt : -1;
+      x2 += 16;
+      if (x2 >= g.W) { x2 -= g.W; ++r2; }
+    }
+    rr = r2; xx = x2;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float val = 0.f;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const float* wt = wg + t * 64 + c4 * 4;           // uniform address: scalar loads
-        s[t] = fmaf(v[0], wt[0], s[t]); s[t] = fmaf(v[1], wt[1], s[t]); s[t] = fmaf(v[2], wt[2], s[t]); s[t] = fmaf(v[3], wt[3], s[t]);
+        float s = v[u][0] * w[t][0];
+        s = fmaf(v[u][1], w[t][1], s); s = fmaf(v[u][2], w[t][2], s); s = fmaf(v[u][3], w[t][3], s);
+        s = RE2E_ROR_ADD(s, 8); s = RE2E_ROR_ADD(s, 4); s = RE2E_ROR_ADD(s, 2); s = RE2E_ROR_ADD(s, 1);
+        val = lt == t ? s : val;
       }
+      if (lt < 9 && ti[u] >= 0) tab[ti[u]] = val;
     }
-    float* dst = tab + (rr * W2 + xx + 1) * 9;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) dst[t] = s[t];
   }
   __syncthreads();
   const float b = bias ? bias[0] : 0.f;
@@ -361,8 +381,9 @@ bool thin_conv_forward(const ConvGeom& g, const float* wg, int Cout, const OutMa
   // 64 channels, 3x3, stride 1, taps within one pixel of the output position, dense single-channel output: row-tile kernel
   static const bool no_rows = exp_env("RE2E_NO_COUT1_ROWS") != nullptr;
   if (!no_rows && g.C == 64 && g.KH == 3 && g.KW == 3 && g.SY == 1 && g.SX == 1 && g.PH == g.H && g.PW == g.W && !o.remap && o.ldc == 1 &&
-      (g.DY == 1 || g.DY == -1) && (g.DX == 1 || g.DX == -1) && g.OY0 == -g.DY && g.OX0 == -g.DX && g.W <= 256) {
-    constexpr int TH = 8;
+      (g.DY == 1 || g.DY == -1) && (g.DX == 1 || g.DX == -1) && g.OY0 == -g.DY && g.OX0 == -g.DX && g.W >= 16 && g.W <= 256 &&
+      (long)g.H * g.W * 256 < 0x7fffffffL) {
+    constexpr int TH = 16;
     const size_t lds = (size_t)(TH + 2) * (g.W + 2) * 9 * sizeof(float);
     auto kern = conv_cout1_rows3x3_kernel<TH>;
     static LdsLimit lim;

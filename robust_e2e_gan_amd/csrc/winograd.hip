@@ -389,6 +389,9 @@ extern "C" int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, c
   a.dbg = dbg_env;
   static const char* st_env = exp_env("RE2E_WINO_STAMPS");      // device address (hex) of a 4096 x 4 x 8 x 8-byte buffer
   a.stamps = st_env ? (unsigned long long*)strtoull(st_env, nullptr, 16) : nullptr;
+  static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
+  if (log_calls)
+    fprintf(stderr, "[igemm] A=Wino%s B=DenseK tile=128x64x8 vec=1 M=%ld N=%d K=%d splits=1\n", dgrad ? "D" : "F", (long)NI * H * W, Cout, 9 * C);
   if (wide) launch_wino<8>(a, stream); else launch_wino<4>(a, stream);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
-ABI_VERSION = 300      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
+ABI_VERSION = 301      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
@@ -56,8 +56,8 @@ SIGNATURES = {
     're2e_mask_rows': (I, [P, P, P, I, I, I, P]),
     're2e_pack_pad': (I, [P, P, P, I, I, I, P, P]),
     're2e_kaldi_decode_pad': (I, [P, P, P, P, I, I, I, P, P, P, P]),
-    're2e_fbank_fwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P]),
-    're2e_fbank_bwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P, P]),
+    're2e_fbank_fwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P, P]),
+    're2e_fbank_bwd': (I, [P, L, I, I, P, P, P, I, P, P, P, P, P, P]),
     're2e_logclamp_fwd': (I, [P, P, L, I, P, P]),
     're2e_logclamp_bwd': (I, [P, P, L, I, P, P, P]),
     're2e_cmvn_stats': (I, [P, P, I, I, I, P, P, P]),

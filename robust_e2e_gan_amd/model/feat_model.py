@@ -25,29 +25,34 @@ def mel_matrix(nfilt=80, nfft=512, sr=16000.0, low=20.0):
     return W.astype(np.float32)
 
 
+def _runs(Wn, what, limit):
+    """Per column of ``Wn``: first non-zero row, run length (first to last non-zero) and the run's values."""
+    n = Wn.shape[1]
+    offs, lens = [], []
+    for j in range(n):
+        nz = np.nonzero(Wn[:, j])[0]
+        offs.append(int(nz[0]) if len(nz) else 0)
+        lens.append(int(nz[-1] - nz[0] + 1) if len(nz) else 0)
+    width = max(max(lens), 1)
+    if width > limit:
+        raise Re2eError('filterbank is not banded (max %d %s > %d): the banded kernels (re2e_fbank_fwd / _bwd) cover the frozen mel '
+                        'matrix only; a dense matrix runs through the trainable path (--fbank-opti-type train: x^2 W on the GEMM engine)'
+                        % (width, what, limit))
+    taps = np.zeros((n, width), np.float32)
+    for j in range(n):
+        taps[j, :lens[j]] = Wn[offs[j]:offs[j] + lens[j], j]
+    return offs, lens, taps, width
+
+
 def band_from_matrix(W, device):
-    """Banded form of the (F, NF) filterbank for re2e_fbank_*: (offsets, lengths, taps, maxw, NF)."""
+    """Banded forms of the (F, NF) filterbank for re2e_fbank_*: by filter (offsets, lengths, taps, maxw), NF, and by bin -- the
+    filters covering a bin are a contiguous run too -- (offsets, lengths, weights, maxc) for the backward kernel."""
     Wn = W.detach().cpu().numpy() if isinstance(W, torch.Tensor) else np.asarray(W)
     F, NF = Wn.shape
-    offs, lens = [], []
-    for j in range(NF):
-        nz = np.nonzero(Wn[:, j])[0]
-        if len(nz) == 0:
-            offs.append(0)
-            lens.append(0)
-        else:
-            offs.append(int(nz[0]))
-            lens.append(int(nz[-1] - nz[0] + 1))
-    maxw = max(max(lens), 1)
-    if maxw > 32:
-        raise Re2eError('filterbank is not banded (max %d taps per filter > 32): the banded gather kernel (re2e_fbank_fwd) covers the '
-                        'frozen mel matrix only; a dense matrix runs through the trainable path (--fbank-opti-type train: x^2 W on '
-                        'the GEMM engine)' % maxw)
-    taps = np.zeros((NF, maxw), np.float32)
-    for j in range(NF):
-        taps[j, :lens[j]] = Wn[offs[j]:offs[j] + lens[j], j]
-    return (torch.tensor(offs, dtype=torch.int32, device=device), torch.tensor(lens, dtype=torch.int32, device=device),
-            torch.from_numpy(taps).to(device), maxw, NF)
+    offs, lens, taps, maxw = _runs(Wn, 'taps per filter', 32)
+    toffs, tlens, tw, maxc = _runs(Wn.T, 'filters per bin', 128)
+    dev_i = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+    return (dev_i(offs), dev_i(lens), torch.from_numpy(taps).to(device), maxw, NF, dev_i(toffs), dev_i(tlens), torch.from_numpy(tw).to(device), maxc)
 
 
 class FbankModel(ModelBase):

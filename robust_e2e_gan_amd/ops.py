@@ -274,13 +274,16 @@ class FbankFn(torch.autograd.Function):
     def forward(ctx, x, band, cmvn, want_raw, want_norm):
         _need_gpu(x)
         x = _f32(x)
-        off, ln, w, maxw, NF = band
+        off, ln, w, maxw, NF = band[:5]
         rows, F = x.numel() // x.shape[-1], x.shape[-1]
         raw = empty(x.shape[:-1] + (NF,), x) if want_raw else None
         nrm = empty(x.shape[:-1] + (NF,), x) if want_norm else None
-        call('re2e_fbank_fwd', x.data_ptr(), rows, F, NF, off.data_ptr(), ln.data_ptr(), w.data_ptr(), maxw, ptr(raw), ptr(nrm), ptr(cmvn))
+        pw = empty(x.shape[:-1] + (NF,), x) if x.requires_grad else None      # the band power itself, for the backward kernel
+        call('re2e_fbank_fwd', x.data_ptr(), rows, F, NF, off.data_ptr(), ln.data_ptr(), w.data_ptr(), maxw, ptr(raw), ptr(nrm), ptr(cmvn),
+             ptr(pw))
         ctx.band, ctx.cmvn = band, cmvn
-        ctx.save_for_backward(x)
+        if pw is not None:
+            ctx.save_for_backward(x, pw)
         outs = (raw if want_raw else x.new_empty(0), nrm if want_norm else x.new_empty(0))
         ctx.mark_non_differentiable(*[o for o, w_ in zip(outs, (want_raw, want_norm)) if not w_])
         ctx.want = (want_raw, want_norm)
@@ -288,16 +291,16 @@ class FbankFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, draw, dnorm):
-        (x,) = ctx.saved_tensors
-        off, ln, w, maxw, NF = ctx.band
+        x, pw = ctx.saved_tensors
+        NF, toff, tln, tw, maxc = ctx.band[4:]
         rows, F = x.numel() // x.shape[-1], x.shape[-1]
         draw = _f32(draw) if (ctx.want[0] and draw is not None) else None
         dnorm = _f32(dnorm) if (ctx.want[1] and dnorm is not None) else None
         if draw is None and dnorm is None:
             return None, None, None, None, None
         dx = empty(x.shape, x)
-        call('re2e_fbank_bwd', x.data_ptr(), rows, F, NF, off.data_ptr(), ln.data_ptr(), w.data_ptr(), maxw, ptr(draw), ptr(dnorm),
-             ptr(ctx.cmvn), dx.data_ptr())
+        call('re2e_fbank_bwd', x.data_ptr(), rows, F, NF, toff.data_ptr(), tln.data_ptr(), tw.data_ptr(), maxc, pw.data_ptr(), ptr(draw),
+             ptr(dnorm), ptr(ctx.cmvn), dx.data_ptr())
         return dx, None, None, None, None
 
 

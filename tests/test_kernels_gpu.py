@@ -207,6 +207,9 @@ CONVS = [  # N, H, W, Cin, Cout, k, stride, pad, act, bias
     (2, 11, 7, 64, 1, 3, 1, 1, None, False),
     (2, 9, 8, 1, 12, 3, 1, 1, None, True),
     (2, 9, 8, 12, 1, 3, 1, 1, 'lrelu', True),
+    # the row-tile Cout == 1 kernel (16 lanes per pixel): full-width rows, a width that is not a multiple of 16, ragged last row tile
+    (2, 19, 80, 1, 64, 3, 1, 1, 'relu', True),
+    (1, 13, 23, 64, 1, 3, 1, 1, None, True),
     # halo-patch 3x3 kernels (conv3x3.hip): C % 16 == 0 and Cout % 64 == 0; 16x16 patches (ragged in both directions) and
     # the 32x8 patches chosen for narrow images; one / two 64-channel groups; 1, 4 and 8 channel chunks
     (1, 35, 80, 64, 64, 3, 1, 1, 'relu', True),

@@ -1,0 +1,55 @@
+"""Time single kernels at the config-4 shapes through the package's ops (HIP events on the current stream).
+usage: python tools/bench_kernels.py [name ...]"""
+import sys, time
+import torch
+sys.path.insert(0, '.')
+from robust_e2e_gan_amd import lib, ops
+DEV = 'cuda:0'
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def conv1_1_dgrad():
+    B, T, F = 32, 800, 80
+    dz = torch.randn(B, T, F, 64, device=DEV)
+    w = torch.randn(64, 1, 3, 3, device=DEV)
+    us = timeit(lambda: ops.conv_dgrad(dz, w, (B, T, F, 1), 1, 1))
+    print('conv1_1 dgrad  %.1f us  %.2f TB/s' % (us, dz.numel() * 4 / us / 1e6))
+
+
+def fbank():
+    from robust_e2e_gan_amd.model.feat_model import band_from_matrix, mel_matrix
+    B, T = 32, 800
+    band = band_from_matrix(torch.from_numpy(mel_matrix()), DEV)
+    x = (torch.randn(B, T, 257, device=DEV) * 20).abs().requires_grad_(True)
+    cm = torch.stack([torch.linspace(10, 14, 80), torch.linspace(0.3, 0.6, 80)]).to(DEV)
+    us = timeit(lambda: ops.fbank(x.detach(), band, cm, True, True))
+    print('fbank fwd (raw + norm)  %.1f us' % us)
+    raw, nrm = ops.fbank(x, band, cm, True, True)
+    g0, g1 = torch.randn_like(raw), torch.randn_like(nrm)
+    off, ln, w, maxw, NF, toff, tln, tw, maxc = band
+    dx, pw = torch.empty_like(x), torch.empty_like(raw)
+    lib.call('re2e_fbank_fwd', x.data_ptr(), B * T, 257, NF, off.data_ptr(), ln.data_ptr(), w.data_ptr(), maxw, 0, 0, 0, pw.data_ptr())
+    us = timeit(lambda: lib.call('re2e_fbank_fwd', x.data_ptr(), B * T, 257, NF, off.data_ptr(), ln.data_ptr(), w.data_ptr(), maxw, raw.data_ptr(),
+                                 nrm.data_ptr(), cm.data_ptr(), pw.data_ptr()))
+    print('fbank fwd direct call (raw + norm + pw)  %.1f us' % us)
+    us = timeit(lambda: lib.call('re2e_fbank_bwd', x.data_ptr(), B * T, 257, NF, toff.data_ptr(), tln.data_ptr(), tw.data_ptr(), maxc, pw.data_ptr(),
+                                 g0.data_ptr(), g1.data_ptr(), cm.data_ptr(), dx.data_ptr()))
+    print('fbank bwd  %.1f us' % us)
+
+
+ALL = {'conv1_1_dgrad': conv1_1_dgrad, 'fbank': fbank}
+if __name__ == '__main__':
+    for n in (sys.argv[1:] or ALL):
+        ALL[n]()

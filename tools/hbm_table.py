@@ -3,9 +3,10 @@
 RE2E_NO_OVERLAP=1, so durations are not inflated by co-running kernels) against ALGORITHMIC bytes -- every tensor a kernel
 must read or write once, summed over its launches in one step.
 
-    python3 tools/hbm_table.py profiles/r02_bench_nooverlap_kernel_stats.csv 7 > profiles/r02_hbm_kernels.md
+    python3 tools/hbm_table.py profiles/r03_bench_nooverlap_kernel_stats.csv 7 > profiles/r03_hbm_kernels.md
 
-Second argument = number of training steps in the profiled run (warm-up + timed).  Shapes: B=32, T=800, F=257, NF=80, V=4233,
+Second argument = number of training steps in the profiled run (every step the process ran: first / warm-up / timed / input-side leg);
+omitted: counted from the Adadelta launches (3 per step).  Shapes: B=32, T=800, F=257, NF=80, V=4233,
 T'=200; the single-stream run batches both VGG branches (2B = 64 images)."""
 import csv
 import sys
@@ -21,9 +22,9 @@ NPAR = 29147557 + 2831361 + 2764609                                             
 
 # kernel-name substring -> (what, algorithmic bytes per STEP, formula)
 KERNELS = [
-    ('fbank_fwd_kernel', 'K2 fbank forward (enhanced + clean, raw log-mel only)', 2 * (rows_bt * F + rows_bt * NF) * f4,
+    ('fbank_fwd_', 'K2 fbank forward (enhanced + clean, raw log-mel only)', 2 * (rows_bt * F + rows_bt * NF) * f4,
      '2 calls x (read (B*T,257) + write (B*T,80))'),
-    ('fbank_bwd_kernel', 'K2 fbank backward', (2 * rows_bt * F + rows_bt * NF) * f4, 'read x, dy; write dx'),
+    ('fbank_bwd_', 'K2 fbank backward', (2 * rows_bt * F + rows_bt * NF) * f4, 'read x, dy; write dx'),
     ('conv_cin1_fwd_kernel<3, 3>', 'K5 VGG conv1_1 forward (Cin = 1 direct kernel)', (px1 + px1 * 64) * f4, 'read (2B,800,80,1), write (2B,800,80,64)'),
     ('conv_cout1_rows3x3_kernel', 'K5 VGG conv1_1 data gradient (Cout = 1 row-tile kernel; only the enhanced branch needs it)', (px1 * 64 + px1) / 2 * f4, 'read dz (B,800,80,64), write dx'),
     ('wgrad_cin1_kernel', 'K5/K9 Cin = 1 weight gradients (VGG conv1_1; D conv1 real + fake)',
@@ -53,8 +54,12 @@ def main(path, steps):
     stats = {}
     for r in csv.DictReader(open(path)):
         stats[r['Name']] = (int(r['Calls']), float(r['TotalDurationNs']))
-    print('# HBM-bound kernels of one config-4 training step: achieved GB/s against 8 TB/s (r02)\n')
-    print('Source: `%s` (rocprofv3 --kernel-trace --stats of `RE2E_NO_OVERLAP=1 bench.py --steps 5 --warmup 2`: ONE stream, so a kernel\'s '
+    if not steps:                                        # three Adadelta launches (one per network) per training step
+        steps = sum(v[0] for n, v in stats.items() if 'adadelta_kernel' in n) // 3
+    import os, re
+    m = re.match(r'(r\d+)_', os.path.basename(path))
+    print('# HBM-bound kernels of one config-4 training step: achieved GB/s against 8 TB/s (%s)\n' % (m.group(1) if m else '?'))
+    print('Source: `%s` (rocprofv3 --kernel-trace --stats of `RE2E_NO_OVERLAP=1 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline`: ONE stream, so a kernel\'s '
           'duration is its own; %d steps in the run).  Bytes are ALGORITHMIC (each tensor the kernel has to touch, once), summed over the '
           'kernel\'s launches in one step; formulas in `tools/hbm_table.py`.  Peak 8.0 TB/s (MI355X_MICROARCH.md; 6.3 TB/s is what a float4 copy '
           'reaches).  Rows marked approx. mix several shapes whose exact launch mix was not separated.\n' % (path, steps))
@@ -74,4 +79,4 @@ def main(path, steps):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]))
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
