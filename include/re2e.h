@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 301
+#define RE2E_ABI_VERSION 302
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -113,6 +113,15 @@ size_t re2e_conv3x3_wino_workspace_bytes(int C, int Cout);
 int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int dgrad, const float* bias, int relu,
                       const float* mask, float* out, float* pool_out, unsigned char* pool_idx, void* workspace, size_t workspace_bytes,
                       re2e_stream_t stream);
+
+/* 4x4 / stride-1 convolution as Winograd F(2x2,4x4) (csrc/wino44.hip; the discriminator's conv4, model/networks.py NLayerDiscriminator
+ * `nn.Conv2d(ndf*4, ndf*8, kernel_size=4, stride=1, padding=1)`, and its data gradient): filter / input transform, ONE K-sliced launch
+ * of the GEMM engine (25 positions), output transform.  in (NI,H,W,C) NHWC, out (NI, H+2*pad-3, W+2*pad-3, Cout), no bias / activation.
+ * w is the layer's weight in PyTorch layout in BOTH directions: dgrad = 0: (Cout, C, 4, 4); dgrad = 1: `in` is dy, w is (C, Cout, 4, 4),
+ * pad = 3 - the layer's padding, out = dx.  C % 16 == 0, Cout % 4 == 0, 16-byte aligned tensors, else RE2E_EUNSUPPORTED. */
+size_t re2e_conv4x4_wino_workspace_bytes(int NI, int H, int W, int C, int Cout, int pad);
+int re2e_conv4x4_wino(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int pad, int dgrad, float* out,
+                      void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW);
 /* dW[Cout][C][KH][KW] = beta*dW + sum_pix dout[pix][co] * in[n][py*SY+kh+OY0][px*SX+kw+OX0][ci] */
 int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, int KH, int KW, int PH,

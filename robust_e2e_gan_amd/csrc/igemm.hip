@@ -719,6 +719,13 @@ int pick_splits(int M, int N, int K, int bm, int bn) {
     const double t = compute / eff + (sp > 1 ? (double)sp * M * N * 8.0 / 3e12 : 0.0);
     if (t < best - 1e-12) { best = t; best_s = sp; }
   }
+  static const int cap_kt = exp_env("RE2E_SPLIT_MAXKT") ? atoi(exp_env("RE2E_SPLIT_MAXKT")) : 0;   // experiment: bound a workgroup's lifetime
+  if (cap_kt > 0 && nkt / best_s > cap_kt) {
+    const long rounds = (nkt / best_s + cap_kt - 1) / cap_kt;         // keep the fill of the best choice: whole multiples of its workgroup count
+    long sp = best_s * rounds;
+    if (sp > maxs) sp = maxs;
+    best_s = sp;
+  }
   return (int)best_s;
 }
 
@@ -954,6 +961,23 @@ static void gemm_dispatch(int transa, int transb, int M, int N, int K, const flo
     DenseM lb{B, kbytes(K, ldb, N), ldb, N, K};
     launch_big<DenseM, DenseM, V, true>(la, lb, ep, K, st);
   }
+}
+
+// K-sliced x W^T product: out[z][M][N] = A[:, z*K/ns : (z+1)*K/ns] . B[:, same]^T for z < ns -- the engine's split-K launch with the
+// caller's slice count and WITHOUT the reduce pass: the slabs are the result (a batch of ns products whose operands are interleaved
+// along K; wino44.hip).  K / ns must be a multiple of the k-tile.
+int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st) {
+  if (ns < 2 || K % ns || (K / ns) % BKD || !aligned16(A) || !aligned16(B) || lda % 4 || ldb % 4 || !fits32(M, lda, K) || !fits32(N, ldb, K)) {
+    re2e_set_error("gemm_kslices: unsupported slicing (M=%d N=%d K=%d ns=%d)", M, N, K, ns);
+    return RE2E_EUNSUPPORTED;
+  }
+  Epi ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.C = out; ep.ldc = N; ep.M = M; ep.N = N; ep.act = RE2E_ACT_NONE; ep.ws = out; ep.nsplit = ns;
+  DenseK la{A, kbytes(M, lda, K), lda, M, K};
+  DenseK lb{B, kbytes(N, ldb, K), ldb, N, K};
+  launch_big<DenseK, DenseK, true, true>(la, lb, ep, K, st);
+  return RE2E_OK;
 }
 
 extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const float* A, long lda, const float* B,

@@ -465,6 +465,24 @@ def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool
     return y
 
 
+def _wino44_ok(N, H, Wd, C, Cout, k, stride, pad):
+    """4x4 / stride-1 / pad-1 layers with enough channels and pixels for Winograd F(2x2,4x4) to pay (re2e_conv4x4_wino: the
+    discriminator's conv4 and its data gradient -- both directions need C % 16 == 0 and Cout % 16 == 0)."""
+    return (WINOGRAD and k == (4, 4) and stride == 1 and pad == 1 and C % 16 == 0 and Cout % 16 == 0 and min(C, Cout) >= 64
+            and N * H * Wd >= 4096 and H >= 3 and Wd >= 3)
+
+
+def conv4x4_wino(x, W, Cout, pad, dgrad=False):
+    """re2e_conv4x4_wino on NHWC ``x`` with the layer's weight ``W`` in PyTorch layout: forward (pad = the layer's padding) or data
+    gradient (``x`` is dy, ``Cout`` the layer's input channels, pad = 3 - the layer's padding)."""
+    N, H, Wd, C = x.shape
+    wsb = query('re2e_conv4x4_wino_workspace_bytes', N, H, Wd, C, Cout, pad)
+    ws = workspace(wsb, x.device, 'wino44')
+    y = empty((N, H + 2 * pad - 3, Wd + 2 * pad - 3, Cout), x)
+    call('re2e_conv4x4_wino', x.data_ptr(), N, H, Wd, C, W.data_ptr(), Cout, pad, int(bool(dgrad)), y.data_ptr(), ws.data_ptr(), wsb)
+    return y
+
+
 class Conv2dFn(torch.autograd.Function):
     """x: (N,H,W,Cin) NHWC; W: (Cout,Cin,KH,KW) PyTorch layout; returns (N,OH,OW,Cout)."""
 
@@ -487,6 +505,10 @@ class Conv2dFn(torch.autograd.Function):
                 return yp
             y = conv3x3_wino(x, W, Cout, bias=b, relu=act == lib.ACT_RELU)
             ctx.save_for_backward(x, y if (act != lib.ACT_NONE and not ctx.act_bwd_done) else None)
+            return y
+        if act == lib.ACT_NONE and b is None and not pool and _wino44_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and W.is_contiguous():
+            y = conv4x4_wino(x.contiguous(), W, Cout, pad)            # the discriminator's conv4: F(2x2,4x4), 2.56x fewer matrix FLOPs
+            ctx.save_for_backward(x, None)
             return y
         wg = empty((Cout, KH, KW, Cin), x)
         call('re2e_conv_weight_gather', W.data_ptr(), wg.data_ptr(), Cout, Cin, KH, KW, 0, KH, KW, 0, 0, 1)
@@ -554,6 +576,8 @@ def conv_dgrad(dz, W, xshape, stride, pad, relu_out=None):
     OH, OW = dz.shape[1], dz.shape[2]
     if stride == 1 and _wino_ok(N, H, Wd, Cout, Cin, (KH, KW), stride, pad) and (OH, OW) == (H, Wd) and W.is_contiguous():
         return conv3x3_wino(_f32(dz), W, Cin, dgrad=True, mask=relu_out)
+    if relu_out is None and _wino44_ok(N, OH, OW, Cout, Cin, (KH, KW), stride, pad) and (OH, OW) == (H - 1, Wd - 1) and W.is_contiguous():
+        return conv4x4_wino(_f32(dz).contiguous(), W, Cin, 3 - pad, dgrad=True)
     if stride == 1:
         wt = empty((Cin, KH, KW, Cout), dz)
         call('re2e_conv_weight_gather', W.data_ptr(), wt.data_ptr(), Cout, Cin, KH, KW, 1, KH, KW, 0, 0, 1)

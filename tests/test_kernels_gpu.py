@@ -217,6 +217,9 @@ CONVS = [  # N, H, W, Cin, Cout, k, stride, pad, act, bias
     (2, 33, 8, 16, 64, 3, 1, 1, 'relu', True),
     (1, 67, 40, 64, 128, 3, 1, 1, 'relu', True),
     (3, 5, 3, 32, 128, 3, 1, 1, None, True),
+    # Winograd F(2x2,4x4) (wino44.hip): 4x4 / stride 1 / pad 1, >= 64 channels both ways; odd output sizes (ragged tiles)
+    (2, 50, 48, 64, 128, 4, 1, 1, None, False),
+    (1, 67, 65, 128, 64, 4, 1, 1, None, False),
 ]
 
 

@@ -49,7 +49,23 @@ def fbank():
     print('fbank bwd  %.1f us' % us)
 
 
-ALL = {'conv1_1_dgrad': conv1_1_dgrad, 'fbank': fbank}
+def d_conv4():
+    import torch.nn.functional as Fn
+    N, H, W, C, K = 32, 100, 10, 256, 512
+    x = torch.randn(N, H, W, C, device=DEV)
+    Wt = torch.randn(K, C, 4, 4, device=DEV) * 0.02
+    dz = torch.randn(N, H - 1, W - 1, K, device=DEV)
+    fl = 2.0 * 16 * C * K * N * (H - 1) * (W - 1)
+    us = timeit(lambda: ops.conv4x4_wino(x, Wt, K, 1))
+    print('D conv4 fwd  wino44 %.1f us  %.1f TFLOP/s direct-equivalent' % (us, fl / us / 1e6))
+    us = timeit(lambda: ops.conv4x4_wino(dz, Wt, C, 2, dgrad=True))
+    print('D conv4 dgrad wino44 %.1f us  %.1f TFLOP/s direct-equivalent' % (us, 2.0 * 16 * C * K * N * H * W / us / 1e6))
+    y = ops.conv4x4_wino(x, Wt, K, 1)
+    ref = Fn.conv2d(x.permute(0, 3, 1, 2), Wt, padding=1).permute(0, 2, 3, 1)
+    print('  fwd max rel err vs torch %.2e' % ((y - ref).abs().max() / ref.abs().max()).item())
+
+
+ALL = {'conv1_1_dgrad': conv1_1_dgrad, 'fbank': fbank, 'd_conv4': d_conv4}
 if __name__ == '__main__':
     for n in (sys.argv[1:] or ALL):
         ALL[n]()
