@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 302
+#define RE2E_ABI_VERSION 303
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -122,6 +122,11 @@ int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, const float*
 size_t re2e_conv4x4_wino_workspace_bytes(int NI, int H, int W, int C, int Cout, int pad);
 int re2e_conv4x4_wino(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int pad, int dgrad, float* out,
                       void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+/* Its weight gradient the same way: gw (Cout, C, 4, 4) (+)= G^T [ sum_tiles (B^T d B) (x) (A dy A^T) ] G, the sum over tiles as a K-sliced
+ * A^T B launch of the engine.  in (NI,H,W,C), dout (NI, H+2*pad-3, W+2*pad-3, Cout); beta 0 / 1; C % 4 == 0, Cout % 4 == 0. */
+size_t re2e_conv4x4_wino_wgrad_workspace_bytes(int NI, int H, int W, int C, int Cout, int pad);
+int re2e_conv4x4_wino_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, int pad, float* gw, float beta,
+                            void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 size_t re2e_conv_wgrad_workspace_bytes(int NI, int PH, int PW, int C, int Cout, int KH, int KW);
 /* dW[Cout][C][KH][KW] = beta*dW + sum_pix dout[pix][co] * in[n][py*SY+kh+OY0][px*SX+kw+OX0][ci] */
 int re2e_conv_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, int KH, int KW, int PH,

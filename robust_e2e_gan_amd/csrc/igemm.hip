@@ -980,6 +980,22 @@ int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const fl
   return RE2E_OK;
 }
 
+// The same for A^T B (weight-gradient form): out[z][M][N] = A[zK/ns : (z+1)K/ns, :M]^T . B[same rows, :N]; A (K, M), B (K, N) row-major.
+int gemm_kslices_tn(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st) {
+  if (ns < 2 || K % ns || (K / ns) % BKD || M % 4 || N % 4 || !aligned16(A) || !aligned16(B) || lda % 4 || ldb % 4 || !fits32(K, lda, M) ||
+      !fits32(K, ldb, N)) {
+    re2e_set_error("gemm_kslices_tn: unsupported slicing (M=%d N=%d K=%d ns=%d)", M, N, K, ns);
+    return RE2E_EUNSUPPORTED;
+  }
+  Epi ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.C = out; ep.ldc = N; ep.M = M; ep.N = N; ep.act = RE2E_ACT_NONE; ep.ws = out; ep.nsplit = ns;
+  DenseM la{A, kbytes(K, lda, M), lda, M, K};
+  DenseM lb{B, kbytes(K, ldb, N), ldb, N, K};
+  launch_big<DenseM, DenseM, true, true>(la, lb, ep, K, st);
+  return RE2E_OK;
+}
+
 extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const float* A, long lda, const float* B,
                          long ldb, float* C, long ldc, const float* bias, const float* bias2, int act, float beta,
                          const float* mul, float* mask_out, const int* lens_dev, int T, void* workspace,

@@ -69,15 +69,17 @@ __global__ __launch_bounds__(256) void w44_filter_kernel(const float* __restrict
 }
 
 // V[tile][pos][c]: one thread per (tile, 4 channels); a wavefront covers 256 consecutive channels of one tile (1 KiB loads / stores)
+// Element (tile p, position, channel c) goes to V[p * tile_stride + position * pos_stride + c]: tile-major [tile][pos][c] for the forward /
+// data-gradient products (K = channels), position-major [pos][tile][c] for the weight gradient (K = tiles; tiles P .. Ppad-1 are zero rows).
 __global__ __launch_bounds__(256) void w44_input_kernel(const float* __restrict__ in, int NI, int H, int W, int C, int pad, int ty, int tx,
-                                                        float* __restrict__ V) {
+                                                        float* __restrict__ V, long tile_stride, long pos_stride, long Ppad) {
   const int c4n = C >> 2;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long P = (long)NI * ty * tx;
-  if (i >= P * c4n) return;
+  if (i >= Ppad * c4n) return;
   const int c4 = (int)(i % c4n);
   const long p = i / c4n;
-  const int x = (int)(p % tx), y = (int)((p / tx) % ty), n = (int)(p / ((long)tx * ty));
+  const int x = (int)(p % tx), y = (int)((p / tx) % ty), n = p < P ? (int)(p / ((long)tx * ty)) : -1;
   const int iy0 = 2 * y - pad, ix0 = 2 * x - pad;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 t[5][5];                                                       // B^T d, column by column
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void w44_input_kernel(const float* __restrict_
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
       const int iy = iy0 + a;
-      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const bool ok = n >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       d[a] = ok ? *reinterpret_cast<const f32x4*>(in + (((long)n * H + iy) * W + ix) * C + c4 * 4) : zero;
     }
     f32x4 r[5];
@@ -96,13 +98,13 @@ __global__ __launch_bounds__(256) void w44_input_kernel(const float* __restrict_
 #pragma unroll
     for (int a = 0; a < 5; ++a) t[a][b] = r[a];
   }
-  float* vp = V + p * 25 * C + c4 * 4;
+  float* vp = V + p * tile_stride + c4 * 4;
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
     f32x4 r[5];
     bt5(t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], r);               // (B^T d) B
 #pragma unroll
-    for (int b = 0; b < 5; ++b) *reinterpret_cast<f32x4*>(vp + (long)(a * 5 + b) * C) = r[b];
+    for (int b = 0; b < 5; ++b) *reinterpret_cast<f32x4*>(vp + (long)(a * 5 + b) * pos_stride) = r[b];
   }
 }
 
@@ -135,6 +137,82 @@ __global__ __launch_bounds__(256) void w44_output_kernel(const float* __restrict
     float* op = out + (((long)n * OH + oy) * OW + 2 * x) * Cout + o4 * 4;
     *reinterpret_cast<f32x4*>(op) = y0;
     if (2 * x + 1 < OW) *reinterpret_cast<f32x4*>(op + Cout) = y1;
+  }
+}
+
+// weight gradient, output side: dM[pos][tile][o] = (A dY A^T)[pos] of the tile's 2x2 output gradients (zero outside the image and for the
+// zero-row tiles P .. Ppad-1); A rows: (1,0) (1,1) (1,-1) (1,2) (0,1)
+template <class T>
+__device__ __forceinline__ void a5(const T& y0, const T& y1, T (&r)[5]) {
+  r[0] = y0; r[1] = y0 + y1; r[2] = y0 - y1; r[3] = y0 + 2.f * y1; r[4] = y1;
+}
+__global__ __launch_bounds__(256) void w44_dout_kernel(const float* __restrict__ dy, int NI, int OH, int OW, int Cout, int ty, int tx, long P, long Ppad,
+                                                       float* __restrict__ dM) {
+  const int o4n = Cout >> 2;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= Ppad * o4n) return;
+  const int o4 = (int)(i % o4n);
+  const long p = i / o4n;
+  const int x = (int)(p % tx), y = (int)((p / tx) % ty), n = p < P ? (int)(p / ((long)tx * ty)) : -1;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 g[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int oy = 2 * y + a, ox = 2 * x + b;
+      g[a][b] = (n >= 0 && oy < OH && ox < OW) ? *reinterpret_cast<const f32x4*>(dy + (((long)n * OH + oy) * OW + ox) * Cout + o4 * 4) : zero;
+    }
+  f32x4 t0[5], t1[5];                                                 // A dY, column by column
+  a5(g[0][0], g[1][0], t0);
+  a5(g[0][1], g[1][1], t1);
+  float* mp = dM + p * Cout + o4 * 4;
+  const long ps = Ppad * Cout;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    f32x4 r[5];
+    a5(t0[a], t1[a], r);                                               // (A dY) A^T
+#pragma unroll
+    for (int b = 0; b < 5; ++b) *reinterpret_cast<f32x4*>(mp + (long)(a * 5 + b) * ps) = r[b];
+  }
+}
+
+// dW[o][c][a][b] (+)= sum_xy G[x][a] G[y][b] dU[x*5+y][c][o], dU[pos] = the sum of the position's `sub` K-slices of the engine launch
+__global__ __launch_bounds__(256) void w44_wgrad_final_kernel(const float* __restrict__ slabs, int C, int Cout, int sub, float* __restrict__ gw, float beta) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)C * Cout) return;
+  const int o = (int)(i % Cout), c = (int)(i / Cout);
+  const long ss = (long)C * Cout;
+  float u[5][5];
+#pragma unroll
+  for (int pos = 0; pos < 25; ++pos) {
+    float v = 0.f;
+    for (int z = 0; z < sub; ++z) v += slabs[((long)pos * sub + z) * ss + i];
+    u[pos / 5][pos % 5] = v;
+  }
+  // G^T rows: column a of G = (1/2, -1/2, -1/6, 1/6, 0), (0, -1/2, 1/6, 1/3, 0), (0, -1/2, -1/6, 2/3, 0), (0, -1/2, 1/6, 4/3, 1)
+  auto gt = [](float v0, float v1, float v2, float v3, float v4, float (&r)[4]) {
+    const float s6 = 1.f / 6.f;
+    r[0] = 0.5f * v0 - 0.5f * v1 - s6 * v2 + s6 * v3;
+    r[1] = -0.5f * v1 + s6 * v2 + 2.f * s6 * v3;
+    r[2] = -0.5f * v1 - s6 * v2 + 4.f * s6 * v3;
+    r[3] = -0.5f * v1 + s6 * v2 + 8.f * s6 * v3 + v4;
+  };
+  float t[4][5];                                                       // G^T dU
+#pragma unroll
+  for (int y = 0; y < 5; ++y) {
+    float r[4];
+    gt(u[0][y], u[1][y], u[2][y], u[3][y], u[4][y], r);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) t[a][y] = r[a];
+  }
+  float* wp = gw + ((long)o * C + c) * 16;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float r[4];
+    gt(t[a][0], t[a][1], t[a][2], t[a][3], t[a][4], r);                // (G^T dU) G
+#pragma unroll
+    for (int b = 0; b < 4; ++b) wp[a * 4 + b] = beta != 0.f ? wp[a * 4 + b] + r[b] : r[b];
   }
 }
 
@@ -176,10 +254,65 @@ extern "C" int re2e_conv4x4_wino(const float* in, int NI, int H, int W, int C, c
   float* M = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.m_off);
   // the weight tensor is (Cout_fwd, Cin_fwd, 4, 4) in both directions: forward Cout_fwd = Cout, Cin_fwd = C; data gradient the reverse
   hipLaunchKernelGGL(w44_filter_kernel, dim3((unsigned)cdiv((long)C * Cout, 256)), dim3(256), 0, stream, w, dgrad ? C : Cout, dgrad ? Cout : C, dgrad, U);
-  hipLaunchKernelGGL(w44_input_kernel, dim3((unsigned)cdiv(p.P * (C / 4), 256)), dim3(256), 0, stream, in, NI, H, W, C, pad, p.ty, p.tx, V);
+  hipLaunchKernelGGL(w44_input_kernel, dim3((unsigned)cdiv(p.P * (C / 4), 256)), dim3(256), 0, stream, in, NI, H, W, C, pad, p.ty, p.tx, V, 25L * C, (long)C, p.P);
   const int rc = gemm_kslices((int)p.P, Cout, 25 * C, 25, V, 25L * C, U, 25L * C, M, stream);
   if (rc != RE2E_OK) return rc;
   hipLaunchKernelGGL(w44_output_kernel, dim3((unsigned)cdiv(p.P * (Cout / 4), 256)), dim3(256), 0, stream, M, p.P, Cout, p.OH, p.OW, p.ty, p.tx, out);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+namespace {
+struct W44WgradPlan { int OH, OW, ty, tx, sub; long P, Ppad; size_t v_off, m_off, s_off, total; };
+W44WgradPlan w44_wgrad_plan(int NI, int H, int W, int C, int Cout, int pad) {
+  W44WgradPlan p;
+  p.OH = H + 2 * pad - 3; p.OW = W + 2 * pad - 3;
+  p.ty = (p.OH + 1) / 2; p.tx = (p.OW + 1) / 2;
+  p.P = (long)NI * p.ty * p.tx;
+  // K-slices per position: enough workgroups (C/128 x Cout/128 tiles x 25 x sub) for two rounds of the chip, >= 64 k-tiles each
+  const long tiles = (long)cdiv(C, 128) * cdiv(Cout, 128) * 25;
+  int sub = (int)((1024 + tiles - 1) / tiles);
+  const long maxsub = p.P / (16 * 64);
+  if (sub > maxsub) sub = (int)maxsub;
+  if (sub < 1) sub = 1;
+  p.sub = sub;
+  const long q = 16L * sub;
+  p.Ppad = (p.P + q - 1) / q * q;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  p.v_off = 0;
+  p.m_off = up((size_t)25 * p.Ppad * C * 4);
+  p.s_off = p.m_off + up((size_t)25 * p.Ppad * Cout * 4);
+  p.total = p.s_off + up((size_t)25 * sub * C * Cout * 4);
+  return p;
+}
+}  // namespace
+
+extern "C" size_t re2e_conv4x4_wino_wgrad_workspace_bytes(int NI, int H, int W, int C, int Cout, int pad) {
+  if (NI <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0 || pad < 0 || H + 2 * pad < 4 || W + 2 * pad < 4) return 0;
+  return w44_wgrad_plan(NI, H, W, C, Cout, pad).total;
+}
+
+extern "C" int re2e_conv4x4_wino_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, int pad, float* gw, float beta,
+                                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(in && dout && gw && workspace, "null operand");
+  RE2E_CHECK_ARG(NI > 0 && H > 0 && W > 0 && C > 0 && Cout > 0 && pad >= 0 && H + 2 * pad >= 4 && W + 2 * pad >= 4, "bad geometry");
+  RE2E_CHECK_ARG(beta == 0.f || beta == 1.f, "beta must be 0 or 1");
+  if (C % 4 || Cout % 4) { re2e_set_error("re2e_conv4x4_wino_wgrad: C and Cout must be multiples of 4 (got %d, %d)", C, Cout); return RE2E_EUNSUPPORTED; }
+  const W44WgradPlan p = w44_wgrad_plan(NI, H, W, C, Cout, pad);
+  RE2E_CHECK_ARG(workspace_bytes >= p.total, "workspace too small (re2e_conv4x4_wino_wgrad_workspace_bytes)");
+  RE2E_CHECK_ARG((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "in / dout / workspace must be 16-byte aligned");
+  if (25 * p.Ppad * (long)(C > Cout ? C : Cout) * 4 >= 0xFFFFFFF0L) { re2e_set_error("re2e_conv4x4_wino_wgrad: transformed operand larger than 4 GiB"); return RE2E_EUNSUPPORTED; }
+  float* V = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.v_off);
+  float* dM = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.m_off);
+  float* S = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.s_off);
+  hipLaunchKernelGGL(w44_input_kernel, dim3((unsigned)cdiv(p.Ppad * (C / 4), 256)), dim3(256), 0, stream, in, NI, H, W, C, pad, p.ty, p.tx, V, (long)C,
+                     p.Ppad * C, p.Ppad);
+  hipLaunchKernelGGL(w44_dout_kernel, dim3((unsigned)cdiv(p.Ppad * (Cout / 4), 256)), dim3(256), 0, stream, dout, NI, p.OH, p.OW, Cout, p.ty, p.tx, p.P,
+                     p.Ppad, dM);
+  const int rc = gemm_kslices_tn(C, Cout, (int)(25 * p.Ppad), 25 * p.sub, V, (long)C, dM, (long)Cout, S, stream);
+  if (rc != RE2E_OK) return rc;
+  hipLaunchKernelGGL(w44_wgrad_final_kernel, dim3((unsigned)cdiv((long)C * Cout, 256)), dim3(256), 0, stream, S, C, Cout, p.sub, gw, beta);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

@@ -556,7 +556,12 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad, relu_out=x if ctx.x_is_relu_out else None)
         with param_grads(dz, x):
-            if need_w:
+            if need_w and _wino44_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and x.is_contiguous() and dz.is_contiguous():
+                wsb = query('re2e_conv4x4_wino_wgrad_workspace_bytes', N, H, Wd, Cin, Cout, pad)
+                ws = workspace(wsb, x.device, 'wino44w')
+                with accumulate(W) as (gw, beta):
+                    call('re2e_conv4x4_wino_wgrad', x.data_ptr(), N, H, Wd, Cin, dz.data_ptr(), Cout, pad, gw.data_ptr(), beta, ws.data_ptr(), wsb)
+            elif need_w:
                 wsb = query('re2e_conv_wgrad_workspace_bytes', N, OH, OW, Cin, Cout, KH, KW)
                 ws = workspace(wsb, x.device, 'wgrad')
                 with accumulate(W) as (gw, beta):

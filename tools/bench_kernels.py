@@ -60,6 +60,11 @@ def d_conv4():
     print('D conv4 fwd  wino44 %.1f us  %.1f TFLOP/s direct-equivalent' % (us, fl / us / 1e6))
     us = timeit(lambda: ops.conv4x4_wino(dz, Wt, C, 2, dgrad=True))
     print('D conv4 dgrad wino44 %.1f us  %.1f TFLOP/s direct-equivalent' % (us, 2.0 * 16 * C * K * N * H * W / us / 1e6))
+    gw = torch.zeros_like(Wt)
+    wsb = lib.query('re2e_conv4x4_wino_wgrad_workspace_bytes', N, H, W, C, K, 1)
+    ws = lib.workspace(wsb, x.device, 'b')
+    us = timeit(lambda: lib.call('re2e_conv4x4_wino_wgrad', x.data_ptr(), N, H, W, C, dz.data_ptr(), K, 1, gw.data_ptr(), 0.0, ws.data_ptr(), wsb))
+    print('D conv4 wgrad wino44 %.1f us  %.1f TFLOP/s direct-equivalent' % (us, fl / us / 1e6))
     y = ops.conv4x4_wino(x, Wt, K, 1)
     ref = Fn.conv2d(x.permute(0, 3, 1, 2), Wt, padding=1).permute(0, 2, 3, 1)
     print('  fwd max rel err vs torch %.2e' % ((y - ref).abs().max() / ref.abs().max()).item())
