@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 303
+#define RE2E_ABI_VERSION 304
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -113,6 +113,14 @@ size_t re2e_conv3x3_wino_workspace_bytes(int C, int Cout);
 int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int dgrad, const float* bias, int relu,
                       const float* mask, float* out, float* pool_out, unsigned char* pool_idx, void* workspace, size_t workspace_bytes,
                       re2e_stream_t stream);
+
+/* Weight gradient of the same layers the same way (csrc/wino_wgrad.hip): gw (Cout, C, 3, 3) (+)= G^T [ sum over 2x2 output tiles of
+ * (B^T d B)[c] (x) (A dy A^T)[o] ] G -- transform + product in one kernel (split over patch ranges into `workspace` slabs), a second
+ * one sums the slabs and applies G^T . G.  in (NI,H,W,C), dout (NI,H,W,Cout) NHWC, beta 0 / 1; C % 64 == 0, Cout % 32 == 0,
+ * tensors < 2 GiB and 16-byte aligned, else RE2E_EUNSUPPORTED (the caller uses re2e_conv_wgrad). */
+size_t re2e_conv3x3_wino_wgrad_workspace_bytes(int NI, int H, int W, int C, int Cout);
+int re2e_conv3x3_wino_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, float* gw, float beta,
+                            void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 
 /* 4x4 / stride-1 convolution as Winograd F(2x2,4x4) (csrc/wino44.hip; the discriminator's conv4, model/networks.py NLayerDiscriminator
  * `nn.Conv2d(ndf*4, ndf*8, kernel_size=4, stride=1, padding=1)`, and its data gradient): filter / input transform, ONE K-sliced launch

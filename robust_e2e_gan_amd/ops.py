@@ -437,7 +437,8 @@ def _conv_out(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-WINOGRAD = lib.exp_env('RE2E_NO_WINOGRAD') is None      # A/B switch (RE2E_EXPERIMENTS=1): the direct halo-patch / engine kernels instead
+WINOGRAD = lib.exp_env('RE2E_NO_WINOGRAD') is None
+WINO_WGRAD = lib.exp_env('RE2E_NO_WINO_WGRAD') is None      # A/B switch (RE2E_EXPERIMENTS=1): the direct halo-patch / engine kernels instead
 
 
 def _wino_ok(N, H, Wd, C, Cout, k, stride, pad):
@@ -556,7 +557,14 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad, relu_out=x if ctx.x_is_relu_out else None)
         with param_grads(dz, x):
-            if need_w and _wino44_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and x.is_contiguous() and dz.is_contiguous():
+            if need_w and WINO_WGRAD and _wino_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and Cin % 64 == 0 and x.is_contiguous() \
+                    and dz.is_contiguous():
+                # 3x3 / stride-1 VGG layers: the sum over pixels in the Winograd domain (re2e_conv3x3_wino_wgrad), 2.25x fewer matrix FLOPs
+                wsb = query('re2e_conv3x3_wino_wgrad_workspace_bytes', N, H, Wd, Cin, Cout)
+                ws = workspace(wsb, x.device, 'winow')
+                with accumulate(W) as (gw, beta):
+                    call('re2e_conv3x3_wino_wgrad', x.data_ptr(), N, H, Wd, Cin, dz.data_ptr(), Cout, gw.data_ptr(), beta, ws.data_ptr(), wsb)
+            elif need_w and _wino44_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and x.is_contiguous() and dz.is_contiguous():
                 wsb = query('re2e_conv4x4_wino_wgrad_workspace_bytes', N, H, Wd, Cin, Cout, pad)
                 ws = workspace(wsb, x.device, 'wino44w')
                 with accumulate(W) as (gw, beta):

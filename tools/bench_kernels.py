@@ -70,7 +70,26 @@ def d_conv4():
     print('  fwd max rel err vs torch %.2e' % ((y - ref).abs().max() / ref.abs().max()).item())
 
 
-ALL = {'conv1_1_dgrad': conv1_1_dgrad, 'fbank': fbank, 'd_conv4': d_conv4}
+def vgg_wgrad():
+    for (N, H, W, C, K) in ((64, 800, 80, 64, 64), (64, 400, 40, 64, 128), (64, 400, 40, 128, 128)):
+        x = torch.randn(N, H, W, C, device=DEV)
+        dz = torch.randn(N, H, W, K, device=DEV)
+        gw = torch.zeros(K, C, 3, 3, device=DEV)
+        fl = 2.0 * 9 * C * K * N * H * W
+        wsb = lib.query('re2e_conv3x3_wino_wgrad_workspace_bytes', N, H, W, C, K)
+        ws = lib.workspace(wsb, x.device, 'b')
+        us = timeit(lambda: lib.call('re2e_conv3x3_wino_wgrad', x.data_ptr(), N, H, W, C, dz.data_ptr(), K, gw.data_ptr(), 0.0, ws.data_ptr(), wsb), n=10)
+        wsb2 = lib.query('re2e_conv_wgrad_workspace_bytes', N, H, W, C, K, 3, 3)
+        ws2 = lib.workspace(wsb2, x.device, 'b2')
+        gw2 = torch.zeros_like(gw)
+        us2 = timeit(lambda: lib.call('re2e_conv_wgrad', x.data_ptr(), N, H, W, C, dz.data_ptr(), K, 3, 3, H, W, 1, 1, -1, -1, gw2.data_ptr(), 0.0, ws2.data_ptr(), wsb2), n=10)
+        err = ((gw - gw2).abs().max() / gw2.abs().max()).item()
+        print('3x3 wgrad %dx%dx%d %d->%d  wino %.1f us (%.1f TFLOP/s direct-equivalent, %.1f executed)  direct %.1f us (%.1f)  rel diff %.1e'
+              % (N, H, W, C, K, us, fl / us / 1e6, fl / 2.25 / us / 1e6, us2, fl / us2 / 1e6, err))
+        del x, dz
+
+
+ALL = {'vgg_wgrad': vgg_wgrad, 'conv1_1_dgrad': conv1_1_dgrad, 'fbank': fbank, 'd_conv4': d_conv4}
 if __name__ == '__main__':
     for n in (sys.argv[1:] or ALL):
         ALL[n]()
