@@ -4,15 +4,16 @@
 //
 //     dW[o][c] = G^T ( sum_tiles  (B^T d B)[c]  (x)  (A dY A^T)[o] ) G         -- 16 instead of 4 * 9 multiply-adds per tile, 2.25x fewer
 //
-// One kernel does transform + product, a small one finishes (sum of the split-K slabs, G^T . G):
+// One kernel does transform + product, two small ones finish (sum of the split-K slabs; G^T . G):
 //   * a workgroup owns a 64-channel x 32-output-channel block of all 16 positions and a range of 16x8-pixel patches (32 tiles each);
 //     per patch the raw input patch (+ 1-pixel halo, zero outside the image) and the dy patch are staged in LDS with 16-byte loads,
-//     the loads of patch k+1 are in flight in registers while patch k is multiplied;
+//     no prefetch: the second workgroup of the CU covers the load phase (prefetching patch k+1 into registers under the products of
+//     patch k changed nothing: 1875 vs 1861 us at the conv1_2 shape);
 //   * wavefront i owns row i of the transformed tile.  A k-step of v_mfma_f32_32x32x2_f32 contracts TWO tiles: lane (r, h) builds, for
 //     tile 2s + h, row i of B^T d B for channels 2r and 2r + 1 (8 ds_read_b64 + 16 vector ops) and row i of A dY A^T for output channel r
 //     (4 ds_read_b32 + 7 vector ops); 8 MFMAs per k-step, accumulators [4 positions][2 channel tiles] x 16 registers;
-//   * LDS addresses are a lane constant + compile-time offsets (the k-step loop is unrolled, the second tile of the pair is the next
-//     one in the same tile row), no bounds logic in the loop.
+//   * LDS addresses are a lane constant + compile-time offsets (the k-step loop is unrolled; the two tiles of a k-step lie in the two
+//     halves of the patch and walk along their tile rows), no bounds logic in the loop.
 #include <hip/hip_runtime.h>
 #include "../../include/re2e.h"
 #include "common.h"
@@ -84,9 +85,12 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs p) {
   const int rA = wid == 0 ? 0 : (wid == 2 ? 2 : 1), rB = wid == 3 ? 3 : (wid == 2 ? 1 : 2);
   const float sg = wid == 1 ? 1.f : -1.f;
   const float a0 = wid == 3 ? 0.f : 1.f, a1 = wid == 0 ? 0.f : (wid == 1 ? 1.f : -1.f);
-  const float* xA = xs + (rA * XW + 2 * lh) * WW_CB + 2 * lr;
-  const float* xB = xs + (rB * XW + 2 * lh) * WW_CB + 2 * lr;
-  const float* dB = ds + 2 * lh * WW_OB + lr;
+  // the two tiles of a k-step: tile row (TYH / 2) * lh + s / TXW, tile column s % TXW -- the k-steps walk along a tile row in each half
+  // of the patch, so two of the four input columns of a tile are the previous k-step's (4 instead of 8 LDS reads and row combinations)
+  constexpr int HR = TYH / 2;
+  const float* xA = xs + ((rA + 2 * HR * lh) * XW) * WW_CB + 2 * lr;
+  const float* xB = xs + ((rB + 2 * HR * lh) * XW) * WW_CB + 2 * lr;
+  const float* dB = ds + (2 * HR * lh * PW) * WW_OB + lr;
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -96,30 +100,46 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][ct][r] = 0.f;
 
-  if (pbeg < pend) load_patch(pbeg);
   for (int pi = pbeg; pi < pend; ++pi) {
+    load_patch(pi);
     store_patch();
     __syncthreads();
-    if (pi + 1 < pend) load_patch(pi + 1);
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int tyl = (2 * s) / TXW, txl = (2 * s) % TXW;
-      f32x2 t[4];
+    // The operands of k-step s + 1 (LDS reads + transforms) are independent of the MFMAs of k-step s: both are written into the loop
+    // body and the scheduling groups below spread the former BETWEEN the latter -- a vector / LDS instruction outside a wave's MFMA
+    // sequence is issued about once per MFMA of the SIMD's other wave (winograd.hip), inside it it is free.
+    f32x2 t[4], v[2][4];
+    float m[2][4];
+    auto prep = [&](const int s, f32x2 (&vv)[4], float (&mm)[4]) {
+      const int tyl = s / TXW, txl = s % TXW;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (txl != 0 && j < 2) { t[j] = t[j + 2]; continue; }
         const f32x2 da = *reinterpret_cast<const f32x2*>(xA + ((2 * tyl) * XW + 2 * txl + j) * WW_CB);
         const f32x2 db = *reinterpret_cast<const f32x2*>(xB + ((2 * tyl) * XW + 2 * txl + j) * WW_CB);
         t[j] = da + sg * db;
       }
-      const f32x2 v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+      vv[0] = t[0] - t[2]; vv[1] = t[1] + t[2]; vv[2] = t[2] - t[1]; vv[3] = t[1] - t[3];
       const float e00 = dB[((2 * tyl) * PW + 2 * txl) * WW_OB], e01 = dB[((2 * tyl) * PW + 2 * txl + 1) * WW_OB];
       const float e10 = dB[((2 * tyl + 1) * PW + 2 * txl) * WW_OB], e11 = dB[((2 * tyl + 1) * PW + 2 * txl + 1) * WW_OB];
       const float s0 = a0 * e00 + a1 * e10, s1 = a0 * e01 + a1 * e11;
-      const float m[4] = {s0, s0 + s1, s0 - s1, -s1};
+      mm[0] = s0; mm[1] = s0 + s1; mm[2] = s0 - s1; mm[3] = -s1;
+    };
+    prep(0, v[0], m[0]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) prep(s + 1, v[(s + 1) & 1], m[(s + 1) & 1]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][0], m[j], acc[j][0], 0, 0, 0);
-        acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][1], m[j], acc[j][1], 0, 0, 0);
+        acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s & 1][j][0], m[s & 1][j], acc[j][0], 0, 0, 0);
+        acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s & 1][j][1], m[s & 1][j], acc[j][1], 0, 0, 0);
+      }
+      if (s + 1 < 16) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four vector instructions
+        }
       }
     }
     __syncthreads();
@@ -135,6 +155,25 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs p) {
         const int c = c0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + ct;
         sl[((long)j * p.C + c) * p.Cout + o0 + lr] = acc[j][ct][r];
       }
+}
+
+// red[e] = sum over the patch ranges of slabs[split][e], e < 16 * C * Cout: 16 slab lanes per element, combined through LDS in a fixed
+// order (deterministic).  A thread per (c, o) walking 768 slabs on its own made the finishing pass as long as the products for the
+// 64-channel layers (4096 threads, one dependent round trip per slab).
+__global__ __launch_bounds__(1024) void wino_wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long tot, float* __restrict__ red) {
+  __shared__ float part[16][64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + e;
+  float s = 0.f;
+  if (i < tot)
+    for (int z = sl; z < nsplit; z += 16) s += slabs[(long)z * tot + i];
+  part[sl][e] = s;
+  __syncthreads();
+  if (sl != 0 || i >= tot) return;
+  s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += part[q][e];
+  red[i] = s;
 }
 
 // gw[o][c][a][b] (+)= sum_ij G[i][a] G[j][b] sum_splits slabs[split][4i+j][c][o];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
@@ -181,7 +220,7 @@ WwPlan ww_plan(int NI, int H, int W, int C, int Cout) {
   if (s > q.npatch / 8) s = q.npatch / 8;
   if (s < 1) s = 1;
   q.nsplit = s;
-  q.bytes = (size_t)s * 16 * C * Cout * sizeof(float);
+  q.bytes = (size_t)(s + 1) * 16 * C * Cout * sizeof(float);      // the slabs + their sum
   return q;
 }
 
@@ -220,7 +259,10 @@ extern "C" int re2e_conv3x3_wino_wgrad(const float* in, int NI, int H, int W, in
   if (log_calls)
     fprintf(stderr, "[igemm] A=WinoW B=DenseM tile=64x32x2 vec=1 M=%d N=%d K=%ld splits=%d\n", 9 * C, Cout, (long)NI * H * W, q.nsplit);
   if (q.wide) launch_ww<8>(a, stream); else launch_ww<4>(a, stream);
-  hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3((unsigned)cdiv((long)C * Cout, 256)), dim3(256), 0, stream, a.slabs, q.nsplit, C, Cout, gw, beta);
+  const long tot = 16L * C * Cout;
+  float* red = a.slabs + (long)q.nsplit * tot;
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)cdiv(tot, 64)), dim3(1024), 0, stream, a.slabs, q.nsplit, tot, red);
+  hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3((unsigned)cdiv((long)C * Cout, 256)), dim3(256), 0, stream, red, 1, C, Cout, gw, beta);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
