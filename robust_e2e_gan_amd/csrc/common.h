@@ -143,7 +143,7 @@ void thin_wgrad(const ConvGeom& g, const float* dout, int Cout, float* slabs, in
 
 // 3x3 / stride-1 / pad-1 convolutions with C % 16 == 0 and Cout % 64 == 0 (conv3x3.hip: halo patch staged once per channel
 // chunk, taps walked in LDS).  Returns false when the geometry is not covered (the caller then uses the implicit GEMM).
-int gemm_kslices_tn(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st);
-int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st);   // igemm.hip
+int gemm_kslices_tn(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st, int nolog = 0);
+int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st, int nolog = 0);   // igemm.hip
 bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, const float* bias, int act, float beta, const float* mask,
                   hipStream_t st, float* pool_out = nullptr, unsigned char* pool_idx = nullptr);

@@ -199,6 +199,7 @@ struct Epi {
   // gathered-weight sets (re2e_conv_dgrad_s2)
   int ncls; int cls_oy0[2], cls_ox0[2]; long cls_wstride;
   int nomem;
+  int nolog;        // the caller prints its own RE2E_IGEMM_LOG line (wino44.hip: direct-equivalent shape of the whole convolution)
 };
 
 template <class LA, class LB, class CF, bool VEC>
@@ -636,7 +637,7 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
   static const bool nomem = exp_env("RE2E_IGEMM_NOMEM") != nullptr;
   ep.nomem = nomem ? 1 : 0;
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
-  if (log_calls)
+  if (log_calls && !ep.nolog)
     fprintf(stderr, "[igemm] A=%s B=%s tile=%dx%dx%d vec=%d M=%d N=%d K=%d splits=%d\n", LA::NAME, LB::NAME, CF::BM, CF::BN,
             CF::BK, (int)VEC, ep.ncls ? ep.M * ep.ncls : ep.M, ep.N, K, ep.nsplit);   // M = rows of ALL parity classes of the launch
   hipLaunchKernelGGL((igemm_kernel<LA, LB, CF, VEC>), grid, dim3(CF::THREADS), lds, st, la, lb, ep, K);
@@ -966,14 +967,14 @@ static void gemm_dispatch(int transa, int transb, int M, int N, int K, const flo
 // K-sliced x W^T product: out[z][M][N] = A[:, z*K/ns : (z+1)*K/ns] . B[:, same]^T for z < ns -- the engine's split-K launch with the
 // caller's slice count and WITHOUT the reduce pass: the slabs are the result (a batch of ns products whose operands are interleaved
 // along K; wino44.hip).  K / ns must be a multiple of the k-tile.
-int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st) {
+int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st, int nolog) {
   if (ns < 2 || K % ns || (K / ns) % BKD || !aligned16(A) || !aligned16(B) || lda % 4 || ldb % 4 || !fits32(M, lda, K) || !fits32(N, ldb, K)) {
     re2e_set_error("gemm_kslices: unsupported slicing (M=%d N=%d K=%d ns=%d)", M, N, K, ns);
     return RE2E_EUNSUPPORTED;
   }
   Epi ep;
   memset(&ep, 0, sizeof(ep));
-  ep.C = out; ep.ldc = N; ep.M = M; ep.N = N; ep.act = RE2E_ACT_NONE; ep.ws = out; ep.nsplit = ns;
+  ep.C = out; ep.ldc = N; ep.M = M; ep.N = N; ep.act = RE2E_ACT_NONE; ep.ws = out; ep.nsplit = ns; ep.nolog = nolog;
   DenseK la{A, kbytes(M, lda, K), lda, M, K};
   DenseK lb{B, kbytes(N, ldb, K), ldb, N, K};
   launch_big<DenseK, DenseK, true, true>(la, lb, ep, K, st);
@@ -981,7 +982,7 @@ int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const fl
 }
 
 // The same for A^T B (weight-gradient form): out[z][M][N] = A[zK/ns : (z+1)K/ns, :M]^T . B[same rows, :N]; A (K, M), B (K, N) row-major.
-int gemm_kslices_tn(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st) {
+int gemm_kslices_tn(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st, int nolog) {
   if (ns < 2 || K % ns || (K / ns) % BKD || M % 4 || N % 4 || !aligned16(A) || !aligned16(B) || lda % 4 || ldb % 4 || !fits32(K, lda, M) ||
       !fits32(K, ldb, N)) {
     re2e_set_error("gemm_kslices_tn: unsupported slicing (M=%d N=%d K=%d ns=%d)", M, N, K, ns);
@@ -989,7 +990,7 @@ int gemm_kslices_tn(int M, int N, int K, int ns, const float* A, long lda, const
   }
   Epi ep;
   memset(&ep, 0, sizeof(ep));
-  ep.C = out; ep.ldc = N; ep.M = M; ep.N = N; ep.act = RE2E_ACT_NONE; ep.ws = out; ep.nsplit = ns;
+  ep.C = out; ep.ldc = N; ep.M = M; ep.N = N; ep.act = RE2E_ACT_NONE; ep.ws = out; ep.nsplit = ns; ep.nolog = nolog;
   DenseM la{A, kbytes(K, lda, M), lda, M, K};
   DenseM lb{B, kbytes(K, ldb, N), ldb, N, K};
   launch_big<DenseM, DenseM, true, true>(la, lb, ep, K, st);

@@ -110,11 +110,8 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvGeom g, const float
 // conv_cout1_kernel reads every pixel's 64 channels once per tap (9x, served by L2: ~1 TB/s of useful input).  Here the product is
 // split the other way round: a workgroup owns TH output rows of one image, FIRST projects every input pixel of its TH + 2 rows onto
 // the 9 tap vectors into a [row][column][9] table in LDS, THEN every output pixel adds its 9 table entries.  HBM traffic =
-// (TH + 2) / TH of the input.  The projection reads the rows as the contiguous byte range they are: 16 consecutive lanes take the
-// 256 bytes of one pixel (a wave instruction = 1 KiB contiguous), every lane multiplies its 4 channels into 9 partial sums against
-// weights it keeps in registers, and a rotate-and-add over the 16-lane DPP row finishes the sums; lane t of the row stores tap t.
+// (TH + 2) / TH of the input.  The projection reads the rows as the contiguous byte range they are and runs on the matrix cores (below).
 // ---------------------------------------------------------------------------------------------
-#define RE2E_ROR_ADD(v, n) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x120 + (n), 0xf, 0xf, false)))
 
 template <int TH>
 __global__ __launch_bounds__(256) void conv_cout1_rows3x3_kernel(ConvGeom g, const float* __restrict__ wg, OutMap o, const float* __restrict__ bias,
@@ -128,40 +125,55 @@ __global__ __launch_bounds__(256) void conv_cout1_rows3x3_kernel(ConvGeom g, con
     const int r = i / 18, j = i - r * 18;
     tab[(r * W2 + (j < 9 ? 0 : g.W + 1)) * 9 + (j < 9 ? j : j - 9)] = 0.f;
   }
-  const int lt = tid & 15, slot = tid >> 4;               // channel quad of the pixel, pixel slot of the 16 a workgroup pass covers
-  f32x4 w[9];
+  // projection on the matrix cores: v_mfma_f32_16x16x4_f32 with M = 16 consecutive pixels of the workgroup's contiguous pixel range, N = the 9
+  // taps (padded to 16), K = the 64 channels in 16 k-steps.  Lane (p, kq) loads pixel p's channels 16j + 4kq .. + 3 as one 16-byte load per
+  // j (A operand of k-steps (j, 0..3)); the weights of tap (lane & 15) at the same channels sit in 16 registers (B operand); the accumulator
+  // holds tap (lane & 15) of pixels 4kq .. 4kq + 3: stored straight into the table, no cross-lane reduction (the vector form -- 36 FMAs +
+  // 36 DPP adds + 9 selects per 4 pixels -- kept the SIMDs busier than the 2.2 TB/s it streamed: 240 us in the step, 0.28 of the HBM peak).
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const int lane = tid & 63, wave = tid >> 6, pp = lane & 15, kq = lane >> 4;
+  f32x4v wr[4];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const f32x4*>(wg + t * 64 + lt * 4);
+  for (int j = 0; j < 4; ++j) {
+    wr[j] = pp < 9 ? *reinterpret_cast<const f32x4v*>(wg + pp * 64 + 16 * j + 4 * kq) : f32x4v{0.f, 0.f, 0.f, 0.f};
+  }
   const unsigned img_bytes = (unsigned)g.H * g.W * 256u;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.in) + (long)n * g.H * g.W * 64, 0, img_bytes, 0x00020000);
-  const int npx = (TH + 2) * g.W;
-  int rr = slot / g.W, xx = slot - rr * g.W;              // g.W >= 16: a pass never skips a row
-  constexpr int U = 3;
-  for (int q0 = slot; q0 < npx; q0 += 16 * U) {
-    f32x4 v[U];
-    int ti[U];
-    int r2 = rr, x2 = xx;
+  const int npx = (TH + 2) * g.W, ngrp = (npx + 15) >> 4;
+  const int lin0 = (y0 - 1) * g.W;                         // flattened pixel index of the range's first pixel (negative above the image)
+  const int hw = g.H * g.W;
+  int q0 = wave * 16 + 4 * kq;                             // first of the 4 pixels this lane's accumulator holds
+  int rr = q0 / g.W, xx = q0 - rr * g.W;
+  constexpr int U = 3;                                     // pixel groups in flight per wavefront (12 x 16-byte loads per lane)
+  for (int grp = wave; grp < ngrp; grp += 4 * U) {
+    f32x4v v[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int iy = y0 - 1 + r2;
-      const bool ok = (q0 + 16 * u < npx) & ((unsigned)iy < (unsigned)g.H);
-      v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)((iy * g.W + x2) * 256 + lt * 16) : 0x80000000u, 0, 0));
-      ti[u] = (q0 + 16 * u < npx) ? (r2 * W2 + x2 + 1) * 9 + lt : -1;
-      x2 += 16;
-      if (x2 >= g.W) { x2 -= g.W; ++r2; }
+      const int q = (grp + 4 * u) * 16 + pp, lin = lin0 + q;
+      const bool ok = q < npx && (unsigned)lin < (unsigned)hw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        v[u][j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(lin * 256 + j * 64 + kq * 16) : 0x80000000u, 0, 0));
     }
-    rr = r2; xx = x2;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float val = 0.f;
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        float s = v[u][0] * w[t][0];
-        s = fmaf(v[u][1], w[t][1], s); s = fmaf(v[u][2], w[t][2], s); s = fmaf(v[u][3], w[t][3], s);
-        s = RE2E_ROR_ADD(s, 8); s = RE2E_ROR_ADD(s, 4); s = RE2E_ROR_ADD(s, 2); s = RE2E_ROR_ADD(s, 1);
-        val = lt == t ? s : val;
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][j][i], wr[j][i], acc, 0, 0, 0);
+      if (pp < 9) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int x2 = xx + i, r2 = rr;
+          if (x2 >= g.W) { x2 -= g.W; ++r2; }
+          if (q0 + i < npx) tab[(r2 * W2 + x2 + 1) * 9 + pp] = acc[i];
+        }
       }
-      if (lt < 9 && ti[u] >= 0) tab[ti[u]] = val;
+      q0 += 64; xx += 64;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (xx >= g.W) { xx -= g.W; ++rr; }
     }
   }
   __syncthreads();

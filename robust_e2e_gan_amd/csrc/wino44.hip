@@ -255,7 +255,10 @@ extern "C" int re2e_conv4x4_wino(const float* in, int NI, int H, int W, int C, c
   // the weight tensor is (Cout_fwd, Cin_fwd, 4, 4) in both directions: forward Cout_fwd = Cout, Cin_fwd = C; data gradient the reverse
   hipLaunchKernelGGL(w44_filter_kernel, dim3((unsigned)cdiv((long)C * Cout, 256)), dim3(256), 0, stream, w, dgrad ? C : Cout, dgrad ? Cout : C, dgrad, U);
   hipLaunchKernelGGL(w44_input_kernel, dim3((unsigned)cdiv(p.P * (C / 4), 256)), dim3(256), 0, stream, in, NI, H, W, C, pad, p.ty, p.tx, V, 25L * C, (long)C, p.P);
-  const int rc = gemm_kslices((int)p.P, Cout, 25 * C, 25, V, 25L * C, U, 25L * C, M, stream);
+  static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py: ONE line for the engine launch, with the convolution's direct-form shape
+  if (log_calls)
+    fprintf(stderr, "[igemm] A=W44%s B=DenseK tile=256x128x16 vec=1 M=%ld N=%d K=%d splits=25\n", dgrad ? "D" : "F", (long)NI * p.OH * p.OW, Cout, 16 * C);
+  const int rc = gemm_kslices((int)p.P, Cout, 25 * C, 25, V, 25L * C, U, 25L * C, M, stream, 1);
   if (rc != RE2E_OK) return rc;
   hipLaunchKernelGGL(w44_output_kernel, dim3((unsigned)cdiv(p.P * (Cout / 4), 256)), dim3(256), 0, stream, M, p.P, Cout, p.OH, p.OW, p.ty, p.tx, out);
   RE2E_LAUNCH_CHECK();
@@ -310,7 +313,10 @@ extern "C" int re2e_conv4x4_wino_wgrad(const float* in, int NI, int H, int W, in
                      p.Ppad * C, p.Ppad);
   hipLaunchKernelGGL(w44_dout_kernel, dim3((unsigned)cdiv(p.Ppad * (Cout / 4), 256)), dim3(256), 0, stream, dout, NI, p.OH, p.OW, Cout, p.ty, p.tx, p.P,
                      p.Ppad, dM);
-  const int rc = gemm_kslices_tn(C, Cout, (int)(25 * p.Ppad), 25 * p.sub, V, (long)C, dM, (long)Cout, S, stream);
+  static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;
+  if (log_calls)
+    fprintf(stderr, "[igemm] A=W44W B=DenseM tile=128x128x16 vec=1 M=%d N=%d K=%ld splits=%d\n", 16 * C, Cout, (long)NI * p.OH * p.OW, 25 * p.sub);
+  const int rc = gemm_kslices_tn(C, Cout, (int)(25 * p.Ppad), 25 * p.sub, V, (long)C, dM, (long)Cout, S, stream, 1);
   if (rc != RE2E_OK) return rc;
   hipLaunchKernelGGL(w44_wgrad_final_kernel, dim3((unsigned)cdiv((long)C * Cout, 256)), dim3(256), 0, stream, S, C, Cout, p.sub, gw, beta);
   RE2E_LAUNCH_CHECK();

@@ -1,4 +1,4 @@
-# Round-3 evidence run on the GPU box:  bash tools/final_evidence_r3.sh [skip-bench]
+# Round-3 evidence run on the GPU box:  bash tools/final_evidence_r3.sh [skip-bench|bench] [tests]
 # Everything lands in gpurun_out/r3_final; tools/collect_evidence_r3.py copies the summaries into profiles/r03_*.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -41,4 +41,5 @@ python3 tools/trace_bins.py $DB 2 > $O/step_bins_2ms.txt 2>&1
 rm -rf $O/t
 RE2E_TIMELINE=1 python3 tools/step_timeline.py 2>&1 | grep -v amdgpu.ids > $O/step_timeline.txt
 python tools/bench_kernels.py 2>&1 | grep -v amdgpu.ids > $O/bench_kernels.txt
+if [ "$2" = "tests" ]; then python -m pytest tests -m gpu -q --durations=8 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; grep -E "passed|failed|rc=" $O/pytest_gpu.log | tail -3; fi
 ls -la $O

@@ -22,7 +22,7 @@ def main(log_path, trace_path):
             calls.append((a, b) + tuple(int(x) for x in m.groups()[2:]))
     kern = []
     for r in csv.DictReader(open(trace_path)):
-        if "igemm_kernel" in r["Kernel_Name"] or "conv3x3_halo_kernel" in r["Kernel_Name"] or "conv3x3_wgrad_kernel" in r["Kernel_Name"] or "wino_conv3x3_kernel" in r["Kernel_Name"]:
+        if "igemm_kernel" in r["Kernel_Name"] or "conv3x3_halo_kernel" in r["Kernel_Name"] or "conv3x3_wgrad_kernel" in r["Kernel_Name"] or "wino_conv3x3_kernel" in r["Kernel_Name"] or "wino_wgrad_kernel" in r["Kernel_Name"]:
             kern.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     kern.sort()
     if len(kern) != len(calls):
@@ -45,9 +45,11 @@ def main(log_path, trace_path):
     for (a, b, tile, vec, M, N, K, s), (cnt, us, fl) in rows:
         print(f"{a:7}{b:7}{tile:11}{vec:<2}{M:9d}{N:6d}{K:9d}{s:4d}{cnt:6d}{us / cnt:9.1f}{fl / us * 1e-6:7.1f}{us / tot_us:7.1%}")
     wino_fl = sum(v[2] for k, v in rows if k[0].startswith("Wino"))
-    exe_fl = tot_fl - wino_fl * (1.0 - 1.0 / 2.25)
+    w44_fl = sum(v[2] for k, v in rows if k[0].startswith("W44"))
+    exe_fl = tot_fl - wino_fl * (1.0 - 1.0 / 2.25) - w44_fl * (1.0 - 25.0 / 64.0)
     print(f"total {tot_us * 1e-3:.2f} ms, {tot_fl * 1e-12:.3f} TFLOP, {tot_fl / tot_us * 1e-6:.1f} TFLOP/s average")
-    print(f"(Wino rows: direct-equivalent FLOPs of 3x3 convolutions run as Winograd F(2x2,3x3), which executes 1/2.25 of them; "
+    print(f"(Wino / W44 rows: direct-equivalent FLOPs of 3x3 / 4x4 convolutions run as Winograd F(2x2,3x3) / F(2x2,4x4), which execute 1/2.25 / 25/64 of them "
+          f"(W44 rows: the engine launch only, the transform launches around it are not engine kernels); "
           f"executed by the matrix cores: {exe_fl * 1e-12:.3f} TFLOP = {exe_fl / tot_us * 1e-6:.1f} TFLOP/s average)")
 
 
