@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
 
     // The chunk loop has no branch -- the very last chunk of the workgroup re-fetches itself instead of fetching nothing -- so the
     // compiler's s_waitcnt counts stay exact: a wait only covers the loads it needs, never the ones issued a few instructions
-    // earlier.  In the last chunk of an item the fetches already address chunk 0 of the NEXT item.
+    // earlier.  (Measured and rejected, same GPU session: a two-chunk-deep pipeline that transforms chunk k + 1's pixels between the third
+    // and fourth position group of chunk k -- 241 registers, conv1_2 1.44 -> 1.53 ms, conv2_2 1.28 -> 1.32 / 1.42 ms.)
     for (int chunk = 0; chunk < nch; ++chunk) {
       f32x4 T[4], V[4];
 #pragma unroll
