@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 304
+#define RE2E_ABI_VERSION 305
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -328,10 +328,12 @@ size_t re2e_ctc_workspace_bytes(int T, int B, int Lmax);
 int re2e_ctc_fwd(const float* logits, int T, int B, int V, const int* hlens_dev, const int* labels_dev,
                  const int* label_off_dev, const int* label_len_dev, int Lmax, float* loss_out, float* nll_per_utt,
                  void* workspace, size_t workspace_bytes, re2e_stream_t stream);
-/* dlogits = (*gscale_dev)/B * (softmax - occupancy) for t<hlens[b], 0 otherwise; uses the workspace of fwd */
+/* dlogits = (*gscale_dev)/B * (softmax - occupancy) for t<hlens[b], 0 otherwise; uses the workspace of fwd.  dlogits has rows of
+ * ldd >= V floats (columns V .. ldd-1 are written as zeros): an odd vocabulary (V = 4233) padded to a multiple of 16 lets the two
+ * products of the projection's backward run on the engine's 16-byte-load path. */
 int re2e_ctc_bwd(const float* logits, int T, int B, int V, const int* hlens_dev, const int* labels_dev,
                  const int* label_off_dev, const int* label_len_dev, int Lmax, const float* nll_per_utt,
-                 const float* gscale_dev, float* dlogits, const void* workspace, re2e_stream_t stream);
+                 const float* gscale_dev, float* dlogits, int ldd, const void* workspace, re2e_stream_t stream);
 
 /* ---- N3 CTC prefix scores for joint CTC/attention beam search (CTCPrefixScore model/e2e_ctc.py:78-155 as called per
  * hypothesis at model/e2e_decoder.py:231-263), all `nh` live hypotheses of one output position in one launch.

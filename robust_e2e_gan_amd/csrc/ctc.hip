@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void ctc_grad(const float* __restrict__ logits
                                                 const float* __restrict__ lse, const float* __restrict__ lp,
                                                 const float* __restrict__ alpha, const float* __restrict__ beta,
                                                 const float* __restrict__ nll, const float* __restrict__ gscale,
-                                                float* __restrict__ dlogits) {
+                                                float* __restrict__ dlogits, int ldd) {
   extern __shared__ float occ[];     // [4][S]
   int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + wv;
@@ -187,8 +187,9 @@ __global__ __launch_bounds__(256) void ctc_grad(const float* __restrict__ logits
     }
     blank = wave_sum(blank);
   }
-  float* dst = dlogits + (long)row * V;
+  float* dst = dlogits + (long)row * ldd;              // rows of ldd >= V floats; the padding columns are written as zeros
   if (live) {
+    for (int v = V + lane; v < ldd; v += 64) dst[v] = 0.f;
     if (!active) {
       for (int v = lane; v < V; v += 64) dst[v] = 0.f;
     } else {
@@ -249,17 +250,17 @@ extern "C" int re2e_ctc_fwd(const float* logits, int T, int B, int V, const int*
 }
 
 extern "C" int re2e_ctc_bwd(const float* logits, int T, int B, int V, const int* hlens, const int* labels, const int* loff,
-                            const int* llen, int Lmax, const float* nll_per_utt, const float* gscale, float* dlogits,
+                            const int* llen, int Lmax, const float* nll_per_utt, const float* gscale, float* dlogits, int ldd,
                             const void* workspace, hipStream_t stream) {
   RE2E_CHECK_ARG(logits && hlens && labels && loff && llen && nll_per_utt && dlogits && workspace, "null arg");
-  RE2E_CHECK_ARG(T > 0 && B > 0 && V > 1 && Lmax >= 0, "bad shape");
+  RE2E_CHECK_ARG(T > 0 && B > 0 && V > 1 && Lmax >= 0 && ldd >= V, "bad shape");
   int S = 2 * Lmax + 1;
   const float* lse = (const float*)workspace;
   const float* lp = lse + (size_t)T * B;
   const float* alpha = lp + (size_t)T * B * S;
   const float* beta = alpha + (size_t)T * B * S;
   hipLaunchKernelGGL(ctc_grad, dim3(cdiv((long)T * B, 4)), dim3(256), (size_t)4 * S * sizeof(float), stream, logits, T, B, V, hlens,
-                     labels, loff, llen, S, lse, lp, alpha, beta, nll_per_utt, gscale, dlogits);
+                     labels, loff, llen, S, lse, lp, alpha, beta, nll_per_utt, gscale, dlogits, ldd);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
