@@ -17,7 +17,10 @@ for src, dst in (('bench_default.json', 'r03_bench_default.json'), ('bench_kerne
         shutil.copyfile(os.path.join(F, src), os.path.join(O, dst))
     else:
         print('missing', src)
-# the HBM table names its source by the path it was given on the GPU box
+# the HBM table is regenerated here from the copied CSV (same numbers, repository-relative source path)
+import subprocess, sys
+subprocess.run([sys.executable, os.path.join(R, 'tools', 'hbm_table.py'), 'profiles/r03_bench_nooverlap_kernel_stats.csv'], cwd=R,
+               stdout=open(os.path.join(O, 'r03_hbm_kernels.md'), 'w'), check=True)
 p = os.path.join(O, 'r03_hbm_kernels.md')
 if os.path.exists(p):
     t = open(p).read()

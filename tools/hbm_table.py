@@ -22,11 +22,11 @@ NPAR = 29147557 + 2831361 + 2764609                                             
 
 # kernel-name substring -> (what, algorithmic bytes per STEP, formula)
 KERNELS = [
-    ('fbank_fwd_', 'K2 fbank forward (enhanced + clean, raw log-mel only)', 2 * (rows_bt * F + rows_bt * NF) * f4,
+    ('fbank_fwd_', 'K2 fbank forward (enhanced + clean; since round 3 a matrix-core kernel, 25 us launches: latency-bound, listed for continuity)', 2 * (rows_bt * F + rows_bt * NF) * f4,
      '2 calls x (read (B*T,257) + write (B*T,80))'),
-    ('fbank_bwd_', 'K2 fbank backward', (2 * rows_bt * F + rows_bt * NF) * f4, 'read x, dy; write dx'),
+    ('fbank_bwd_', 'K2 fbank backward (matrix-core kernel, 35-40 us launch; reads the saved band power as well)', (2 * rows_bt * F + rows_bt * NF) * f4, 'read x, dy; write dx'),
     ('conv_cin1_fwd_kernel<3, 3>', 'K5 VGG conv1_1 forward (Cin = 1 direct kernel)', (px1 + px1 * 64) * f4, 'read (2B,800,80,1), write (2B,800,80,64)'),
-    ('conv_cout1_rows3x3_kernel', 'K5 VGG conv1_1 data gradient (Cout = 1 row-tile kernel; only the enhanced branch needs it)', (px1 * 64 + px1) / 2 * f4, 'read dz (B,800,80,64), write dx'),
+    ('conv_cout1_rows3x3_kernel', 'K5 VGG conv1_1 data gradient (Cout = 1 row-tile kernel, projection on the matrix cores; only the enhanced branch needs it; 0.5 of peak alone, profiles/r03_kernels_alone.txt)', (px1 * 64 + px1) / 2 * f4, 'read dz (B,800,80,64), write dx'),
     ('wgrad_cin1_kernel', 'K5/K9 Cin = 1 weight gradients (VGG conv1_1; D conv1 real + fake)',
      (px1 * 64 + px1) * f4 + 2 * (B * 400 * 40 * 64 + B * 800 * 80) * f4, 'read dout + input, three launches'),
     ('maxpool2_fwd_vec_kernel', 'K5 2x2 max pooling forward (both pools; absent when the pools run in the convolutions\' epilogue)',
@@ -73,6 +73,8 @@ def main(path, steps):
         ms = sum(v[1] for _, v in hit) / steps / 1e6
         gbs = nbytes / (ms * 1e-3) / 1e9
         print('| `%s` | %s (%s) | %.1f | %.3f | %.0f | %.0f | %.2f |' % (sub, what, formula, calls, ms, nbytes / MB, gbs, gbs / 8000.0))
+    print('\nRows below 0.40: the two fbank launches and `loss_partial_kernel` are 7-40 us launches (latency, not bandwidth); the conv1_1 data gradient streams, in the '
+          'single-stream step, 0.5 GB that the previous kernel has just written (alone it reaches 4.1 TB/s).')
     print('\nNot in the table: the attention-step kernels (K7: 41 launches of 5-23 us each, latency-bound, 21 MB of encoder states re-read from '
           'L2 / Infinity Cache per step -- `attloc_*` rows of the CSV) and the persistent recurrences (K4: dependent-step latency, `profiles/'
           'r01_recurrence_chain_rates.txt`).')
