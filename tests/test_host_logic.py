@@ -150,3 +150,35 @@ def test_dropout_stream_is_checkpointed():
     assert ops.dropout_state() == (99, 17)
     JointTrainer.restore_dropout({})                   # checkpoints without the key: untouched
     assert ops.dropout_state() == (99, 17)
+
+
+def test_filterbank_band_tables_rebuild_the_matrix():
+    """band_from_matrix: the by-filter and the by-bin banded forms (forward / backward kernels of re2e_fbank_*) are both exact
+    re-statements of the dense (257, 80) mel matrix."""
+    import numpy as np
+    from robust_e2e_gan_amd.model.feat_model import band_from_matrix, mel_matrix
+    W = mel_matrix()
+    off, ln, taps, maxw, NF, toff, tln, tw, maxc = band_from_matrix(W, 'cpu')
+    F_ = W.shape[0]
+    A, Bm = np.zeros_like(W), np.zeros_like(W)
+    for j in range(NF):
+        A[int(off[j]):int(off[j]) + int(ln[j]), j] = taps[j, :int(ln[j])].numpy()
+    for f in range(F_):
+        Bm[f, int(toff[f]):int(toff[f]) + int(tln[f])] = tw[f, :int(tln[f])].numpy()
+    assert np.array_equal(A, W) and np.array_equal(Bm, W)
+    assert maxw <= 32 and maxc <= 4 and NF == 80
+
+
+def test_winograd_f24_matrices_reproduce_the_correlation():
+    """tools/wino_f24_matrices.py: the F(2,4) matrices hard-coded in csrc/wino44.hip (points 0, 1, -1, 2, inf)."""
+    import importlib.util
+    import os
+    from fractions import Fraction as Fr
+    spec = importlib.util.spec_from_file_location('wino_f24', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'wino_f24_matrices.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    AT, G, BT = m.matrices((0, 1, -1, 2))
+    m.check(AT, G, BT)
+    assert AT == [[1, 1, 1, 1, 0], [0, 1, -1, 2, 1]]
+    assert BT == [[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]]
+    assert G == [[Fr(1, 2), 0, 0, 0], [Fr(-1, 2)] * 4, [Fr(-1, 6), Fr(1, 6), Fr(-1, 6), Fr(1, 6)], [Fr(1, 6), Fr(1, 3), Fr(2, 3), Fr(4, 3)], [0, 0, 0, 1]]

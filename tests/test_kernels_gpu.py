@@ -513,6 +513,36 @@ def test_ctc():
     assert (lg.grad[20:, 1] == 0).all()
 
 
+def test_ctc_projection_with_odd_vocabulary_uses_padded_gradient():
+    """V % 4 != 0 and >= 2048 rows (config 4: V = 4233, 6400 rows): CtcFn.backward writes the gradient with rows padded to a multiple of
+    16 and LinearFn.backward runs the projection's input / weight / bias gradients over the padded width -- against torch end to end."""
+    ops, lib = _ops()
+    T, B, V, E = 70, 32, 37, 24
+    h = rnd(T, B, E, scale=1.0)
+    W, b = rnd(V, E, seed=1, scale=0.3), rnd(V, seed=2, scale=0.1)
+    g = torch.Generator().manual_seed(5)
+    hlens = sorted((int(x) for x in torch.randint(40, T + 1, (B,), generator=g)), reverse=True)
+    labels = [[int(x) for x in torch.randint(1, V, (int(n),), generator=g)] for n in torch.randint(1, 9, (B,), generator=g)]
+    ll = [len(l) for l in labels]
+    hr, Wr, br = h.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.ctc_loss(F.linear(hr, Wr, br).log_softmax(2), torch.tensor(sum(labels, [])), torch.tensor(hlens), torch.tensor(ll), blank=0,
+                     reduction='sum') / B
+    (ref * 0.7).backward()
+    hg = h.to(DEV).requires_grad_(True)
+    Wg, bg = torch.nn.Parameter(W.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    flat = torch.tensor(sum(labels, []), dtype=torch.int32, device=DEV)
+    off = torch.tensor(np.concatenate([[0], np.cumsum(ll)[:-1]]), dtype=torch.int32, device=DEV)
+    assert not ops._PADDED_GRADS
+    loss = ops.ctc_loss(ops.linear(hg, Wg, bg), torch.tensor(hlens, dtype=torch.int32, device=DEV), flat, off,
+                        torch.tensor(ll, dtype=torch.int32, device=DEV), max(ll))
+    (loss * 0.7).sum().backward()
+    assert not ops._PADDED_GRADS                           # the padded buffer was claimed by LinearFn.backward
+    close('loss', loss.view(1), ref.view(1), tol=1e-5)
+    close('dh', hg.grad, hr.grad, tol=2e-4)
+    close('dW', Wg.grad, Wr.grad, tol=2e-4)
+    close('db', bg.grad, br.grad, tol=2e-4)
+
+
 def test_decoder_loop_and_ce(golden_dir):
     import os
     ops, lib = _ops()
