@@ -979,11 +979,17 @@ class BiLstmFn(torch.autograd.Function):
                         hprev = yflat[(0 if d == 0 else 2 * B):, d * H:]
                         with accumulate(w_hh) as (gw, beta):
                             call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
-                    if n_bi:
-                        with accumulate(b_ih) as (gb, beta):
-                            colsum_into(dG[d], M, 4 * H, gb, beta)
-                    if n_bh:
-                        with accumulate(b_hh) as (gb, beta):
+                    if n_bi and n_bh:                         # the same column sums: ONE pass over d(gates) (105 MB per direction and layer)
+                        csum = empty((4 * H,), dy)
+                        colsum_into(dG[d], M, 4 * H, csum, 0.0)
+                        for b_ in (b_ih, b_hh):
+                            with accumulate(b_) as (gb, beta):
+                                if beta == 0.0:
+                                    gb.copy_(csum)
+                                else:
+                                    gb.add_(csum)
+                    elif n_bi or n_bh:
+                        with accumulate(b_ih if n_bi else b_hh) as (gb, beta):
                             colsum_into(dG[d], M, 4 * H, gb, beta)
 
         weight_grads(last)
