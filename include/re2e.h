@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 305
+#define RE2E_ABI_VERSION 306
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -168,6 +168,9 @@ int re2e_act_bwd_colsum(const float* dy, const float* y, float* dz, int M, int N
 /* enhancer mask epilogue backward: dlin = dout * mix * m * (1-m)   (enhance_model.py:156-164) */
 int re2e_mask_mul_bwd(const float* dout, const float* mix, const float* mask, float* dlin, long n,
                       re2e_stream_t stream);
+/* the same with dlin's rows padded to ldd >= N floats (zeros): (rows, N) operands, (rows, ldd) result */
+int re2e_mask_mul_bwd_ld(const float* dout, const float* mix, const float* mask, float* dlin, long rows, int N, int ldd,
+                         re2e_stream_t stream);
 /* out = a*b elementwise (clean*cos target of the mask-L1 loss, enhance_model.py:170) */
 int re2e_mul(const float* a, const float* b, float* out, long n, re2e_stream_t stream);
 /* CMVN: out[r][j] = (x[r][j] + c0[j]) * c1[j]; c0==NULL gives x*c1 (its backward)  (feat_model.py:132-134) */

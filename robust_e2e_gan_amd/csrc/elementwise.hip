@@ -203,6 +203,26 @@ __global__ void mask_mul_bwd_kernel(const float* __restrict__ dout, const float*
     dlin[i] = dout[i] * mix[i] * m * (1.f - m);
   }
 }
+// the same with the result's rows padded to ldd >= N floats (padding written as zeros): an odd width (N = 257) then feeds the
+// engine's 16-byte-load path in both products of the layer's backward
+__global__ void mask_mul_bwd_ld_kernel(const float* __restrict__ dout, const float* __restrict__ mix, const float* __restrict__ mask,
+                                       float* __restrict__ dlin, long rows, int N, int ldd) {
+  const long tot = rows * ldd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / ldd;
+    const int c = (int)(i - r * ldd);
+    float v = 0.f;
+    if (c < N) { const long j = r * N + c; const float m = mask[j]; v = dout[j] * mix[j] * m * (1.f - m); }
+    dlin[i] = v;
+  }
+}
+extern "C" int re2e_mask_mul_bwd_ld(const float* dout, const float* mix, const float* mask, float* dlin, long rows, int N, int ldd,
+                                    hipStream_t stream) {
+  RE2E_CHECK_ARG(dout && mix && mask && dlin && rows > 0 && N > 0 && ldd >= N, "bad args");
+  hipLaunchKernelGGL(mask_mul_bwd_ld_kernel, dim3(grid_for(rows * ldd)), dim3(TPB), 0, stream, dout, mix, mask, dlin, rows, N, ldd);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
 extern "C" int re2e_mask_mul_bwd(const float* dout, const float* mix, const float* mask, float* dlin, long n,
                                  hipStream_t stream) {
   RE2E_CHECK_ARG(dout && mix && mask && dlin && n > 0, "bad args");

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
-ABI_VERSION = 305      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
+ABI_VERSION = 306      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
@@ -53,6 +53,7 @@ SIGNATURES = {
     're2e_colsum_workspace_bytes': (Z, [I, I]),
     're2e_colsum': (I, [P, I, I, L, P, F, P, Z, P]),
     're2e_mask_mul_bwd': (I, [P, P, P, P, L, P]),
+    're2e_mask_mul_bwd_ld': (I, [P, P, P, P, L, I, I, P]),
     're2e_mul': (I, [P, P, P, L, P]),
     're2e_affine_cols': (I, [P, P, P, P, L, I, P]),
     're2e_dropout': (I, [P, P, L, F, c_ulonglong, c_uint, P]),

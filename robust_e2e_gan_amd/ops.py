@@ -415,6 +415,29 @@ class MaskFcFn(torch.autograd.Function):
         M, K = p2.shape
         N = W.shape[0]
         dout = _f32(dout)
+        if N % 4 and M >= 2048 and K % 4 == 0 and W.is_contiguous() and dout.is_contiguous():
+            # odd width (the 257 STFT bins): d(linear) with rows zero-padded to a multiple of 4 floats, both products over the padded
+            # width on the engine's 16-byte-load path (the same move as for the CTC projection, _linear_backward_padded)
+            Np = (N + 3) // 4 * 4
+            dlin = empty((M, Np), p2)
+            call('re2e_mask_mul_bwd_ld', dout.data_ptr(), mix.data_ptr(), mask.data_ptr(), dlin.data_ptr(), M, N, Np)
+            dp = None
+            if ctx.needs_input_grad[0]:
+                wt = zeros((K, Np), p2)
+                wt[:, :N].copy_(W.t())
+                dp = empty((M, K), p2)
+                gemm(dlin, wt, dp, M, K, Np, transb=True)
+                dp = dp.view(ctx.oshape[:-1] + (K,))
+            if ctx.needs_input_grad[1]:
+                with param_grads(dlin, p2):
+                    tmp = empty((Np, K), p2)
+                    gemm(dlin, p2, tmp, Np, K, M, transa=True)
+                    with accumulate(W) as (gw, beta):
+                        if beta:
+                            gw.add_(tmp[:N])
+                        else:
+                            gw.copy_(tmp[:N])
+            return dp, None, None, None, None
         dlin = empty((M, N), p2)
         call('re2e_mask_mul_bwd', dout.data_ptr(), mix.data_ptr(), mask.data_ptr(), dlin.data_ptr(), dlin.numel())
         dp = None

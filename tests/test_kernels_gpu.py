@@ -130,10 +130,12 @@ def test_linear_input_grad_many_rows():
     close('dx beta', dx, dx0 + g.view(-1, 44) @ W)
 
 
-def test_mask_fc():
+@pytest.mark.parametrize('shape', [(3, 11, 16, 257, [11, 7, 4]), (3, 700, 16, 37, [700, 512, 33])])
+def test_mask_fc(shape):
+    """Second shape: >= 2048 rows and an odd width -- the backward writes d(linear) with padded rows (re2e_mask_mul_bwd_ld) and runs
+    both products over the padded width."""
     ops, lib = _ops()
-    B, T, K, N = 3, 11, 16, 257
-    lens = [11, 7, 4]
+    B, T, K, N, lens = shape
     proj, W, mix = rnd(B, T, K), rnd(N, K, seed=1), rnd(B, T, N, seed=2).abs()
     pr, Wr = proj.clone().requires_grad_(True), W.clone().requires_grad_(True)
     valid = (torch.arange(T).unsqueeze(0) < torch.tensor(lens).view(-1, 1)).unsqueeze(-1).float()
@@ -144,9 +146,9 @@ def test_mask_fc():
     out, mask = ops.mask_fc(pg, Wg, mix.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), T)
     (out * rnd(B, T, N, seed=3).to(DEV)).sum().backward()
     close('out', out, ref)
-    assert (out[1, 7:] == 0).all() and (out[2, 4:] == 0).all()
-    close('dproj', pg.grad, pr.grad)
-    close('dW', Wg.grad, Wr.grad)
+    assert (out[1, lens[1]:] == 0).all() and (out[2, lens[2]:] == 0).all()
+    close('dproj', pg.grad, pr.grad, tol=2e-4 if T > 100 else 1e-4)
+    close('dW', Wg.grad, Wr.grad, tol=2e-4 if T > 100 else 1e-4)
 
 
 def test_fbank():
