@@ -19,6 +19,19 @@ class BatchNormParams(torch.nn.Module):
         self.momentum, self.eps = momentum, eps
 
 
+class InstanceNormParams(torch.nn.Module):
+    """nn.InstanceNorm2d(affine=False, track_running_stats=False) (gan_model.py:46): no parameters, no buffers -- a slot in the
+    Sequential numbering and the eps."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super(InstanceNormParams, self).__init__()
+        self.num_features, self.eps = num_features, eps
+
+
+def _norm(kind, ch):
+    return BatchNormParams(ch) if kind == 'batch' else InstanceNormParams(ch)
+
+
 class _Act(torch.nn.Module):
     """placeholder that keeps nn.Sequential's numbering (LeakyReLU is fused into the conv / BN kernels)."""
 
@@ -27,26 +40,28 @@ class _Sigmoid(torch.nn.Module):
     """nn.Sigmoid() appended by ``use_sigmoid`` (--no_lsgan): fused into the last convolution's epilogue."""
 
 
-def init_NLayerDiscriminator(input_nc, ndf=64, n_layers=3, use_sigmoid=False):
-    """gan_model.py:55-95 with norm_layer = BatchNorm2d (use_bias False on the normalised convs)."""
+def init_NLayerDiscriminator(input_nc, ndf=64, n_layers=3, use_sigmoid=False, norm='batch'):
+    """gan_model.py:55-95; norm_layer = BatchNorm2d (use_bias False on the normalised convs) or InstanceNorm2d (use_bias True, :57)."""
+    ub = norm == 'instance'
     seq = [ConvParams(input_nc, ndf, 4, stride=2, padding=1), _Act()]
     nf_mult = 1
     for n in range(1, n_layers):
         nf_prev, nf_mult = nf_mult, min(2 ** n, 8)
-        seq += [ConvParams(ndf * nf_prev, ndf * nf_mult, 4, bias=False, stride=2, padding=1), BatchNormParams(ndf * nf_mult), _Act()]
+        seq += [ConvParams(ndf * nf_prev, ndf * nf_mult, 4, bias=ub, stride=2, padding=1), _norm(norm, ndf * nf_mult), _Act()]
     nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
-    seq += [ConvParams(ndf * nf_prev, ndf * nf_mult, 4, bias=False, stride=1, padding=1), BatchNormParams(ndf * nf_mult), _Act()]
+    seq += [ConvParams(ndf * nf_prev, ndf * nf_mult, 4, bias=ub, stride=1, padding=1), _norm(norm, ndf * nf_mult), _Act()]
     seq += [ConvParams(ndf * nf_mult, 1, 4, stride=1, padding=1)]
     if use_sigmoid:
         seq += [_Sigmoid()]
     return torch.nn.Sequential(*seq)
 
 
-def init_PixelDiscriminator(input_nc, ndf=64, use_sigmoid=False):
-    """gan_model.py:98-116 (1x1 PatchGAN) with norm_layer = BatchNorm2d: only the first conv has a bias."""
+def init_PixelDiscriminator(input_nc, ndf=64, use_sigmoid=False, norm='batch'):
+    """gan_model.py:98-116 (1x1 PatchGAN): with BatchNorm2d only the first conv has a bias, with InstanceNorm2d all three (:100)."""
+    ub = norm == 'instance'
     seq = [ConvParams(input_nc, ndf, 1, stride=1, padding=0), _Act(),
-           ConvParams(ndf, ndf * 2, 1, bias=False, stride=1, padding=0), BatchNormParams(ndf * 2), _Act(),
-           ConvParams(ndf * 2, 1, 1, bias=False, stride=1, padding=0)]
+           ConvParams(ndf, ndf * 2, 1, bias=ub, stride=1, padding=0), _norm(norm, ndf * 2), _Act(),
+           ConvParams(ndf * 2, 1, 1, bias=ub, stride=1, padding=0)]
     if use_sigmoid:
         seq += [_Sigmoid()]
     return torch.nn.Sequential(*seq)
@@ -68,17 +83,20 @@ class GANModel(ModelBase):
     def __init__(self, args):
         super(GANModel, self).__init__()
         self.opt = args
-        if args.norm_D != 'batch':
-            raise Re2eError('norm_D=%s: only BatchNorm discriminators are on the hot path' % args.norm_D)
+        norm = getattr(args, 'norm_D', 'batch')
+        if norm not in ('batch', 'instance'):
+            # gan_model.py:46-49: 'none' gives norm_layer = None, which upstream's constructors then call (TypeError); anything else
+            # raises NotImplementedError there
+            raise Re2eError('norm_D=%s: normalization layer is not usable (gan_model.py:42-49: batch | instance)' % norm)
         use_sigmoid = bool(args.no_lsgan)                   # gan_model.py:126: the plain-GAN discriminator ends in a Sigmoid
         if args.netD_type == 'basic':
-            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, n_layers=3, use_sigmoid=use_sigmoid)
+            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, n_layers=3, use_sigmoid=use_sigmoid, norm=norm)
         elif args.netD_type == 'n_layers':
-            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, args.n_layers_D, use_sigmoid=use_sigmoid)
+            self.model = init_NLayerDiscriminator(args.input_nc, args.ndf, args.n_layers_D, use_sigmoid=use_sigmoid, norm=norm)
         elif args.netD_type == 'pixel':
             # the module itself is built; upstream's joint loop cannot drive it (joint_train.py:178 reads an undefined
             # mix_feat at train time and applies the 80-wide CMVN to the 160-wide concatenation)
-            self.model = init_PixelDiscriminator(args.input_nc, args.ndf, use_sigmoid=use_sigmoid)
+            self.model = init_PixelDiscriminator(args.input_nc, args.ndf, use_sigmoid=use_sigmoid, norm=norm)
         else:
             raise NotImplementedError('Discriminator model name [%s] is not recognized' % args.netD_type)
         init_net(self.model, 0.02)
@@ -109,6 +127,10 @@ class GANModel(ModelBase):
                     if self.training:
                         nxt.num_batches_tracked += 1
                         self._bn_layers_last.append(nxt)
+                    i += 3
+                elif isinstance(nxt, InstanceNormParams):
+                    h = ops.conv2d(h, m.weight, m.bias, m.stride, m.padding, None)
+                    h = ops.instance_norm_lrelu(h, nxt.eps)
                     i += 3
                 else:
                     h = ops.conv2d(h, m.weight, m.bias, m.stride, m.padding, 'sigmoid' if isinstance(nxt, _Sigmoid) else None)

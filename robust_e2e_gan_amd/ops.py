@@ -902,6 +902,51 @@ class BnLreluFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None, None
 
 
+class InstanceNormLreluFn(torch.autograd.Function):
+    """InstanceNorm2d(affine=False, track_running_stats=False) + LeakyReLU(slope) over NHWC (--norm_D instance, gan_model.py:42-46):
+    per-sample, per-channel statistics = the BatchNorm kernels on one sample at a time (N launches per pass: an option off the
+    benchmarked path, kept simple)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, slope):
+        _need_gpu(x)
+        x = _f32(x).contiguous()
+        N, C = x.shape[0], x.shape[-1]
+        Pn = x.numel() // (N * C)
+        y = empty(x.shape, x)
+        sm, si = empty((N, C), x), empty((N, C), x)
+        ones, zero = torch.ones(C, device=x.device), torch.zeros(C, device=x.device)
+        rm, rv = torch.zeros(C, device=x.device), torch.ones(C, device=x.device)          # momentum 0: never moved, never read back
+        wsb = query('re2e_bn_workspace_bytes', Pn, C)
+        ws = workspace(wsb, x.device, 'bn')
+        st = Pn * C * 4
+        for n in range(N):
+            call('re2e_bn_lrelu_fwd', x.data_ptr() + n * st, Pn, C, ones.data_ptr(), zero.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.0, float(eps), 1,
+                 float(slope), y.data_ptr() + n * st, sm[n].data_ptr(), si[n].data_ptr(), ws.data_ptr(), wsb)
+        ctx.save_for_backward(x, sm, si, ones, zero)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sm, si, ones, zero = ctx.saved_tensors
+        N, C = x.shape[0], x.shape[-1]
+        Pn = x.numel() // (N * C)
+        dy = _f32(dy).contiguous()
+        dx = empty(x.shape, x)
+        wsb = query('re2e_bn_workspace_bytes', Pn, C)
+        ws = workspace(wsb, x.device, 'bn')
+        st = Pn * C * 4
+        for n in range(N):
+            call('re2e_bn_lrelu_bwd', dy.data_ptr() + n * st, x.data_ptr() + n * st, Pn, C, ones.data_ptr(), zero.data_ptr(), sm[n].data_ptr(),
+                 si[n].data_ptr(), ctx.slope, dx.data_ptr() + n * st, None, None, 0.0, ws.data_ptr(), wsb)
+        return dx, None, None
+
+
+def instance_norm_lrelu(x, eps=1e-5, slope=0.2):
+    return InstanceNormLreluFn.apply(x, eps, slope)
+
+
 def bn_lrelu(x, gamma, beta, rm, rv, train=True, momentum=0.1, eps=1e-5, slope=0.2):
     """BatchNorm2d + LeakyReLU(slope); slope=1.0 is plain BatchNorm2d."""
     return BnLreluFn.apply(x, gamma, beta, rm, rv, train, momentum, eps, slope)

@@ -324,3 +324,42 @@ def test_joint_step_ragged_shapes_vs_oracle(golden_dir, lens, tls):
         for k, p in m.named_parameters():
             if k in gd:
                 rel(pre + '.' + k, p.grad, gd[k].numpy(), tol=4e-3, atol=1e-7)
+
+
+def test_instance_norm_discriminator_vs_torch():
+    """--norm_D instance (gan_model.py:42-46,57): InstanceNorm2d(affine=False) between the convolutions, which then carry biases; the
+    module against the same network built from torch.nn layers with the same weights (forward, input gradient, weight gradients)."""
+    import torch.nn as nn
+    import __graft_entry__ as g
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    opt = g._tiny_opt()
+    opt.norm_D, opt.netD_type, opt.ndf = 'instance', 'basic', 8
+    torch.manual_seed(3)
+    gan = GANModel(opt).to(DEV).train()
+    sd = gan.state_dict()
+    assert not any('running' in k for k in sd), sd.keys()
+    ndf = opt.ndf
+    seq = [nn.Conv2d(1, ndf, 4, 2, 1), nn.LeakyReLU(0.2)]
+    chans = [(ndf, 2 * ndf, 2), (2 * ndf, 4 * ndf, 2), (4 * ndf, 8 * ndf, 1)]
+    for ci, co, st in chans:
+        seq += [nn.Conv2d(ci, co, 4, st, 1, bias=True), nn.InstanceNorm2d(co, affine=False, track_running_stats=False), nn.LeakyReLU(0.2)]
+    seq += [nn.Conv2d(8 * ndf, 1, 4, 1, 1)]
+    ref = nn.Sequential(*seq)
+    ref.load_state_dict({k.replace('model.', ''): v.cpu() for k, v in sd.items()})
+    x = torch.randn(3, 64, 80)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr.unsqueeze(1))
+    w = torch.randn_like(yr)
+    (yr * w).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    y = gan(xg)
+    (y * w.to(DEV)).sum().backward()
+    assert y.shape == yr.shape
+    tol = lambda a, b, t: float((a.cpu() - b).abs().max()) <= t * float(b.abs().max()) + 1e-7
+    assert tol(y.detach(), yr.detach(), 2e-4)
+    assert tol(xg.grad, xr.grad, 1e-3)
+    # (a bias in front of an InstanceNorm has an exactly-zero gradient: both sides hold rounding noise there, so the yardstick is the
+    # largest gradient of the network, not the tensor's own)
+    gscale = max(float(pr.grad.abs().max()) for pr in ref.parameters())
+    for (k, p), (kr, pr) in zip(gan.model.named_parameters(), ref.named_parameters()):
+        assert k == kr and float((p.grad.cpu() - pr.grad).abs().max()) <= 1e-3 * max(float(pr.grad.abs().max()), 1e-2 * gscale), k
