@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 306
+#define RE2E_ABI_VERSION 307
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -347,6 +347,11 @@ int re2e_ctc_bwd(const float* logits, int T, int B, int V, const int* hlens_dev,
 int re2e_ctc_prefix_score(const float* lpz, int T, int V, const float* att_lsm, int nh, const float* r_prev, const int* last_label_dev,
                           const int* out_len_dev, const float* prev_score_dev, int ctc_beam, float att_weight, float ctc_weight, int blank,
                           int eos, int* cand_out, float* local_out, float* ctc_score_out, float* r_new, re2e_stream_t stream);
+/* The same scores for a caller-given candidate list cand_dev (nh, ncand) -- ctc_weight == 1.0 scores all V labels in the order of their
+ * attention scores (a device-side stable sort): one thread per candidate, outputs (nh, ncand) in the list's order, r_new (nh*ncand, T, 2). */
+int re2e_ctc_prefix_score_cands(const float* lpz, int T, int V, const float* att_lsm, int nh, const float* r_prev, const int* last_label_dev,
+                                const int* out_len_dev, const float* prev_score_dev, const int* cand_dev, int ncand, float att_weight,
+                                float ctc_weight, int blank, int eos, float* local_out, float* ctc_score_out, float* r_new, re2e_stream_t stream);
 
 /* ---- K7 location-aware attention step (model/e2e_attention.py:258-297) -------------------- */
 /* per utterance b: w = softmax_t(2*(gvec . tanh(W_att conv(att_prev) + pre[b,t] + W_dec z[b]) + gb)),

@@ -287,6 +287,34 @@ __device__ __forceinline__ float logaddexp_(float x, float y) {      // numpy's 
   return d > 0.f ? x + log1pf(expf(-d)) : y + log1pf(expf(d));
 }
 
+// CTCPrefixScore.__call__ for ONE candidate label c of one hypothesis (e2e_ctc.py:113-155): new forward variables -> rn (T, 2), prefix score.
+__device__ __forceinline__ void prefix_recursion(const float* __restrict__ lpz, int T, int V, const float* rp, const float* rsum, int c, float c_att,
+                                                 int n, int last, float prev, float att_weight, float ctc_weight, int blank, int eos,
+                                                 float* __restrict__ rn, int* cand_o, float* local_o, float* ctc_o) {
+  // a hypothesis longer than the T frames (recog maxlenratio > 1): upstream's r[start - 1] raises IndexError there and the host
+  // caller raises it too (beam_search.py); here the state writes are clamped to the candidate's own (T, 2) block
+  const int start = min(n > 1 ? n : 1, T);
+  float rn_n, rn_b;                                   // r[t-1][0], r[t-1][1]
+  for (int t = 0; t < start - 1; ++t) { rn[2 * t] = CTC_LOGZERO; rn[2 * t + 1] = CTC_LOGZERO; }     // never read (numpy leaves them unset)
+  if (n == 0) { rn_n = lpz[c]; rn_b = CTC_LOGZERO; } else { rn_n = CTC_LOGZERO; rn_b = CTC_LOGZERO; }
+  rn[2 * (start - 1)] = rn_n; rn[2 * (start - 1) + 1] = rn_b;
+  const bool rep = n > 0 && c == last;                // a repeated label needs a blank in between
+  float log_psi = rn_n;
+  for (int t = start; t < T; ++t) {
+    const float phi = rep ? rp[2 * (t - 1) + 1] : rsum[t - 1];
+    const float xs = lpz[(long)t * V + c], xb = lpz[(long)t * V + blank];
+    const float nn = logaddexp_(rn_n, phi) + xs;
+    const float nb = logaddexp_(rn_n, rn_b) + xb;
+    log_psi = logaddexp_(log_psi, phi + xs);
+    rn_n = nn; rn_b = nb;
+    rn[2 * t] = nn; rn[2 * t + 1] = nb;
+  }
+  if (c == eos) log_psi = rsum[T - 1];
+  *cand_o = c;
+  *ctc_o = log_psi;
+  *local_o = att_weight * c_att + ctc_weight * (log_psi - prev);
+}
+
 __global__ __launch_bounds__(256) void ctc_prefix_kernel(const float* __restrict__ lpz, int T, int V, const float* __restrict__ att, const float* __restrict__ r_prev,
                                                          const int* __restrict__ last_label, const int* __restrict__ out_len,
                                                          const float* __restrict__ prev_score, int ctc_beam, float att_weight, float ctc_weight, int blank, int eos,
@@ -325,32 +353,33 @@ __global__ __launch_bounds__(256) void ctc_prefix_kernel(const float* __restrict
     }
     __syncthreads();
   }
-  if (tid < ctc_beam) {
-    const int c = cand[tid], n = out_len[h], last = last_label[h];
-    float* rn = r_new + ((long)h * ctc_beam + tid) * 2 * T;
-    // a hypothesis longer than the T frames (recog maxlenratio > 1): upstream's r[start - 1] raises IndexError there and the host
-    // caller raises it too (beam_search.py); here the state writes are clamped to the candidate's own (T, 2) block
-    const int start = min(n > 1 ? n : 1, T);
-    float rn_n, rn_b;                                   // r[t-1][0], r[t-1][1]
-    for (int t = 0; t < start - 1; ++t) { rn[2 * t] = CTC_LOGZERO; rn[2 * t + 1] = CTC_LOGZERO; }     // never read (numpy leaves them unset)
-    if (n == 0) { rn_n = lpz[c]; rn_b = CTC_LOGZERO; } else { rn_n = CTC_LOGZERO; rn_b = CTC_LOGZERO; }
-    rn[2 * (start - 1)] = rn_n; rn[2 * (start - 1) + 1] = rn_b;
-    const bool rep = n > 0 && c == last;                // a repeated label needs a blank in between
-    float log_psi = rn_n;
-    for (int t = start; t < T; ++t) {
-      const float phi = rep ? rp[2 * (t - 1) + 1] : rsum[t - 1];
-      const float xs = lpz[(long)t * V + c], xb = lpz[(long)t * V + blank];
-      const float nn = logaddexp_(rn_n, phi) + xs;
-      const float nb = logaddexp_(rn_n, rn_b) + xb;
-      log_psi = logaddexp_(log_psi, phi + xs);
-      rn_n = nn; rn_b = nb;
-      rn[2 * t] = nn; rn[2 * t + 1] = nb;
-    }
-    if (c == eos) log_psi = rsum[T - 1];
-    cand_out[(long)h * ctc_beam + tid] = c;
-    ctc_out[(long)h * ctc_beam + tid] = log_psi;
-    local_out[(long)h * ctc_beam + tid] = att_weight * cand_att[tid] + ctc_weight * (log_psi - prev_score[h]);
-  }
+  if (tid < ctc_beam)
+    prefix_recursion(lpz, T, V, rp, rsum, cand[tid], cand_att[tid], out_len[h], last_label[h], prev_score[h], att_weight, ctc_weight, blank, eos,
+                     r_new + ((long)h * ctc_beam + tid) * 2 * T, cand_out + (long)h * ctc_beam + tid, local_out + (long)h * ctc_beam + tid,
+                     ctc_out + (long)h * ctc_beam + tid);
+}
+
+// The same scores for a GIVEN candidate list (ctc_weight == 1.0 scores all V labels, in the order of their attention scores: the list
+// is a device-side stable sort of the attention row): grid (ceil(ncand / 256), hypotheses), one thread per candidate.
+__global__ __launch_bounds__(256) void ctc_prefix_cands_kernel(const float* __restrict__ lpz, int T, int V, const float* __restrict__ att,
+                                                               const float* __restrict__ r_prev, const int* __restrict__ last_label,
+                                                               const int* __restrict__ out_len, const float* __restrict__ prev_score,
+                                                               const int* __restrict__ cand_in, int ncand, float att_weight, float ctc_weight,
+                                                               int blank, int eos, float* __restrict__ local_out, float* __restrict__ ctc_out,
+                                                               float* __restrict__ r_new) {
+  extern __shared__ float sm[];
+  float* rp = sm;                        // [T][2]
+  float* rsum = rp + 2 * T;              // [T]
+  const int h = blockIdx.y, tid = threadIdx.x, k = blockIdx.x * 256 + tid;
+  for (int i = tid; i < 2 * T; i += 256) rp[i] = r_prev[(long)h * 2 * T + i];
+  __syncthreads();
+  for (int t = tid; t < T; t += 256) rsum[t] = logaddexp_(rp[2 * t], rp[2 * t + 1]);
+  __syncthreads();
+  if (k >= ncand) return;
+  const int c = cand_in[(long)h * ncand + k];
+  int dummy;
+  prefix_recursion(lpz, T, V, rp, rsum, c, att[(long)h * V + c], out_len[h], last_label[h], prev_score[h], att_weight, ctc_weight, blank, eos,
+                   r_new + ((long)h * ncand + k) * 2 * T, &dummy, local_out + (long)h * ncand + k, ctc_out + (long)h * ncand + k);
 }
 }  // namespace
 
@@ -367,6 +396,21 @@ extern "C" int re2e_ctc_prefix_score(const float* lpz, int T, int V, const float
   lim.ensure(reinterpret_cast<const void*>(&ctc_prefix_kernel), lds);
   hipLaunchKernelGGL(ctc_prefix_kernel, dim3(nh), dim3(256), lds, stream, lpz, T, V, att_lsm, r_prev, last_label_dev, out_len_dev, prev_score_dev,
                      ctc_beam, att_weight, ctc_weight, blank, eos, cand_out, local_out, ctc_score_out, r_new);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+extern "C" int re2e_ctc_prefix_score_cands(const float* lpz, int T, int V, const float* att_lsm, int nh, const float* r_prev, const int* last_label_dev,
+                                           const int* out_len_dev, const float* prev_score_dev, const int* cand_dev, int ncand, float att_weight,
+                                           float ctc_weight, int blank, int eos, float* local_out, float* ctc_score_out, float* r_new, hipStream_t stream) {
+  RE2E_CHECK_ARG(lpz && att_lsm && r_prev && last_label_dev && out_len_dev && prev_score_dev && cand_dev && local_out && ctc_score_out && r_new, "null operand");
+  RE2E_CHECK_ARG(T > 0 && V > 0 && nh > 0 && ncand > 0 && ncand <= V && blank >= 0 && blank < V && eos >= 0 && eos < V, "bad geometry");
+  const size_t lds = 3 * (size_t)T * sizeof(float);
+  if (lds > 150 * 1024) { re2e_set_error("re2e_ctc_prefix_score_cands: 3T floats exceed the LDS"); return RE2E_EUNSUPPORTED; }
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&ctc_prefix_cands_kernel), lds);
+  hipLaunchKernelGGL(ctc_prefix_cands_kernel, dim3(cdiv(ncand, 256), nh), dim3(256), lds, stream, lpz, T, V, att_lsm, r_prev, last_label_dev, out_len_dev,
+                     prev_score_dev, cand_dev, ncand, att_weight, ctc_weight, blank, eos, local_out, ctc_score_out, r_new);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

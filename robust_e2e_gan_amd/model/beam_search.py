@@ -12,7 +12,9 @@ launch per position (re2e_ctc_prefix_score: top-k pre-selection, Algorithm 2's r
 LDS / registers, the combined local score); the hypotheses' CTC states never leave the GPU and only
 3 x nh x ctc_beam numbers (candidate labels, local scores, prefix scores) are copied to the host per position -- instead of
 the (nh, V) attention scores plus a numpy recursion per hypothesis.  ``ctc_beam`` > 64 (ctc_weight == 1.0 scores all V
-labels upstream, e2e_decoder.py:233-234) keeps the host scorer below, which is upstream's own numpy algorithm."""
+labels upstream, e2e_decoder.py:233-234) takes its candidate list from a device-side stable sort of the attention scores
+(re2e_ctc_prefix_score_cands, one thread per candidate).  The host scorer below -- upstream's own numpy algorithm -- is kept as the
+tests' arbiter (HOST_CTC_SCORER)."""
 import numpy as np
 import torch
 
@@ -76,7 +78,9 @@ def _topk(row, k):
     return row[idx], idx
 
 
-DEVICE_CTC_MAX_BEAM = 64        # re2e_ctc_prefix_score: one thread per candidate label, <= 64 candidates per hypothesis
+DEVICE_CTC_MAX_BEAM = 64        # re2e_ctc_prefix_score: one thread per candidate label, <= 64 candidates per hypothesis (in-kernel top-k);
+#                                 more candidates (ctc_weight == 1.0: all V labels): re2e_ctc_prefix_score_cands on a device-sorted list
+HOST_CTC_SCORER = False         # tests: upstream's numpy CTCPrefixScore on the host instead (the arbiter of the device scorers)
 
 
 def recognize_beam(p, h, lpz, recog_args, eos, prefix='', lpz_dev=None):
@@ -109,7 +113,7 @@ def recognize_beam(p, h, lpz, recog_args, eos, prefix='', lpz_dev=None):
             ctc = CTCPrefixScore(lpz, 0, eos)
             hyps[0]['ctc_state'], hyps[0]['ctc_score'] = ctc.initial_state(), np.float32(0.0)
             ctc_beam = min(V, int(beam * CTC_SCORING_RATIO)) if ctc_weight != 1.0 else V
-            dev_ctc = ctc_beam <= DEVICE_CTC_MAX_BEAM
+            dev_ctc = not HOST_CTC_SCORER
             if dev_ctc:
                 lpz_d = lpz_dev.float().contiguous() if lpz_dev is not None else torch.from_numpy(np.ascontiguousarray(lpz, np.float32)).to(dev)
                 r_prev = torch.from_numpy(hyps[0].pop('ctc_state')).to(dev).view(1, T, 2)      # states stay on the device from here on
@@ -143,12 +147,21 @@ def recognize_beam(p, h, lpz, recog_args, eos, prefix='', lpz_dev=None):
                                      % (max(len(hp['yseq']) - 1 for hp in hyps), T))
                 olen = host_to_dev(np.asarray([len(hp['yseq']) - 1 for hp in hyps], np.int32), dev)
                 prev = host_to_dev(np.asarray([hp['ctc_score'] for hp in hyps], np.float32), dev, torch.float32)
-                cand_d = torch.empty(nh, ctc_beam, dtype=torch.int32, device=dev)
                 out_d = torch.empty(2, nh, ctc_beam, device=dev)                  # [0] local scores, [1] prefix scores
                 r_new = torch.empty(nh * ctc_beam, 2 * T, device=dev)
-                call('re2e_ctc_prefix_score', lpz_d.data_ptr(), T, V, lsm.data_ptr(), nh, r_prev.data_ptr(), last.data_ptr(), olen.data_ptr(),
-                     prev.data_ptr(), ctc_beam, float(np.float32(1.0 - ctc_weight)), float(np.float32(ctc_weight)), 0, eos, cand_d.data_ptr(),
-                     out_d[0].data_ptr(), out_d[1].data_ptr(), r_new.data_ptr())
+                if ctc_beam <= DEVICE_CTC_MAX_BEAM:
+                    cand_d = torch.empty(nh, ctc_beam, dtype=torch.int32, device=dev)
+                    call('re2e_ctc_prefix_score', lpz_d.data_ptr(), T, V, lsm.data_ptr(), nh, r_prev.data_ptr(), last.data_ptr(), olen.data_ptr(),
+                         prev.data_ptr(), ctc_beam, float(np.float32(1.0 - ctc_weight)), float(np.float32(ctc_weight)), 0, eos, cand_d.data_ptr(),
+                         out_d[0].data_ptr(), out_d[1].data_ptr(), r_new.data_ptr())
+                else:
+                    # the candidates in the order torch.topk / _topk give them: attention score descending, ties -> lower label (stable sort;
+                    # NaN scores last, as the kernel's own selection ranks them)
+                    order = torch.sort(torch.nan_to_num(lsm, nan=float('-inf')), dim=1, descending=True, stable=True)[1]
+                    cand_d = order[:, :ctc_beam].to(torch.int32).contiguous()
+                    call('re2e_ctc_prefix_score_cands', lpz_d.data_ptr(), T, V, lsm.data_ptr(), nh, r_prev.data_ptr(), last.data_ptr(), olen.data_ptr(),
+                         prev.data_ptr(), cand_d.data_ptr(), ctc_beam, float(np.float32(1.0 - ctc_weight)), float(np.float32(ctc_weight)), 0, eos,
+                         out_d[0].data_ptr(), out_d[1].data_ptr(), r_new.data_ptr())
                 cand_all, out_all = cand_d.cpu().numpy(), out_d.cpu().numpy()      # 3 x nh x ctc_beam numbers: this position's host round trip
             else:
                 local_all = lsm.cpu().numpy()                             # host scorer: the (nh, V) local scores cross once per position

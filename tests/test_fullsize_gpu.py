@@ -344,10 +344,11 @@ def test_config2_asr_full_size():
     assert 150.0 < first['train/loss_att'] < 260.0             # ~ L * ln(V) = 25 * 8.35 for a random-initialised model
 
 
-def test_recognize_full_width_device_ctc_vs_host_ctc():
-    """Joint CTC/attention beam search at the config-4 width (V = 4233, T' = 200, beam 10 -> 15 CTC candidates per hypothesis):
-    the device prefix scorer (re2e_ctc_prefix_score, states resident on the GPU) and the host scorer (upstream's numpy
-    algorithm, selected by an impossible device limit) must return the same n-best list."""
+@pytest.mark.parametrize('ctc_weight', [0.3, 1.0])
+def test_recognize_full_width_device_ctc_vs_host_ctc(ctc_weight):
+    """Joint CTC/attention beam search at the config-4 width (V = 4233, T' = 200, beam 10): the device prefix scorers -- 15 candidates
+    per hypothesis chosen in the kernel (re2e_ctc_prefix_score), or with ctc_weight = 1.0 all 4233 labels from a device-sorted list
+    (re2e_ctc_prefix_score_cands) -- and the host scorer (upstream's numpy algorithm) must return the same n-best list."""
     import argparse
     from robust_e2e_gan_amd.joint_train import config4_opt
     from robust_e2e_gan_amd.model import beam_search
@@ -357,14 +358,14 @@ def test_recognize_full_width_device_ctc_vs_host_ctc():
     asr = E2E(opt).to(DEV)
     g = torch.Generator().manual_seed(4)
     feats = torch.randn(1, 800, 80, generator=g)
-    args = argparse.Namespace(beam_size=10, penalty=0.0, ctc_weight=0.3, maxlenratio=0.08, minlenratio=0.0, nbest=5, lm_weight=0.0)
+    args = argparse.Namespace(beam_size=10, penalty=0.0, ctc_weight=ctc_weight, maxlenratio=0.08 if ctc_weight < 1.0 else 0.03, minlenratio=0.0, nbest=5,
+                              lm_weight=0.0)
     dev_nbest = asr.recognize(feats, args, opt.char_list)
-    saved = beam_search.DEVICE_CTC_MAX_BEAM
-    beam_search.DEVICE_CTC_MAX_BEAM = 0
+    beam_search.HOST_CTC_SCORER = True
     try:
         host_nbest = asr.recognize(feats, args, opt.char_list)
     finally:
-        beam_search.DEVICE_CTC_MAX_BEAM = saved
+        beam_search.HOST_CTC_SCORER = False
     assert len(dev_nbest) == len(host_nbest) == 5
     for a, b in zip(dev_nbest, host_nbest):
         assert a['yseq'] == b['yseq'], (a['yseq'], b['yseq'])

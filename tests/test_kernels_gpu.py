@@ -721,6 +721,48 @@ def test_ctc_prefix_score_device_vs_numpy():
                  prev.data_ptr(), 65, 0.7, 0.3, 0, eos, cand.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), r_new.data_ptr())
 
 
+def test_ctc_prefix_score_all_labels_vs_numpy():
+    """re2e_ctc_prefix_score_cands with ALL V labels as candidates in attention order (ctc_weight == 1.0 decoding, e2e_decoder.py:233-234)
+    against the numpy CTCPrefixScore, chained over three positions (V = 300: two candidate blocks, the last one ragged)."""
+    import numpy as np
+    ops, lib = _ops()
+    from robust_e2e_gan_amd.model.beam_search import CTCPrefixScore, _topk
+    rng = np.random.default_rng(7)
+    T, V, eos, w = 41, 300, 299, 1.0
+    lpz = torch.log_softmax(torch.from_numpy(rng.normal(size=(T, V)).astype(np.float32)) * 2.0, 1).numpy()
+    ctc = CTCPrefixScore(lpz, 0, eos)
+    lpz_d = torch.from_numpy(lpz).to(DEV)
+    hyps = [{'yseq': [eos], 'state': ctc.initial_state(), 'score': np.float32(0.0)}]
+    for pos in range(3):
+        nh = len(hyps)
+        att = torch.log_softmax(torch.from_numpy(rng.normal(size=(nh, V)).astype(np.float32)), 1).numpy()
+        att[:, 17] = att[:, 4]                                         # a tie: the lower label first
+        att_d = torch.from_numpy(att).to(DEV)
+        order = torch.sort(att_d, dim=1, descending=True, stable=True)[1].to(torch.int32).contiguous()
+        r_prev = torch.from_numpy(np.stack([hp['state'] for hp in hyps])).to(DEV)
+        last = torch.tensor([hp['yseq'][-1] for hp in hyps], dtype=torch.int32, device=DEV)
+        olen = torch.tensor([len(hp['yseq']) - 1 for hp in hyps], dtype=torch.int32, device=DEV)
+        prev = torch.tensor([float(hp['score']) for hp in hyps], dtype=torch.float32, device=DEV)
+        out = torch.empty(2, nh, V, device=DEV)
+        r_new = torch.full((nh * V, 2 * T), float('nan'), device=DEV)
+        lib.call('re2e_ctc_prefix_score_cands', lpz_d.data_ptr(), T, V, att_d.data_ptr(), nh, r_prev.data_ptr(), last.data_ptr(), olen.data_ptr(),
+                 prev.data_ptr(), order.data_ptr(), V, float(np.float32(1.0 - w)), float(np.float32(w)), 0, eos, out[0].data_ptr(), out[1].data_ptr(),
+                 r_new.data_ptr())
+        out_h, r_h = out.cpu().numpy(), r_new.cpu().numpy().reshape(nh, V, T, 2)
+        nxt = []
+        for k, hp in enumerate(hyps):
+            _, want_c = _topk(att[k], V)
+            assert order[k].cpu().numpy().tolist() == want_c.tolist(), (pos, k)
+            sc, st = ctc(hp['yseq'], want_c, hp['state'])
+            np.testing.assert_allclose(out_h[1, k], sc, rtol=2e-5, atol=2e-4)
+            np.testing.assert_allclose(out_h[0, k], np.float32(w) * (sc - hp['score']), rtol=2e-5, atol=2e-4)
+            first = max(len(hp['yseq']) - 1, 1) - 1
+            np.testing.assert_allclose(r_h[k][:, first:], st[:, first:], rtol=2e-5, atol=2e-3)
+            for j in (0, V // 2, V - 1):
+                nxt.append({'yseq': hp['yseq'] + [int(want_c[j])], 'state': st[j].copy(), 'score': sc[j]})
+        hyps = nxt[:4]
+
+
 @pytest.mark.parametrize('B,E,D', [(32, 512, 300), (5, 20, 12), (32, 64, 8), (40, 128, 36)])
 def test_dec_gates_cell_fused_vs_unfused(B, E, D):
     """re2e_dec_gates_cell_fwd (one launch) against the three launches it replaces (two skinny GEMMs with beta = 1 + the cell
