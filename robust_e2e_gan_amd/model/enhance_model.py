@@ -9,7 +9,7 @@ from .. import lib, ops
 from ..lib import Re2eError
 from .e2e_common import ConvParams, LinearParams, ModelBase, lecun_normal_init_parameters, lens_dev, lens_list, to_cuda
 from .e2e_encoder import BLSTM, BLSTMP
-from .gan_model import BatchNormParams, init_net
+from .gan_model import BatchNormParams, InstanceNormParams, _norm, init_net
 
 
 class SequenceWise(torch.nn.Module):
@@ -38,22 +38,24 @@ class _Mod(torch.nn.Module):
 
 
 class UnetSkipConnectionBlock(torch.nn.Module):
-    """enhance_model.py:249-303 with norm_layer = BatchNorm2d (use_bias False).  ``self.model`` is an nn.Sequential with
+    """enhance_model.py:249-303 with norm_layer = BatchNorm2d (use_bias False) or InstanceNorm2d(affine=False) (use_bias True, :258-261:
+    --enhance_norm instance).  ``self.model`` is an nn.Sequential with
     upstream's member order, so state_dict keys agree (model.1.weight = downconv, model.2.* = downnorm, ...).  NHWC inside;
     the skip connection concatenates along the channel (= last) axis."""
 
-    def __init__(self, outer_nc, inner_nc, input_nc=None, submodule=None, outermost=False, innermost=False, use_dropout=0.0):
+    def __init__(self, outer_nc, inner_nc, input_nc=None, submodule=None, outermost=False, innermost=False, use_dropout=0.0, norm='batch'):
         super().__init__()
         self.outermost = outermost
         input_nc = outer_nc if input_nc is None else input_nc
-        downconv = ConvParams(input_nc, inner_nc, 4, bias=False, stride=2, padding=1)
+        ub = norm == 'instance'
+        downconv = ConvParams(input_nc, inner_nc, 4, bias=ub, stride=2, padding=1)
         if outermost:
             model = [downconv, submodule, _Mod('relu'), ConvTransposeParams(inner_nc * 2, outer_nc, 4, bias=True), _Mod('sigmoid')]
         elif innermost:
-            model = [_Mod('lrelu'), downconv, _Mod('relu'), ConvTransposeParams(inner_nc, outer_nc, 4, bias=False), BatchNormParams(outer_nc)]
+            model = [_Mod('lrelu'), downconv, _Mod('relu'), ConvTransposeParams(inner_nc, outer_nc, 4, bias=ub), _norm(norm, outer_nc)]
         else:
-            model = [_Mod('lrelu'), downconv, BatchNormParams(inner_nc), submodule, _Mod('relu'),
-                     ConvTransposeParams(inner_nc * 2, outer_nc, 4, bias=False), BatchNormParams(outer_nc)]
+            model = [_Mod('lrelu'), downconv, _norm(norm, inner_nc), submodule, _Mod('relu'),
+                     ConvTransposeParams(inner_nc * 2, outer_nc, 4, bias=ub), _norm(norm, outer_nc)]
             if use_dropout > 0.0:
                 model.append(_Mod('dropout', use_dropout))
         self.model = torch.nn.Sequential(*model)
@@ -74,6 +76,8 @@ class UnetSkipConnectionBlock(torch.nn.Module):
                 h = ops.bn_lrelu(h, m.weight, m.bias, m.running_mean, m.running_var, self.training, m.momentum, m.eps, slope=1.0)
                 if self.training:
                     m.num_batches_tracked += 1
+            elif isinstance(m, InstanceNormParams):
+                h = ops.instance_norm_lrelu(h, m.eps, slope=1.0)
             else:
                 h = m(h)
         return h if self.outermost else torch.cat([x, h], -1)
@@ -82,15 +86,15 @@ class UnetSkipConnectionBlock(torch.nn.Module):
 class UnetGenerator(torch.nn.Module):
     """enhance_model.py:224-246: ``num_downs`` stride-2 stages (5 = unet_128, 8 = unet_256)."""
 
-    def __init__(self, input_nc, output_nc, num_downs, ngf=64, use_dropout=0.0):
+    def __init__(self, input_nc, output_nc, num_downs, ngf=64, use_dropout=0.0, norm='batch'):
         super().__init__()
-        block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, innermost=True)
+        block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, innermost=True, norm=norm)
         for _ in range(num_downs - 5):
-            block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=block, use_dropout=use_dropout)
-        block = UnetSkipConnectionBlock(ngf * 4, ngf * 8, submodule=block)
-        block = UnetSkipConnectionBlock(ngf * 2, ngf * 4, submodule=block)
-        block = UnetSkipConnectionBlock(ngf, ngf * 2, submodule=block)
-        self.model = UnetSkipConnectionBlock(output_nc, ngf, input_nc=input_nc, submodule=block, outermost=True)
+            block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=block, use_dropout=use_dropout, norm=norm)
+        block = UnetSkipConnectionBlock(ngf * 4, ngf * 8, submodule=block, norm=norm)
+        block = UnetSkipConnectionBlock(ngf * 2, ngf * 4, submodule=block, norm=norm)
+        block = UnetSkipConnectionBlock(ngf, ngf * 2, submodule=block, norm=norm)
+        self.model = UnetSkipConnectionBlock(output_nc, ngf, input_nc=input_nc, submodule=block, outermost=True, norm=norm)
         self.num_downs = num_downs
 
     def forward(self, x_nhwc, ilens):
@@ -117,12 +121,13 @@ class EnhanceModel(ModelBase):
             self.enc1 = BLSTMP(idim, args.enhance_layers, args.enhance_units, args.enhance_projs, self.subsample, args.subsample_type,
                                args.dropout_rate)
         elif self.enhance_type in ('unet_128', 'unet_256'):
-            # enhance_model.py:58-63,94-101: pix2pix U-Net over the (T, F) log-spectrogram image; BatchNorm only
-            if getattr(args, 'enhance_norm', 'batch') != 'batch':
-                raise Re2eError('enhance_norm=%s: only BatchNorm U-Nets are built' % args.enhance_norm)
+            # enhance_model.py:58-63,94-101: pix2pix U-Net over the (T, F) log-spectrogram image
+            unorm = getattr(args, 'enhance_norm', 'batch')
+            if unorm not in ('batch', 'instance'):
+                raise Re2eError('enhance_norm=%s: normalization layer is not usable (e2e_common.get_norm_layer: batch | instance)' % unorm)
             if getattr(args, 'enhance_input_nc', 1) != 1 or getattr(args, 'enhance_output_nc', 1) != 1:
                 raise Re2eError('the U-Net enhancer maps ONE log-spectrogram image to ONE mask (enhance_model.py:153 squeezes channel 1)')
-            self.enc1 = UnetGenerator(1, 1, 5 if self.enhance_type == 'unet_128' else 8, getattr(args, 'enhance_ngf', 64), args.dropout_rate)
+            self.enc1 = UnetGenerator(1, 1, 5 if self.enhance_type == 'unet_128' else 8, getattr(args, 'enhance_ngf', 64), args.dropout_rate, norm=unorm)
             init_net(self.enc1, 0.02)
         elif self.enhance_type in ('vggblstmp', 'vggblstm'):
             raise Re2eError('enhance_type %s is dead code upstream (enhance_model.py:94,100 reference an undefined name)' % self.enhance_type)

@@ -363,3 +363,55 @@ def test_instance_norm_discriminator_vs_torch():
     gscale = max(float(pr.grad.abs().max()) for pr in ref.parameters())
     for (k, p), (kr, pr) in zip(gan.model.named_parameters(), ref.named_parameters()):
         assert k == kr and float((p.grad.cpu() - pr.grad).abs().max()) <= 1e-3 * max(float(pr.grad.abs().max()), 1e-2 * gscale), k
+
+
+def test_instance_norm_unet_vs_torch():
+    """--enhance_norm instance (enhance_model.py:258-261): the pix2pix U-Net with InstanceNorm2d(affine=False) and biased convolutions,
+    unet_128 on a (2, 64, 32) image, against the same network built from torch.nn layers with the same weights."""
+    import argparse
+    import torch.nn as nn
+    import __graft_entry__ as g
+    from robust_e2e_gan_amd.model.enhance_model import UnetGenerator
+
+    class Block(nn.Module):                       # enhance_model.py:249-303, norm_layer = InstanceNorm2d
+        def __init__(self, outer, inner, inp=None, sub=None, outermost=False, innermost=False):
+            super().__init__()
+            self.outermost = outermost
+            inp = outer if inp is None else inp
+            down = nn.Conv2d(inp, inner, 4, 2, 1, bias=True)
+            IN = lambda c: nn.InstanceNorm2d(c, affine=False, track_running_stats=False)
+            if outermost:
+                m = [down, sub, nn.ReLU(), nn.ConvTranspose2d(inner * 2, outer, 4, 2, 1), nn.Sigmoid()]
+            elif innermost:
+                m = [nn.LeakyReLU(0.2), down, nn.ReLU(), nn.ConvTranspose2d(inner, outer, 4, 2, 1, bias=True), IN(outer)]
+            else:
+                m = [nn.LeakyReLU(0.2), down, IN(inner), sub, nn.ReLU(), nn.ConvTranspose2d(inner * 2, outer, 4, 2, 1, bias=True), IN(outer)]
+            self.model = nn.Sequential(*m)
+
+        def forward(self, x):
+            return self.model(x) if self.outermost else torch.cat([x, self.model(x)], 1)
+    ngf = 4
+    torch.manual_seed(9)
+    net = UnetGenerator(1, 1, 5, ngf, 0.0, norm='instance').to(DEV).train()
+    for p_ in net.parameters():
+        torch.nn.init.normal_(p_, 0.0, 0.2)
+    b = Block(ngf * 8, ngf * 8, innermost=True)
+    b = Block(ngf * 4, ngf * 8, sub=b)
+    b = Block(ngf * 2, ngf * 4, sub=b)
+    b = Block(ngf, ngf * 2, sub=b)
+    ref = Block(1, ngf, inp=1, sub=b, outermost=True)
+    ref.load_state_dict({k[len('model.'):]: v.cpu() for k, v in net.state_dict().items()})
+    x = torch.randn(2, 1, 64, 32)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    w = torch.randn_like(yr)
+    (yr * w).sum().backward()
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    y, _ = net(xg, None)
+    (y * w.permute(0, 2, 3, 1).to(DEV)).sum().backward()
+    err = lambda a, b_: float((a.cpu() - b_).abs().max())
+    assert err(y.detach().permute(0, 3, 1, 2), yr.detach()) <= 2e-4 * float(yr.detach().abs().max())
+    assert err(xg.grad.permute(0, 3, 1, 2), xr.grad) <= 1e-3 * float(xr.grad.abs().max())
+    gscale = max(float(p_.grad.abs().max()) for p_ in ref.parameters())
+    for (k, p_), (kr, pr) in zip(net.named_parameters(), ref.named_parameters()):
+        assert k == 'model.' + kr and err(p_.grad, pr.grad) <= 1e-3 * max(float(pr.grad.abs().max()), 1e-2 * gscale), k
