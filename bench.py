@@ -391,6 +391,9 @@ def main():
         if B < world:
             raise SystemExit('bench: strong scaling needs at least one utterance per rank (global batch %d, %d ranks)' % (B, world))
         gbatch = make_batch(B, T, L, opt.odim, seed=1234)                       # the SAME global batch on every rank
+        # ONE batch over the ranks: the discriminator's BatchNorm statistics are those of the global batch (synchronised BatchNorm:
+        # three small all-reduces per layer and pass) when the shards are equal; ragged shards keep per-rank statistics
+        opt.sync_bn = world > 1 and B % world == 0
         batch = shard_batch(gbatch, rdist.shard_indices(B, rank, world), L)
         global_b = B
     else:

@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 307
+#define RE2E_ABI_VERSION 308
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -261,6 +261,21 @@ int re2e_bn_lrelu_fwd(const float* x, long P, int C, const float* gamma, const f
 int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C, const float* gamma, const float* beta,
                       const float* save_mean, const float* save_invstd, float slope, float* dx, float* dgamma, float* dbeta,
                       float gbeta, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+/* Synchronised BatchNorm for data-parallel runs that shard ONE global batch (the same kernels, cut where the caller all-reduces):
+ * re2e_bn_sync_partial: out[C] = sum over the LOCAL rows of (x - mean) (mean may be NULL) or of its square; the caller all-reduces and
+ * divides by the global row count; re2e_bn_sync_finalize: global mean / biased variance -> save_mean, save_invstd, running statistics;
+ * re2e_bn_apply: y = lrelu((x - mean) invstd gamma + beta); re2e_bn_sync_bwd_partial: out[2C] = local sum dz | sum dz*xhat;
+ * re2e_bn_sync_bwd_apply: dx from the all-reduced sums scaled by P / Ptotal (the kernel divides by its own row count). */
+int re2e_bn_sync_partial(const float* x, long P, int C, const float* mean, int square, float* out, void* workspace, size_t workspace_bytes,
+                         re2e_stream_t stream);
+int re2e_bn_sync_finalize(const float* mean, const float* var, long Ptotal, int C, float momentum, float eps, float* running_mean,
+                          float* running_var, float* save_mean, float* save_invstd, re2e_stream_t stream);
+int re2e_bn_apply(const float* x, long P, int C, const float* save_mean, const float* save_invstd, const float* gamma, const float* beta,
+                  float slope, float* y, re2e_stream_t stream);
+int re2e_bn_sync_bwd_partial(const float* dy, const float* x, long P, int C, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, float slope, float* out, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+int re2e_bn_sync_bwd_apply(const float* dy, const float* x, long P, int C, const float* gamma, const float* beta, const float* save_mean,
+                           const float* save_invstd, float slope, const float* sums, float* dx, re2e_stream_t stream);
 
 /* ---- K4 bidirectional LSTM recurrence, packed-sequence semantics (nn.LSTM call sites
  * e2e_encoder.py:128-132,168-170).  Time-major.  xg_f/xg_r [T*B,4H] hold x W_ih^T + b_ih + b_hh

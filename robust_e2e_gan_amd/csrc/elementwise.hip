@@ -913,6 +913,76 @@ extern "C" int re2e_bn_lrelu_bwd(const float* dy, const float* x, long P, int C,
   return RE2E_OK;
 }
 
+// ---- synchronised BatchNorm (data-parallel runs that shard ONE global batch: bench.py --scaling strong): the same kernels, cut at the
+// points where the caller all-reduces -- (1) sum x, (2) sum (x - mean)^2 with the GLOBAL mean, (3) sum dz / sum dz*xhat in the backward.
+// out = sum over the LOCAL rows of (x - mean) (square = 0; mean may be null) or of its square (square = 1)
+extern "C" int re2e_bn_sync_partial(const float* x, long P, int C, const float* mean, int square, float* out, void* workspace, size_t workspace_bytes,
+                                    hipStream_t stream) {
+  RE2E_CHECK_ARG(x && out && workspace && P > 0 && C > 0, "bad args");
+  RE2E_CHECK_ARG(workspace_bytes >= re2e_bn_workspace_bytes(P, C), "workspace too small");
+  const int chunks = bn_chunks(P);
+  const long rpc = (P + chunks - 1) / chunks;
+  float* part = (float*)workspace;
+  dim3 g(cdiv(C, 64), chunks);
+  if (bn_vec_ok(x, nullptr, C) && (!mean || al16(mean)))
+    hipLaunchKernelGGL(bn_partial_vec_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, square ? 1 : 0, mean, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, part, 1.f);
+  else
+    hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, (const float*)nullptr, P, C, rpc, square ? 1 : 0, mean, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, part, 1.f);
+  hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f, 0.f, out, (float*)nullptr);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+// GLOBAL mean / biased variance over Ptotal rows -> save_mean, save_invstd, running statistics (unbiased variance with Ptotal)
+extern "C" int re2e_bn_sync_finalize(const float* mean, const float* var, long Ptotal, int C, float momentum, float eps, float* running_mean,
+                                     float* running_var, float* save_mean, float* save_invstd, hipStream_t stream) {
+  RE2E_CHECK_ARG(mean && var && running_mean && running_var && save_mean && save_invstd && Ptotal > 0 && C > 0, "bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, mean, var, Ptotal, C, momentum, eps, running_mean, running_var,
+                     save_mean, save_invstd);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+// y = lrelu((x - mean) * invstd * gamma + beta)
+extern "C" int re2e_bn_apply(const float* x, long P, int C, const float* save_mean, const float* save_invstd, const float* gamma, const float* beta,
+                             float slope, float* y, hipStream_t stream) {
+  RE2E_CHECK_ARG(x && save_mean && save_invstd && gamma && beta && y && P > 0 && C > 0, "bad args");
+  if (C % 4 == 0 && al16(x) && al16(y) && al16(save_mean) && al16(save_invstd) && al16(gamma) && al16(beta))
+    hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(grid_for(P * C / 4)), dim3(TPB), 0, stream, x, P, C / 4, save_mean, save_invstd, gamma, beta, y, slope);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, x, P, C, save_mean, save_invstd, gamma, beta, y, slope);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+// out[0:C] = sum dz, out[C:2C] = sum dz * xhat over the LOCAL rows (dz = dy through the LeakyReLU)
+extern "C" int re2e_bn_sync_bwd_partial(const float* dy, const float* x, long P, int C, const float* gamma, const float* beta, const float* save_mean,
+                                        const float* save_invstd, float slope, float* out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && out && workspace && P > 0 && C > 0, "bad args");
+  RE2E_CHECK_ARG(workspace_bytes >= re2e_bn_workspace_bytes(P, C), "workspace too small");
+  const int chunks = bn_chunks(P);
+  const long rpc = (P + chunks - 1) / chunks;
+  float* part = (float*)workspace;
+  dim3 g(cdiv(C, 64), chunks);
+  if (bn_vec_ok(x, dy, C)) hipLaunchKernelGGL(bn_partial_vec_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part, slope);
+  else hipLaunchKernelGGL(bn_partial_kernel, g, dim3(256), 0, stream, x, dy, P, C, rpc, 2, save_mean, save_invstd, gamma, beta, part, slope);
+  hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, stream, (const float*)part, chunks, C, 1.0f, 1.0f, out, out + C);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+// dx from sums the caller has all-reduced AND scaled by P / Ptotal (the kernels divide by the local row count P)
+extern "C" int re2e_bn_sync_bwd_apply(const float* dy, const float* x, long P, int C, const float* gamma, const float* beta, const float* save_mean,
+                                      const float* save_invstd, float slope, const float* sums, float* dx, hipStream_t stream) {
+  RE2E_CHECK_ARG(dy && x && gamma && beta && save_mean && save_invstd && sums && dx && P > 0 && C > 0, "bad args");
+  if (C % 4 == 0 && al16(dy) && al16(x) && al16(dx) && al16(save_mean) && al16(save_invstd) && al16(gamma) && al16(beta) && al16(sums))
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(grid_for(P * C / 4)), dim3(TPB), 0, stream, dy, x, P, C / 4, save_mean, save_invstd, gamma, beta,
+                       sums, sums + C, dx, slope);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * C)), dim3(TPB), 0, stream, dy, x, P, C, save_mean, save_invstd, gamma, beta, sums, sums + C,
+                       dx, slope);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
 // ---- K11 optimizer ------------------------------------------------------------------------
 __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* stats) {
   float n = sqrtf(sumsq[0]);

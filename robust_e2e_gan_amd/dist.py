@@ -49,6 +49,14 @@ def allreduce_mean_(flat, async_op=False):
     return None
 
 
+def allreduce_sum_(t):
+    """In-place SUM over ranks of a small device tensor (synchronised BatchNorm statistics): enqueued behind the current stream, the
+    current stream continues behind it.  No-op at world_size 1."""
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def any_rank(flag_value):
     """max over ranks of a small non-negative host integer (an error count / flag).  Collective: EVERY rank must call it at the
     same point.  Used so that a failure seen by one replica raises on all of them -- a lone raise would leave the others blocked

@@ -144,6 +144,7 @@ class JointTrainer(object):
         finally:
             # the stream routing is this step's: ops used outside it (validation, other trainers, tests) stay on ONE stream
             ops.MULTI_STREAM, ops.WGRAD_STREAM, ops.AUX_STREAM, ops.MARKS = False, None, None, None
+            ops.SYNC_BN = False
 
     def _mark(self, label):
         """RE2E_TIMELINE=1: remember (label, host time, event on the current stream) -- ``timeline()`` prints how far the
@@ -168,6 +169,7 @@ class JointTrainer(object):
         clean_inputs, mix_inputs, mix_log_inputs, targets, input_sizes, target_sizes = data[2], data[4], data[5], data[7], data[8], data[9]
         overlap = self.overlap_dstep
         ops.MULTI_STREAM = bool(overlap)
+        ops.SYNC_BN = bool(getattr(opt, 'sync_bn', False)) and rdist.world_size() > 1     # ONE global batch sharded over the ranks
         ops.WGRAD_STREAM = self.wgrad_stream if overlap else None
         ops.AUX_STREAM = self.side_stream if (overlap and lib.exp_env('RE2E_CTC_MAIN') != '1') else None
         main = torch.cuda.current_stream()

@@ -80,6 +80,7 @@ AUX_STREAM = None        # optional filler stream for independent branches insid
 FROZEN_PARAMS = frozenset()   # id()s of parameters whose gradients must NOT be produced by the backward now running (the trainer
 #                               builds D's graph once with trainable parameters and walks it twice: G-step = input gradient only)
 MARKS = None             # RE2E_TIMELINE: list of (label, host time, event) shared with JointTrainer (see ``mark_grad``)
+SYNC_BN = False          # data-parallel runs that shard ONE global batch: BatchNorm statistics over all ranks' rows (BnLreluFn)
 BN_DEFER_RUNNING = False  # with a sink: leave the running statistics alone in this forward (the owner replays the update later, in order)
 BN_STATS_SINK = None     # optional list: every BatchNorm forward appends (running_mean, running_var, mean, invstd, P, momentum, eps)
 
@@ -858,8 +859,15 @@ def vgg_pack_multi(xs, lens_list):
     return VggPackFn.apply(list(lens_list), *xs)
 
 
+def _sync_world():
+    from . import dist as rdist
+    return rdist.world_size() if SYNC_BN else 1
+
+
 class BnLreluFn(torch.autograd.Function):
-    """BatchNorm2d (train-mode statistics, running-stat update) + LeakyReLU(0.2) over NHWC."""
+    """BatchNorm2d (train-mode statistics, running-stat update) + LeakyReLU(0.2) over NHWC.  With ``SYNC_BN`` in a data-parallel run the
+    statistics are those of the GLOBAL batch: three small all-reduces per layer and step (sum x; sum (x - mean)^2; sum dz | sum dz xhat),
+    torch.nn.SyncBatchNorm's arithmetic -- the parameter gradients stay local sums (the gradient average makes them global)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rm, rv, train, momentum, eps, slope=0.2):
@@ -872,12 +880,30 @@ class BnLreluFn(torch.autograd.Function):
         wsb = query('re2e_bn_workspace_bytes', Pn, C)
         ws = workspace(wsb, x.device, 'bn')
         defer = BN_DEFER_RUNNING and BN_STATS_SINK is not None and train      # momentum 0 keeps running_mean / running_var bit-identical
-        call('re2e_bn_lrelu_fwd', x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
-             0.0 if defer else float(momentum), float(eps), int(train), float(slope), y.data_ptr(), sm.data_ptr(), si.data_ptr(), ws.data_ptr(), wsb)
+        world = _sync_world() if train else 1
+        ctx.ptot = Pn
+        if world > 1:
+            from . import dist as rdist
+            acc = empty((C,), x)
+            call('re2e_bn_sync_partial', x.data_ptr(), Pn, C, None, 0, acc.data_ptr(), ws.data_ptr(), wsb)
+            rdist.allreduce_sum_(acc)
+            ptot = Pn * world                                                 # equal shards (bench.py --scaling strong): no host sync for a count
+            mean = acc / float(ptot)
+            var = empty((C,), x)
+            call('re2e_bn_sync_partial', x.data_ptr(), Pn, C, mean.data_ptr(), 1, var.data_ptr(), ws.data_ptr(), wsb)
+            rdist.allreduce_sum_(var)
+            var = (var / float(ptot)).contiguous()
+            call('re2e_bn_sync_finalize', mean.data_ptr(), var.data_ptr(), ptot, C, 0.0 if defer else float(momentum), float(eps), rm.data_ptr(),
+                 rv.data_ptr(), sm.data_ptr(), si.data_ptr())
+            call('re2e_bn_apply', x.data_ptr(), Pn, C, sm.data_ptr(), si.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(slope), y.data_ptr())
+            ctx.ptot = ptot
+        else:
+            call('re2e_bn_lrelu_fwd', x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                 0.0 if defer else float(momentum), float(eps), int(train), float(slope), y.data_ptr(), sm.data_ptr(), si.data_ptr(), ws.data_ptr(), wsb)
         ctx.gamma, ctx.beta, ctx.train, ctx.slope = gamma, beta, train, float(slope)
         ctx.save_for_backward(x, sm, si)
         if BN_STATS_SINK is not None and train:
-            BN_STATS_SINK.append((rm, rv, sm, si, Pn, float(momentum), float(eps)))
+            BN_STATS_SINK.append((rm, rv, sm, si, ctx.ptot, float(momentum), float(eps)))
         return y
 
     @staticmethod
@@ -892,6 +918,23 @@ class BnLreluFn(torch.autograd.Function):
         dx = empty(x.shape, x)
         wsb = query('re2e_bn_workspace_bytes', Pn, C)
         ws = workspace(wsb, x.device, 'bn')
+        if ctx.ptot != Pn:                                                    # synchronised statistics
+            from . import dist as rdist
+            sums = empty((2 * C,), x)
+            call('re2e_bn_sync_bwd_partial', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
+                 ctx.slope, sums.data_ptr(), ws.data_ptr(), wsb)
+            if _wants(ctx, 1, gamma):                                         # LOCAL sums: the gradient exchange averages them over the ranks
+                with accumulate(gamma) as (dg, gbeta), accumulate(beta) as (db, _):
+                    if gbeta:
+                        dg.add_(sums[C:]); db.add_(sums[:C])
+                    else:
+                        dg.copy_(sums[C:]); db.copy_(sums[:C])
+            tot = sums.clone()
+            rdist.allreduce_sum_(tot)
+            tot.mul_(float(Pn) / float(ctx.ptot))                             # the apply kernel divides by its own row count
+            call('re2e_bn_sync_bwd_apply', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),
+                 ctx.slope, tot.data_ptr(), dx.data_ptr())
+            return dx, None, None, None, None, None, None, None, None
         if _wants(ctx, 1, gamma):
             with accumulate(gamma) as (dg, gbeta), accumulate(beta) as (db, _):
                 call('re2e_bn_lrelu_bwd', dy.data_ptr(), x.data_ptr(), Pn, C, gamma.data_ptr(), beta.data_ptr(), sm.data_ptr(), si.data_ptr(),

@@ -112,3 +112,53 @@ def test_allreduce_beside_persistent_recurrence(one_rank_group):
     assert lib.query('re2e_lstm_abort_count') == base, 'a persistent recurrence gave up beside a co-resident RCCL kernel'
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+def test_sync_batchnorm_equals_global_batch(monkeypatch):
+    """ops.SYNC_BN: rank 0's half of a batch, with the all-reduces completed by the OTHER half's contributions (computed here with
+    torch), must give the rows of the full-batch BatchNorm + LeakyReLU: output, input gradient, and local parameter-gradient sums that
+    add up to the global ones."""
+    import torch.nn.functional as F
+    from robust_e2e_gan_amd import ops
+    from robust_e2e_gan_amd import dist as rdist
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C, slope, eps = 4, 9, 7, 64, 0.2, 1e-5
+    x = torch.randn(N, H, W, C, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    w = torch.randn(N, H, W, C, generator=g)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.leaky_relu(F.batch_norm(xr.permute(0, 3, 1, 2), None, None, gr, br, True, 0.1, eps), slope).permute(0, 2, 3, 1)
+    (yr * w).sum().backward()
+    P = N * H * W
+    xf = x.reshape(P, C).double()
+    mean = xf.mean(0)
+    var = ((xf - mean) ** 2).mean(0)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    half = P // 2
+    xB, wB = xf[half:], w.reshape(P, C).double()[half:]
+    xhB = (xB - mean) * invstd
+    dzB = torch.where(xhB * gamma.double() + beta.double() > 0, wB, slope * wB)
+    other = [xB.sum(0), ((xB - mean) ** 2).sum(0), torch.cat([dzB.sum(0), (dzB * xhB).sum(0)])]   # what rank 1 would contribute, in call order
+    calls = []
+
+    def fake_allreduce(t):
+        t.add_(other[len(calls)].float().to(t.device))
+        calls.append(t.numel())
+        return t
+    monkeypatch.setattr(rdist, 'world_size', lambda: 2)
+    monkeypatch.setattr(rdist, 'allreduce_sum_', fake_allreduce)
+    monkeypatch.setattr(ops, 'SYNC_BN', True)
+    xa = x[:N // 2].to(DEV).requires_grad_(True)
+    ga, ba = torch.nn.Parameter(gamma.to(DEV)), torch.nn.Parameter(beta.to(DEV))
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y = ops.bn_lrelu(xa, ga, ba, rm, rv, True, 0.1, eps, slope)
+    (y * w[:N // 2].to(DEV)).sum().backward()
+    assert calls == [C, C, 2 * C]
+    err = lambda a, b: float((a.detach().cpu() - b.detach()).abs().max())
+    assert err(y, yr[:N // 2]) <= 2e-5 * float(yr.detach().abs().max())
+    assert err(xa.grad, xr.grad[:N // 2]) <= 2e-5 * float(xr.grad.abs().max())
+    # local parameter gradients + the other half's = the global ones
+    assert err(ga.grad + (dzB * xhB).sum(0).float().to(DEV), gr.grad) <= 1e-4 * float(gr.grad.abs().max())
+    assert err(ba.grad + dzB.sum(0).float().to(DEV), br.grad) <= 1e-4 * float(br.grad.abs().max())
+    # running statistics of the GLOBAL batch (unbiased variance over all P rows)
+    assert err(rm, 0.1 * mean.float()) <= 1e-5 and err(rv, 0.9 + 0.1 * (var * P / (P - 1)).float()) <= 1e-4
