@@ -18,6 +18,30 @@
 
 namespace {
 
+// RE2E_EXPERIMENTS builds only (tools/lstm_stamps.py): s_memtime stamps of the phases of 16 consecutive steps of a persistent
+// recurrence, per wavefront: stamps[((workgroup * 16 + wave) * 16 + slot) * 12 + phase]; entries 10 / 11 = s_memrealtime (100 MHz,
+// chip-wide) at the top of the step and at the publish.  The shipped build contains none of it.
+#ifdef RE2E_EXPERIMENTS
+__device__ unsigned long long* g_lstm_stamps = nullptr;
+constexpr int kStampStep0 = 64;
+#define LSTM_STAMP_DECL unsigned long long* const stamp_p = g_lstm_stamps
+#define LSTM_STAMP(ph)                                                                                                              \
+  do {                                                                                                                              \
+    if (stamp_p && (threadIdx.x & 63) == 0 && s >= kStampStep0 && s < kStampStep0 + 16)                                             \
+      stamp_p[((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 192 + (s - kStampStep0) * 12 + (ph)] = \
+          (ph) >= 10 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();                                             \
+  } while (0)
+static void lstm_stamps_arm() {
+  const char* v = getenv("RE2E_LSTM_STAMPS");
+  unsigned long long* p = v ? (unsigned long long*)strtoull(v, nullptr, 16) : nullptr;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_stamps), &p, sizeof(p));
+}
+#else
+#define LSTM_STAMP_DECL
+#define LSTM_STAMP(ph)
+static void lstm_stamps_arm() {}
+#endif
+
 __device__ __forceinline__ void store_acc(float* red, const f32x16& acc, int lane) {
   int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -206,9 +230,11 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
 #pragma unroll
     for (int g = 0; g < 4; ++g) pre[g] = gp[g * H];
   }
+  LSTM_STAMP_DECL;
   __syncthreads();
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
+    LSTM_STAMP(0); LSTM_STAMP(10);
     f32x16 acc[UW];
 #pragma unroll
     for (int u = 0; u < UW; ++u)
@@ -238,6 +264,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
         if (spins > kSpinLimit) { if (lane == 0) { red[kAbort] = 1.f; if (atomicExch(err, 1u) == 0u) atomicAdd(&g_persist_aborts, 1u); } break; }
         __builtin_amdgcn_s_sleep(1);
       }
+      LSTM_STAMP(1);
 #pragma unroll
       for (int q = 0; q < QN; ++q)
 #pragma unroll
@@ -253,7 +280,9 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
     }
 #pragma unroll
     for (int u = 0; u < UW; ++u) store_acc(red + (u * WAVES + wid) * (32 * 33), acc[u], lane);
+    LSTM_STAMP(2);
     __syncthreads();
+    LSTM_STAMP(3);
     if (red[kAbort] != 0.f) break;
     if (pw) {
       float v[4];
@@ -272,6 +301,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
       if (s + 1 < T)
         __hip_atomic_store(hx + (s & 1) * par_sz + wr_off, ((u64)(unsigned)(s + 1) << 32) | (u64)__float_as_uint(h), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+      LSTM_STAMP(4); LSTM_STAMP(11);
       if (ok) {
         float* go_ = xg + ((long)t * B + b) * 4 * H + j;
         go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
@@ -281,7 +311,9 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) pre[g] = nxt[g];
+    LSTM_STAMP(5);
     __syncthreads();
+    LSTM_STAMP(6);
   }
   if (red[kAbort] != 0.f && ok) {                         // a peer never published: make the failure visible downstream
     for (int t = 0; t < T; ++t) ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = __uint_as_float(0x7fc00000u);
@@ -470,9 +502,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
     n_c[u] = cbuf[((long)(t + 1) * B + bb) * H2 + dir * H + j];
     n_cp[u] = cbuf[((long)prev_blk * B + bb) * H2 + dir * H + j];
   }
+  LSTM_STAMP_DECL;
   __syncthreads();
   for (int s = 0; s < T; ++s) {
     const int t = dir ? s : T - 1 - s;
+    LSTM_STAMP(0); LSTM_STAMP(10);
     float dh[UW], gi[UW], gf[UW], gg[UW], go[UW], c[UW], cp[UW];
 #pragma unroll
     for (int u = 0; u < UW; ++u) {
@@ -505,7 +539,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      LSTM_STAMP(1);
       __syncthreads();
+      LSTM_STAMP(2);
       if (aborted) break;
       // partials of this workgroup's units from every producer: 16-byte sc1 buffer loads.  A producer's block is UW x (64 x 16 B):
       // wavefront w takes part w % UW of producers w / UW, w / UW + 4 / UW, ...; the wave sums are combined through LDS in a fixed order
@@ -524,6 +560,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
         for (; xp < NX; xp += XS) a += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, blk_b + (unsigned)xp * (unsigned)(BLK * 4), 0, 16));
         *reinterpret_cast<f32x4*>(psum + wid * 256 + lane * 4) = a;
       }
+      LSTM_STAMP(3);
       __syncthreads();
       {
         const int e = jj * 32 + bm;
@@ -556,7 +593,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
       float* dq = dgs + bm * LDG + 32 * u + jj;
       dq[0] = di; dq[8] = df; dq[16] = dg; dq[24] = dout;
     }
+    LSTM_STAMP(4);
     __syncthreads();
+    LSTM_STAMP(5);
     if (s == T - 1) break;                         // nothing consumes the last partials
     // ---- produce: P_x = dG_x . W_hh[n in x][:] , written write-through in the consumers' order ----
     f32x4 a4[4 * UW];
@@ -584,8 +623,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
         }
       }
     }
+    LSTM_STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains before the barrier ...
+    LSTM_STAMP(7);
     __syncthreads();
+    LSTM_STAMP(8); LSTM_STAMP(11);
     if (tid == 0)                                               // ... behind which ONE lane publishes the step tag
       __hip_atomic_store(flags + (s & 1) * f_par + f_grp + (long)x * 32, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -669,6 +711,7 @@ bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* w
   static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 1;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
   fwd_lim<W, QN, UW>().ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN, UW>), lds);
+  lstm_stamps_arm();
   (void)hipMemsetAsync(hxmem, 0, hxbytes, st);                             // tags and the error word start at zero, every call
   unsigned* err = (unsigned*)hxmem;
   u64* hx = (u64*)((char*)hxmem + 16);
@@ -680,6 +723,7 @@ template <int TPW, int UW>
 bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs,
                         void* flagmem, size_t flagbytes, const int* lens, int T, int B, int H) {
   dim3 grid(H / (8 * UW), cdiv(B, 32), 2);
+  lstm_stamps_arm();
   (void)hipMemsetAsync(flagmem, 0, flagbytes, st);
   unsigned* err = (unsigned*)flagmem;
   unsigned* flags = (unsigned*)((char*)flagmem + 16);
