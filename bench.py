@@ -104,18 +104,20 @@ def _profile_json(names):
 
 
 def engine_average():
-    """Average TFLOP/s of the fp32-MFMA engine over every GEMM / convolution call of one single-stream step: the 'total' line of the
-    committed per-call table (tools/igemm_table.py over a RE2E_NO_OVERLAP=1 rocprofv3 kernel trace of this script)."""
+    """Average TFLOP/s of the fp32-MFMA engine over every GEMM / convolution call of one single-stream step, from the committed per-call
+    table (tools/igemm_table.py over a RE2E_NO_OVERLAP=1 rocprofv3 kernel trace of this script): (direct-equivalent, executed, source).
+    Direct-equivalent counts a Winograd call with the FLOPs of the direct convolution it replaces; executed is what the matrix cores did."""
     import re
-    for n in ('r03_igemm_calls_nooverlap.txt', 'r02_igemm_calls_nooverlap.txt'):
+    for n in ('r04_igemm_calls_nooverlap.txt', 'r03_igemm_calls_nooverlap.txt'):
         try:
-            tail = [l for l in open(os.path.join(ROOT, 'profiles', n)).read().strip().splitlines() if l.startswith('total ')]
-            m = re.search(r'([\d.]+) TFLOP/s average', tail[-1]) if tail else None
+            txt = open(os.path.join(ROOT, 'profiles', n)).read()
+            m = re.search(r'total .*?([\d.]+) TFLOP/s average', txt)
+            e = re.search(r'executed by the matrix cores: [\d.]+ TFLOP = ([\d.]+) TFLOP/s average', txt)
             if m:
-                return float(m.group(1)), 'profiles/' + n
+                return float(m.group(1)), (float(e.group(1)) if e else None), 'profiles/' + n
         except Exception:
             pass
-    return None, None
+    return None, None, None
 
 
 def conv_roofline(dev, iters=20):
@@ -144,23 +146,25 @@ def conv_roofline(dev, iters=20):
     sec_plain = _time_launches(lambda: lib.call('re2e_conv_igemm', *args), iters)
     sec_pool = _time_launches(lambda: lib.call('re2e_conv3x3_relu_pool', x.data_ptr(), N, H, W, C, wg.data_ptr(), K, b.data_ptr(),
                                                pooled.data_ptr(), idx.data_ptr()), iters)
-    flops = 2.0 * 9 * C * K * N * H * W
-    ach = flops / sec_wino / 1e12
+    flops = 2.0 * 9 * C * K * N * H * W                 # direct form
+    exe = flops / 2.25                                  # what F(2x2,3x3) executes on the matrix cores: 16 instead of 36 multiply-adds per 2x2 outputs
+    ach = exe / sec_wino / 1e12
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
     # kernel and shape, tools/roofline_conv.py); a counter pass cannot run inside this process.
-    pj, tsrc = _profile_json(['r03_conv1_2_wino_pmc_traffic.json'])
+    pj, tsrc = _profile_json(['r04_conv1_2_wino_pmc_traffic.json', 'r03_conv1_2_wino_pmc_traffic.json'])
     pj2, tsrc2 = _profile_json(['r03_conv1_2_pmc_traffic.json', 'r02_conv1_2_pmc_traffic.json'])
-    eng, esrc = engine_average()
+    eng, eng_exe, esrc = engine_average()
     pk = PEAK_FP32_MFMA_TFLOPS
     return {'bound': 'mfma', 'kernel': 'wino_conv3x3_kernel (VGG conv1_2 fwd as the step launches it: fused Winograd F(2x2,3x3) + bias + ReLU + 2x2 max '
                                        'pool in one launch, 64x800x80, 64->64, 3x3)',
             'achieved': round(ach, 2), 'peak': pk, 'unit': 'TFLOP/s', 'frac': round(ach / pk, 4),
-            'note': 'achieved = algorithmic (direct-form) FLOPs / time; the kernel executes 1/2.25 of them: see executed_*',
-            'executed_tflops': round(ach / 2.25, 2), 'executed_frac': round(ach / 2.25 / pk, 4),
+            'note': 'achieved = EXECUTED matrix-core FLOPs (the Winograd form: direct FLOPs / 2.25) / launch time, so frac <= 1 is a utilisation of the '
+                    'fp32-MFMA peak; the direct-form figure is direct_equivalent_tflops',
+            'direct_equivalent_tflops': round(flops / sec_wino / 1e12, 2), 'algorithmic_speedup_vs_direct': 2.25,
             'traffic': pj['traffic_bytes_per_launch'] if pj else None,
             'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': tsrc,
             'algorithmic_bytes_per_launch': 4.0 * (N * H * W * C + 16 * K * C) + 5.0 * pooled.numel(),
-            'avg_launch_ms': round(sec_wino * 1e3, 4), 'algorithmic_flop_per_launch': flops, 'executed_flop_per_launch': flops / 2.25,
+            'avg_launch_ms': round(sec_wino * 1e3, 4), 'executed_flop_per_launch': exe, 'direct_flop_per_launch': flops,
             'direct_kernels': {
                 'relu_pool': {'entry': 're2e_conv3x3_relu_pool (halo-patch direct kernel, fused pool)', 'avg_launch_ms': round(sec_pool * 1e3, 4),
                               'achieved': round(flops / sec_pool / 1e12, 2), 'frac': round(flops / sec_pool / 1e12 / pk, 4)},
@@ -168,8 +172,56 @@ def conv_roofline(dev, iters=20):
                           'avg_launch_ms': round(sec_plain * 1e3, 4), 'achieved': round(flops / sec_plain / 1e12, 2),
                           'frac': round(flops / sec_plain / 1e12 / pk, 4), 'traffic': pj2['traffic_bytes_per_launch'] if pj2 else None,
                           'traffic_source': tsrc2, 'algorithmic_bytes_per_launch': 4.0 * (N * H * W * C + N * H * W * K + K * 9 * C)}},
-            'engine_avg_tflops': eng, 'engine_avg_frac': round(eng / pk, 4) if eng else None, 'engine_avg_source': esrc,
-            'engine_avg_note': 'per-call table of one single-stream step; 3x3 convolutions run as Winograd are counted with their direct-equivalent FLOPs'}
+            'engine_avg_executed_tflops': eng_exe, 'engine_avg_executed_frac': round(eng_exe / pk, 4) if eng_exe else None,
+            'engine_avg_direct_equivalent_tflops': eng, 'engine_avg_source': esrc,
+            'engine_avg_note': 'per-call table of one single-stream step over every GEMM / convolution call; executed = matrix-core FLOPs, '
+                               'direct-equivalent counts Winograd calls with the FLOPs of the direct convolution they replace'}
+
+
+def chain_roofline(dev):
+    """The recurrent chains' own roofline (they are latency-bound: neither HBM nor MFMA describes them).  Measured live: microseconds
+    per step of the persistent bi-LSTM kernels alone on the chip at this workload's two shapes (enhancer 2 x 800 steps at H=256 / B=32,
+    BLSTMP 3 x 200 steps at H=512 / B=64).  Floors: ``handoff_floor_us`` = the bare exchange of one step's state between the same
+    number of workgroups with nothing computed (tools/micro/handoff_probe.hip, committed run profiles/r04_handoff_probe*.txt: a step
+    cannot be shorter than the hand-off it contains); ``mfma_floor_us`` = the step's matrix FLOPs / (the CUs the chain runs on x their
+    fp32-MFMA rate)."""
+    from robust_e2e_gan_amd import lib
+    out = {}
+    floors = {(256, 32): {'fwd': 2.14, 'bwd': 3.12}, (512, 64): {'fwd': 3.02, 'bwd': 5.38}}      # profiles/r04_handoff_probe.txt (protos 1 / 5, 3)
+    for name, T, B, H in (('enhancer_blstm_H256_B32', 800, 32, 256), ('blstmp_H512_B64', 200, 64, 512)):
+        g = torch.Generator().manual_seed(T + B + H)
+        xg0 = [(torch.randn(T * B, 4 * H, generator=g) * 0.5).to(dev) for _ in range(2)]
+        whh = [(torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev) for _ in range(2)]
+        lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+        dy = (torch.randn(T * B, 2 * H, generator=g) * 0.3).to(dev)
+        wsb = lib.query('re2e_lstm_workspace_bytes', B, H)
+        ws = torch.empty(wsb // 4 + 16, device=dev)
+        ybuf, cbuf = torch.zeros(T + 2, B, 2 * H, device=dev), torch.zeros(T + 2, B, 2 * H, device=dev)
+        dc = torch.zeros(B, 2 * H, device=dev)
+        best = [1e9, 1e9]
+        for rep in range(4):
+            xg = [x.clone() for x in xg0]
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            torch.cuda.synchronize()
+            ev[0].record()
+            lib.call('re2e_lstm_seq_fwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), ybuf.data_ptr(), cbuf.data_ptr(),
+                     lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+            ev[1].record()
+            lib.call('re2e_lstm_seq_bwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
+                     cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+            ev[2].record()
+            torch.cuda.synchronize()
+            if rep:
+                best = [min(best[0], ev[0].elapsed_time(ev[1]) * 1e3 / T), min(best[1], ev[1].elapsed_time(ev[2]) * 1e3 / T)]
+        flop = 2.0 * B * 4 * H * H * 2                   # both directions, one step
+        fl = floors[(H, B)]
+        out[name] = {'steps_per_layer_and_pass': T, 'fwd': {'us_per_step': round(best[0], 2), 'handoff_floor_us': fl['fwd'],
+                                                            'mfma_floor_us': round(flop / (PEAK_FP32_MFMA_TFLOPS * 1e6), 2)},
+                     'bwd': {'us_per_step': round(best[1], 2), 'handoff_floor_us': fl['bwd'],
+                             'mfma_floor_us': round(flop / (PEAK_FP32_MFMA_TFLOPS * 1e6), 2)}}
+    out['note'] = ('us_per_step: persistent bi-LSTM kernels alone on the chip, best of 3 sequences; handoff_floor_us: the same exchange with nothing '
+                   'computed (profiles/r04_handoff_probe.txt); mfma_floor_us: step FLOPs / whole-chip fp32-MFMA peak')
+    return out
 
 
 PARITY_TOL = 1e-3

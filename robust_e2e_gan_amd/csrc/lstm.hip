@@ -320,6 +320,242 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
   }
 }
 
+// ---- round 4: the forward recurrence rebuilt around what its step is made of (profiles/r04_chain_budget.md) ---------------
+// Stamps of the kernel above at H = 256 / B = 32 (3.4 us per step): 0.8-1.5 us waiting for h(t-1) (the bare exchange of 64 KB of
+// {value, tag} granules per workgroup is 2.7 us of the step, tools/micro/handoff_probe.hip; a CU pulls handed-off bytes from the
+// memory side at ~50 GB/s, and a sweep that comes too early is paid again), 0.7-0.8 MFMA, 0.7 for summing the eight K-split
+// partial tiles out of LDS + the cell (0.5 of it waiting for the NEXT step's pre-activations: s_waitcnt vmcnt(0) behind loads
+// issued just in front), two workgroup barriers.  This form removes what can be removed:
+//  * h(t) travels as the 4-byte value itself: |h| <= 1, so bit 30 of its fp32 pattern is always clear and carries a ONE-BIT step
+//    tag (it flips with every rewrite of a parity buffer; the buffers start zeroed = tag 0, the first write carries 1).  Half the
+//    bytes of the 8-byte granules through the fabric, published as 16-byte sc1 stores, swept with one 16-byte sc1 load per lane
+//    and 16 k.  A NaN h is published as the pattern of 1.5 (impossible otherwise) and turned back into a NaN by the consumer, so
+//    non-finite inputs still poison exactly what they poison in nn.LSTM.
+//  * a workgroup owns 16 UTTERANCES (not 32) x 4 TILES units: what it has to pull per step halves again (16 KB at H = 256,
+//    32 KB at H = 512) and the matrix work of a step spreads over twice the CUs.
+//  * v_mfma_f32_16x16x4_f32 with the GATE ROWS as M and the utterances as N: a wavefront owns 16 utterances x (TILES x 4 units x
+//    4 gates) over its quarter of K; a lane's four accumulator registers are the four gates of ONE (unit, utterance) cell, so the
+//    cell non-linearity runs on the accumulators: no 32 x 33 tiles through LDS, no 32 LDS reads per cell.  What crosses waves is
+//    one 16-byte partial per lane, tile and K quarter.
+//  * the wait for h(t-1) is a cheap poll -- ONE 16-byte piece of every producer in the wave's K quarter, one load instruction --
+//    and the state is swept ONCE, when the poll says it is there; chunks of 16 k are then consumed in arrival order (the MFMAs
+//    of chunk j issue while chunks j+1.. are in flight); a chunk that is stale anyway is polled alone.
+//  * ONE workgroup barrier per step (the partials are double-buffered by step parity); the next pre-activations are loaded a
+//    whole step before the cell needs them.
+//  * W_hh stays in registers as before, but is read straight from the row-major matrix (16-byte loads, once per sequence): no pack kernel.
+// The launch-per-step twin (PERSIST = false) runs the SAME instruction sequence on plain loads, so the two are bitwise equal.
+__device__ __forceinline__ void store16u_sc1(unsigned* p, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+constexpr unsigned kTagBit = 0x40000000u, kNanPub = 0x3FC00000u;
+__device__ __forceinline__ bool tags_are(const u32x4& v, unsigned want) {
+  return (((v[0] & v[1] & v[2] & v[3]) ^ want) & kTagBit) == 0u && (((v[0] | v[1] | v[2] | v[3]) ^ want) & kTagBit) == 0u;
+}
+
+template <int TILES, int NJ, bool PERSIST>
+__global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                 float* ybuf, float* cbuf, unsigned* hx_, unsigned* err, const int* __restrict__ lens, int T,
+                                                 int B, int H, int s_arg, int mode) {
+  constexpr int KS = 4;                                         // K quarters = waves
+  extern __shared__ __attribute__((aligned(16))) float lds2[];  // part[2][TILES][KS][64] f32x4 | abort word
+  f32x4* part = reinterpret_cast<f32x4*>(lds2);
+  int* abortw = reinterpret_cast<int*>(lds2 + 2 * TILES * KS * 64 * 4);
+  const int dir = blockIdx.z, mt = blockIdx.y, MT = gridDim.y, x = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6, n = lane & 15, kk = lane >> 4;
+  const int b = 16 * mt + n;
+  const int ft = ks < TILES ? ks : -1;                           // the tile this wave finishes (gates, cell, publish), if any
+  float* xg = dir ? xg_r : xg_f;
+  const float* whh = dir ? whh_r : whh_f;
+  const long H2 = 2L * H;
+  if (PERSIST && tid == 0) *abortw = 0;
+  // recurrent weights of this wave's rows and K quarter: registers for the whole sequence.  A operand of 16x16x4: lane holds
+  // A[m = lane & 15][k = lane >> 4]; row m = 4 * unit + gate.
+  f32x4 w[TILES][NJ];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const long row = (long)(n & 3) * H + 4 * TILES * x + 4 * t + (n >> 2);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) w[t][jj] = *reinterpret_cast<const f32x4*>(whh + row * H + 16 * (ks * NJ + jj) + 4 * kk);
+  }
+  // exchange buffer (words): [parity][dir][mt][k / 4][16 utterances][4]
+  const int par_w = 2 * MT * H * 16;
+  const int grp = (dir * MT + mt) * H * 16;
+  const __amdgpu_buffer_rsrc_t hx_rs = __builtin_amdgcn_make_buffer_rsrc(hx_, 0, (int)(2 * par_w * 4), 0x00020000);
+  const unsigned rd_w = (unsigned)(grp + ((4 * ks * NJ + kk) * 16 + n) * 4);          // + jj * 256 words
+  const unsigned poll_w = (unsigned)(grp + ((4 * ks * NJ + (lane < 4 * NJ ? lane : 0)) * 16) * 4);     // utterance 0 of piece lane of this quarter
+  const bool fin = ft >= 0;
+  const int j = 4 * TILES * x + 4 * (fin ? ft : 0) + kk;                               // the unit whose cell this lane owns
+  const bool ok = fin && b < B;
+  const int ln = ok ? lens[b] : 0;
+  const unsigned wr_w = (unsigned)(grp + ((TILES * x + (fin ? ft : 0)) * 16 + n) * 4);
+  float c = 0.f, pre[4] = {0.f, 0.f, 0.f, 0.f};
+  const int s0 = PERSIST ? 0 : s_arg, s1 = PERSIST ? T : s_arg + 1;
+  if (ok) {
+    const int t0 = dir ? T - 1 - s0 : s0;
+    const float* gp = xg + ((long)t0 * B + b) * 4 * H + j;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = gp[g * H];
+    if (!PERSIST) c = cbuf[((long)(dir ? t0 + 2 : t0) * B + b) * H2 + dir * H + j];
+  }
+  u32x4 ld[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) ld[jj] = u32x4{0u, 0u, 0u, 0u};
+  if (!PERSIST && s0 > 0) {                       // plain loads: the previous launch wrote them
+    const u32x4* src = reinterpret_cast<const u32x4*>(hx_ + ((s0 & 1) ^ 1) * par_w) + rd_w / 4;
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) ld[jj] = src[jj * 64];
+  }
+  LSTM_STAMP_DECL;
+  if (PERSIST) __syncthreads();
+  for (int s = s0; s < s1; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    LSTM_STAMP(0); LSTM_STAMP(10);
+    constexpr int NACC = TILES == 1 ? 2 : TILES;            // one tile: two chains (even / odd k) hide the 40-cycle dependent latency
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int tt = 0; tt < NACC; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      const unsigned want = PERSIST ? (unsigned)((((s - 1) >> 1) + 1) & 1) << 30 : 0u;
+      const unsigned rd_b = (unsigned)((((s & 1) ^ 1) * par_w) * 4) + rd_w * 4u;
+      const unsigned pl_b = (unsigned)((((s & 1) ^ 1) * par_w) * 4) + poll_w * 4u;
+      // cheap poll: one 16-byte piece of every producer of this K quarter (lanes 0 .. 4 NJ - 1), one load instruction per pass
+      auto wait_producers = [&]() {
+        for (unsigned spins = 0;; ++spins) {
+          asm volatile("" ::: "memory");
+          const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, pl_b, 0, 16);
+          if (__all(tags_are(pv, want))) break;
+          if (spins > kSpinLimit) { if (lane == 0) { *abortw = 1; if (atomicExch(err, 1u) == 0u) atomicAdd(&g_persist_aborts, 1u); } break; }
+        }
+        asm volatile("" ::: "memory");
+      };
+      if (PERSIST) {
+        if (mode & 1) {                         // poll first, sweep once
+          wait_producers();
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj) ld[jj] = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)jj * 1024u, 0, 16);
+        }
+        LSTM_STAMP(7);
+      }
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        u32x4 v = ld[jj];
+        if (PERSIST) {
+          if (!__all(tags_are(v, want))) {
+            // the sweep came before this chunk's producer had published: wait for all producers (cheap poll), read this and the
+            // later chunks again; should the chunk still be stale (the poll looks at one piece per producer), poll it alone
+            wait_producers();
+#pragma unroll
+            for (int j2 = jj; j2 < NJ; ++j2) ld[j2] = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)j2 * 1024u, 0, 16);
+            v = ld[jj];
+            for (unsigned spins = 0; !__all(tags_are(v, want)); ++spins) {
+              asm volatile("" ::: "memory");
+              v = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)jj * 1024u, 0, 16);
+              if (spins > kSpinLimit) { if (lane == 0) { *abortw = 1; if (atomicExch(err, 1u) == 0u) atomicAdd(&g_persist_aborts, 1u); } break; }
+            }
+          }
+        }
+        float hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned u = PERSIST ? (v[i] & ~kTagBit) : v[i];
+          if (PERSIST) u = u == kNanPub ? 0x7fc00000u : u;
+          hv[i] = __uint_as_float(u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int tt = 0; tt < TILES; ++tt) {
+            const int a = TILES == 1 ? (i & 1) : tt;
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tt][jj][i], hv[i], acc[a], 0, 0, 0);
+          }
+      }
+      if (TILES == 1) acc[0] += acc[1];
+    }
+    LSTM_STAMP(1);
+    // K-quarter partials of the tiles this wave does not finish -> LDS (double-buffered by step parity: one barrier per step)
+    f32x4* pp = part + (s & 1) * (TILES * KS * 64);
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt)
+      if (tt != ft) pp[(tt * KS + ks) * 64 + lane] = acc[tt];
+    LSTM_STAMP(2);
+    __syncthreads();
+    LSTM_STAMP(3);
+    if (PERSIST && *abortw) break;
+    float og[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // activated gates, c, h of this lane's cell: written after the next sweep is on its way
+    if (fin) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      f32x4 mine = acc[0];
+#pragma unroll
+      for (int tt = 1; tt < TILES; ++tt) mine = ft == tt ? acc[tt] : mine;
+#pragma unroll
+      for (int k2 = 0; k2 < KS; ++k2) v += k2 == ks ? mine : pp[(ft * KS + k2) * 64 + lane];      // fixed order
+      float gi, gf, gg, go, cn, h;
+#ifdef RE2E_EXPERIMENTS
+      if (mode & 16) {                           // v_rcp_f32 (1 ulp) instead of the IEEE division: experiment
+        auto sg = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); };
+        auto th = [](float x) { float e = __expf(-2.0f * fabsf(x)); return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x); };
+        gi = sg(v[0] + pre[0]); gf = sg(v[1] + pre[1]); gg = th(v[2] + pre[2]); go = sg(v[3] + pre[3]);
+        cn = gf * c + gi * gg;
+        h = go * th(cn);
+      } else
+#endif
+      {
+        gi = sigmoidf_(v[0] + pre[0]); gf = sigmoidf_(v[1] + pre[1]); gg = tanhf_(v[2] + pre[2]); go = sigmoidf_(v[3] + pre[3]);
+        cn = gf * c + gi * gg;
+        h = go * tanhf_(cn);
+      }
+      if (t >= ln) { cn = 0.f; h = 0.f; }        // packed semantics (also rows b >= B: ln = 0)
+      c = cn;
+      if (!PERSIST || s + 1 < T) {
+        // the four units of a 16-byte piece sit in lanes n, n + 16, n + 32, n + 48: gather them into lane n, one store per piece
+        unsigned hb = __float_as_uint(h);
+        if (PERSIST) hb = (h != h ? kNanPub : hb) | ((unsigned)(((s >> 1) + 1) & 1) << 30);
+        u32x4 pv;
+        pv[0] = hb;
+        pv[1] = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) * 4, (int)hb);
+        pv[2] = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 32) & 63) * 4, (int)hb);
+        pv[3] = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 48) & 63) * 4, (int)hb);
+        if (kk == 0) {
+          if (PERSIST) store16u_sc1(hx_ + (s & 1) * par_w + wr_w, pv);
+          else *reinterpret_cast<u32x4*>(hx_ + (s & 1) * par_w + wr_w) = pv;
+        }
+      }
+      LSTM_STAMP(4); LSTM_STAMP(11);
+      og[0] = gi; og[1] = gf; og[2] = gg; og[3] = go; og[4] = cn; og[5] = h;
+    }
+    // (Measured and rejected: the speculative sweep timed by a per-wave delay behind the publish that hovers at the edge of being too
+    // early -- one late wave anywhere delays its workgroup's publish and with it EVERY peer's next sweep, so with 512 waves a
+    // per-wave miss rate of 1 in 64 is a miss on every step: 2.85 against 2.93 us at H = 256, no gain at 512, 43 us at B = 8.)
+    // Order of the vector-memory queue from here on: (mode 0: the next step's sweep right behind the publish, THEN) the next
+    // pre-activations and this step's outputs.  The cell waits for `pre` with s_waitcnt vmcnt(0) (the compiler cannot count across the
+    // poll loops), so its loads are issued a whole step before their use and never just in front of it: loaded in front of the
+    // barrier, as rounds 1-3 did, the cell waited ~0.5 us per step for HBM.
+    auto next_sweep = [&]() {
+      const unsigned rd_n = (unsigned)(((s & 1) * par_w) * 4) + rd_w * 4u;
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) ld[jj] = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_n + (unsigned)jj * 1024u, 0, 16);
+    };
+    if (PERSIST && (mode & 1) == 0 && s + 1 < T) next_sweep();
+    LSTM_STAMP(5);
+    if (PERSIST && ok && s + 1 < T) {
+      const float* gp = xg + ((long)(dir ? t - 1 : t + 1) * B + b) * 4 * H + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pre[g] = gp[g * H];
+    }
+    if (ok) {
+      float* go_ = xg + ((long)t * B + b) * 4 * H + j;
+      go_[0] = og[0]; go_[H] = og[1]; go_[2 * H] = og[2]; go_[3 * H] = og[3];
+      cbuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = og[4];
+      ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = og[5];
+    }
+    LSTM_STAMP(6);
+  }
+  if (PERSIST && *abortw && ok) {                           // a peer never published: make the failure visible downstream
+    for (int t = 0; t < T; ++t) ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = __uint_as_float(0x7fc00000u);
+  }
+}
+
 // BPTT step.  Workgroup x owns hidden units j in [8x, 8x+8) for 32 utterances, exactly like the forward:
 //   consume: dh_rec[b][j] = sum over ALL workgroups x' of the partial slabs P_x'[b][j] written by the previous launch,
 //            then the cell backward -> d(gates) for its 32 gate columns n (kept in LDS, written to G);
@@ -527,30 +763,27 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
       }
     }
     if (s > 0) {
-      // ---- wait for the NX producers of step s-1, then sum their partials for (b, j) ----
-      if (wid == 0) {
-        const gu32* fl = flags + ((s & 1) ^ 1) * f_par + f_grp + (long)(lane < NX ? lane : 0) * 32;
-        const gu32* fl2 = flags + ((s & 1) ^ 1) * f_par + f_grp + (long)(lane + 64 < NX ? lane + 64 : 0) * 32;
+      // ---- each wavefront waits for ITS producers of step s-1 (wave w sums part w % UW of producers w / UW, w / UW + 4 / UW, ...) and loads
+      // their blocks: the wave that polled is the wave that loads, so no workgroup barrier stands between the flags and the data.  Of a
+      // producer only the wave that computed this consumer's 32-unit tile has to have drained: its flag word is the one polled. ----
+      {
+        constexpr int XS = 4 / UW;                 // producer stride of a wavefront
+        const int part = wid % UW, xp0 = wid / UW;
+        const int nmine = (NX - xp0 + XS - 1) / XS;                                   // producers of this wave (<= 64: NX <= 128 checked by the launcher)
+        const int fw = ((x * UN) >> 5) & 3;                                          // the producer wave that owns tile (x * UN) / 32
+        const gu32* fl = flags + ((s & 1) ^ 1) * f_par + f_grp + (long)(lane < nmine ? xp0 + XS * lane : 0) * 32 + fw * 8;
         for (unsigned spins = 0;; ++spins) {
-          bool good = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)s;
-          if (NX > 64) good &= __hip_atomic_load(fl2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)s;
+          const bool good = lane >= nmine || __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)s;
           if (__all(good)) break;
           if (spins > kSpinLimit) { if (lane == 0) { aborted = 1; if (atomicExch(err, 1u) == 0u) atomicAdd(&g_persist_aborts, 1u); } break; }
           __builtin_amdgcn_s_sleep(1);
         }
-      }
-      LSTM_STAMP(1);
-      __syncthreads();
-      LSTM_STAMP(2);
-      if (aborted) break;
-      // partials of this workgroup's units from every producer: 16-byte sc1 buffer loads.  A producer's block is UW x (64 x 16 B):
-      // wavefront w takes part w % UW of producers w / UW, w / UW + 4 / UW, ...; the wave sums are combined through LDS in a fixed order
-      {
-        const int part = wid % UW;
+        LSTM_STAMP(1);
+        // partials of this workgroup's units from every producer: 16-byte sc1 buffer loads of [32 b][UN units] blocks (UW x 1 KB);
+        // the wave sums are combined through LDS in a fixed order
         const unsigned blk_b = (unsigned)((((s & 1) ^ 1) * x_par + grp * NX * NX * BLK + (long)x * NX * BLK) * 4) + (unsigned)part * 1024u + (unsigned)lane * 16u;
-        constexpr int XS = 4 / UW;                 // producer stride of a wavefront
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        int xp = wid / UW;
+        int xp = xp0;
         for (; xp + 7 * XS < NX; xp += 8 * XS) {
           f32x4 v[8];
 #pragma unroll
@@ -560,14 +793,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
         for (; xp < NX; xp += XS) a += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, blk_b + (unsigned)xp * (unsigned)(BLK * 4), 0, 16));
         *reinterpret_cast<f32x4*>(psum + wid * 256 + lane * 4) = a;
       }
-      LSTM_STAMP(3);
+      LSTM_STAMP(2);
       __syncthreads();
+      LSTM_STAMP(3);
+      if (aborted) break;
       {
-        const int e = jj * 32 + bm;
+        // block float index of (utterance bm, unit u * 8 + jj): bm * UN + 8 u + jj; part p = the 1 KB it lies in, held by waves p, p + UW, ...
 #pragma unroll
-        for (int u = 0; u < UW; ++u) {             // element (8u + jj) * 32 + bm of the block lies in part u: waves u, u + UW, ...
+        for (int u = 0; u < UW; ++u) {
+          const int e = bm * UN + 8 * u + jj;
           if (UW == 1) dh[u] += (psum[e] + psum[256 + e]) + (psum[512 + e] + psum[768 + e]);
-          else dh[u] += psum[u * 256 + e] + psum[(u + 2) * 256 + e];
+          else dh[u] += psum[(e >> 8) * 256 + (e & 255)] + psum[((e >> 8) + 2) * 256 + (e & 255)];
         }
       }
     }
@@ -597,39 +833,48 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
     __syncthreads();
     LSTM_STAMP(5);
     if (s == T - 1) break;                         // nothing consumes the last partials
-    // ---- produce: P_x = dG_x . W_hh[n in x][:] , written write-through in the consumers' order ----
+    // ---- produce: P_x^T = W_hh[n in x][:]^T . dG_x^T : the unit axis is M, the utterances are N, so a lane (utterance lr) holds 4 consecutive
+    // units per accumulator quad and ONE store instruction writes a whole (consumer, producer) block [32 b][8 units] = 1 KB contiguous
+    // (round 1-3 had the utterances as M: 64 separate 16-byte pieces per store instruction, 32-byte write-through fragments).
+    // The stores of tile u-1 are issued between the MFMAs of tile u (a dependent chain leaves the wave ~60 idle cycles per MFMA).
     f32x4 a4[4 * UW];
 #pragma unroll
     for (int Q = 0; Q < 4 * UW; ++Q) a4[Q] = *reinterpret_cast<const f32x4*>(dgs + lr * LDG + 8 * Q + 4 * lh);
     float* xw = xg + (s & 1) * x_par;
+    f32x16 acc[TPW];
+    auto store_quad = [&](int u, int k) {
+      const int jt = wid + 4 * u;
+      const int jc0 = 32 * jt + 8 * k + 4 * lh;                  // first of this lane's 4 consecutive units
+      if (jt < njt && jc0 < H) {
+        float* dst = xw + ((long)(jc0 / UN) * NX + x) * BLK + lr * UN + (jc0 % UN);
+        f32x4 v = {acc[u][4 * k], acc[u][4 * k + 1], acc[u][4 * k + 2], acc[u][4 * k + 3]};
+        store16_sc1(dst, v);
+      }
+    };
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
-      const int jt = wid + 4 * u;
-      f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
 #pragma unroll
       for (int Q = 0; Q < 4 * UW; ++Q)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[Q][i], wreg[u][Q][i], acc, 0, 0, 0);
-      if (jt < njt && 32 * jt + lr < H) {
-        // column j = 32 jt + lr -> consumer j / UN, unit j % UN; rows (r&3) + 8 (r>>2) + 4 lh: 4 consecutive b per store
-        const int jc = 32 * jt + lr;
-        float* dst = xw + ((long)(jc / UN) * NX + x) * BLK + (jc % UN) * 32 + 4 * lh;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          f32x4 v = {acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]};
-          store16_sc1(dst + 8 * k, v);
+        for (int i = 0; i < 4; ++i) {
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[u][Q][i], a4[Q][i], acc[u], 0, 0, 0);
+          if (u > 0 && Q < 4 && i == 1) {           // one quad of the previous tile behind MFMAs 2, 6, 10, 14
+            __builtin_amdgcn_sched_barrier(0);
+            store_quad(u - 1, Q);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-      }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_quad(TPW - 1, k);
     LSTM_STAMP(6);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains before the barrier ...
-    LSTM_STAMP(7);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores are through: its flag word may say so (no barrier:
+    LSTM_STAMP(7);                                                // a flag signals for the stores of its own wave only)
     LSTM_STAMP(8); LSTM_STAMP(11);
-    if (tid == 0)                                               // ... behind which ONE lane publishes the step tag
-      __hip_atomic_store(flags + (s & 1) * f_par + f_grp + (long)x * 32, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0)
+      __hip_atomic_store(flags + (s & 1) * f_par + f_grp + (long)x * 32 + wid * 8, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int u = 0; u < UW; ++u) {
@@ -659,6 +904,7 @@ int pick_waves(int K, int min_kc, const char* env = nullptr) {
 //                     bwd  = wtfrag[2][nx*(H/2)*256] | gfrag[2][2][MT][4H*32]
 size_t fwd_ws_floats(int B, int H) { long MT = (B + 31) / 32; return (size_t)2 * 4 * H * H + (size_t)2 * 2 * MT * H * 32; }
 // persistent forward: + hx header (16 B: error word) + granules [2][2][MT][H/8][256] x 8 B
+// (the round-4 form needs [2][2][cdiv(B, 16)][H / 4][16] x 16 B, at most half of this)
 size_t fwd_hx_bytes(int B, int H) { long MT = (B + 31) / 32; return 16 + (size_t)2 * 2 * MT * (H / 8) * 256 * 8; }
 size_t bwd_ws_floats(int B, int H) {
   long MT = (B + 31) / 32, NX = H / 8, njt = (H + 31) / 32;
@@ -736,6 +982,72 @@ bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb,
   return true;
 }
 
+// ---- round-4 forward (lstm_fwd2): configuration, launch of the persistent kernel and of its launch-per-step twin ----------
+struct Fwd2Cfg { int tiles, nj; };
+template <int TILES, int NJ, bool P> LdsLimit& fwd2_lim() { static LdsLimit l; return l; }
+
+// RE2E_LSTM_FWD2=0 keeps the round-1..3 forward kernels (also used for widths this form is not instantiated for: H % 64 != 0)
+bool fwd2_config(int B, int H, const float* whh_f, const float* whh_r, Fwd2Cfg& c) {
+  const char* v = getenv("RE2E_LSTM_FWD2");
+  if (v && atoi(v) == 0) return false;
+  if ((reinterpret_cast<uintptr_t>(whh_f) | reinterpret_cast<uintptr_t>(whh_r)) & 15) return false;
+  if (H % 64 != 0) return false;
+  c.nj = H / 64;
+  if (!(c.nj == 1 || c.nj == 2 || c.nj == 4 || c.nj == 5 || c.nj == 8)) return false;
+  // units per workgroup = 4 x tiles: the smallest that keeps the grid within half of the chip (the rest stays with the filler
+  // streams), else within the chip
+  const long per = (long)cdiv(B, 16) * 2;
+  const int te = exp_env("RE2E_LSTM_FWD2_TILES") ? atoi(exp_env("RE2E_LSTM_FWD2_TILES")) : 0;
+  c.tiles = 0;
+  for (int lim = cu_count() / 2; lim <= cu_count() && !c.tiles; lim *= 2)
+    for (int tl = 1; tl <= 4; tl *= 2)
+      if (H % (4 * tl) == 0 && (long)(H / (4 * tl)) * per <= lim) { c.tiles = tl; break; }
+  if (te == 1 || te == 2 || te == 4) c.tiles = te;
+  if (!c.tiles) c.tiles = 4;                          // does not fit: only the launch-per-step twin can run it
+  return true;
+}
+
+template <int TILES, int NJ>
+bool launch_fwd2(bool persist, hipStream_t st, float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf, void* hxmem,
+                 size_t hxbytes, const int* lens, int T, int B, int H) {
+  size_t lds = (size_t)TILES * 8192 + 16;
+  dim3 grid(H / (4 * TILES), cdiv(B, 16), 2);
+  unsigned* err = (unsigned*)hxmem;
+  unsigned* hx = (unsigned*)((char*)hxmem + 16);
+  if (!persist) {
+    fwd2_lim<TILES, NJ, false>().ensure(reinterpret_cast<const void*>(&lstm_fwd2<TILES, NJ, false>), lds);
+    for (int s = 0; s < T; ++s)
+      hipLaunchKernelGGL((lstm_fwd2<TILES, NJ, false>), grid, dim3(256), lds, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hx, err, lens, T, B, H, s, 0);
+    return true;
+  }
+  if ((long)grid.x * grid.y * grid.z > cu_count()) return false;          // every workgroup must be resident
+  static const int hog = exp_env("RE2E_LSTM_OWN_CU") ? atoi(exp_env("RE2E_LSTM_OWN_CU")) : 160;      // see launch_fwd_persist
+  // mode 1 (default): poll one piece per producer, then sweep once.  mode 0: sweep right behind the publish and fall back to the poll when it
+  // came too early -- within the run-to-run spread of mode 1 where a sweep is small (H = 256: 3.14 / 3.43 against 3.18 / 3.17 us per step in two
+  // sessions), worse where it is not (H = 512, B = 64: 6.05 against 5.39)
+  static const int mode_env = exp_env("RE2E_LSTM_FWD2_MODE") ? atoi(exp_env("RE2E_LSTM_FWD2_MODE")) : -1;
+  const int mode = mode_env >= 0 ? mode_env : 1;
+  if (hog) lds = (size_t)hog * 1024;
+  fwd2_lim<TILES, NJ, true>().ensure(reinterpret_cast<const void*>(&lstm_fwd2<TILES, NJ, true>), lds);
+  lstm_stamps_arm();
+  (void)hipMemsetAsync(hxmem, 0, hxbytes, st);                             // tags and the error word start at zero, every call
+  hipLaunchKernelGGL((lstm_fwd2<TILES, NJ, true>), grid, dim3(256), lds, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hx, err, lens, T, B, H, 0, mode);
+  return true;
+}
+
+// RE2E_FWD2_ALL(M): M(TILES, NJ) for every instantiation
+#define RE2E_FWD2_NJ(M, TL) M(TL, 1) M(TL, 2) M(TL, 4) M(TL, 5) M(TL, 8)
+#define RE2E_FWD2_ALL(M) RE2E_FWD2_NJ(M, 1) RE2E_FWD2_NJ(M, 2) RE2E_FWD2_NJ(M, 4)
+
+bool try_fwd2(const Fwd2Cfg& c, bool persist, hipStream_t st, float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
+              void* hxmem, size_t hxbytes, const int* lens, int T, int B, int H) {
+#define RE2E_F2(TL, NJV) \
+  if (c.tiles == TL && c.nj == NJV) return launch_fwd2<TL, NJV>(persist, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
+  RE2E_FWD2_ALL(RE2E_F2)
+#undef RE2E_F2
+  return false;
+}
+
 // 0: launch per step; 1 / 2: persistent kernel with 8 / 16 hidden units per workgroup (the weights must be packed for that width)
 int bwd_persist_width(int T, int B, int H) {
   const char* v = getenv("RE2E_LSTM_PERSIST_BWD");
@@ -801,6 +1113,9 @@ extern "C" int re2e_warmup(void) {
                    bwd_lim<T, 2>().ensure(reinterpret_cast<const void*>(&lstm_bwd_persist<T, 2>), kOwnCuLds - 16 * 1024)
   RE2E_WB(1); RE2E_WB(2); RE2E_WB(3); RE2E_WB(4);
 #undef RE2E_WB
+#define RE2E_W2(TL, NJV) fwd2_lim<TL, NJV, true>().ensure(reinterpret_cast<const void*>(&lstm_fwd2<TL, NJV, true>), kOwnCuLds);
+  RE2E_FWD2_ALL(RE2E_W2)
+#undef RE2E_W2
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { re2e_set_error("re2e_warmup: %s", hipGetErrorString(e)); return RE2E_EHIP; }
   return RE2E_OK;
@@ -828,6 +1143,19 @@ extern "C" int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, c
   float* hfrag = wfrag + (size_t)2 * 4 * H * H;
   void* hxmem = (char*)workspace + fwd_ws_floats(B, H) * sizeof(float);
   long wn = (long)4 * H * H, hn = (long)2 * 2 * cdiv(B, 32) * H * 32;
+  Fwd2Cfg f2;
+  if (fwd2_config(B, H, whh_f, whh_r, f2)) {
+    const char* pv = getenv("RE2E_LSTM_PERSIST");
+    const bool want_persist = !(pv && atoi(pv) == 0) && T >= 2;
+    if (want_persist && try_fwd2(f2, true, stream, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hxmem, fwd_hx_bytes(B, H), lens_dev, T, B, H)) {
+      RE2E_LAUNCH_CHECK();
+      return RE2E_OK;
+    }
+    if (try_fwd2(f2, false, stream, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hxmem, fwd_hx_bytes(B, H), lens_dev, T, B, H)) {
+      RE2E_LAUNCH_CHECK();
+      return RE2E_OK;
+    }
+  }
   hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wfrag, H);
   hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wfrag + wn, H);
   if (try_fwd_persist(stream, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, fwd_hx_bytes(B, H), lens_dev, T, B, H)) {

@@ -428,12 +428,18 @@ def test_bilstm(B, T, I, H, lens):
             i += 1
 
 
-@pytest.mark.parametrize('B,T,H,uw', [(32, 60, 256, None), (40, 37, 320, None), (64, 25, 512, None), (3, 21, 32, None),
-                                       (40, 19, 320, '2'), (3, 9, 32, '2'), (64, 11, 512, '1')])       # forced backward widths
-def test_lstm_persistent_vs_stepwise(B, T, H, uw, monkeypatch):
-    """K4 forward: the persistent kernel (workgroups resident for the whole sequence, h_t handed over as tagged granules)
-    against the launch-per-step kernels on the same inputs -- every output buffer, ragged lengths."""
+@pytest.mark.parametrize('B,T,H,uw,fwd2', [(32, 60, 256, None, '1'), (40, 37, 320, None, '1'), (64, 25, 512, None, '1'), (3, 21, 32, None, '1'),
+                                            (40, 19, 320, '2', '1'), (3, 9, 32, '2', '1'), (64, 11, 512, '1', '1'),       # forced backward widths
+                                            # round-4 forward: <= 16 utterances (K split over four waves), 4-k-chunk counts 2 .. 16, two utterance tiles
+                                            (8, 45, 256, None, '1'), (16, 33, 512, None, '1'), (12, 17, 128, None, '1'), (9, 14, 320, None, '1'),
+                                            (40, 21, 64, None, '1'), (33, 29, 128, None, '1'), (70, 13, 256, None, '1'),
+                                            # the round-1..3 forward kernels (RE2E_LSTM_FWD2=0), still used for widths fwd2 is not built for
+                                            (32, 60, 256, None, '0'), (64, 25, 512, None, '0'), (40, 37, 320, None, '0'), (8, 45, 256, None, '0')])
+def test_lstm_persistent_vs_stepwise(B, T, H, uw, fwd2, monkeypatch):
+    """K4 forward: the persistent kernel (workgroups resident for the whole sequence, h_t handed over in-launch: one-bit-tagged values,
+    round 4; tagged 8-byte granules, rounds 1-3) against the launch-per-step kernels on the same inputs -- every output buffer, ragged lengths."""
     ops, lib = _ops()
+    monkeypatch.setenv('RE2E_LSTM_FWD2', fwd2)
     if uw is not None:
         monkeypatch.setenv('RE2E_LSTM_BWD_UW', uw)       # 8 (1) or 16 (2) hidden units per backward workgroup
     g = torch.Generator().manual_seed(B * 1000 + T)
@@ -459,6 +465,8 @@ def test_lstm_persistent_vs_stepwise(B, T, H, uw, monkeypatch):
     for name, a, b in zip(('gates_f', 'gates_r', 'y', 'c'), outs['0'], outs['1']):
         assert torch.isfinite(b).all(), name
         close(name, b, a, tol=2e-6)
+        if fwd2 == '1' and H % 64 == 0:                  # the round-4 pair runs one instruction sequence: bit for bit
+            assert torch.equal(a, b), name
     # backward: persistent (flagged write-through hand-off of the partial slabs) against launch-per-step, from the same forward state
     gf, gr, ybuf, cbuf = outs['0']
     dy = (torch.randn(T * B, 2 * H, generator=g) * 0.3).to(DEV)
@@ -476,6 +484,44 @@ def test_lstm_persistent_vs_stepwise(B, T, H, uw, monkeypatch):
     for name, a, b in zip(('dgates_f', 'dgates_r'), bouts['0'], bouts['1']):
         assert torch.isfinite(b).all(), name
         close(name, b, a, tol=5e-6)
+    assert lib.query('re2e_lstm_abort_count') == 0
+
+
+@pytest.mark.parametrize('B,H', [(32, 256), (8, 256), (64, 512)])
+def test_lstm_forward_nan_poisons_what_nn_lstm_poisons(B, H, monkeypatch):
+    """The round-4 forward hands h(t) over with a tag in bit 30 of its fp32 pattern; a NaN travels as a reserved pattern.  A NaN
+    pre-activation at (t0, b0) must poison utterance b0 from t0 on (both directions' later steps) and nothing else, exactly as in
+    the launch-per-step kernels and nn.LSTM, and the recurrence must not give up on it."""
+    ops, lib = _ops()
+    T = 12
+    g = torch.Generator().manual_seed(B + H)
+    xg0 = [(torch.randn(T * B, 4 * H, generator=g) * 0.5).to(DEV) for _ in range(2)]
+    t0, b0 = 4, min(5, B - 1)
+    for d in range(2):
+        xg0[d].view(T, B, 4 * H)[t0, b0, 7] = float('nan')
+    whh = [(torch.randn(4 * H, H, generator=g) / H ** 0.5).to(DEV) for _ in range(2)]
+    lens = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    wsb = lib.query('re2e_lstm_workspace_bytes', B, H)
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('RE2E_LSTM_PERSIST', mode)
+        xg = [x.clone() for x in xg0]
+        ws = torch.zeros(wsb // 4 + 16, device=DEV)
+        ybuf, cbuf = torch.zeros(T + 2, B, 2 * H, device=DEV), torch.zeros(T + 2, B, 2 * H, device=DEV)
+        lib.call('re2e_lstm_seq_fwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), ybuf.data_ptr(), cbuf.data_ptr(),
+                 lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+        torch.cuda.synchronize()
+        outs[mode] = ybuf[1:T + 1].clone()
+    y0, y1 = outs['0'], outs['1']
+    assert torch.equal(torch.isnan(y0), torch.isnan(y1))
+    nanmask = torch.isnan(y1)
+    assert torch.equal(y0[~nanmask], y1[~nanmask])
+    exp = torch.zeros_like(nanmask)
+    exp[t0, b0, 7] = True                   # the step itself: only the unit whose pre-activation is NaN (forward half) ...
+    exp[t0, b0, H + 7] = True               # ... and the same unit of the reverse half
+    exp[t0 + 1:, b0, :H] = True             # forward direction: every later step of that utterance
+    exp[:t0, b0, H:] = True                 # reverse direction runs T-1 .. 0: every earlier time index
+    assert torch.equal(nanmask, exp)
     assert lib.query('re2e_lstm_abort_count') == 0
 
 

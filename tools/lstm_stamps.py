@@ -21,16 +21,21 @@ from robust_e2e_gan_amd.lib import call, query   # noqa: E402
 
 FWD = ['wait for h(t-1): sweep until every tag matches', 'MFMA h.W_hh (+ next pre-activation loads issued, partial tiles -> LDS)',
        'barrier', 'sum partial tiles + gates + cell + publish h(t)', 'write gates / c / y', 'barrier']
-BWD = ['next operands issued + poll the producers\' flags (wave 0)', 'barrier', 'load + sum the partial blocks -> LDS', 'barrier + dh sum + cell backward + d(gates) -> LDS',
-       'barrier', 'MFMA dG.W_hh + sc1 stores of the partials', 'drain (s_waitcnt vmcnt(0))', 'barrier (-> flag store)']
+FWD2 = ['wait for h(t-1): poll one piece per producer, then issue the sweep', 'chunks of 16 k consumed in arrival order (MFMA)', 'K-quarter partials -> LDS', 'barrier',
+        'sum K quarters + gates + cell + publish h(t)', '(mode 0: issue the next sweep)', 'next pre-activation loads + write gates / c / y']
+FWD2_ORDER = [0, 7, 1, 2, 3, 4, 5, 6]
+BWD = ['next operands issued + each wave polls the flags of ITS producers', 'load + sum their partial blocks -> LDS', 'barrier', 'dh sum + cell backward + d(gates) -> LDS',
+       'barrier', 'MFMA (dG.W_hh)^T with the sc1 stores of the previous tile between the MFMAs', 'drain (s_waitcnt vmcnt(0)), then the wave\'s own flag', '-']
 
 
-def analyse(name, nwg, waves, phases, nph):
+def analyse(name, nwg, waves, phases, nph, order=None):
     st = stamps.view(512, NW, NS, NP)[:nwg, :waves].cpu().double()
     if (st[:, 0, 2:-2, 0] == 0).any():
         print('%s: no stamps (is this the experiments build? RE2E_LIB=%s)' % (name, os.environ.get('RE2E_LIB')))
         return
     st = st[:, :, 2:-2]                                   # steady-state slots
+    if order is not None:                                 # stamps in program order
+        st = torch.cat([st[..., order], st[..., 8:]], -1) if len(order) == 8 else st
     # clock: memtime ticks per us, from consecutive step tops on wave 0 against the 100 MHz counter
     dt_cyc = (st[:, 0, -1, 0] - st[:, 0, 0, 0])
     dt_us = (st[:, 0, -1, 10] - st[:, 0, 0, 10]) / 100.0
@@ -74,8 +79,12 @@ def run(T, B, H):
         call('re2e_lstm_seq_fwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), ybuf.data_ptr(), cbuf.data_ptr(),
              lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
         torch.cuda.synchronize()
-    fw = int(os.environ.get('RE2E_STAMP_FWD_WAVES', 8))
-    analyse('forward  T=%d B=%d H=%d' % (T, B, H), (H // 8) * MT * 2, fw, FWD, 6)
+    if os.environ.get('RE2E_LSTM_FWD2', '1') != '0':
+        tiles = int(os.environ.get('RE2E_STAMP_TILES', 2 if H == 256 else 4))
+        analyse('forward (fwd2, %d units x 16 utterances per workgroup) T=%d B=%d H=%d' % (4 * tiles, T, B, H), (H // (4 * tiles)) * ((B + 15) // 16) * 2, 4, FWD2, 7,
+                FWD2_ORDER)
+    else:
+        analyse('forward  T=%d B=%d H=%d' % (T, B, H), (H // 8) * MT * 2, int(os.environ.get('RE2E_STAMP_FWD_WAVES', 8)), FWD, 6)
     dc = torch.zeros(B, 2 * H, device=DEV)
     uw = int(os.environ.get('RE2E_LSTM_BWD_UW', 2 if H >= 512 else 1))
     for rep in range(2):
