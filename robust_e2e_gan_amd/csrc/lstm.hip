@@ -501,11 +501,21 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
 #endif
       {
         gi = sigmoidf_(v[0] + pre[0]); gf = sigmoidf_(v[1] + pre[1]); gg = tanhf_(v[2] + pre[2]); go = sigmoidf_(v[3] + pre[3]);
-        cn = gf * c + gi * gg;
+        cn = __builtin_fmaf(gf, c, gi * gg);     // spelled out: the persistent kernel and its launch-per-step twin must not contract differently
         h = go * tanhf_(cn);
       }
       if (t >= ln) { cn = 0.f; h = 0.f; }        // packed semantics (also rows b >= B: ln = 0)
       c = cn;
+      // The next step's pre-activations are loaded HERE: a whole step before the cell needs them, and in front of the publish.  The
+      // compiler guards a load into registers it cannot prove idle with s_waitcnt vmcnt(0) (the poll loops have exits it cannot count
+      // across): behind the publish that wait is the write-through latency of the sc1 store (0.7 us per step at H = 512), just in front
+      // of the cell (rounds 1-3: loaded before the barrier) it is the HBM latency of these very loads (0.5 us); here nothing recent is
+      // outstanding.
+      if (PERSIST && ok && s + 1 < T) {
+        const float* gp = xg + ((long)(dir ? t - 1 : t + 1) * B + b) * 4 * H + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = gp[g * H];
+      }
       if (!PERSIST || s + 1 < T) {
         // the four units of a 16-byte piece sit in lanes n, n + 16, n + 32, n + 48: gather them into lane n, one store per piece
         unsigned hb = __float_as_uint(h);
@@ -526,10 +536,7 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
     // (Measured and rejected: the speculative sweep timed by a per-wave delay behind the publish that hovers at the edge of being too
     // early -- one late wave anywhere delays its workgroup's publish and with it EVERY peer's next sweep, so with 512 waves a
     // per-wave miss rate of 1 in 64 is a miss on every step: 2.85 against 2.93 us at H = 256, no gain at 512, 43 us at B = 8.)
-    // Order of the vector-memory queue from here on: (mode 0: the next step's sweep right behind the publish, THEN) the next
-    // pre-activations and this step's outputs.  The cell waits for `pre` with s_waitcnt vmcnt(0) (the compiler cannot count across the
-    // poll loops), so its loads are issued a whole step before their use and never just in front of it: loaded in front of the
-    // barrier, as rounds 1-3 did, the cell waited ~0.5 us per step for HBM.
+    // Behind the publish: (mode 0: the next step's sweep, then) this step's outputs -- stores write no register, so no wait guards them.
     auto next_sweep = [&]() {
       const unsigned rd_n = (unsigned)(((s & 1) * par_w) * 4) + rd_w * 4u;
       asm volatile("" ::: "memory");
@@ -538,11 +545,6 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
     };
     if (PERSIST && (mode & 1) == 0 && s + 1 < T) next_sweep();
     LSTM_STAMP(5);
-    if (PERSIST && ok && s + 1 < T) {
-      const float* gp = xg + ((long)(dir ? t - 1 : t + 1) * B + b) * 4 * H + j;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) pre[g] = gp[g * H];
-    }
     if (ok) {
       float* go_ = xg + ((long)t * B + b) * 4 * H + j;
       go_[0] = og[0]; go_[H] = og[1]; go_[2 * H] = og[2]; go_[3 * H] = og[3];
@@ -886,6 +888,216 @@ __global__ __launch_bounds__(256) void lstm_bwd_persist(float* g_f, float* g_r, 
   }
 }
 
+// ---- round 4: the persistent backward on 16-UTTERANCE tiles (lstm_bwd3) ---------------------------------------------------------
+// Same K-split decomposition and flagged hand-off as lstm_bwd_persist, but a workgroup owns UN units x 16 (not 32) utterances:
+// twice the workgroups, each with half the matrix work and half the bytes to publish and to pull per step -- what the stamps name
+// as the step's two largest parts (profiles/r04_chain_budget.md: H = 512 / B = 64 ran 128 workgroups at 4.2 us of MFMA and 1.3 us
+// of block loads per step of 9.0).  v_mfma_f32_16x16x4_f32 with the UNITS as M and the utterances as N: a lane holds 4 consecutive
+// units of one utterance per tile, one store instruction writes a whole [16 b][16 units] block (1 KB contiguous).  The K order
+// inside a workgroup is kappa = 4-quad-major (lane quad kq reads d(gates)[b][kq * UN + ks]), so the B operand of all UN k-steps
+// is UN / 4 ds_read_b128; W_hh[x] is packed to match (pack_w_bwd3_kernel).  Two tiles are accumulated in turns (the 16x16x4
+// chain has 40 cycles of dependent latency at 32 of issue); the stores of the previous pair go between the MFMAs.
+__global__ void pack_w_bwd3_kernel(const float* __restrict__ whh, float* __restrict__ wb, int H, int UN) {
+  // wb[(((x * (H/16) + jt) * UN + ks) * 64 + lane)] = whh[row(x, kappa) * H + 16 jt + (lane & 15)],  kappa = (lane >> 4) * UN + ks,
+  // row(x, kappa) = (kappa / UN) * H + x * UN + kappa % UN   (d(gates) tile columns: gate-major, [gate][unit])
+  const long tot = (long)(H / UN) * (H / 16) * UN * 64;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(e & 63); long r = e >> 6; const int ks = (int)(r % UN); r /= UN; const int jt = (int)(r % (H / 16)); const int x = (int)(r / (H / 16));
+    const int kappa = (lane >> 4) * UN + ks;
+    wb[e] = whh[((long)(kappa / UN) * H + (long)x * UN + kappa % UN) * H + 16 * jt + (lane & 15)];
+  }
+}
+
+template <int UN, int TPW>       // UN: hidden units per workgroup (8 | 16); TPW: 16-unit output tiles per wave (H = 64 TPW)
+__global__ __launch_bounds__(256) void lstm_bwd3(float* g_f, float* g_r, const float* __restrict__ wb, const float* __restrict__ dy,
+                                                 const float* __restrict__ cbuf, float* dc_state, float* xbuf, unsigned* flags_, unsigned* err,
+                                                 const int* __restrict__ lens, int T, int B, int H) {
+  constexpr int KG = 4 * UN;              // gate rows per workgroup = K of the partial product
+  constexpr int LDG = KG + 4;             // padded row of the d(gates) tile
+  constexpr int BLK = 16 * UN;            // floats per (consumer, producer) block: [16 b][UN units]
+  constexpr int BPI = 1024 / (BLK * 4);   // blocks one 1 KB load instruction of a wave covers (1 | 2)
+  __shared__ __attribute__((aligned(16))) float dgs[16 * LDG];    // d(gates) tile [b][gate * UN + unit]
+  __shared__ __attribute__((aligned(16))) float psum[4 * 256];    // per-wave sums of the producers' partial blocks
+  __shared__ int aborted;
+  const int dir = blockIdx.z, mt = blockIdx.y, x = blockIdx.x, MT = gridDim.y, NX = gridDim.x;
+  float* G = dir ? g_r : g_f;
+  const int j0 = x * UN, b0 = mt * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n = lane & 15, kq = lane >> 4;
+  const int K4 = 4 * H;
+  const long H2 = 2L * H;
+  if (tid == 0) aborted = 0;
+  // W_hh rows of this workgroup, tiles of this wave (jt = wid + 4 u): registers for the whole sequence
+  float wreg[TPW][UN];
+  {
+    const float* wp = wb + ((long)(dir * NX + x) * (H / 16)) * UN * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u)
+#pragma unroll
+      for (int ks = 0; ks < UN; ++ks) wreg[u][ks] = wp[((long)(wid + 4 * u) * UN + ks) * 64];
+  }
+  const long grp = (long)(dir * MT + mt);
+  const long x_par = (long)2 * MT * NX * NX * BLK;             // floats per parity buffer: [dir][mt][consumer][producer][16 b][UN]
+  float* xg = xbuf + grp * NX * NX * BLK;
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(xbuf, 0, (int)(2 * x_par * 4), 0x00020000);
+  gu32* flags = (gu32*)flags_;
+  const long f_par = (long)2 * MT * NX * 32;                    // words per parity: one 128-byte line per producer, a word per wave at 32 B
+  const long f_grp = grp * NX * 32;
+  // cell-backward ownership: thread = (utterance bm, unit jj), 16 * UN threads
+  const bool cell = tid < 16 * UN;
+  const int bm = cell ? tid / UN : 0, jj = tid % UN, b = b0 + bm, j = j0 + jj;
+  const bool ok = cell && b < B;
+  const long bb = ok ? b : 0;
+  const int ln = lens[bb];
+  float dcr = 0.f;                                              // d(cell state) carried across steps
+  float n_dy, n_g[4], n_c, n_cp;
+  {
+    const int t = dir ? 0 : T - 1;
+    const int prev_blk = dir ? t + 2 : t;
+    n_dy = dy[((long)t * B + bb) * H2 + dir * H + j];
+    const float* gp0 = G + ((long)t * B + bb) * K4 + j;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) n_g[g] = gp0[g * H];
+    n_c = cbuf[((long)(t + 1) * B + bb) * H2 + dir * H + j];
+    n_cp = cbuf[((long)prev_blk * B + bb) * H2 + dir * H + j];
+  }
+  // consumer side: wave w sums producers w, w + 4, ...; with 512-byte blocks one load instruction covers two of them (lanes >= 32: the next)
+  const int xsub = BPI == 2 ? (lane >> 5) : 0;                   // which of the instruction's blocks this lane reads
+  const int nprod = (NX - wid + 3) / 4;                          // producers of this wave
+  const int fw = ((x * UN) >> 4) & 3;                            // the producer wave that owns this consumer's 16-unit tile
+  LSTM_STAMP_DECL;
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? s : T - 1 - s;
+    LSTM_STAMP(0); LSTM_STAMP(10);
+    float dh = n_dy;
+    const float gi = n_g[0], gf = n_g[1], gg = n_g[2], go = n_g[3], c = n_c, cp = n_cp;
+    if (s + 1 < T) {                               // next step's operands: in flight during this step
+      const int tn = dir ? t + 1 : t - 1;
+      const int pbn = dir ? tn + 2 : tn;
+      n_dy = dy[((long)tn * B + bb) * H2 + dir * H + j];
+      const float* gpn = G + ((long)tn * B + bb) * K4 + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) n_g[g] = gpn[g * H];
+      n_c = cbuf[((long)(tn + 1) * B + bb) * H2 + dir * H + j];
+      n_cp = cbuf[((long)pbn * B + bb) * H2 + dir * H + j];
+    }
+    if (s > 0) {
+      {
+        const gu32* fl = flags + ((s & 1) ^ 1) * f_par + f_grp + (long)(lane < nprod ? wid + 4 * lane : 0) * 32 + fw * 8;
+        for (unsigned spins = 0;; ++spins) {
+          const bool good = lane >= nprod || __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)s;
+          if (__all(good)) break;
+          if (spins > kSpinLimit) { if (lane == 0) { aborted = 1; if (atomicExch(err, 1u) == 0u) atomicAdd(&g_persist_aborts, 1u); } break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        LSTM_STAMP(1);
+        // this consumer's blocks: [x][producer][16 b][UN]; lane reads 16 bytes of block (wid + 4 (BPI i + xsub))
+        const unsigned blk_b = (unsigned)((((s & 1) ^ 1) * x_par + grp * NX * NX * BLK + (long)x * NX * BLK) * 4) + (unsigned)(lane & (64 / BPI - 1)) * 16u;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        const int ninstr = (nprod + BPI - 1) / BPI;
+        auto ldblk = [&](int i) {
+          const int xp = wid + 4 * (BPI * i + xsub);
+          return xp < NX ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, blk_b + (unsigned)xp * (unsigned)(BLK * 4), 0, 16)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        int i = 0;                                 // every batch issues all its loads before the first add (fixed order: deterministic)
+        for (; i + 8 <= ninstr; i += 8) {
+          f32x4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = ldblk(i + u);
+          a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        if (i + 4 <= ninstr) {
+          f32x4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = ldblk(i + u);
+          a += (v[0] + v[1]) + (v[2] + v[3]);
+          i += 4;
+        }
+        if (i + 2 <= ninstr) {
+          const f32x4 v0 = ldblk(i), v1 = ldblk(i + 1);
+          a += v0 + v1;
+          i += 2;
+        }
+        if (i < ninstr) a += ldblk(i);
+        *reinterpret_cast<f32x4*>(psum + wid * 256 + lane * 4) = a;
+      }
+      LSTM_STAMP(2);
+      __syncthreads();
+      LSTM_STAMP(3);
+      if (aborted) break;
+      if (cell) {
+        const int e = bm * UN + jj;               // float index inside a block
+        if (BPI == 1) dh += (psum[e] + psum[256 + e]) + (psum[512 + e] + psum[768 + e]);
+        else dh += ((psum[e] + psum[128 + e]) + (psum[256 + e] + psum[384 + e])) + ((psum[512 + e] + psum[640 + e]) + (psum[768 + e] + psum[896 + e]));
+      }
+    }
+    // ---- cell backward ----
+    if (cell) {
+      float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = dcr;
+      if (ok && t < ln) {
+        float tc = tanhf_(c);
+        float dct = dh * go * (1.f - tc * tc) + dcr;
+        dout = dh * tc * go * (1.f - go);
+        di = dct * gg * gi * (1.f - gi);
+        df = dct * cp * gf * (1.f - gf);
+        dg = dct * gi * (1.f - gg * gg);
+        dcp = dct * gf;
+      }
+      dcr = dcp;
+      if (ok) {
+        float* gp = G + ((long)t * B + b) * K4 + j;
+        gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dout;
+      }
+      float* dq = dgs + bm * LDG + jj;
+      dq[0] = di; dq[UN] = df; dq[2 * UN] = dg; dq[3 * UN] = dout;
+    }
+    LSTM_STAMP(4);
+    __syncthreads();
+    LSTM_STAMP(5);
+    if (s == T - 1) break;                         // nothing consumes the last partials
+    // ---- produce: P_x^T = W_hh[rows of x][:]^T . dG_x^T, tile pairs, stores of the previous pair between the MFMAs ----
+    float bv[UN];
+#pragma unroll
+    for (int q = 0; q < UN / 4; ++q) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(dgs + n * LDG + kq * UN + 4 * q);
+      bv[4 * q] = t4[0]; bv[4 * q + 1] = t4[1]; bv[4 * q + 2] = t4[2]; bv[4 * q + 3] = t4[3];
+    }
+    float* xw = xg + (s & 1) * x_par;
+    f32x4 acc[TPW];
+    auto store_tile = [&](int u) {
+      const int jc0 = 16 * (wid + 4 * u) + 4 * kq;               // first of this lane's 4 consecutive units
+      float* dst = xw + ((long)(jc0 / UN) * NX + x) * BLK + n * UN + (jc0 % UN);
+      store16_sc1(dst, acc[u]);
+    };
+#pragma unroll
+    for (int u0 = 0; u0 < TPW; u0 += 2) {
+      acc[u0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u0 + 1 < TPW) acc[u0 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < UN; ++ks) {
+        acc[u0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[u0][ks], bv[ks], acc[u0], 0, 0, 0);
+        if (u0 + 1 < TPW) acc[u0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[u0 + 1][ks], bv[ks], acc[u0 + 1], 0, 0, 0);
+        if (u0 >= 2 && (ks == 1 || ks == 3)) {
+          __builtin_amdgcn_sched_barrier(0);
+          store_tile(u0 - 2 + (ks >> 1));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (TPW % 2 == 0) store_tile(TPW - 2);       // (an odd count's last pair was stored beside the single last tile)
+    store_tile(TPW - 1);
+    LSTM_STAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's stores are through: its flag word may say so
+    LSTM_STAMP(7); LSTM_STAMP(8); LSTM_STAMP(11);
+    if (lane == 0)
+      __hip_atomic_store(flags + (s & 1) * f_par + f_grp + (long)x * 32 + wid * 8, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (ok) dc_state[(long)b * H2 + dir * H + j] = dcr;
+  if (aborted && ok) {                              // a peer never published: make the failure visible downstream
+    for (int t = 0; t < T; ++t) G[((long)t * B + b) * K4 + j] = __uint_as_float(0x7fc00000u);
+  }
+}
+
 __global__ void zero_kernel(float* p, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
 }
@@ -911,7 +1123,8 @@ size_t bwd_ws_floats(int B, int H) {
   return (size_t)2 * NX * njt * 1024 + (size_t)2 * 2 * MT * NX * NX * 256;
 }
 // persistent backward: + header (16 B: error word) + flag lines [2][2][MT][NX] x 128 B
-size_t bwd_flag_bytes(int B, int H) { long MT = (B + 31) / 32, NX = H / 8; return 16 + (size_t)2 * 2 * MT * NX * 128; }
+// (the 16-utterance-tile form has cdiv(B, 16) tiles of up to H / 8 producers)
+size_t bwd_flag_bytes(int B, int H) { long MT = (B + 15) / 16, NX = H / 8; return 16 + (size_t)2 * 2 * MT * NX * 128; }
 
 template <int W>
 void launch_fwd(hipStream_t st, float* xg_f, float* xg_r, const float* wfrag, float* ybuf, float* cbuf, float* hfrag, const int* lens,
@@ -1048,6 +1261,43 @@ bool try_fwd2(const Fwd2Cfg& c, bool persist, hipStream_t st, float* xg_f, float
   return false;
 }
 
+// round-4 backward on 16-utterance tiles: units per workgroup (0: not applicable -> the round-1..3 kernels).  RE2E_LSTM_BWD3=0 turns it off.
+int bwd3_units(int T, int B, int H) {
+  const char* v = getenv("RE2E_LSTM_BWD3");
+  const char* pv = getenv("RE2E_LSTM_PERSIST_BWD");
+  if ((v && atoi(v) == 0) || (pv && atoi(pv) == 0) || T < 2 || H % 64 != 0 || H / 64 > 8) return 0;
+  const long per = (long)cdiv(B, 16) * 2;
+  const int ue = exp_env("RE2E_LSTM_BWD3_UN") ? atoi(exp_env("RE2E_LSTM_BWD3_UN")) : 0;
+  if (ue == 8 || ue == 16) return (long)(H / ue) * per <= cu_count() ? ue : 0;
+  // 8 units while that fits half of the chip (narrow layers: the matrix work per workgroup halves), else 16 (half the slab traffic)
+  if ((long)(H / 8) * per <= cu_count() / 2) return 8;
+  if ((long)(H / 16) * per <= cu_count()) return 16;
+  return 0;
+}
+template <int UN, int TPW> LdsLimit& bwd3_lim() { static LdsLimit l; return l; }
+template <int UN, int TPW>
+bool launch_bwd3(hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs, void* flagmem,
+                 size_t flagbytes, const int* lens, int T, int B, int H) {
+  dim3 grid(H / UN, cdiv(B, 16), 2);
+  lstm_stamps_arm();
+  (void)hipMemsetAsync(flagmem, 0, flagbytes, st);
+  unsigned* err = (unsigned*)flagmem;
+  unsigned* flags = (unsigned*)((char*)flagmem + 16);
+  static const int hog = exp_env("RE2E_LSTM_OWN_CU") ? atoi(exp_env("RE2E_LSTM_OWN_CU")) : 160;      // see launch_fwd_persist
+  size_t lds = hog ? (size_t)(hog - 16) * 1024 : 0;                                                  // + ~9 KB static
+  bwd3_lim<UN, TPW>().ensure(reinterpret_cast<const void*>(&lstm_bwd3<UN, TPW>), lds);
+  hipLaunchKernelGGL((lstm_bwd3<UN, TPW>), grid, dim3(256), lds, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
+  return true;
+}
+#define RE2E_BWD3_ALL(M) M(8, 1) M(8, 2) M(8, 3) M(8, 4) M(8, 5) M(8, 6) M(8, 7) M(8, 8) M(16, 1) M(16, 2) M(16, 3) M(16, 4) M(16, 5) M(16, 6) M(16, 7) M(16, 8)
+bool try_bwd3(int un, hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs, void* flagmem,
+              size_t flagbytes, const int* lens, int T, int B, int H) {
+#define RE2E_B3(U, TP) if (un == U && H == 64 * TP) return launch_bwd3<U, TP>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
+  RE2E_BWD3_ALL(RE2E_B3)
+#undef RE2E_B3
+  return false;
+}
+
 // 0: launch per step; 1 / 2: persistent kernel with 8 / 16 hidden units per workgroup (the weights must be packed for that width)
 int bwd_persist_width(int T, int B, int H) {
   const char* v = getenv("RE2E_LSTM_PERSIST_BWD");
@@ -1113,6 +1363,9 @@ extern "C" int re2e_warmup(void) {
                    bwd_lim<T, 2>().ensure(reinterpret_cast<const void*>(&lstm_bwd_persist<T, 2>), kOwnCuLds - 16 * 1024)
   RE2E_WB(1); RE2E_WB(2); RE2E_WB(3); RE2E_WB(4);
 #undef RE2E_WB
+#define RE2E_W3(U, TP) bwd3_lim<U, TP>().ensure(reinterpret_cast<const void*>(&lstm_bwd3<U, TP>), kOwnCuLds - 16 * 1024);
+  RE2E_BWD3_ALL(RE2E_W3)
+#undef RE2E_W3
 #define RE2E_W2(TL, NJV) fwd2_lim<TL, NJV, true>().ensure(reinterpret_cast<const void*>(&lstm_fwd2<TL, NJV, true>), kOwnCuLds);
   RE2E_FWD2_ALL(RE2E_W2)
 #undef RE2E_W2
@@ -1186,6 +1439,18 @@ extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, con
   long wn = (long)(H / 8) * ((H + 31) / 32) * 1024;
   float* wb = (float*)workspace;
   float* slabs = wb + 2 * wn;
+  if (const int un = bwd3_units(T, B, H)) {                     // round-4 form: 16-utterance tiles (same workspace regions, its own layouts)
+    const long w3 = (long)4 * H * H;                            // = wn: [x][H / 16][UN][64] floats per direction
+    hipLaunchKernelGGL(pack_w_bwd3_kernel, dim3(cdiv(w3, 256) > 2048 ? 2048 : cdiv(w3, 256)), dim3(256), 0, stream, whh_f, wb, H, un);
+    hipLaunchKernelGGL(pack_w_bwd3_kernel, dim3(cdiv(w3, 256) > 2048 ? 2048 : cdiv(w3, 256)), dim3(256), 0, stream, whh_r, wb + w3, H, un);
+    long nz3 = (long)B * 2 * H;
+    hipLaunchKernelGGL(zero_kernel, dim3(cdiv(nz3, 256)), dim3(256), 0, stream, dc_state, nz3);
+    void* flagmem3 = (char*)workspace + bwd_ws_floats(B, H) * sizeof(float);
+    if (try_bwd3(un, stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, flagmem3, bwd_flag_bytes(B, H), lens_dev, T, B, H)) {
+      RE2E_LAUNCH_CHECK();
+      return RE2E_OK;
+    }
+  }
   const int uw = bwd_persist_width(T, B, H);
   hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_f, wb, H, uw ? uw : 1);
   hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(cdiv(wn, 256) > 2048 ? 2048 : cdiv(wn, 256)), dim3(256), 0, stream, whh_r, wb + wn, H, uw ? uw : 1);

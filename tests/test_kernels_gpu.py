@@ -440,8 +440,10 @@ def test_lstm_persistent_vs_stepwise(B, T, H, uw, fwd2, monkeypatch):
     round 4; tagged 8-byte granules, rounds 1-3) against the launch-per-step kernels on the same inputs -- every output buffer, ragged lengths."""
     ops, lib = _ops()
     monkeypatch.setenv('RE2E_LSTM_FWD2', fwd2)
+    if uw is not None or fwd2 == '0':
+        monkeypatch.setenv('RE2E_LSTM_BWD3', '0')        # the round-1..3 backward kernel ...
     if uw is not None:
-        monkeypatch.setenv('RE2E_LSTM_BWD_UW', uw)       # 8 (1) or 16 (2) hidden units per backward workgroup
+        monkeypatch.setenv('RE2E_LSTM_BWD_UW', uw)       # ... with 8 (1) or 16 (2) hidden units per workgroup
     g = torch.Generator().manual_seed(B * 1000 + T)
     xg0 = [(torch.randn(T * B, 4 * H, generator=g) * 0.5).to(DEV) for _ in range(2)]
     whh = [(torch.randn(4 * H, H, generator=g) / H ** 0.5).to(DEV) for _ in range(2)]

@@ -86,13 +86,17 @@ def run(T, B, H):
     else:
         analyse('forward  T=%d B=%d H=%d' % (T, B, H), (H // 8) * MT * 2, int(os.environ.get('RE2E_STAMP_FWD_WAVES', 8)), FWD, 6)
     dc = torch.zeros(B, 2 * H, device=DEV)
+    un3 = 0 if os.environ.get('RE2E_LSTM_BWD3') == '0' else int(os.environ.get('RE2E_LSTM_BWD3_UN', 16 if H >= 512 else 8))
     uw = int(os.environ.get('RE2E_LSTM_BWD_UW', 2 if H >= 512 else 1))
     for rep in range(2):
         stamps.zero_()
         call('re2e_lstm_seq_bwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
              cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
         torch.cuda.synchronize()
-    analyse('backward T=%d B=%d H=%d' % (T, B, H), (H // (8 * uw)) * MT * 2, 4, BWD, 8)
+    if un3:
+        analyse('backward (bwd3, %d units x 16 utterances per workgroup) T=%d B=%d H=%d' % (un3, T, B, H), (H // un3) * ((B + 15) // 16) * 2, 4, BWD, 8)
+    else:
+        analyse('backward T=%d B=%d H=%d' % (T, B, H), (H // (8 * uw)) * MT * 2, 4, BWD, 8)
     print('aborts', query('re2e_lstm_abort_count'), flush=True)
 
 
