@@ -15,9 +15,13 @@ flat gradient buffers are averaged with RCCL.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline     -- the dominant convolution (3x3 at the VGG conv1_2 shape of this workload, as the step launches it:
-                  fused Winograd + ReLU + pool) timed live with HIP events on the launch stream
-  cpu_baseline -- the CPU oracle (oracle/joint.py, "port") timed on this box's host cores on a
-                  bounded sample of the same workload (rank 0, N=1 only): 1 warm-up + 3 timed steps, median
+                  fused Winograd + ReLU + pool) timed live with HIP events on the launch stream; achieved / frac = EXECUTED
+                  matrix-core FLOPs against the fp32-MFMA peak (<= 1), the direct-form figure is direct_equivalent_tflops
+  roofline_chain -- the latency-bound recurrent chains: us per step of the persistent bi-LSTM kernels alone on the chip, measured
+                  live, next to the bare hand-off floor (tools/micro/handoff_probe.hip) and the MFMA floor
+  other_configs -- configurations 2, 3 and 5 of BASELINE.json, 5 timed steps each in this same process (N = 1, --config 4)
+  cpu_baseline -- the CPU oracle (oracle/joint.py, "port") timed on this box's host cores on the metric's own configuration
+                  (rank 0, N=1 only): B=32, 1 warm-up (the parity step) + 3 timed steps, median; a B=8 sample next to it
   parity       -- the FIRST GPU step against the oracle's step on the SAME full batch, initial weights and cmvn
                   (relative errors of the losses, the clipped-gradient norm and enhance_out); the bench FAILS
                   if any exceeds 1e-3 (north_star's fp32 bar, SURVEY 8d "parity gate in the same run")
@@ -236,14 +240,14 @@ def _oracle_state(opt, sd, fbank_W):
     return oj.JointState(sd[0], sd[1], sd[2], fbank_W, cfg)
 
 
-def cpu_baseline_and_parity(opt, sd0, fbank_W, batch, cmvn, gpu_first, sample_b=8):
+def cpu_baseline_and_parity(opt, sd0, fbank_W, batch, cmvn, gpu_first, sample_b=8, full_reps=3):
     """The oracle ('port') on the host cores.
 
     (1) parity: ONE joint step on the full batch of the GPU leg -- same synthetic batch, same initial weights (``sd0`` =
         the GPU nets' state_dicts before their first step), same cmvn -- compared with the GPU's first step.
-    (2) cpu_baseline: a bounded sample of the same workload (the first ``sample_b`` utterances of that batch: same T, L, V
-        and architecture), 1 warm-up + 3 timed steps on identical inputs, median.  The full-batch step of (1) is timed
-        too and reported next to it."""
+    (2) cpu_baseline.value: the metric's own configuration (config 4, 1 warm-up + >= 3 timed): the step of (1) is the
+        warm-up, ``full_reps`` more full-batch steps on identical inputs are timed, median.
+    (3) ``sample_b8``: the first ``sample_b`` utterances of that batch (same T, L, V and architecture), 1 warm-up + 3 timed, next to it."""
     from oracle import joint as oj
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -267,26 +271,37 @@ def cpu_baseline_and_parity(opt, sd0, fbank_W, batch, cmvn, gpu_first, sample_b=
                       'the ASR grad norm, max|d|/max|ref| for enhance_out' % B,
               'gpu': {k: gpu_first['train/' + k] for k in PARITY_KEYS}, 'oracle': {k: float(ref[k]) for k in PARITY_KEYS}}
     del ref
-    # (2) bounded timing sample
-    sb = min(sample_b, B)
+    # (2) the metric's own configuration: the parity step above was the warm-up; ``full_reps`` more full-batch steps, timed, median
     L = int(tl[0])
+    full_times = []
+    for i in range(full_reps):
+        st = _oracle_state(opt, sd0, fbank_W)            # identical inputs AND weights every repetition
+        t0 = time.time()
+        oj.joint_step(st, (clean, mix, mix_log, targets, il.tolist(), tl.tolist()), cmvn)
+        full_times.append(time.time() - t0)
+        log('cpu_baseline: full B=%d step %d took %.1fs' % (B, i + 1, full_times[-1]))
+    ft = sorted(full_times)
+    fmed = ft[len(ft) // 2] if ft else full_s
+    # (3) a bounded sample next to it (the first ``sample_b`` utterances of that batch: same T, L, V and architecture): torch's CPU step is
+    #     super-linear in the batch at this size, so the sample is the figure that is kinder to the CPU
+    sb = min(sample_b, B)
     sub = (clean[:sb], mix[:sb], mix_log[:sb], targets[:sb * L], il[:sb].tolist(), tl[:sb].tolist())
     times = []
     for i in range(4):
-        st = _oracle_state(opt, sd0, fbank_W)            # identical inputs AND weights every repetition
+        st = _oracle_state(opt, sd0, fbank_W)
         t0 = time.time()
         oj.joint_step(st, sub, cmvn)
         times.append(time.time() - t0)
         log('cpu_baseline: B=%d sample step %d took %.1fs%s' % (sb, i, times[-1], ' (warm-up)' if i == 0 else ''))
     timed = sorted(times[1:])
     med = timed[len(timed) // 2]
-    base = {'value': round(sb / med, 4), 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
-            'sample': 'oracle/joint.py joint_step on the first %d utterances of the GPU leg\'s batch (T=%d, L=%d, V=%d, config-4 architecture, '
-                      'same initial weights and cmvn): 1 warm-up + 3 timed steps, median; torch CPU fp32, %d threads'
-                      % (sb, clean.shape[1], L, opt.odim, cores),
-            'seconds_timed': [round(t, 2) for t in times[1:]], 'seconds_warmup': round(times[0], 2),
-            'full_batch': {'utterances': B, 'seconds': round(full_s, 2), 'value': round(B / full_s, 4),
-                           'note': 'the single full-batch oracle step of the parity gate (un-repeated)'}}
+    base = {'value': round(B / fmed, 4), 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle/joint.py joint_step on the FULL batch of the GPU leg (B=%d, T=%d, L=%d, V=%d, config-4 architecture, same initial weights '
+                      'and cmvn): 1 warm-up (the parity step) + %d timed steps, median; torch CPU fp32, %d threads'
+                      % (B, clean.shape[1], L, opt.odim, len(full_times), cores),
+            'seconds_timed': [round(t, 2) for t in full_times], 'seconds_warmup': round(full_s, 2),
+            'sample_b8': {'utterances': sb, 'value': round(sb / med, 4), 'seconds_timed': [round(t, 2) for t in times[1:]], 'seconds_warmup': round(times[0], 2),
+                          'note': 'the first %d utterances of the same batch, 1 warm-up + 3 timed steps, median' % sb}}
     return base, parity
 
 
@@ -392,6 +407,46 @@ def make_stepper(cfg_id, opt, nets, batch, cmvn_d, dev):
     raise SystemExit('bench: --config must be 2, 3, 4 or 5 (config 1 is the CPU plumbing case of the tests)')
 
 
+def time_other_config(cfg_id, dev, steps=5, warmup=2):
+    """One of the other BASELINE configurations (2: asr_train, 3: enhance_gan_train, 5: joint_train on long utterances) in THIS process:
+    fresh networks, its own synthetic batch and CMVN, ``warmup`` untimed + ``steps`` timed steps.  N = 1 only."""
+    from robust_e2e_gan_amd.data.synthetic import make_batch
+    from robust_e2e_gan_amd.joint_train import config4_opt
+    opt = config4_opt()
+    B, T, L = CONFIG_SHAPES[cfg_id]
+    if cfg_id == 2:
+        from robust_e2e_gan_amd.model.e2e_model import E2E
+        from robust_e2e_gan_amd.model.feat_model import FbankModel
+        torch.manual_seed(1234)
+        enh, gan = None, None
+        fb, asr = FbankModel(opt).to(dev).train(), E2E(opt).to(dev).train()
+    else:
+        enh, fb, asr, gan = build(opt, dev)
+    batch = make_batch(B, T, L, opt.odim, seed=1234)
+    cmvn_batches = [make_batch(B, T, L, opt.odim, seed=77 + i) for i in range(2)]
+    if enh is not None:
+        cmvn = synthetic_cmvn(enh, fb, cmvn_batches, dev)
+    else:
+        with torch.no_grad():
+            f = torch.cat([fb(b[0].to(dev))[i, :l] for b in cmvn_batches for i, l in enumerate(b[4].tolist())], 0)
+            cmvn = torch.stack([-f.mean(0), 1.0 / f.std(0)]).cpu()
+    step, tr, _ = make_stepper(cfg_id, opt, (enh, fb, asr, gan), batch, cmvn.to(dev), dev)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    utt_s = B * steps / dt
+    out = {'ms': round(dt / steps * 1e3, 3), 'utt_s': round(utt_s, 2), 'frac': round(utt_s * FLOP_PER_UTT[cfg_id] / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+           'steps': steps, 'warmup': warmup, 'workload': '%s, B=%d, T=%d, L=%d' % (CONFIG_NAMES[cfg_id], B, T, L)}
+    del step, tr, enh, fb, asr, gan
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -406,6 +461,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-input-side', action='store_true', help='skip the second timed loop that feeds HOST batches through the device prefetcher')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the 5-step runs of configurations 2, 3 and 5 (N = 1, --config 4 only)')
     a = ap.parse_args()
 
     # The step runs on three streams besides the default one; the input-side loop adds a copy stream.  A process gets four hardware
@@ -549,6 +605,11 @@ def main():
         line['input_side'] = input_side
     if not a.no_roofline:
         line['roofline'] = conv_roofline(dev)
+        line['roofline_chain'] = chain_roofline(dev)
+    if world == 1 and a.config == 4 and default_shape and not a.no_other_configs:
+        # step_mfma_frac of the other configurations, measured by THIS run (5 timed steps each): `frac` = utt/s x SURVEY 8(d) FLOP / fp32-MFMA peak
+        line['other_configs'] = {str(c): time_other_config(c, dev) for c in (2, 3, 5)}
+        log('other configurations: %s' % {c: v['ms'] for c, v in line['other_configs'].items()})
     if want_cpu:
         from robust_e2e_gan_amd.model.feat_model import mel_matrix
         line['cpu_baseline'], line['parity'] = cpu_baseline_and_parity(opt, sd0, torch.from_numpy(mel_matrix()), batch, cmvn, gpu_first)

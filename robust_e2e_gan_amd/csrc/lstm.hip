@@ -272,12 +272,6 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
 #pragma unroll
           for (int u = 0; u < UW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[q][i], w[u][q][i], acc[u], 0, 0, 0);
     }
-    float nxt[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ok && s + 1 < T) {                       // next step's pre-activations: HBM latency hidden behind this step
-      const float* gp = xg + ((long)(dir ? t - 1 : t + 1) * B + b) * 4 * H + j;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) nxt[g] = gp[g * H];
-    }
 #pragma unroll
     for (int u = 0; u < UW; ++u) store_acc(red + (u * WAVES + wid) * (32 * 33), acc[u], lane);
     LSTM_STAMP(2);
@@ -298,6 +292,13 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
       float h = go * tanhf_(cn);
       if (t >= ln) { cn = 0.f; h = 0.f; }        // packed semantics (also rows b >= B: ln = 0)
       c = cn;
+      // next step's pre-activations: loaded a whole step before the cell needs them, in front of the publish (round 4: issued before the
+      // barrier above, as rounds 1-3 did, the cell's s_waitcnt vmcnt(0) waited ~0.5 us per step for these very loads -- see lstm_fwd2)
+      if (ok && s + 1 < T) {
+        const float* gp = xg + ((long)(dir ? t - 1 : t + 1) * B + b) * 4 * H + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = gp[g * H];
+      }
       if (s + 1 < T)
         __hip_atomic_store(hx + (s & 1) * par_sz + wr_off, ((u64)(unsigned)(s + 1) << 32) | (u64)__float_as_uint(h), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -309,8 +310,6 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_fwd_persist(float* xg_f, floa
         ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = h;
       }
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = nxt[g];
     LSTM_STAMP(5);
     __syncthreads();
     LSTM_STAMP(6);
@@ -1203,8 +1202,16 @@ template <int TILES, int NJ, bool P> LdsLimit& fwd2_lim() { static LdsLimit l; r
 bool fwd2_config(int B, int H, const float* whh_f, const float* whh_r, Fwd2Cfg& c) {
   const char* v = getenv("RE2E_LSTM_FWD2");
   if (v && atoi(v) == 0) return false;
+  if (exp_env("RE2E_LSTM_FWD2_MAXH") && H > atoi(exp_env("RE2E_LSTM_FWD2_MAXH"))) return false;
+  if (exp_env("RE2E_LSTM_FWD2_MINH") && H < atoi(exp_env("RE2E_LSTM_FWD2_MINH"))) return false;
   if ((reinterpret_cast<uintptr_t>(whh_f) | reinterpret_cast<uintptr_t>(whh_r)) & 15) return false;
   if (H % 64 != 0) return false;
+  // Where it runs.  In the training step a chain is paid for in CUs x time (it owns its CUs; behind the forward half the step is bound
+  // by the sum of all streams' work): at H = 256 / B = 32 this form is faster alone (2.9 against 3.2 us per step) on TWICE the CUs
+  // (128 against 64) and the step loses 1.7 ms with it (57.4 against 55.7, two A/B rounds); on as many CUs (64: 16 units per workgroup)
+  // it is slower than the round-1..3 kernel (3.7).  It is the better kernel where that one wastes its tile or is bound by its matrix
+  // work: <= 16 utterances (half of a 32-row tile empty: 2.5 against 3.2 us, same CUs) and wide layers (H = 512, B = 64: 5.2 against 6.2).
+  if (!exp_env("RE2E_LSTM_FWD2_MINH") && !exp_env("RE2E_LSTM_FWD2_MAXH") && B > 16 && H < 384) return false;
   c.nj = H / 64;
   if (!(c.nj == 1 || c.nj == 2 || c.nj == 4 || c.nj == 5 || c.nj == 8)) return false;
   // units per workgroup = 4 x tiles: the smallest that keeps the grid within half of the chip (the rest stays with the filler
@@ -1238,9 +1245,10 @@ bool launch_fwd2(bool persist, hipStream_t st, float* xg_f, float* xg_r, const f
   // mode 1 (default): poll one piece per producer, then sweep once.  mode 0: sweep right behind the publish and fall back to the poll when it
   // came too early -- within the run-to-run spread of mode 1 where a sweep is small (H = 256: 3.14 / 3.43 against 3.18 / 3.17 us per step in two
   // sessions), worse where it is not (H = 512, B = 64: 6.05 against 5.39)
+  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 1;
   static const int mode_env = exp_env("RE2E_LSTM_FWD2_MODE") ? atoi(exp_env("RE2E_LSTM_FWD2_MODE")) : -1;
   const int mode = mode_env >= 0 ? mode_env : 1;
-  if (hog) lds = (size_t)hog * 1024;
+  if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
   fwd2_lim<TILES, NJ, true>().ensure(reinterpret_cast<const void*>(&lstm_fwd2<TILES, NJ, true>), lds);
   lstm_stamps_arm();
   (void)hipMemsetAsync(hxmem, 0, hxbytes, st);                             // tags and the error word start at zero, every call
@@ -1266,11 +1274,14 @@ int bwd3_units(int T, int B, int H) {
   const char* v = getenv("RE2E_LSTM_BWD3");
   const char* pv = getenv("RE2E_LSTM_PERSIST_BWD");
   if ((v && atoi(v) == 0) || (pv && atoi(pv) == 0) || T < 2 || H % 64 != 0 || H / 64 > 8) return 0;
+  if (exp_env("RE2E_LSTM_BWD3_MAXH") && H > atoi(exp_env("RE2E_LSTM_BWD3_MAXH"))) return 0;
+  if (exp_env("RE2E_LSTM_BWD3_MINH") && H < atoi(exp_env("RE2E_LSTM_BWD3_MINH"))) return 0;
   const long per = (long)cdiv(B, 16) * 2;
   const int ue = exp_env("RE2E_LSTM_BWD3_UN") ? atoi(exp_env("RE2E_LSTM_BWD3_UN")) : 0;
   if (ue == 8 || ue == 16) return (long)(H / ue) * per <= cu_count() ? ue : 0;
-  // 8 units while that fits half of the chip (narrow layers: the matrix work per workgroup halves), else 16 (half the slab traffic)
-  if ((long)(H / 8) * per <= cu_count() / 2) return 8;
+  // 8 units while that fits a quarter of the chip, else 16 (half the workgroups, half the slab traffic): at H = 256 / B = 32 the 128-workgroup
+  // form is faster alone (3.35 against 3.66 us per step) and costs the training step 1.1 ms (57.4 against 56.3: CUs x time, see fwd2_config)
+  if ((long)(H / 8) * per <= cu_count() / 4) return 8;
   if ((long)(H / 16) * per <= cu_count()) return 16;
   return 0;
 }
@@ -1284,7 +1295,8 @@ bool launch_bwd3(hipStream_t st, float* g_f, float* g_r, const float* wb, const 
   unsigned* err = (unsigned*)flagmem;
   unsigned* flags = (unsigned*)((char*)flagmem + 16);
   static const int hog = exp_env("RE2E_LSTM_OWN_CU") ? atoi(exp_env("RE2E_LSTM_OWN_CU")) : 160;      // see launch_fwd_persist
-  size_t lds = hog ? (size_t)(hog - 16) * 1024 : 0;                                                  // + ~9 KB static
+  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 1;
+  size_t lds = hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac ? (size_t)(hog - 16) * 1024 : 0;     // + ~9 KB static
   bwd3_lim<UN, TPW>().ensure(reinterpret_cast<const void*>(&lstm_bwd3<UN, TPW>), lds);
   hipLaunchKernelGGL((lstm_bwd3<UN, TPW>), grid, dim3(256), lds, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
   return true;

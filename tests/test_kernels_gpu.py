@@ -428,11 +428,16 @@ def test_bilstm(B, T, I, H, lens):
             i += 1
 
 
+def _fwd2_runs(B, H):
+    """csrc/lstm.hip fwd2_config: the round-4 forward serves <= 16 utterances and wide layers (multiples of 64 units)."""
+    return H % 64 == 0 and H // 64 in (1, 2, 4, 5, 8) and (B <= 16 or H >= 384)
+
+
 @pytest.mark.parametrize('B,T,H,uw,fwd2', [(32, 60, 256, None, '1'), (40, 37, 320, None, '1'), (64, 25, 512, None, '1'), (3, 21, 32, None, '1'),
                                             (40, 19, 320, '2', '1'), (3, 9, 32, '2', '1'), (64, 11, 512, '1', '1'),       # forced backward widths
                                             # round-4 forward: <= 16 utterances (K split over four waves), 4-k-chunk counts 2 .. 16, two utterance tiles
                                             (8, 45, 256, None, '1'), (16, 33, 512, None, '1'), (12, 17, 128, None, '1'), (9, 14, 320, None, '1'),
-                                            (40, 21, 64, None, '1'), (33, 29, 128, None, '1'), (70, 13, 256, None, '1'),
+                                            (40, 21, 64, None, '1'), (33, 29, 128, None, '1'), (70, 13, 256, None, '1'), (24, 15, 512, None, '1'),
                                             # the round-1..3 forward kernels (RE2E_LSTM_FWD2=0), still used for widths fwd2 is not built for
                                             (32, 60, 256, None, '0'), (64, 25, 512, None, '0'), (40, 37, 320, None, '0'), (8, 45, 256, None, '0')])
 def test_lstm_persistent_vs_stepwise(B, T, H, uw, fwd2, monkeypatch):
@@ -467,7 +472,7 @@ def test_lstm_persistent_vs_stepwise(B, T, H, uw, fwd2, monkeypatch):
     for name, a, b in zip(('gates_f', 'gates_r', 'y', 'c'), outs['0'], outs['1']):
         assert torch.isfinite(b).all(), name
         close(name, b, a, tol=2e-6)
-        if fwd2 == '1' and H % 64 == 0:                  # the round-4 pair runs one instruction sequence: bit for bit
+        if fwd2 == '1' and _fwd2_runs(B, H):             # the round-4 pair runs one instruction sequence: bit for bit
             assert torch.equal(a, b), name
     # backward: persistent (flagged write-through hand-off of the partial slabs) against launch-per-step, from the same forward state
     gf, gr, ybuf, cbuf = outs['0']
@@ -517,7 +522,10 @@ def test_lstm_forward_nan_poisons_what_nn_lstm_poisons(B, H, monkeypatch):
     y0, y1 = outs['0'], outs['1']
     assert torch.equal(torch.isnan(y0), torch.isnan(y1))
     nanmask = torch.isnan(y1)
-    assert torch.equal(y0[~nanmask], y1[~nanmask])
+    if _fwd2_runs(B, H):
+        assert torch.equal(y0[~nanmask], y1[~nanmask])
+    else:
+        close('finite outputs', y1[~nanmask], y0[~nanmask], tol=2e-6)
     exp = torch.zeros_like(nanmask)
     exp[t0, b0, 7] = True                   # the step itself: only the unit whose pre-activation is NaN (forward half) ...
     exp[t0, b0, H + 7] = True               # ... and the same unit of the reverse half
