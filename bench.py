@@ -545,6 +545,23 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    comm = None
+    if world > 1:
+        # ONE more, untimed step with an event timeline of its gradient all-reduces: when each was issued and when the step could
+        # continue behind it, in ms from the step's start, on every rank -- the first multi-GPU run shows exposed communication directly
+        rdist.COMM_TIMING = True
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        step()
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        torch.cuda.synchronize()
+        rdist.COMM_TIMING = False
+        mine = {'rank': rank, 'step_ms': round(ev0.elapsed_time(ev1), 3),
+                'allreduces': [{'bytes': b, 'issued_ms': i, 'done_ms': d} for b, i, d in rdist.comm_report(ev0)]}
+        every = [None] * world
+        torch.distributed.all_gather_object(every, mine)
+        comm = every
     rank_ms = [dt / a.steps * 1e3]
     if world > 1:
         mine = torch.tensor([dt], device=dev)
@@ -600,6 +617,10 @@ def main():
         'rank_ms_per_step': {'min': round(min(rank_ms), 3), 'max': round(max(rank_ms), 3)},
         'host_enqueue_ms_per_step': round(host_ms, 2) if host_ms is not None else None,
     }
+    if comm is not None:
+        line['comm_timeline'] = {'what': 'one extra untimed step per rank: every gradient all-reduce with the time it was issued and the time the step '
+                                         'could continue behind it (HIP events, ms from the step\'s start); ASR (largest) is issued after backward '
+                                         'phase 1 and runs under the enhancer\'s backward, the enhancer\'s and D\'s follow at the end', 'ranks': comm}
     if input_side is not None:
         input_side['delta_ms'] = round(input_side['ms_per_step'] - line['ms_per_step'], 3)
         line['input_side'] = input_side

@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 308
+#define RE2E_ABI_VERSION 309
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -286,6 +286,13 @@ size_t re2e_lstm_workspace_bytes(int B, int H);
  * workgroup never published its step (bounded spin; the outputs of such a sequence are NaN).  0 in a healthy run.
  * Synchronises the device; -1 if the counter cannot be read. */
 int re2e_lstm_abort_count(void);
+/* Test hooks (tests/test_dp_gpu.py, tests/test_trainers_gpu.py; no reference counterpart -- the reference is single-device and has no
+ * persistent kernels).  re2e_debug_force_abort(n): the next n persistent FORWARD sequences behave as given up (outputs NaN, the
+ * counter above rises) without running -- what JointTrainer.fit's recovery path is tested with.  re2e_debug_occupy: a kernel of
+ * `workgroups` x 256 threads that holds `lds_bytes` of LDS each and spins for `usec` microseconds on `stream`: what a ring
+ * all-reduce waiting for a slow peer looks like to the workgroup scheduler. */
+int re2e_debug_force_abort(int n);
+int re2e_debug_occupy(int workgroups, int lds_bytes, int usec, re2e_stream_t stream);
 int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
                       const int* lens_dev, int T, int B, int H, void* workspace, size_t workspace_bytes,
                       re2e_stream_t stream);

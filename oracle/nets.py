@@ -147,7 +147,7 @@ def unet_enhance_forward(p, buf, mix, mix_log, lens, num_downs=5, clean=None, co
 def fbank_forward(x, W, cmvn=None):
     n, t = x.size(0), x.size(1)
     y = (x ** 2).reshape(n * t, -1).mm(W).view(n, t, -1)
-    keep = (y > 1e-7)                                   # :130 in-place clamp => zero grad there
+    keep = ~(y <= 1e-7)                                 # :130 in-place clamp `out[out <= 1e-7] = 1e-7` => zero grad there; a NaN is NOT replaced
     y = torch.where(keep, y, torch.full_like(y, 1e-7))
     y = torch.log(y)
     if cmvn is not None:

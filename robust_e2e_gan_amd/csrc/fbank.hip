@@ -123,7 +123,8 @@ __global__ __launch_bounds__(64) void fbank_fwd_mfma_kernel(const float* __restr
   for (int i = 0; i < 16; ++i) {
     const long frame = fg * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
     if (frame >= rows) continue;
-    const float lg = __logf(acc[i] > 1e-7f ? acc[i] : 1e-7f);
+    const float lg = __logf(acc[i] <= 1e-7f ? 1e-7f : acc[i]);     // feat_model.py:130 `out[out <= 1e-7] = 1e-7`: a NaN stays a NaN (`acc > c ? acc : c` and fmaxf drop it -- round 4:
+                                                                  // a NaN enhancer output came out of here as log(1e-7) and the NaN gate never saw it)
     if (y_raw) y_raw[frame * NF + j] = lg;
     if (y_norm) y_norm[frame * NF + j] = (lg + c0) * c1;
     if (pw_out) pw_out[frame * NF + j] = acc[i];
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const float gy = gr[b] + gn[b] * c1[b];
-      g[b] = pp[b] > 1e-7f ? gy / pp[b] : 0.f;           // in-place clamp => zero gradient (feat_model.py:130)
+      g[b] = pp[b] <= 1e-7f ? 0.f : gy / pp[b];          // in-place clamp => zero gradient (feat_model.py:130); a NaN was not clamped
     }
     fetch(base + 8, gr, gn, pp, c1, wv);                 // in flight under the MFMAs; beyond jmax the tap lookups are out of range: zeros
 #pragma unroll
@@ -255,7 +256,7 @@ __global__ void logclamp_fwd_kernel(const float* __restrict__ z, const float* __
   const long tot = rows * N;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) {
     const int j = (int)(i % N);
-    float v = logf(fmaxf(z[i], 1e-7f));
+    float v = logf(z[i] <= 1e-7f ? 1e-7f : z[i]);         // `out[out <= 1e-7] = 1e-7`: a NaN stays a NaN
     if (cmvn) v = (v + cmvn[j]) * cmvn[N + j];
     y[i] = v;
   }
@@ -268,7 +269,7 @@ __global__ void logclamp_bwd_kernel(const float* __restrict__ z, const float* __
     const float zz = z[i];
     float g = dy[i];
     if (cmvn) g *= cmvn[N + j];
-    dz[i] = zz > 1e-7f ? g / zz : 0.f;
+    dz[i] = zz <= 1e-7f ? 0.f : g / zz;
   }
 }
 extern "C" int re2e_logclamp_fwd(const float* z, const float* cmvn, long rows, int N, float* y, hipStream_t stream) {

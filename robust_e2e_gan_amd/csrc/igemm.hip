@@ -749,6 +749,9 @@ int gemm_splits(int transa, int transb, int M, int N, int K) {
   if (transa && !transb) return pick_splits(M, N, K, M >= 2048 ? 256 : 128, 128);
   // x W^T / dy W with few output tiles and a long K (decoder output layer gradient: 1312 x 300 x 4233)
   if ((long)cdiv(M, 128) * cdiv(N, 128) <= 64) return pick_splits(M, N, K, 128, 128);
+  // many rows, few columns, long K (round 4: the CTC projection's input gradient 6400 x 512 x 4240 is 100 tiles of 256x128 on 256 CUs -- 39 % of
+  // the chip at 51 TFLOP/s, 0.55 ms on the path the main stream waits for at the encoder output): K slices fill the round
+  if (M >= 2048 && K >= 1024 && (long)cdiv(M, 256) * cdiv(N, 128) * 20 <= tile_slots(256, 128) * 11) return pick_splits(M, N, K, 256, 128);
   return 1;
 }
 

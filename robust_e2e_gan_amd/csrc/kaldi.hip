@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void kaldi_decode_pad_kernel(const unsigned ch
     if (t < rows) {
       float v = tile[f][tr + 8 * i];
       if (dst_log) {               // mix_data_loader.py:200-203: the clamp is applied in place, so the linear stream sees it too
-        v = fmaxf(v, 1e-7f);
+        v = v < 1e-7f ? 1e-7f : v;            // NaN-propagating, as np.maximum / torch.clamp
         dst_log[o] = (10.f * log10f(v) + m0) * m1;
       }
       dst[o] = v;

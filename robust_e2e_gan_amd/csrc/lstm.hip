@@ -184,7 +184,11 @@ typedef unsigned long long u64;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) u64 gu64;
 __device__ unsigned g_persist_aborts = 0;      // sequences given up because a peer workgroup never published (re2e_lstm_abort_count)
-constexpr unsigned kSpinLimit = 1u << 18;      // polls (~1-2 us each, i.e. ~0.3-0.5 s) before a workgroup gives up on a peer
+// Polls (~0.7-2 us each) before a workgroup gives up on a peer: ~10-30 s.  The bound exists so that a protocol bug hangs nothing; it is
+// NOT a scheduling deadline -- a peer workgroup that is not resident yet (a co-running kernel, e.g. a ring all-reduce waiting for a slow
+// rank that is writing a checkpoint, holds the CU it needs) arrives when that kernel ends, and waiting for it is the right thing to do
+// (rounds 1-3 gave up after ~0.4 s: one slow replica would have ended an 8-GPU job).
+constexpr unsigned kSpinLimit = 1u << 24;
 
 // UW = 2: a workgroup owns 16 hidden units (two 32-column gate tiles): it sweeps the recurrent state ONCE for both, runs two MFMA
 // chains on it, and 512 of its threads apply the cell.  Half as many workgroups sweep (the swept traffic through the fabric
@@ -1366,6 +1370,44 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
 // forward layer): raising the kernel's dynamic-LDS limit loads its code object and reconfigures the function.  re2e_warmup does that
 // for every persistent instantiation up front (no launch, no stream, idempotent), so that the first sequence of a run -- smoke(),
 // short jobs -- runs at the speed of the thousandth.
+// ---- test hooks -------------------------------------------------------------------------------------------------------------
+namespace {
+int g_force_abort = 0;                        // host side: persistent forward sequences still to be "given up" (re2e_debug_force_abort)
+__global__ void forced_abort_kernel(float* ybuf, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ybuf[i] = __uint_as_float(0x7fc00000u);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_persist_aborts, 1u);
+}
+bool forced_abort(hipStream_t st, float* ybuf, int T, int B, int H) {
+  if (g_force_abort <= 0) return false;
+  --g_force_abort;
+  const long n = (long)T * B * 2 * H;
+  hipLaunchKernelGGL(forced_abort_kernel, dim3(1024), dim3(256), 0, st, ybuf + (long)B * 2 * H, n);
+  return true;
+}
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks, float* sink) {
+  extern __shared__ float occ_lds[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+  float x = 0.f;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) { occ_lds[threadIdx.x] = x; x += 1.f; __builtin_amdgcn_s_sleep(8); }
+  if (x < 0.f) sink[0] = occ_lds[0];
+}
+}  // namespace
+
+extern "C" int re2e_debug_force_abort(int n) {
+  RE2E_CHECK_ARG(n >= 0, "n must be >= 0");
+  g_force_abort = n;
+  return RE2E_OK;
+}
+
+extern "C" int re2e_debug_occupy(int workgroups, int lds_bytes, int usec, hipStream_t stream) {
+  RE2E_CHECK_ARG(workgroups > 0 && workgroups <= 4096 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && usec > 0 && usec <= 1000000, "bad argument");
+  static LdsLimit lim;
+  lim.ensure(reinterpret_cast<const void*>(&occupy_kernel), (size_t)lds_bytes);
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, stream, (unsigned long long)usec * 100ull, (float*)nullptr);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
 extern "C" int re2e_warmup(void) {
 #define RE2E_WF(W, Q, U) fwd_lim<W, Q, U>().ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, Q, U>), kOwnCuLds)
   RE2E_WF(8, 8, 2); RE2E_WF(8, 8, 1); RE2E_WF(16, 4, 1); RE2E_WF(8, 5, 1); RE2E_WF(8, 4, 1); RE2E_WF(8, 3, 1); RE2E_WF(4, 4, 1); RE2E_WF(4, 2, 1);
@@ -1408,6 +1450,10 @@ extern "C" int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, c
   float* hfrag = wfrag + (size_t)2 * 4 * H * H;
   void* hxmem = (char*)workspace + fwd_ws_floats(B, H) * sizeof(float);
   long wn = (long)4 * H * H, hn = (long)2 * 2 * cdiv(B, 32) * H * 32;
+  {
+    const char* pv0 = getenv("RE2E_LSTM_PERSIST");                   // test hook: only where a persistent kernel would have run
+    if (!(pv0 && atoi(pv0) == 0) && T >= 2 && forced_abort(stream, ybuf, T, B, H)) { RE2E_LAUNCH_CHECK(); return RE2E_OK; }
+  }
   Fwd2Cfg f2;
   if (fwd2_config(B, H, whh_f, whh_r, f2)) {
     const char* pv = getenv("RE2E_LSTM_PERSIST");

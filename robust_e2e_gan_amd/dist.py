@@ -38,11 +38,48 @@ def shard_indices(n, rank, world):
     return list(range(rank, n, world))
 
 
+# Communication timeline (bench.py --gpus N): with COMM_TIMING on, every gradient all-reduce leaves a record
+# (bytes, event at issue on the issuing stream, event after the collective on RCCL's stream, seen from a stream that waits for it).
+COMM_TIMING = False
+COMM_EVENTS = []
+
+
+class _TimedWork:
+    """A collective's work handle plus the event that marks its completion on the device."""
+
+    def __init__(self, work, rec):
+        self.work, self.rec = work, rec
+
+    def wait(self):
+        self.work.wait()                                 # the current stream now runs behind the collective ...
+        if self.rec.get('done') is None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                                  # ... so this event is its completion as the step sees it
+            self.rec['done'] = ev
+            self.rec['host_wait_called'] = True
+
+
+def comm_report(t0_event):
+    """[(bytes, issue_ms, done_ms)] of the recorded all-reduces relative to ``t0_event``; clears the list.  Call after a device sync."""
+    out = []
+    for r in COMM_EVENTS:
+        if r.get('done') is None:
+            continue
+        out.append((r['bytes'], round(t0_event.elapsed_time(r['issue']), 3), round(t0_event.elapsed_time(r['done']), 3)))
+    del COMM_EVENTS[:]
+    return out
+
+
 def allreduce_mean_(flat, async_op=False):
     """In-place mean over ranks of a flat gradient buffer.  No-op at world_size 1 (no RCCL needed)."""
     if world_size() == 1:
         return None
     if dist.get_backend() == 'nccl':
+        if COMM_TIMING and async_op:
+            rec = {'bytes': flat.numel() * flat.element_size(), 'issue': torch.cuda.Event(enable_timing=True), 'done': None}
+            rec['issue'].record()
+            COMM_EVENTS.append(rec)
+            return _TimedWork(dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True), rec)
         return dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=async_op)
     work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=False)     # gloo (CPU tests): SUM then scale
     flat.div_(world_size())

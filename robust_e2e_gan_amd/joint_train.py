@@ -498,26 +498,34 @@ class JointTrainer(object):
                 vals = self.to_floats(pending)
                 gn = vals.pop('grad_norm', 0.0)
                 if not math.isfinite(gn):             # joint_train.py:189-193: the update was skipped on the device
-                    logging.warning('grad norm is nan. Do not update model.')
+                    # ... either by non-finite numbers of the model's own (upstream: warn and go on), or because a persistent recurrence
+                    # gave up on a peer workgroup and poisoned its outputs: then the step is REPEATED with the launch-per-step kernels
+                    redo = self.recover_aborted_step(pending['_entry']) if pending.get('_entry') is not None else None
+                    if redo is None:
+                        logging.warning('grad norm is nan. Do not update model.')
+                    else:
+                        vals = redo
                 visualizer.set_current_errors(vals)
                 pending = None
 
         def check_recurrences():
-            # a persistent recurrence that gave up on a peer workgroup poisons its outputs with NaN, the NaN gate then skips
-            # every update: training would "run" without learning.  (The query synchronises the device: only called where
-            # the loop reads the meters back anyway.)
-            n = rdist.any_rank(lib.query('re2e_lstm_abort_count'))      # collective: all replicas fail together, none is left in an all-reduce
+            # a persistent recurrence that gave up on a peer workgroup poisons its outputs with NaN, the NaN gate then skips the
+            # update; flush() repeats such a step.  What is left to check here is an abort that did NOT show up as a skipped update.
+            # (The query synchronises the device: only called where the loop reads the meters back anyway.)
+            n = rdist.any_rank(max(0, lib.query('re2e_lstm_abort_count') - self.aborts_seen))      # collective: all replicas fail together
             if n != 0:
                 raise lib.Re2eError('%d recurrent sequences were aborted by a persistent LSTM kernel (a peer workgroup never '
-                                    'arrived); their outputs are NaN and the updates were skipped' % n)
+                                    'arrived) without a skipped update to show for it' % n)
 
         for epoch in range(start_epoch, opt.epochs):
             if train_sampler is not None and epoch > opt.shuffle_epoch:
                 train_sampler.shuffle(epoch)
             for data in loader():
+                entry = (data, sche_samp_rate, enhance_cmvn, self._bn_snapshot())
                 errors = self.step(data, sche_samp_rate, enhance_cmvn)
                 flush()                                   # previous step's meters, now that this step is queued
                 pending = {k: v for k, v in errors.items() if k.startswith('train/') or k == 'grad_norm'}
+                pending['_entry'] = entry
                 iters += 1
                 if iters % opt.print_freq == 0:
                     flush()
@@ -576,6 +584,48 @@ class JointTrainer(object):
                     return iters, best_loss, best_acc
         flush()
         return iters, best_loss, best_acc
+
+    # ---- a persistent recurrence that gave up (csrc/lstm.hip: bounded spins, NaN outputs, re2e_lstm_abort_count) ----------------
+    aborts_seen = 0            # aborts of this process that a repeated step has made good
+    recovered_steps = 0
+
+    def _bn_snapshot(self):
+        """D's BatchNorm running statistics (a few KB): an aborted step feeds them NaN features."""
+        return [b.detach().clone() for b in self.gan_model.buffers()] if self.isGAN else []
+
+    def recover_aborted_step(self, entry):
+        """Called for a step whose update the device-side NaN gate skipped.  If a persistent recurrence gave up during it (on ANY replica: the
+        averaged gradients carried its NaN to all of them, so every replica is here and the agreement below is a collective all of them
+        reach), the step is repeated with the launch-per-step recurrences -- same arithmetic, no in-launch hand-off that can time out --
+        after D's BatchNorm running statistics have been put back.  Returns the repeated step's meters, or None if no recurrence was aborted
+        (the NaN was the model's own).  Raises if the repeated step is not finite either."""
+        data, rate, cmvn, bn = entry
+        mine = max(0, lib.query('re2e_lstm_abort_count') - self.aborts_seen)        # (synchronises the device)
+        if rdist.any_rank(mine) == 0:
+            return None
+        self.aborts_seen += mine
+        if self.recovered_steps == 0:
+            logging.warning('a persistent recurrence gave up on a peer workgroup (%d sequence(s) on this rank): the step is repeated with the '
+                            'launch-per-step kernels.  Further repeats are counted in JointTrainer.recovered_steps', mine)
+        self.recovered_steps += 1
+        if self.isGAN:
+            for b, s in zip(self.gan_model.buffers(), bn):
+                b.copy_(s)
+        saved = {k: os.environ.get(k) for k in ('RE2E_LSTM_PERSIST', 'RE2E_LSTM_PERSIST_BWD')}
+        os.environ['RE2E_LSTM_PERSIST'] = os.environ['RE2E_LSTM_PERSIST_BWD'] = '0'
+        try:
+            vals = self.to_floats({k: v for k, v in self.step(data, rate, cmvn).items() if k.startswith('train/') or k == 'grad_norm'})
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        gn = vals.pop('grad_norm', 0.0)
+        again = max(0, lib.query('re2e_lstm_abort_count') - self.aborts_seen)
+        if rdist.any_rank(1 if (again or not math.isfinite(gn)) else 0):
+            raise lib.Re2eError('a step that a persistent recurrence had aborted is not finite with the launch-per-step kernels either (grad norm %r)' % gn)
+        return vals
 
     @staticmethod
     def to_floats(errors):

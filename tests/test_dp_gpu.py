@@ -114,6 +114,84 @@ def test_allreduce_beside_persistent_recurrence(one_rank_group):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('T,B,H,nocc', [(800, 32, 256, 32), (200, 64, 512, 16), (200, 64, 512, 64)])
+def test_occupied_cus_delay_a_persistent_recurrence_but_never_abort_it(T, B, H, nocc):
+    """What a ring all-reduce that waits for a slow peer looks like to the workgroup scheduler: ``nocc`` workgroups that each hold 64 KB of
+    LDS and spin for 0.5 - 5 ms, launched from a second stream at random offsets while a persistent forward + BPTT runs (the 512-wide
+    layer's grid is every CU of the chip: its workgroups cannot all be resident until the occupiers have left).  No sequence may give up,
+    every output and gradient must be bitwise equal to the undisturbed run, and the delay must stay within the occupiers' own time."""
+    import random
+    import time
+    from robust_e2e_gan_amd import lib, ops
+    I = 64
+    g = torch.Generator().manual_seed(T + H)
+    x0 = torch.randn(T, B, I, generator=g).to(DEV)
+    lens = torch.tensor([T - (3 * b) % (T // 2) for b in range(B)], dtype=torch.int32, device=DEV)
+    lens[0] = T
+    lens, _ = torch.sort(lens, descending=True)
+    ws = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.05).to(DEV))
+          for s in ((4 * H, I), (4 * H, H), (4 * H,), (4 * H,), (4 * H, I), (4 * H, H), (4 * H,), (4 * H,))]
+    dy = torch.randn(T, B, 2 * H, generator=g).to(DEV)
+    side = torch.cuda.Stream()
+    base = lib.query('re2e_lstm_abort_count')
+    rnd = random.Random(5)
+
+    def run(disturb):
+        for p in ws:
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        occ_us = 0
+        if disturb:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(6):                                    # occupiers queued back to back with idle gaps between them
+                    us = rnd.choice((500, 1000, 2500, 5000))
+                    occ_us += us
+                    lib.call('re2e_debug_occupy', nocc, 64 * 1024, us)
+                    lib.call('re2e_debug_occupy', 1, 1024, rnd.choice((200, 700, 1500)))      # a gap: one tiny workgroup
+        y = ops.bilstm(x, lens, ws)
+        (y * dy).sum().backward()
+        torch.cuda.synchronize()
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in ws], time.perf_counter() - t0, occ_us * 1e-6
+    run(False)                                                        # warm-up (first launch of these instantiations)
+    ref, t_alone, _ = run(False)
+    got, t_occ, occ_s = run(True)
+    assert lib.query('re2e_lstm_abort_count') == base, 'a persistent recurrence gave up beside workgroups that only held CUs for a few ms'
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert t_occ <= t_alone + 1.5 * occ_s + 0.02, (t_alone, t_occ, occ_s)
+
+
+def test_comm_timeline_records_every_gradient_allreduce(golden_dir, one_rank_group, monkeypatch):
+    """bench.py --gpus N prints, per rank, when each gradient all-reduce of a step was issued and when the step could continue behind it
+    (dist.COMM_TIMING): on the 1-rank group with world_size() reporting 2 the three buffers of a joint step must each leave a record."""
+    import __graft_entry__ as g
+    from robust_e2e_gan_amd import dist as rdist
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    fx = dict(np.load(os.path.join(golden_dir, 'joint_tiny.npz')))
+    W = dict(np.load(os.path.join(golden_dir, 'fbank_tiny.npz')))['W']
+    t = lambda k: torch.from_numpy(fx[k])
+    data = (None, None, t('clean'), None, t('mix'), t('mix_log'), None, t('targets'), torch.IntTensor(fx['lens']), torch.IntTensor(fx['tlens']))
+    opt = g._tiny_opt()
+    enh, fb, asr, gan = _nets(opt, fx, W)
+    tr = JointTrainer(opt, enh, fb, asr, gan)
+    monkeypatch.setattr(rdist, 'world_size', lambda: 2)
+    tr.step(data, 0.0, t('cmvn'))
+    monkeypatch.setattr(rdist, 'COMM_TIMING', True)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    tr.step(data, 0.0, t('cmvn'))
+    torch.cuda.synchronize()
+    rep = rdist.comm_report(ev0)
+    sizes = sorted(b for b, _, _ in rep)
+    want = sorted(4 * o.grad.numel() for o in (tr.asr_optimizer, tr.enhance_optimizer, tr.gan_optimizer))
+    assert sizes == want, (sizes, want)
+    for _, issued, done in rep:
+        assert 0.0 <= issued <= done
+
+
 def test_sync_batchnorm_equals_global_batch(monkeypatch):
     """ops.SYNC_BN: rank 0's half of a batch, with the all-reduces completed by the OTHER half's contributions (computed here with
     torch), must give the rows of the full-batch BatchNorm + LeakyReLU: output, input gradient, and local parameter-gradient sums that

@@ -173,6 +173,36 @@ def test_fbank():
     close('dx', xg.grad, xr.grad, tol=1e-4)
 
 
+def test_fbank_keeps_a_nan_a_nan():
+    """feat_model.py:130 is torch.clamp(min=1e-7): a NaN bin stays a NaN in every filter that covers it (and the joint step's NaN gate,
+    joint_train.py:189-193, then sees it).  `x > c ? x : c` or fmaxf would turn it into log(1e-7) -- round 4 found the enhancer being
+    updated with NaN gradients behind exactly that."""
+    ops, lib = _ops()
+    from oracle import nets
+    from robust_e2e_gan_amd.model.feat_model import band_from_matrix, mel_matrix
+    W = torch.from_numpy(mel_matrix())
+    x = rnd(2, 40, 257, scale=20.0).abs()
+    x[1, 7, 100] = float('nan')
+    x[0, 33, :] = float('nan')
+    cm = torch.stack([torch.linspace(10, 14, 80), torch.linspace(0.3, 0.6, 80)])
+    ref = nets.fbank_forward(x, W, cm)                    # dense x^2 . W: NaN * 0 = NaN poisons ALL 80 filters of a frame with a NaN bin
+    band = band_from_matrix(W, DEV)
+    _, nrm = ops.fbank(x.to(DEV), band, cm.to(DEV), False, True)
+    got = torch.isnan(nrm.cpu())
+    # the banded kernel multiplies a bin only with the filters of the 32-filter tiles whose bin range holds it: every filter that COVERS a
+    # NaN bin is NaN (and maybe its tile neighbours), never a filter of a frame without one -- between the band-exact and the dense
+    # product's pattern, and never empty where the reference's is not, which is what the NaN gate needs
+    covers = (torch.isnan(x).float() @ (W != 0).float()) > 0
+    assert (covers <= got).all() and (got <= torch.isnan(ref)).all() and got[0, 33].all() and int(got[1, 7].sum()) > 0
+    assert torch.equal(got.any(-1), torch.isnan(ref).any(-1))
+    ok = ~torch.isnan(ref)
+    close('finite part', nrm.cpu()[ok], ref[ok], tol=1e-5)
+    z = (x * x) @ W
+    y = torch.empty(2, 40, 80, device=DEV)
+    lib.call('re2e_logclamp_fwd', z.to(DEV).contiguous().data_ptr(), cm.to(DEV).data_ptr(), 80, 80, y.data_ptr())      # the trainable-matrix path's kernel
+    assert torch.equal(torch.isnan(y.cpu()), torch.isnan(ref))
+
+
 @pytest.mark.parametrize('kind', [0, 1, 2])
 def test_mean_loss(kind):
     ops, lib = _ops()

@@ -513,3 +513,60 @@ def test_fit_with_device_prefetcher_equals_collated_loader(tmp_path):
         finals.append({k: v.clone() for m in (enh, asr, gan) for k, v in m.state_dict().items()})
     for k, v in finals[0].items():
         assert torch.equal(v, finals[1][k]), k
+
+
+def test_fit_repeats_a_step_whose_recurrence_was_aborted(tmp_path):
+    """A persistent recurrence that gives up poisons its outputs; the device-side NaN gate skips the update.  JointTrainer.fit must then
+    repeat that step with the launch-per-step recurrences (after putting D's BatchNorm running statistics back), count it, and end where
+    an undisturbed run ends: four steps on the same batch, the second one aborted by the test hook re2e_debug_force_abort."""
+    from robust_e2e_gan_amd import lib
+    from robust_e2e_gan_amd.data.synthetic import make_batch
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    import __graft_entry__ as g
+
+    class Quiet(object):
+        def __getattr__(self, name):
+            return lambda *a, **k: 0.0
+
+    def run(abort_at):
+        opt = g._tiny_opt()
+        for k, v in dict(exp_path=str(tmp_path), print_freq=100, validate_freq=100, epochs=1, shuffle_epoch=100, criterion='acc', eps_decay=0.01,
+                         sche_samp_start_iter=300, sche_samp_final_iter=600, sche_samp_final_rate=0.0, train_dataset_len=3, num_utt_cmvn=3).items():
+            setattr(opt, k, v)
+        torch.manual_seed(11)
+        enh, fb, asr, gan = (m.to(DEV).train() for m in (EnhanceModel(opt), FbankModel(opt), ShareE2E(opt), GANModel(opt)))
+        clean, mix, mix_log, targets, il, tl = make_batch(3, 40, 4, opt.odim, seed=5)
+        b = (['u%d' % i for i in range(3)], None, clean, None, mix, mix_log, None, targets, il, tl)
+        tr = JointTrainer(opt, enh, fb, asr, gan)
+        base = lib.query('re2e_lstm_abort_count')
+        tr.aborts_seen = base                                  # (the counter is per process: earlier tests may have raised it)
+        n = [0]
+        orig = tr.step
+
+        def step(data, rate, cmvn):
+            n[0] += 1
+            if n[0] == abort_at:
+                lib.query('re2e_debug_force_abort', 1)         # the next persistent forward sequence "gives up"
+            return orig(data, rate, cmvn)
+        tr.step = step
+        iters, _, _ = tr.fit([b, b, b, b], [], Quiet())
+        torch.cuda.synchronize()
+        assert iters == 4
+        state = {k: v.detach().clone() for m in (enh, asr, gan) for k, v in m.state_dict().items()}
+        return tr, state, n[0], lib.query('re2e_lstm_abort_count') - base
+    try:
+        _, ref, calls, aborts = run(None)
+        assert calls == 4 and aborts == 0
+        tr, got, calls, aborts = run(2)
+        assert aborts == 1 and tr.recovered_steps == 1 and calls == 5          # four steps + the repeated one
+        for k in ref:
+            assert torch.isfinite(got[k].float()).all(), k
+            if 'running_' in k or 'num_batches' in k:
+                continue          # D's BatchNorm running statistics are an order-dependent moving average: put back, then fed steps 2', 4 instead of 2, 3, 4
+            rel(k, got[k].float(), ref[k].float().cpu().numpy(), tol=2e-4, atol=1e-6)
+    finally:
+        lib.query('re2e_debug_force_abort', 0)
