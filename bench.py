@@ -501,7 +501,7 @@ def main():
         gbatch = make_batch(B, T, L, opt.odim, seed=1234)                       # the SAME global batch on every rank
         # ONE batch over the ranks: the discriminator's BatchNorm statistics are those of the global batch (synchronised BatchNorm:
         # three small all-reduces per layer and pass) when the shards are equal; ragged shards keep per-rank statistics
-        opt.sync_bn = world > 1 and B % world == 0
+        opt.sync_bn = world > 1 and B % world == 0 and a.config in (4, 5)      # (JointTrainer implements it; config 3's trainer keeps per-rank statistics)
         batch = shard_batch(gbatch, rdist.shard_indices(B, rank, world), L)
         global_b = B
     else:

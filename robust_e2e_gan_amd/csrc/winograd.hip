@@ -366,6 +366,7 @@ extern "C" int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, c
                        reinterpret_cast<uintptr_t>(pool_out) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(workspace);
   if ((al & 15) || (reinterpret_cast<uintptr_t>(pool_idx) & 3)) { re2e_set_error("re2e_conv3x3_wino: operands must be 16-byte aligned"); return RE2E_EUNSUPPORTED; }
   RE2E_CHECK_ARG(workspace_bytes >= (size_t)u_bytes, "workspace too small");
+  if ((Cout / WNT) & (Cout / WNT - 1)) { re2e_set_error("re2e_conv3x3_wino: Cout / 64 must be a power of two (got Cout = %d)", Cout); return RE2E_EUNSUPPORTED; }
   float* uf = (float*)workspace;
   const long total = (long)16 * C * Cout;
   hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)(cdiv(total, 256) > 2048 ? 2048 : cdiv(total, 256))), dim3(256), 0, stream, w, Cout, C, dgrad, uf);

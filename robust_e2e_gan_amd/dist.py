@@ -94,6 +94,13 @@ def allreduce_sum_(t):
     return t
 
 
+def allreduce_max_(t):
+    """In-place MAX over ranks of a small device tensor.  No-op at world_size 1 or without a process group."""
+    if world_size() > 1 and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
 def any_rank(flag_value):
     """max over ranks of a small non-negative host integer (an error count / flag).  Collective: EVERY rank must call it at the
     same point.  Used so that a failure seen by one replica raises on all of them -- a lone raise would leave the others blocked

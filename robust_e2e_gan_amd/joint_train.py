@@ -76,7 +76,7 @@ class JointTrainer(object):
         # eval mode as well (e2e_ctc.py:51), so the training masks after a validation pass depend on validate_freq -- upstream's
         # global RNG has the same property.
         if any(float(getattr(opt, k, 0.0) or 0.0) > 0.0 for k in ('dropout_rate', 'enhance_dropout_rate')):
-            ops.dropout_seed((int(getattr(opt, 'seed', 1234)) * 1000003 + rdist.rank()) & 0xFFFFFFFFFFFF)
+            ops.dropout_seed(self._dropout_stream_seed(int(getattr(opt, 'seed', 1234))))
         # run the D passes on a side HIP stream under the latency-bound recurrent chains (RE2E_NO_OVERLAP=1: profiling)
         self.overlap_dstep = os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
         self.marks = [] if os.environ.get('RE2E_TIMELINE') else None
@@ -640,15 +640,40 @@ class JointTrainer(object):
               'eps': self.opt.eps, 'lr': self.opt.lr, 'best_loss': best_loss, 'best_acc': best_acc, 'acc_report': None, 'loss_report': None}
         if self.isGAN:
             st['gan_state_dict'] = self.gan_model.state_dict()
-        st['dropout_state'] = ops.dropout_state()          # (seed, index of the next mask); not an upstream key
+        # the dropout mask stream: the BASE seed (opt.seed) and the index of the next mask -- not the writing rank's own stream seed, which
+        # every replica would otherwise inherit on resume (the index is the same on all ranks: they make the same calls); not an upstream key
+        st['dropout_state'] = {'base_seed': int(getattr(self.opt, 'seed', 1234)), 'call': int(ops.dropout_state()[1])}
         return st
 
     @staticmethod
-    def restore_dropout(package):
-        """Continue the dropout mask stream of a checkpoint written by ``state()`` (no-op for checkpoints without the key)."""
+    def _dropout_stream_seed(base_seed):
+        """One mask stream per process: replicas draw different masks, as upstream's per-process RNG would."""
+        return (int(base_seed) * 1000003 + rdist.rank()) & 0xFFFFFFFFFFFF
+
+    @classmethod
+    def restore_dropout(cls, package):
+        """Continue the dropout mask stream of a checkpoint written by ``state()``: this rank's stream (re-derived from the base seed) at the
+        saved mask index.  No-op for checkpoints without the key; a (seed, index) pair of an older checkpoint is taken as it is."""
         ds = package.get('dropout_state') if isinstance(package, dict) else None
-        if ds is not None:
+        if isinstance(ds, dict):
+            ops.dropout_seed(cls._dropout_stream_seed(ds['base_seed']), int(ds['call']))
+        elif ds is not None:
             ops.dropout_seed(int(ds[0]), int(ds[1]))
+
+    def load_state(self, package):
+        """Counterpart of ``state()`` (upstream: the ``--joint_resume`` branch, joint_train.py:73-103): the networks' state_dicts, eps / lr
+        into ``opt``, and the dropout mask stream.  Returns (epoch, iters, best_loss, best_acc)."""
+        self.asr_model.load_state_dict(package['asr_state_dict'])
+        self.feat_model.load_state_dict(package['fbank_state_dict'])
+        self.enhance_model.load_state_dict(package['enhance_state_dict'])
+        if self.isGAN and 'gan_state_dict' in package:
+            self.gan_model.load_state_dict(package['gan_state_dict'])
+        for k in ('eps', 'lr'):
+            if k in package:
+                setattr(self.opt, k, package[k])
+        self.restore_dropout(package)
+        return (int(package.get('epoch', 0)), int(package.get('iters', 0)), float(package.get('best_loss', float('inf'))),
+                float(package.get('best_acc', 0.0)))
 
 
 def config4_opt(**over):

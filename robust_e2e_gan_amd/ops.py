@@ -497,11 +497,30 @@ WINOGRAD = lib.exp_env('RE2E_NO_WINOGRAD') is None
 WINO_WGRAD = lib.exp_env('RE2E_NO_WINO_WGRAD') is None      # A/B switch (RE2E_EXPERIMENTS=1): the direct halo-patch / engine kernels instead
 
 
+_WINO_DECLINED = set()
+
+
+def _wino_note(kind, N, H, Wd, C, Cout):
+    """One line on stderr the first time a 3x3 / 4x4 layer that looks like a Winograd layer is declined for its SIZE (>= 2 GiB tensors:
+    B >= 64 per GPU at T = 800): the direct kernels that take it over are 1.5 - 2x slower and nothing else would say so."""
+    if kind not in _WINO_DECLINED:
+        _WINO_DECLINED.add(kind)
+        import sys
+        print('[re2e] note: %s convolution %dx%dx%d, %d -> %d channels is left to the direct kernels (tensors of 2 GiB or more: the '
+              'fused Winograd kernels address with 31-bit offsets); shard the batch further to get them back' % (kind, N, H, Wd, C, Cout),
+              file=sys.stderr, flush=True)
+
+
 def _wino_ok(N, H, Wd, C, Cout, k, stride, pad):
-    """3x3 / stride-1 / pad-1 layers the fused Winograd F(2x2,3x3) kernel covers (re2e_conv3x3_wino: C % 8 == 0, Cout % 64 == 0,
-    tensors < 2 GiB)."""
-    return (WINOGRAD and k == (3, 3) and stride == 1 and pad == 1 and C % 8 == 0 and Cout % 64 == 0
-            and N * H * Wd * max(C, Cout) * 4 < 2 ** 31 - 256)
+    """3x3 / stride-1 / pad-1 layers the fused Winograd F(2x2,3x3) kernel covers (re2e_conv3x3_wino: C % 8 == 0, Cout / 64 a power of
+    two -- 192 or 320 output channels stay with the direct engine --, tensors < 2 GiB)."""
+    g = Cout // 64
+    if not (WINOGRAD and k == (3, 3) and stride == 1 and pad == 1 and C % 8 == 0 and Cout % 64 == 0 and g & (g - 1) == 0):
+        return False
+    if N * H * Wd * max(C, Cout) * 4 >= 2 ** 31 - 256:
+        _wino_note('3x3', N, H, Wd, C, Cout)
+        return False
+    return True
 
 
 def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool=False):
@@ -864,6 +883,24 @@ def _sync_world():
     return rdist.world_size() if SYNC_BN else 1
 
 
+_SYNC_BN_CHECKED = set()
+
+
+def _sync_rows_checked(Pn, C, device):
+    """Synchronised BatchNorm takes the global row count as rows x world (no per-step host sync for a count): true for equal shards only.
+    Checked ONCE per (rows, channels) shape with a MAX all-reduce of (rows, -rows); ragged shards raise instead of normalising with wrong
+    statistics (every rank raises: the reduced pair is the same everywhere)."""
+    key = (Pn, C)
+    if key in _SYNC_BN_CHECKED:
+        return
+    from . import dist as rdist
+    hi, nlo = rdist.allreduce_max_(torch.tensor([float(Pn), -float(Pn)], device=device)).tolist()
+    if hi != -nlo:
+        raise lib.Re2eError('synchronised BatchNorm needs the same number of rows on every rank (this rank %d, the ranks span %d..%d): shard '
+                            'equal utterance counts of equal padded length, or leave opt.sync_bn off' % (Pn, int(-nlo), int(hi)))
+    _SYNC_BN_CHECKED.add(key)
+
+
 class BnLreluFn(torch.autograd.Function):
     """BatchNorm2d (train-mode statistics, running-stat update) + LeakyReLU(0.2) over NHWC.  With ``SYNC_BN`` in a data-parallel run the
     statistics are those of the GLOBAL batch: three small all-reduces per layer and step (sum x; sum (x - mean)^2; sum dz | sum dz xhat),
@@ -884,6 +921,7 @@ class BnLreluFn(torch.autograd.Function):
         ctx.ptot = Pn
         if world > 1:
             from . import dist as rdist
+            _sync_rows_checked(Pn, C, x.device)
             acc = empty((C,), x)
             call('re2e_bn_sync_partial', x.data_ptr(), Pn, C, None, 0, acc.data_ptr(), ws.data_ptr(), wsb)
             rdist.allreduce_sum_(acc)

@@ -150,6 +150,19 @@ def test_dropout_stream_is_checkpointed():
     assert ops.dropout_state() == (99, 17)
     JointTrainer.restore_dropout({})                   # checkpoints without the key: untouched
     assert ops.dropout_state() == (99, 17)
+    # what state() writes since round 4: the BASE seed and the mask index; every rank re-derives ITS stream from them (a checkpoint is
+    # written by rank 0: restoring its own stream seed would give every replica rank 0's masks)
+    from robust_e2e_gan_amd import dist as rdist
+    seeds = []
+    for r in (0, 3):
+        orig = rdist.rank
+        rdist.rank = lambda r=r: r
+        try:
+            JointTrainer.restore_dropout({'dropout_state': {'base_seed': 1234, 'call': 41}})
+        finally:
+            rdist.rank = orig
+        seeds.append(ops.dropout_state())
+    assert seeds[0] == ((1234 * 1000003 + 0) & 0xFFFFFFFFFFFF, 41) and seeds[1] == ((1234 * 1000003 + 3) & 0xFFFFFFFFFFFF, 41)
 
 
 def test_filterbank_band_tables_rebuild_the_matrix():

@@ -570,3 +570,60 @@ def test_fit_repeats_a_step_whose_recurrence_was_aborted(tmp_path):
             rel(k, got[k].float(), ref[k].float().cpu().numpy(), tol=2e-4, atol=1e-6)
     finally:
         lib.query('re2e_debug_force_abort', 0)
+
+
+# ---- InstanceNorm variants against vectors from the reference import (tests/golden/make_fixtures_n4c.py, round 4) ----
+def test_instance_norm_discriminator_vs_reference(golden_dir):
+    """--norm_D instance (gan_model.py:42-46,57): InstanceNorm2d(affine=False) between biased convolutions, against the reference's own run:
+    output, LSGAN real / fake losses, input gradient and every parameter gradient.  (A bias in front of an InstanceNorm has an exactly-zero
+    gradient: both sides hold rounding noise there, so those are held to the network's largest gradient, not their own.)"""
+    import argparse
+    from robust_e2e_gan_amd.model.gan_model import GANModel, GANLoss
+    fx = _fx(golden_dir, 'n4c_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), 'norm_D': 'instance'})
+    gan = _load(GANModel(opt), fx, 'ind.p.')
+    assert not any('running' in k for k in gan.state_dict())
+    crit = GANLoss(use_lsgan=True)
+    x = torch.from_numpy(fx['feats']).to(DEV).requires_grad_(True)
+    d = gan(x)
+    rel('ind.d_out', d, fx['ind.d_out'])
+    lr = crit(d, True)
+    lf = crit(gan(x * 0.9 + 0.1), False)
+    rel('ind.l_real', lr.view(1), fx['ind.l_real'])
+    rel('ind.l_fake', lf.view(1), fx['ind.l_fake'])
+    ((lr + lf) * 0.5).backward()
+    rel('ind.dx', x.grad, fx['ind.dx'], tol=3e-3)
+    gscale = max(float(np.abs(fx[k]).max()) for k in fx if k.startswith('ind.g.'))
+    for k, p in gan.named_parameters():
+        ref = fx['ind.g.' + k]
+        err = float(np.abs(p.grad.detach().cpu().numpy() - ref).max())
+        assert err <= 3e-3 * max(float(np.abs(ref).max()), 1e-2 * gscale), (k, err)
+
+
+def test_instance_norm_unet_vs_reference(golden_dir):
+    """--enhance_norm instance (enhance_model.py:258-261): the pix2pix U-Net with InstanceNorm2d(affine=False) and biased convolutions against
+    the reference's own run: mask product, mask-L1 loss, every gradient."""
+    import argparse
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    fx = _fx(golden_dir, 'n4c_tiny.npz')
+    opt = argparse.Namespace(**{**vars(_opt()), 'enhance_type': 'unet_128', 'idim': 32, 'enhance_input_nc': 1, 'enhance_output_nc': 1,
+                                'enhance_ngf': 4, 'enhance_norm': 'instance'})
+    enh = _load(EnhanceModel(opt), fx, 'inu.p.')
+    assert not any('running' in k for k in enh.state_dict())
+    t = lambda k: torch.from_numpy(fx['inu.' + k])
+    lens = torch.IntTensor(fx['inu.lens'])
+    out = enh(t('mix'), t('mix_log').unsqueeze(1), lens)
+    rel('inu.enhance_out', out, fx['inu.enhance_out'])
+    loss, out2 = enh(t('mix'), t('mix_log').unsqueeze(1), lens, t('clean'), t('cos'))
+    rel('inu.l1_loss', loss.view(1), fx['inu.l1_loss'])
+    (loss + (out2 * torch.linspace(0.5, 1.5, 32).to(DEV)).mean()).backward()
+    named = dict(enh.named_parameters())
+    gscale = max(float(np.abs(fx[k]).max()) for k in fx if k.startswith('inu.g.'))
+    n = 0
+    for k in fx:
+        if k.startswith('inu.g.'):
+            g = named[k[len('inu.g.'):]].grad
+            err = float(np.abs(g.detach().cpu().numpy() - fx[k]).max())
+            assert err <= 3e-3 * max(float(np.abs(fx[k]).max()), 1e-2 * gscale), (k, err)
+            n += 1
+    assert n >= len(named) - 1          # (the reference leaves one parameter without a gradient: not in the fixture)
