@@ -1,6 +1,9 @@
 """Module-surface parity on the GPU against the golden vectors produced from the reference import
 (tests/golden/*.npz) -- EnhanceModel, FbankModel, E2E, GANModel/GANLoss and one composed
-joint_train step.  Calls go through the C ABI (libre2e_hip.so).  Tolerance 1e-3 (north_star)."""
+joint_train step.  Calls go through the C ABI (libre2e_hip.so).  Tolerance 1e-3 (north_star) on outputs and losses; gradients are held to
+1.5e-3 of each tensor's largest entry (round 4: tightened from 3e-3 / 4e-3 -- the largest measured ratio over every comparison of this file
+and tests/test_trainers_gpu.py is 1.0e-3, RE2E_PRINT_WORST=1 prints them; the fp64 arbitration of test_joint_step_gradients_vs_fp64_reference
+shows the fp32 reference run itself up to 5.3e-4 away from the fp64 one, so two fp32 runs of one gradient legitimately differ by ~1e-3)."""
 import os
 
 import numpy as np
@@ -26,11 +29,19 @@ def _load(m, fx, prefix):
     return m.to(DEV).train()
 
 
+WORST = {}         # name -> err / scale of every comparison of the session (tools: RE2E_PRINT_WORST=1 prints the largest at exit)
+
+
 def rel(name, got, ref, tol=1e-3, atol=1e-7):
     got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     ref = np.asarray(ref)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     err = np.abs(got - ref).max()
+    if os.environ.get('RE2E_PRINT_WORST'):
+        WORST[name] = max(WORST.get(name, 0.0), float(err / max(np.abs(ref).max(), 1e-30)))
+        import atexit
+        if len(WORST) == 1:
+            atexit.register(lambda: print('WORST', sorted(((v, k) for k, v in WORST.items() if v > 3e-4), reverse=True)[:25]))
     assert np.isfinite(err) and err <= tol * np.abs(ref).max() + atol, '%s: err %.3e scale %.3e' % (name, err, np.abs(ref).max())
 
 
@@ -100,9 +111,9 @@ def test_e2e(golden_dir):
     rel('loss_att', la.view(()), fx['loss_att'])
     assert abs(float(acc) - float(fx['acc'])) < 1e-6
     (0.5 * lc.view(()) + 0.5 * la).backward()
-    rel('dfeat', feat.grad, fx['dfeat'], tol=3e-3)
+    rel('dfeat', feat.grad, fx['dfeat'], tol=1.5e-3)
     for k, p in m.named_parameters():
-        rel('g.' + k, p.grad, fx['g.' + k], tol=3e-3)
+        rel('g.' + k, p.grad, fx['g.' + k], tol=1.5e-3)
 
 
 def test_gan(golden_dir):
@@ -118,9 +129,9 @@ def test_gan(golden_dir):
     rel('l_real', lr.view(()), fx['l_real'])
     rel('l_fake', lf.view(()), fx['l_fake'])
     ((lr + lf) * 0.5).backward()
-    rel('dx', x.grad, fx['dx'], tol=3e-3)
+    rel('dx', x.grad, fx['dx'], tol=1.5e-3)
     for k, p in m.named_parameters():
-        rel('g.' + k, p.grad, fx['g.' + k], tol=3e-3)
+        rel('g.' + k, p.grad, fx['g.' + k], tol=1.5e-3)
     for k, v in m.state_dict().items():
         if 'running' in k or 'num_batches' in k:
             rel('after.' + k, v, fx['after.' + k], tol=1e-4)
@@ -155,7 +166,7 @@ def test_joint_step(golden_dir):
     assert abs(out['grad_norm'] - float(fx['grad_norm_asr'])) <= 2e-3 * float(fx['grad_norm_asr'])
     for pre, m in (('genh.', enh), ('gasr.', asr), ('ggan.', gan)):
         for k, p in m.named_parameters():
-            rel(pre + k, p.grad, fx[pre + k], tol=3e-3)
+            rel(pre + k, p.grad, fx[pre + k], tol=1.5e-3)
     for pre, m in (('enh_after.', enh), ('asr_after.', asr), ('gan_after.', gan)):
         for k, v in m.state_dict().items():
             if v.dtype.is_floating_point:
@@ -277,7 +288,7 @@ def test_joint_step_without_gan_vs_oracle(golden_dir, overlap):
     for pre, m, gd in (('enh', enh, ref['g_enh']), ('asr', asr, ref['g_asr'])):
         for k, p in m.named_parameters():
             if k in gd:
-                rel(pre + '.' + k, p.grad, gd[k].numpy(), tol=3e-3, atol=1e-7)
+                rel(pre + '.' + k, p.grad, gd[k].numpy(), tol=1.5e-3, atol=1e-7)
 
 
 @pytest.mark.parametrize('lens,tls', [([33], [1]), ([37, 6], [2, 1]), ([33, 33, 32, 17, 5], [4, 1, 3, 2, 1]), ([64, 8], [7, 1])])
@@ -323,7 +334,7 @@ def test_joint_step_ragged_shapes_vs_oracle(golden_dir, lens, tls):
     for pre, m, gd in (('enh', enh, ref['g_enh']), ('asr', asr, ref['g_asr']), ('gan', gan, ref['g_gan'])):
         for k, p in m.named_parameters():
             if k in gd:
-                rel(pre + '.' + k, p.grad, gd[k].numpy(), tol=4e-3, atol=1e-7)
+                rel(pre + '.' + k, p.grad, gd[k].numpy(), tol=2e-3, atol=1e-7)
 
 
 def test_instance_norm_discriminator_vs_torch():
