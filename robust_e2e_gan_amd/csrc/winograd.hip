@@ -204,6 +204,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
 
+    // (Round 4, measured and rejected: not clearing the accumulators -- the first chunk peeled off with the constant 0 as the C operand of its
+    // first MFMA per tile, 128 v_mov per work item less: conv1_2 1.422 -> 1.445 ms, conv2_1 0.716 -> 0.724, conv2_2 unchanged, two A/B
+    // rounds in one session; the second copy of the loop body costs more than the moves.)
     // The chunk loop has no branch -- the very last chunk of the workgroup re-fetches itself instead of fetching nothing -- so the
     // compiler's s_waitcnt counts stay exact: a wait only covers the loads it needs, never the ones issued a few instructions
     // earlier.  (Measured and rejected, same GPU session: a two-chunk-deep pipeline that transforms chunk k + 1's pixels between the third

@@ -282,6 +282,10 @@ class JointTrainer(object):
             self._mark('bwd phase 1 (ASR, D, fbank)')
             ev_bwd1 = torch.cuda.Event()
             ev_bwd1.record(main)
+            phase2_first = lib.exp_env('RE2E_PHASE2_FIRST', '0') == '1' and rdist.world_size() == 1     # experiment: enqueue order only
+            if phase2_first:
+                enhance_out.backward(g_eo)
+                self._mark('bwd phase 2 (enhancer)')
             if cut is not None and gs[1] is not None:
                 # the clean branch's conv-stack backward (reached through CORAL and the shared BLSTMP): side stream, not
                 # joined into main before the enhancer's backward chain starts -- it runs under that chain
@@ -325,8 +329,9 @@ class JointTrainer(object):
                     sync.pending.append(work)
                 armed = True
             # Phase 2: the enhancer backward chain on the main stream.
-            enhance_out.backward(g_eo)
-            self._mark('bwd phase 2 (enhancer)')
+            if not phase2_first:
+                enhance_out.backward(g_eo)
+                self._mark('bwd phase 2 (enhancer)')
             if self.marks is not None:
                 with torch.cuda.stream(self.wgrad_stream):
                     self._mark('  wgrad stream: all weight gradients done')
