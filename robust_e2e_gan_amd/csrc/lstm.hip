@@ -190,6 +190,10 @@ __device__ unsigned g_persist_aborts = 0;      // sequences given up because a p
 // (rounds 1-3 gave up after ~0.4 s: one slow replica would have ended an 8-GPU job).
 constexpr unsigned kSpinLimit = 1u << 24;
 
+// (Round 4, measured and rejected for THIS kernel: lstm_fwd2's exchange -- 4-byte values with a one-bit tag, one piece per producer polled,
+// then one sweep, 16-byte stores -- in place of the granules: half the bytes through the fabric and the same rate alone at 64 workgroups (3.27
+// against 3.24 us per step at H = 256 / B = 32; 5.0 against 6.2 at H = 512 / B = 64, where lstm_fwd2 runs anyway), but the training step
+// loses 0.4 ms with it (56.3 against 55.9, two A/B rounds); consuming the k-groups in arrival order on top of it: 3.55-3.72 alone.)
 // UW = 2: a workgroup owns 16 hidden units (two 32-column gate tiles): it sweeps the recurrent state ONCE for both, runs two MFMA
 // chains on it, and 512 of its threads apply the cell.  Half as many workgroups sweep (the swept traffic through the fabric
 // halves) and the 512-wide layers' grid fits half of the chip, so it can reserve its CUs like the narrower layers do (the
