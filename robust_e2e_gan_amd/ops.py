@@ -886,18 +886,20 @@ def _sync_world():
 _SYNC_BN_CHECKED = set()
 
 
-def _sync_rows_checked(Pn, C, device):
+def _sync_rows_checked(Pn, C, sums):
     """Synchronised BatchNorm takes the global row count as rows x world (no per-step host sync for a count): true for equal shards only.
-    Checked ONCE per (rows, channels) shape with a MAX all-reduce of (rows, -rows); ragged shards raise instead of normalising with wrong
-    statistics (every rank raises: the reduced pair is the same everywhere)."""
+    The first all-reduce of a layer carries (rows, rows^2) of every rank behind its C sums -- the SAME collective on every rank whatever
+    each has seen before --, and the first time THIS rank meets a (rows, channels) shape it reads the two reduced numbers back (one host
+    sync per shape) and refuses ragged shards instead of normalising with wrong statistics."""
     key = (Pn, C)
     if key in _SYNC_BN_CHECKED:
         return
     from . import dist as rdist
-    hi, nlo = rdist.allreduce_max_(torch.tensor([float(Pn), -float(Pn)], device=device)).tolist()
-    if hi != -nlo:
-        raise lib.Re2eError('synchronised BatchNorm needs the same number of rows on every rank (this rank %d, the ranks span %d..%d): shard '
-                            'equal utterance counts of equal padded length, or leave opt.sync_bn off' % (Pn, int(-nlo), int(hi)))
+    world = rdist.world_size()
+    s1, s2 = sums.tolist()
+    if s1 != float(Pn) * world or s2 != float(Pn) * float(Pn) * world:
+        raise lib.Re2eError('synchronised BatchNorm needs the same number of rows on every rank (this rank %d, the ranks sum to %d over %d): '
+                            'shard equal utterance counts of equal padded length, or leave opt.sync_bn off' % (Pn, int(s1), world))
     _SYNC_BN_CHECKED.add(key)
 
 
@@ -921,12 +923,13 @@ class BnLreluFn(torch.autograd.Function):
         ctx.ptot = Pn
         if world > 1:
             from . import dist as rdist
-            _sync_rows_checked(Pn, C, x.device)
-            acc = empty((C,), x)
+            acc = empty((C + 2,), x)                                          # C sums | rows, rows^2 of this rank (see _sync_rows_checked)
             call('re2e_bn_sync_partial', x.data_ptr(), Pn, C, None, 0, acc.data_ptr(), ws.data_ptr(), wsb)
+            acc[C:].copy_(torch.tensor([float(Pn), float(Pn) * float(Pn)]), non_blocking=True)
             rdist.allreduce_sum_(acc)
+            _sync_rows_checked(Pn, C, acc[C:])
             ptot = Pn * world                                                 # equal shards (bench.py --scaling strong): no host sync for a count
-            mean = acc / float(ptot)
+            mean = (acc[:C] / float(ptot)).contiguous()
             var = empty((C,), x)
             call('re2e_bn_sync_partial', x.data_ptr(), Pn, C, mean.data_ptr(), 1, var.data_ptr(), ws.data_ptr(), wsb)
             rdist.allreduce_sum_(var)

@@ -133,3 +133,57 @@ def test_dp_is_mean_of_shard_gradients_world2():
         assert abs(nr - nw) < 1e-5 * nw
     assert abs(res[0][2] - res[1][2]) < 1e-6 * res[0][2]            # both replicas clip with the same norm
     assert abs(res[0][4] - res[1][4]) > 1e-3 * res[0][4]            # ... although their own shards' norms differ
+
+
+def _sync_rows_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from robust_e2e_gan_amd import dist as rdist
+    from robust_e2e_gan_amd import lib, ops
+    rdist.init_from_env()
+    out = {}
+    t = rdist.allreduce_max_(torch.tensor([float(rank), -float(rank)]))
+    out['max'] = t.tolist()
+    def reduced(pn):                                                        # what BnLreluFn's first all-reduce carries behind its C sums
+        return rdist.allreduce_sum_(torch.tensor([float(pn), float(pn) ** 2]))
+    ops._sync_rows_checked(96, 8, reduced(96))                              # equal rows on both ranks: passes, and is remembered
+    out['equal_ok'] = (96, 8) in ops._SYNC_BN_CHECKED
+    # ragged shards: rank 0 has seen its shape before, rank 1 has not -- the collective is the same on both, only rank 1 looks at it ...
+    pn = 96 + 16 * rank
+    try:
+        ops._sync_rows_checked(pn, 8, reduced(pn))
+        out['ragged'] = 'no error'
+    except lib.Re2eError as e:
+        out['ragged'] = 'raised' if 'sum to 208' in str(e) else str(e)
+    # ... and a rank that meets a NEW shape beside a ragged peer raises too
+    pn2 = 48 + 16 * rank
+    try:
+        ops._sync_rows_checked(pn2, 8, reduced(pn2))
+        out['ragged2'] = 'no error'
+    except lib.Re2eError:
+        out['ragged2'] = 'raised'
+
+    # the dropout stream of a checkpoint written by rank 0 is re-derived per rank
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    JointTrainer.restore_dropout({'dropout_state': {'base_seed': 7, 'call': 5}})
+    out['dropout'] = ops.dropout_state()
+    q.put((rank, out))
+    torch.distributed.destroy_process_group()
+
+
+def test_sync_bn_row_check_and_per_rank_dropout_stream_world2():
+    """Round 4 (advisor findings): synchronised BatchNorm refuses ragged shards on every rank at once; a checkpoint's dropout state
+    (base seed, mask index) gives each rank ITS stream back."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29850 + os.getpid() % 100
+    ps = [ctx.Process(target=_sync_rows_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        o = res[rank]
+        assert o['max'] == [1.0, 0.0] and o['equal_ok'] and o['ragged'] == ('raised' if rank == 1 else 'no error') and o['ragged2'] == 'raised', o
+        assert o['dropout'] == ((7 * 1000003 + rank) & 0xFFFFFFFFFFFF, 5)

@@ -220,7 +220,10 @@ def test_sync_batchnorm_equals_global_batch(monkeypatch):
     calls = []
 
     def fake_allreduce(t):
-        t.add_(other[len(calls)].float().to(t.device))
+        o = other[len(calls)].float().to(t.device)
+        t[:o.numel()].add_(o)
+        if t.numel() == o.numel() + 2:                    # the first all-reduce also carries (rows, rows^2) of every rank
+            t[o.numel():].add_(torch.tensor([float(P - half), float(P - half) ** 2], device=t.device))
         calls.append(t.numel())
         return t
     monkeypatch.setattr(rdist, 'world_size', lambda: 2)
@@ -231,7 +234,7 @@ def test_sync_batchnorm_equals_global_batch(monkeypatch):
     rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     y = ops.bn_lrelu(xa, ga, ba, rm, rv, True, 0.1, eps, slope)
     (y * w[:N // 2].to(DEV)).sum().backward()
-    assert calls == [C, C, 2 * C]
+    assert calls == [C + 2, C, 2 * C]
     err = lambda a, b: float((a.detach().cpu() - b.detach()).abs().max())
     assert err(y, yr[:N // 2]) <= 2e-5 * float(yr.detach().abs().max())
     assert err(xa.grad, xr.grad[:N // 2]) <= 2e-5 * float(xr.grad.abs().max())
