@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 309
+#define RE2E_ABI_VERSION 310
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -316,6 +316,18 @@ int re2e_lstm_cell_bwd(float* gates, const float* c_prev, const float* c_cur, co
  * activated gates out, c_prev -> c_out, h_out.  E, D, ldw multiples of 4. */
 int re2e_dec_gates_cell_fwd(const float* cx, const float* z_prev, const float* w_ctx, long ldw, const float* w_hh, float* gates,
                             const float* c_prev, float* c_out, float* h_out, int B, int E, int D, re2e_stream_t stream);
+/* The whole teacher-forced decoder loop (e2e_decoder.py:113-152: AttLoc.forward e2e_attention.py:259-299 + LSTMCell per output token) as ONE
+ * persistent launch (csrc/decloop.hip).  re2e_dec_loop_workspace_bytes returns 0 when the shape is outside the resident form's limits
+ * (B <= 32, D, E <= 320 and multiples of 4, C <= 12, workgroups <= CUs, ...) or RE2E_DEC_PERSIST=0: the caller then runs the launch-per-step
+ * sequence re2e_attloc_fwd + re2e_dec_gates_cell_fwd.  pre (B,T,A) = mlp_enc(enc), enc (B,T,E) masked encoder states, w_decT (D,A) = mlp_dec^T,
+ * w_att (A,C), w_conv (C,2Fh+1), w_ctx = &W_ih[0][Dd] with row pitch ldw, w_hh (4D,D).  gates (L1,B,4D): embedding half of the input projection
+ * + both biases on entry, activated gates on exit; z, c (L1+1,B,D) with block 0 = the initial state; w (L1,B,T), cx (L1,B,E),
+ * conv (L1,B,T,C), dpj (L1,B,A): what re2e_attloc_bwd reads.  A give-up (bounded spin) is counted by re2e_lstm_abort_count. */
+size_t re2e_dec_loop_workspace_bytes(int L1, int B, int T, int E, int D, int A, int C, int Fh);
+int re2e_dec_loop_fwd(const float* pre, const float* enc, const int* hlens_dev, const float* w_decT, const float* w_att, const float* w_conv,
+                      const float* gvec, const float* gvec_b, const float* w_ctx, long ldw, const float* w_hh, float* gates, float* z, float* c,
+                      float* w, float* cx, float* conv, float* dpj, int L1, int B, int T, int E, int D, int A, int C, int Fh,
+                      void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 /* Two skinny products that share A (M <= 32 rows) in one launch: C1 = A[M,K] B1[K,N1], C2 = A B2[K,N2] (B row-major (K,N));
  * the decoder's backward step: d ctx = dgates W_ih[:, Dd:], d z = dgates W_hh. */
 int re2e_gemm_skinny2(int M, int K, const float* A, long lda, const float* B1, long ldb1, int N1, float* C1, long ldc1,

@@ -1437,10 +1437,13 @@ extern "C" size_t re2e_lstm_workspace_bytes(int B, int H) {
   return a > b ? a : b;
 }
 
+int re2e_dec_abort_count_();      // decloop.hip: the persistent decoder loop's give-ups are counted with the recurrences'
+
 extern "C" int re2e_lstm_abort_count(void) {
   unsigned n = 0;
   if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_persist_aborts), sizeof(n)) != hipSuccess) return -1;     // (synchronises the device)
-  return (int)n;
+  const int d = re2e_dec_abort_count_();
+  return d < 0 ? -1 : (int)n + d;
 }
 
 extern "C" int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,

@@ -60,7 +60,11 @@ def decoder_forward_hip(p, hpad, hlens, ys, eos, ss_rate=0.0, return_att=False, 
         Pm.update(out_w=p[prefix + 'dec.output.weight'], out_b=p[prefix + 'dec.output.bias'])
     else:
         sample_steps = None
+    ops.mark_grad(pre, 'pre (decoder loop bwd done)')
+    ops.mark('decoder loop starts')
     z_all, w_all = ops.decoder_loop(hmask, pre, ids_tm, hl_dev, L1, Pm, sample_steps)   # (L1,B,D), (L1,B,T)
+    ops.mark('decoder loop fwd done')
+    ops.mark_grad(z_all, 'decoder states (output layer + CE bwd done: loop bwd starts)')
     D = z_all.shape[2]
     logits = ops.linear(z_all.reshape(L1 * B, D), p[prefix + 'dec.output.weight'], p[prefix + 'dec.output.bias'])
     scale = float(np.mean([len(y) + 1 for y in ylist])) - 1.0                      # :159

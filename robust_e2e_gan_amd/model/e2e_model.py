@@ -177,6 +177,7 @@ class ShareE2E(E2E):
             with torch.cuda.stream(aux):
                 hpad2.record_stream(aux)
                 loss_ctc, clean_context, mix_context, self.last_context_loss = heads_on_aux()
+                ops.mark('aux stream: CTC + CORAL heads fwd done')
         else:
             loss_ctc, clean_context, mix_context, self.last_context_loss = heads_on_aux()
         if self.mtlalpha == 1:

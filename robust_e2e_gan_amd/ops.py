@@ -99,6 +99,14 @@ def mark_grad(t, label):
     return t
 
 
+def mark(label):
+    """RE2E_TIMELINE: an event on the current stream, behind everything enqueued on it so far (forward-side twin of ``mark_grad``)."""
+    if MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        MARKS.append(('  ' + label, time.perf_counter(), ev))
+
+
 def _wants(ctx, i, p):
     return ctx.needs_input_grad[i] and (p is None or id(p) not in FROZEN_PARAMS)
 
@@ -1457,6 +1465,7 @@ def dropout(x, p):
 
 
 DECODER_FUSED = lib.exp_env('RE2E_NO_DECODER_FUSION', '0') != '1'     # fused LSTMCell step kernels (A/B switch)
+DECODER_PERSIST = os.environ.get('RE2E_DEC_PERSIST', '1') != '0'     # the teacher-forced loop as one persistent launch (csrc/decloop.hip)
 
 
 class DecoderLoopFn(torch.autograd.Function):
@@ -1507,7 +1516,16 @@ class DecoderLoopFn(torch.autograd.Function):
             ids_tm = ids_tm.clone()                 # becomes the list of tokens actually fed
             V = Pm['out_w'].shape[0]
             logits = empty((B, V), hmask)
-        for i in range(L1):
+        # the whole loop as ONE persistent launch (csrc/decloop.hip) when no step's token depends on the previous step's output
+        # and the shape is inside the resident form's limits (0 bytes = not); the launch-per-step sequence below otherwise
+        lwsb = 0 if (sampled or not fused or not DECODER_PERSIST) else query('re2e_dec_loop_workspace_bytes', L1, B, T, E, D, A, C, Fh)
+        if lwsb:
+            lws = workspace(lwsb, dev, 'decloop')
+            call('re2e_dec_loop_fwd', pre.data_ptr(), hmask.data_ptr(), hlens_dev.data_ptr(), w_decT.data_ptr(), Pm['mlp_att'].data_ptr(),
+                 Pm['loc_conv'].data_ptr(), Pm['gvec_w'].data_ptr(), Pm['gvec_b'].data_ptr(), w_ctx, ldw, Pm['w_hh'].data_ptr(), gates.data_ptr(),
+                 z.data_ptr(), c.data_ptr(), w.data_ptr(), cx.data_ptr(), conv.data_ptr(), dpj.data_ptr(), L1, B, T, E, D, A, C, Fh,
+                 lws.data_ptr(), lwsb)
+        for i in range(0 if not lwsb else L1, L1):
             if sampled and i > 0 and sample_steps[i]:
                 gemm(z[i], Pm['out_w'], logits, B, V, D, transb=True, bias=Pm['out_b'])          # y_{i-1} = output(z_{i-1})
                 ids_i = ids_tm.data_ptr() + 4 * i * B

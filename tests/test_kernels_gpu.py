@@ -880,6 +880,51 @@ def test_dec_gates_cell_fused_vs_unfused(B, E, D):
         close('h vs unfused', h_out, h2.cpu(), tol=2e-5)
 
 
+@pytest.mark.parametrize('B,T,L1,E,A,D,C,Fh', [(32, 200, 41, 512, 320, 300, 10, 100),     # config 4's decoder
+                                               (8, 750, 12, 512, 320, 300, 10, 100),      # config 5: three frame chunks per utterance
+                                               (32, 200, 5, 320, 320, 300, 10, 100),      # the reference's default widths
+                                               (5, 37, 6, 20, 24, 12, 3, 4),              # ragged everything, partial slices
+                                               (3, 300, 4, 132, 68, 36, 12, 7)])          # two chunks, E and A in different slice counts
+def test_decoder_loop_persistent_vs_stepwise(B, T, L1, E, A, D, C, Fh):
+    """csrc/decloop.hip (the whole teacher-forced loop in one persistent launch) against the launch-per-step sequence it replaces
+    (re2e_attloc_fwd + re2e_dec_gates_cell_fwd per token): outputs and every tensor saved for the backward.  Same arithmetic, other
+    summation orders (slice-partial energies, per-chunk context pieces) and a 1-ulp-rcp tanh in the energies."""
+    ops, lib = _ops()
+    Dd = D
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(DEV)
+    hl = torch.randint(max(1, T // 2), T + 1, (B,), generator=g)
+    hl[0] = T
+    hmask = r(B, T, E)
+    for b in range(B):
+        hmask[b, int(hl[b]):] = 0
+    pre = r(B, T, A)
+    Pm = dict(embed=r(50, Dd, scale=0.5), w_ih=r(4 * D, Dd + E, scale=0.08), w_hh=r(4 * D, D, scale=0.08), b_ih=r(4 * D, scale=0.1), b_hh=r(4 * D, scale=0.1),
+              mlp_dec=r(A, D, scale=0.1), mlp_att=r(A, C, scale=0.5), loc_conv=r(C, 1, 1, 2 * Fh + 1, scale=0.3), gvec_w=r(1, A, scale=0.3), gvec_b=r(1, scale=0.1))
+    ids = torch.randint(0, 50, (L1, B), generator=g).to(torch.int32).to(DEV)
+    hlens = hl.to(torch.int32).to(DEV)
+    if lib.query('re2e_dec_loop_workspace_bytes', L1, B, T, E, D, A, C, Fh) == 0:
+        pytest.skip('shape outside the persistent loop on this device')
+
+    class Ctx:
+        def save_for_backward(self, *t): self.saved = t
+        def mark_non_differentiable(self, *t): pass
+    out = {}
+    for name, flag in (('step', False), ('persist', True)):
+        ops.DECODER_PERSIST = flag
+        try:
+            ctx = Ctx()
+            zs, w = ops.DecoderLoopFn.forward(ctx, hmask, pre, ids, hlens, L1, Pm)
+            torch.cuda.synchronize()
+        finally:
+            ops.DECODER_PERSIST = True
+        out[name] = dict(z=zs.clone(), w=w.clone(), **{k: v.clone() for k, v in zip(('hmask', 'pre', 'emb', 'cx', 'zall', 'c', 'w2', 'gates', 'conv', 'dpj'), ctx.saved)})
+    assert lib.query('re2e_lstm_abort_count') == 0
+    for k in ('z', 'w', 'cx', 'c', 'gates', 'conv', 'dpj', 'zall'):            # first tokens: rounding only; whole loop: what 41 recurrent tokens make of it
+        close(k + ' (first two tokens)', out['persist'][k][:2], out['step'][k][:2].cpu(), tol=2e-5)
+        close(k, out['persist'][k], out['step'][k].cpu(), tol=2e-4)
+
+
 @pytest.mark.parametrize('M,K,N1,N2', [(32, 1200, 512, 300), (3, 56, 20, 14), (17, 40, 33, 1)])
 def test_gemm_skinny2(M, K, N1, N2):
     """re2e_gemm_skinny2: two products sharing the skinny left operand in one launch (decoder backward: d ctx and d z from
