@@ -572,3 +572,561 @@ extern "C" int re2e_dec_loop_fwd(const float* pre, const float* enc, const int* 
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
+
+// =================================================================================================================================
+// The loop's BACKWARD as one persistent launch (the reverse of e2e_decoder.py:113-152 / e2e_attention.py:259-299 per output token):
+//   (a) dh = dz + dZ[i];  LSTMCell backward -> dgates_i                          "unit" workgroups (16 decoder units each)
+//   (b) d cx_i = dgates_i W_ih[:, Dd:],  dz' = dgates_i W_hh                      "column" workgroups (16 projection columns each) / the unit workgroups
+//   (c) attention backward of utterance b: softmax, energies, location conv -> d dec_proj_i, d att_prev (= d w_{i-1}), de_i, d conv_i
+//   (d) dz = dz' + d dec_proj_i mlp_dec                                            the unit workgroups, in front of (a) of token i - 1
+// replacing the 5-6 launches per token of ops.DecoderLoopFn.backward (cell / skinny2 / attloc_bwd_frames / attloc_bwd_conv / skinny: 70 us of
+// kernels per token at config 4 plus their launch gaps, 41 or 151 tokens).  The attention workgroup here owns a chunk of <= 48 FRAMES of
+// one utterance with ALL attention columns (the forward's owns a column slice of all frames): dc . enc[t], d conv[t] and the energy
+// gradient of a frame are then complete inside the workgroup; what crosses workgroups per token is dgates (all-gather, read as MFMA operand),
+// d cx, the per-chunk partial sums of d dec_proj (reduced by the utterance's own workgroups), the d conv rows of the neighbouring chunks
+// (transposed location conv) and one scalar per chunk (the softmax normaliser's w . d w term).  Same flagged hand-off as the forward.
+// Only what the recurrence needs is done per token; d W_conv is summed after the loop from the saved d conv rows (dwconv_all_kernel), d pre /
+// d W_att / d gvec by attloc_dpre, d enc by attloc_denc as before.
+namespace {
+constexpr int FPA = 48;             // frames per attention workgroup (3 tiles of 16)
+constexpr int TPA = 3;
+constexpr int ATW = 5;              // 16-column blocks of the attention dimension per wave: A <= 320
+constexpr int GKU = 19;             // groups of 16 gate rows per wave: 4 D <= 1216
+constexpr int GKA = 5;              // groups of 16 attention columns per wave of the mlp_dec product
+constexpr int NFRMAX = 16;
+
+struct DecBwdArgs {
+  const float *pre, *enc, *cx, *z, *c, *w, *conv, *dpj, *dZ;
+  const int* hlens;
+  const float *w_ctx; long ldw;
+  const float *w_hh, *w_dec, *w_att, *w_conv, *gvec;
+  float *gates, *d_cx, *de_all, *ddp, *d_conv;
+  int L1, B, T, E, D, A, C, Fh;
+  int NU, NC, NFR, FR;              // unit / column workgroups, frame chunks per utterance, frames per chunk
+  unsigned *err, *f1, *f2, *f4, *f5, *f6a, *f6;
+  float *scal, *ddpp;               // [2][B][NFR], [2][B][NFR][AP]
+  int AP, ARW;
+};
+
+__device__ __forceinline__ void store16f_sc1(float* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// sum over the 16 lanes of a DPP row (all 16 end with the total): two quad permutes, the half-row and the row mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
+  return v;
+}
+
+// The product both GEMM roles run per token: out^T[col][b] = sum_k W[k][col] dgates[b][k] over this wave's quarter of the k-groups
+// (k = 16 g + 4 kq + j, g = wave + 4 gi: one 16-byte load of dgates per lane and four MFMAs).  acc[tile]: 16 utterances each.
+template <int NG_, class AOP>
+__device__ __forceinline__ void gather_mfma(const __amdgpu_buffer_rsrc_t rs, const unsigned row_b, const int K, const int wid, const int kq,
+                                            const int ntb, const bool ok0, const bool ok1, const AOP& aop, f32x4 (&acc)[2]) {
+  f32x4 b0[NG_], b1[NG_];
+#pragma unroll
+  for (int gi = 0; gi < NG_; ++gi) {
+    const int k = 16 * (wid + 4 * gi) + 4 * kq;
+    const unsigned off = k < K ? row_b + (unsigned)k * 4u : 0xFFFFFFF0u;
+    b0[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok0 ? off : 0xFFFFFFF0u, 0, 16));
+    b1[gi] = (ntb > 1) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok1 ? off + 16u * (unsigned)K * 4u : 0xFFFFFFF0u, 0, 16)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int gi = 0; gi < NG_; ++gi) {
+    const f32x4 wv4 = aop(gi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[j], b0[gi][j], acc[0], 0, 0, 0);
+      if (ntb > 1) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[j], b1[gi][j], acc[1], 0, 0, 0);
+    }
+  }
+}
+
+__device__ void bwd_unit_role(const DecBwdArgs& a, const int x, float* sm, const bool is_col) {
+  // unit workgroup: 16 decoder units (cell backward + dz); column workgroup (is_col): 16 columns of d cx
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, kq = lane >> 4;
+  const int B = a.B, D = a.D, E = a.E, A = a.A, L1 = a.L1, K = 4 * D;
+  const int ntb = B > 16 ? 2 : 1;
+  const int c0 = 16 * x, ncol = is_col ? E : D;
+  const bool colok = c0 + m < ncol;
+  // A operands W[k][c0 + m]: the 4 D x 16 slice of the gate-row product in LDS as [group of 16 k][kq][m][4] (a lane's four k of a group are one
+  // 16-byte read, issued before the flags are polled); mlp_dec's 16 columns (unit workgroups) in registers
+  float* wl = sm + 4 * 2 * 64 * 4;
+  for (int idx = tid; idx < (K / 16 + 1) * 256; idx += NT) {
+    const int g = idx >> 8, rem = idx & 255, k = 16 * g + 4 * (rem >> 6) + (rem & 3), mm = (rem >> 2) & 15;
+    wl[idx] = (k < K && c0 + mm < ncol) ? (is_col ? a.w_ctx[(long)k * a.ldw + c0 + mm] : a.w_hh[(long)k * D + c0 + mm]) : 0.f;
+  }
+  f32x4 wd[GKA];
+#pragma unroll
+  for (int gi = 0; gi < GKA; ++gi)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 16 * (wid + 4 * gi) + 4 * kq + j;
+      wd[gi][j] = (!is_col && k < A && colok) ? a.w_dec[(long)k * D + c0 + m] : 0.f;
+    }
+  __syncthreads();
+  const int ngrp = K / 16;
+  auto a_lds = [&](int gi) { const int g = wid + 4 * gi; return *reinterpret_cast<const f32x4*>(wl + (((g <= ngrp ? g : ngrp) * 4 + kq) * 16 + m) * 4); };
+  auto a_reg = [&](int gi) { return wd[gi]; };
+  f32x4* red = reinterpret_cast<f32x4*>(sm);                     // [4 waves][2 tiles][64 lanes]
+  const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(a.gates, 0, (int)((long)L1 * B * K * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t p_rs = __builtin_amdgcn_make_buffer_rsrc(a.ddp, 0, (int)((long)L1 * B * A * 4), 0x00020000);
+  const bool ok0 = m < B, ok1 = 16 + m < B;
+  const int NA = B * a.NFR;
+  // the thread's two outputs after the cross-wave sum: utterance bm, columns jj and jj + 8
+  const int bm = tid >> 3, jj = tid & 7;
+  const bool bok = bm < B;
+  float dcr[2] = {0.f, 0.f};
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  bool aborted = false;
+  for (int it = 0; it < L1; ++it) {
+    const int i = L1 - 1 - it;
+    if (!is_col) {
+      // ---- (d) + (a): dz = dz' (in acc since the last token) + d dec_proj_{i+1} mlp_dec, then the cell backward ----
+      float gv[2][4], cp[2], cc[2], dzo[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                                // operands of the cell: in flight during the wait
+        const int u = c0 + jj + 8 * h;
+        const bool ok = bok && u < D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[h][g] = ok ? a.gates[((long)i * B + bm) * K + (long)g * D + u] : 0.f;
+        cp[h] = ok ? a.c[((long)i * B + bm) * D + u] : 0.f;
+        cc[h] = ok ? a.c[((long)(i + 1) * B + bm) * D + u] : 0.f;
+        dzo[h] = ok ? a.dZ[((long)i * B + bm) * D + u] : 0.f;
+      }
+      if (it > 0) {
+        if (!aborted && !wait_flags(a.f6, NA, (unsigned)it, a.err, lane)) aborted = true;
+        gather_mfma<GKA>(p_rs, (unsigned)((((long)(i + 1) * B + m) * A) * 4), A, wid, kq, ntb, ok0, ok1, a_reg, acc);
+      }
+      red[(wid * 2 + 0) * 64 + lane] = acc[0];
+      red[(wid * 2 + 1) * 64 + lane] = acc[1];
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ul = jj + 8 * h, u = c0 + ul;
+        const int rl = (ul >> 2) * 16 + (bm & 15), rt = bm >> 4, rr = ul & 3;
+        float dz = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) dz += red[(w4 * 2 + rt) * 64 + rl][rr];
+        if (bok && u < D) {
+          const float gi = gv[h][0], gf = gv[h][1], gg = gv[h][2], go = gv[h][3];
+          const float tc = tanhf_(cc[h]);
+          float d = dz + dzo[h];
+          if (aborted) d = __uint_as_float(0x7fc00000u);
+          const float dct = d * go * (1.f - tc * tc) + dcr[h];
+          float* gp = a.gates + ((long)i * B + bm) * K + u;
+          store4_sc1(gp, dct * gg * gi * (1.f - gi));
+          store4_sc1(gp + D, dct * cp[h] * gf * (1.f - gf));
+          store4_sc1(gp + 2L * D, dct * gi * (1.f - gg * gg));
+          store4_sc1(gp + 3L * D, d * tc * go * (1.f - go));
+          dcr[h] = dct * gf;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.f1 + (long)x * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i == 0) break;                                           // nothing consumes dz of the initial state
+    }
+    // ---- (b): all of dgates_i, times this workgroup's 16 columns ----
+    if (!aborted && !wait_flags(a.f1, a.NU, (unsigned)(it + 1), a.err, lane)) aborted = true;
+    gather_mfma<GKU>(g_rs, (unsigned)((((long)i * B + m) * K) * 4), K, wid, kq, ntb, ok0, ok1, a_lds, acc);
+    if (is_col) {
+      red[(wid * 2 + 0) * 64 + lane] = acc[0];
+      red[(wid * 2 + 1) * 64 + lane] = acc[1];
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ul = jj + 8 * h, u = c0 + ul;
+        const int rl = (ul >> 2) * 16 + (bm & 15), rt = bm >> 4, rr = ul & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * 2 + rt) * 64 + rl][rr];
+        if (aborted) v = __uint_as_float(0x7fc00000u);
+        if (bok && u < E) store4_sc1(a.d_cx + ((long)i * B + bm) * E + u, v);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.f2 + (long)(x) * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// LDS floats of a backward attention workgroup
+struct AttBwdLds {
+  int ES, W;
+  int o_enc, o_dcs, o_gp, o_de, o_wv, o_dwl, o_dcw, o_wcs, o_rc, o_sc2, o_red, total;
+  __host__ __device__ AttBwdLds(int E, int C, int Fh) {
+    ES = E + 4;                               // enc row pitch: conflict-free 16-byte reads of consecutive rows
+    W = FPA + 2 * Fh + 4;
+    int o = 0;
+    o_enc = o; o += FPA * ES;                 // enc[b, frames, :]
+    o_dcs = o; o += (E + 3) & ~3;             // d cx_i[b]
+    o_gp = o; o += 4 * 64;                    // [4 column quarters][frames] partial dc . enc
+    o_de = o; o += 64;
+    o_wv = o; o += 64;                        // w_i of the own frames
+    o_dwl = o; o += 64;                       // d w_i of the own frames (from the transposed conv of token i + 1)
+    o_dcw = o; o += 16 * W;                   // [channel][window] d conv rows of the frames within Fh of the own ones
+    o_wcs = o; o += 16 * (2 * Fh + 1);        // [channel][tap]
+    o_rc = o; o += 4 * TPA * 64 * 4;          // per-wave d conv partials
+    o_sc2 = o; o += 16 * 64;                  // [channel][frame] of the transposed conv
+    o_red = o; o += 32;
+    total = o;
+    (void)C;
+  }
+};
+
+__device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, kq = lane >> 4;
+  const int B = a.B, T = a.T, E = a.E, A = a.A, C = a.C, Fh = a.Fh, L1 = a.L1, NFR = a.NFR, AP = a.AP;
+  const int b = q / NFR, fr = q % NFR;
+  const int t0 = fr * a.FR, nt = min(a.FR, T - t0);
+  const int Kf = 2 * Fh + 1;
+  const AttBwdLds L(E, C, Fh);
+  const int ES = L.ES, W = L.W;
+  float* encs = sm + L.o_enc;
+  float* dcs = sm + L.o_dcs;
+  float* gp = sm + L.o_gp;
+  float* de = sm + L.o_de;
+  float* wv = sm + L.o_wv;
+  float* dwl = sm + L.o_dwl;
+  float* dcw = sm + L.o_dcw;
+  float* wcs = sm + L.o_wcs;
+  f32x4* rc = reinterpret_cast<f32x4*>(sm + L.o_rc);
+  float* sc2 = sm + L.o_sc2;
+  float* red = sm + L.o_red;
+  // ---- resident operands: lane (m, kq) of wave w is frame m of every tile and columns 16 at + 4 kq + r of the blocks at = w + 4 qq ----
+  f32x4 ptT[TPA][ATW], wAT[ATW];
+#pragma unroll
+  for (int qq = 0; qq < ATW; ++qq) {
+    const int at = wid + 4 * qq;
+#pragma unroll
+    for (int j = 0; j < TPA; ++j) {
+      const int f = 16 * j + m;
+      ptT[j][qq] = (f < nt && 16 * at + 4 * kq < A) ? *reinterpret_cast<const f32x4*>(a.pre + ((long)b * T + t0 + f) * A + 16 * at + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      wAT[qq][r] = (16 * at + 4 * kq + r < A && m < C) ? a.w_att[(long)(16 * at + 4 * kq + r) * C + m] : 0.f;            // d conv^T: A[channel m][column slot kq]
+  }
+  for (int idx = tid; idx < FPA * (E / 4); idx += NT) {
+    const int f = idx / (E / 4), c4 = idx % (E / 4);
+    *reinterpret_cast<f32x4*>(encs + f * ES + 4 * c4) = f < nt ? *reinterpret_cast<const f32x4*>(a.enc + ((long)b * T + t0 + f) * E + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int idx = tid; idx < 16 * Kf; idx += NT) wcs[idx] = idx < C * Kf ? a.w_conv[idx] : 0.f;
+  if (tid < 64) { dwl[tid] = 0.f; de[tid] = 0.f; wv[tid] = 0.f; }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(a.d_cx, 0, (int)((long)L1 * B * E * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t s_rs = __builtin_amdgcn_make_buffer_rsrc(a.scal, 0, (int)(2L * B * NFR * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t pp_rs = __builtin_amdgcn_make_buffer_rsrc(a.ddpp, 0, (int)(2L * B * NFR * AP * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dv_rs = __builtin_amdgcn_make_buffer_rsrc(a.d_conv, 0, (int)((long)L1 * B * T * C * 4), 0x00020000);
+  const int arw = a.ARW;                                          // columns of d dec_proj this workgroup reduces
+  bool aborted = false;
+  for (int it = 0; it < L1; ++it) {
+    const int i = L1 - 1 - it, par = it & 1;
+    // ---- before d cx_i is needed: x = pre + dp + W_att conv_i recomputed from the saved conv rows, dtg = gvec (1 - tanh^2 x) ----
+    f32x4 dtg[TPA][ATW];
+    {
+      f32x4 cvT[TPA], dpr[ATW], gvr[ATW], wA[ATW];               // (gvec and the u^T operand of W_att: re-read per token, registers are short)
+#pragma unroll
+      for (int qq = 0; qq < ATW; ++qq) {
+        const int at = wid + 4 * qq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gvr[qq][r] = 16 * at + 4 * kq + r < A ? a.gvec[16 * at + 4 * kq + r] : 0.f;
+          wA[qq][r] = (16 * at + m < A && 4 * kq + r < C) ? a.w_att[(long)(16 * at + m) * C + 4 * kq + r] : 0.f;          // u^T: A[column m][channel 4 kq + ks]
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TPA; ++j) {
+        const int f = 16 * j + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cvT[j][r] = (f < nt && 4 * kq + r < C) ? a.conv[(((long)i * B + b) * T + t0 + f) * C + 4 * kq + r] : 0.f;
+      }
+#pragma unroll
+      for (int qq = 0; qq < ATW; ++qq) {
+        const int at = wid + 4 * qq;
+        dpr[qq] = 16 * at + 4 * kq < A ? *reinterpret_cast<const f32x4*>(a.dpj + ((long)i * B + b) * A + 16 * at + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (tid < FPA) wv[tid] = tid < nt ? a.w[((long)i * B + b) * T + t0 + tid] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TPA; ++j)
+#pragma unroll
+        for (int qq = 0; qq < ATW; ++qq) {
+          f32x4 u = ptT[j][qq];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) u = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[qq][ks], cvT[j][ks], u, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float th = tanh_fast(u[r] + dpr[qq][r]);
+            dtg[j][qq][r] = gvr[qq][r] * (1.f - th * th);
+          }
+        }
+    }
+    // the normaliser's w . dw term: one scalar per chunk of the utterance, published at the end of the last token
+    float sdot = 0.f;
+    if (it > 0) {
+      if (!aborted && !wait_flags(a.f5 + (long)b * NFR * 32, NFR, (unsigned)it, a.err, lane)) aborted = true;
+      float sv = lane < NFR ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rs, (unsigned)((((long)(par ^ 1) * B + b) * NFR + lane) * 4), 0, 16)) : 0.f;
+      sdot = wave_sum(sv);
+    }
+    const float cx0 = tid < E ? a.cx[((long)i * B + b) * E + tid] : 0.f, cx1 = tid + NT < E ? a.cx[((long)i * B + b) * E + tid + NT] : 0.f;
+    // ---- d cx_i[b] ----
+    if (!aborted && !wait_flags(a.f2, a.NC, (unsigned)(it + 1), a.err, lane)) aborted = true;
+    {
+      const float d0v = tid < E ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (unsigned)((((long)i * B + b) * E + tid) * 4), 0, 16)) : 0.f;
+      const float d1v = tid + NT < E ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (unsigned)((((long)i * B + b) * E + tid + NT) * 4), 0, 16)) : 0.f;
+      if (tid < E) dcs[tid] = d0v;
+      if (tid + NT < E) dcs[tid + NT] = d1v;
+      sdot += block_sum(d0v * cx0 + d1v * cx1, red);            // (its barriers publish dcs)
+    }
+    // g[f] = dc . enc[f]: thread = (frame f, quarter p of the columns), two batches of 16-byte reads
+    {
+      const int f = lane, p = wid, e4 = E / 16;                   // float4 per quarter
+      float s = 0.f;
+      if (f < FPA) {
+        const f32x4* er = reinterpret_cast<const f32x4*>(encs + f * ES) + p * e4;
+        const f32x4* dr = reinterpret_cast<const f32x4*>(dcs) + p * e4;
+        for (int j0 = 0; j0 < e4; j0 += 8) {
+          f32x4 ev[8], dv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ev[j] = j0 + j < e4 ? er[j0 + j] : f32x4{0.f, 0.f, 0.f, 0.f}; dv[j] = j0 + j < e4 ? dr[j0 + j] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s += (ev[j][0] * dv[j][0] + ev[j][1] * dv[j][1]) + (ev[j][2] * dv[j][2] + ev[j][3] * dv[j][3]);
+        }
+      }
+      gp[p * 64 + f] = s;
+    }
+    __syncthreads();
+    if (tid < FPA) {
+      const float g = (gp[tid] + gp[64 + tid]) + (gp[128 + tid] + gp[192 + tid]);
+      float v = tid < nt ? 2.f * wv[tid] * (dwl[tid] + g - sdot) : 0.f;
+      if (aborted) v = __uint_as_float(0x7fc00000u);
+      de[tid] = v;
+      if (tid < nt) a.de_all[((long)i * B + b) * T + t0 + tid] = v;
+    }
+    __syncthreads();
+    // ---- du = de dtg;  d dec_proj partial = sum over the own frames;  d conv^T = W_att^T du ----
+    {
+      f32x4 dsum[ATW], dcv[TPA];
+#pragma unroll
+      for (int qq = 0; qq < ATW; ++qq) dsum[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < TPA; ++j) {
+        const float dej = de[16 * j + m];
+        dcv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qq = 0; qq < ATW; ++qq) {
+          const f32x4 du = dtg[j][qq] * dej;
+          dsum[qq] += du;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dcv[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wAT[qq][r], du[r], dcv[j], 0, 0, 0);
+        }
+        rc[(wid * TPA + j) * 64 + lane] = dcv[j];
+      }
+#pragma unroll
+      for (int qq = 0; qq < ATW; ++qq) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsum[qq][r] = row16_sum(dsum[qq][r]);
+        const int at = wid + 4 * qq;
+        if (m == 0 && 16 * at + 4 * kq < AP) store16f_sc1(a.ddpp + (((long)par * B + b) * NFR + fr) * AP + 16 * at + 4 * kq, dsum[qq]);
+      }
+    }
+    __syncthreads();
+    if (wid < TPA) {                                             // wave j sums the four waves' partials of tile j: lane (frame m, channels 4 kq + r)
+      const f32x4 v = (rc[(0 * TPA + wid) * 64 + lane] + rc[(1 * TPA + wid) * 64 + lane]) + (rc[(2 * TPA + wid) * 64 + lane] + rc[(3 * TPA + wid) * 64 + lane]);
+      const int f = 16 * wid + m;
+      if (f < nt) {
+        float* dst = a.d_conv + (((long)i * B + b) * T + t0 + f) * C + 4 * kq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * kq + r < C) store4_sc1(dst + r, v[r]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(a.f6a + (long)q * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.f4 + (long)q * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- this workgroup's columns of d dec_proj_i: the sum of the utterance's chunk partials ----
+    if (!aborted && !wait_flags(a.f6a + (long)b * NFR * 32, NFR, (unsigned)(it + 1), a.err, lane)) aborted = true;
+    for (int cl = tid; cl < arw; cl += NT) {
+      const int col = fr * arw + cl;
+      float pv[NFRMAX];
+#pragma unroll
+      for (int k2 = 0; k2 < NFRMAX; ++k2)
+        pv[k2] = (k2 < NFR && col < AP) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pp_rs, (unsigned)(((((long)par * B + b) * NFR + k2) * AP + col) * 4), 0, 16)) : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < NFRMAX; ++k2) s += pv[k2];
+      if (aborted) s = __uint_as_float(0x7fc00000u);
+      if (col < A) store4_sc1(a.ddp + ((long)i * B + b) * A + col, s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.f6 + (long)q * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i == 0) break;
+    // ---- (off the critical path) d w_{i-1} of the own frames: transposed location conv over the d conv rows within Fh frames ----
+    if (!aborted && !wait_flags(a.f4 + (long)b * NFR * 32, NFR, (unsigned)(it + 1), a.err, lane)) aborted = true;
+    {
+      const int o = t0 - Fh, wn = nt + 2 * Fh;                    // window of frames [o, o + wn)
+      for (int idx = tid; idx < 16 * W; idx += NT) {
+        const int cch = idx / W, xw = idx % W, t = o + xw;
+        dcw[idx] = (cch < C && xw < wn && t >= 0 && t < T)
+                       ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dv_rs, (unsigned)(((((long)i * B + b) * T + t) * C + cch) * 4), 0, 16)) : 0.f;
+      }
+      __syncthreads();
+      // d w[t0 + f] = sum_c sum_k w_conv[c][k] d conv[t0 + f - k + Fh][c]: item = (channel, frame), frames along the lanes
+      for (int item = tid; item < C * 64; item += NT) {
+        const int cch = item >> 6, f = item & 63;
+        const float* qd = dcw + cch * W + (f < FPA ? f : 0) + 2 * Fh;      // qd[-k] = d conv[t0 + f - k + Fh][cch]
+        const float* wk2 = wcs + cch * Kf;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = 0;
+        for (; k + 8 <= Kf; k += 8) {
+          a0 += wk2[k] * qd[-k] + wk2[k + 4] * qd[-k - 4]; a1 += wk2[k + 1] * qd[-k - 1] + wk2[k + 5] * qd[-k - 5];
+          a2 += wk2[k + 2] * qd[-k - 2] + wk2[k + 6] * qd[-k - 6]; a3 += wk2[k + 3] * qd[-k - 3] + wk2[k + 7] * qd[-k - 7];
+        }
+        for (; k < Kf; ++k) a0 += wk2[k] * qd[-k];
+        sc2[cch * 64 + f] = (a0 + a1) + (a2 + a3);
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float s = 0.f;
+        for (int cch = 0; cch < C; ++cch) s += sc2[cch * 64 + tid];
+        if (tid >= nt) s = 0.f;
+        dwl[tid] = s;
+        const float wprev = tid < nt ? a.w[((long)(i - 1) * B + b) * T + t0 + tid] : 0.f;
+        const float ps = wave_sum(s * wprev);
+        if (tid == 0) {
+          store4_sc1(a.scal + ((long)par * B + b) * NFR + fr, ps);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(a.f5 + (long)q * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void dec_loop_bwd_kernel(DecBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dsm2[];
+  const int wg = blockIdx.x;
+  if (wg < a.NU) bwd_unit_role(a, wg, dsm2, false);
+  else if (wg < a.NU + a.NC) bwd_unit_role(a, wg - a.NU, dsm2, true);
+  else bwd_att_role(a, wg - a.NU - a.NC, dsm2);
+}
+
+// d W_conv of the whole loop from the saved d conv rows: partials[b][off + c Kf + k] += sum_i sum_t d conv_i[b][t][c] att_prev_i[b][t + k - Fh]
+// (att_prev_0 = uniform over the valid frames, att_prev_i = w_{i-1}).  grid (B, C): thread = tap.
+__global__ __launch_bounds__(NT) void dwconv_all_kernel(const float* __restrict__ w_all, const int* __restrict__ hlens, const float* __restrict__ d_conv, int L1,
+                                                        int B, int T, int C, int Fh, int off, int npart, float* partials) {
+  extern __shared__ __attribute__((aligned(16))) float sm3[];
+  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, Kf = 2 * Fh + 1, hl = hlens[b];
+  float* ap = sm3;                                  // [T + 2 Fh + 4]
+  float* dq = ap + ((T + 2 * Fh + 7) & ~3);         // [T + 4]
+  float acc = 0.f;
+  for (int i = 0; i < L1; ++i) {
+    for (int idx = tid; idx < T + 2 * Fh + 4; idx += NT) {
+      const int t = idx - Fh;
+      float v = 0.f;
+      if (t >= 0 && t < T) v = i > 0 ? w_all[((long)(i - 1) * B + b) * T + t] : (t < hl ? 1.0f / (float)hl : 0.f);
+      ap[idx] = v;
+    }
+    for (int t = tid; t < T + 4; t += NT) dq[t] = t < T ? d_conv[(((long)i * B + b) * T + t) * C + c] : 0.f;
+    __syncthreads();
+    if (tid < Kf) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const float* x = ap + tid;
+      for (int t = 0; t < T; t += 4) { a0 += dq[t] * x[t]; a1 += dq[t + 1] * x[t + 1]; a2 += dq[t + 2] * x[t + 2]; a3 += dq[t + 3] * x[t + 3]; }
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+  }
+  if (tid < Kf) partials[(long)b * npart + off + c * Kf + tid] += acc;
+}
+
+struct DecBwdPlan { int NU, NC, NFR, FR, NA, AP, ARW; size_t lds, ws; size_t o_f1, o_f2, o_f4, o_f5, o_f6a, o_f6, o_sc, o_pp, o_dv; };
+
+bool dec_bwd_plan(int L1, int B, int T, int E, int D, int A, int C, int Fh, DecBwdPlan& p) {
+  if (L1 < 1 || B < 1 || B > 32 || T < 1 || E < 16 || D < 4 || A < 4 || C < 1 || C > 16 || Fh < 0) return false;
+  if ((E & 15) || (D & 3) || (A & 3) || E > 512 || 4 * D > 16 * 4 * GKU || A > 16 * 4 * GKA || A > 64 * ATW) return false;
+  p.NU = cdiv(D, 16);
+  p.NC = E / 16;
+  p.NFR = cdiv(T, FPA);
+  if (p.NFR > NFRMAX) return false;
+  p.FR = cdiv(T, p.NFR);
+  p.NA = B * p.NFR;
+  p.AP = 64 * cdiv(A, 64);
+  p.ARW = 4 * cdiv(cdiv(p.AP, p.NFR), 4);
+  if (2 * Fh + 1 > 255) return false;                             // (dwconv_all_kernel: one thread per tap)
+  if (p.NU + p.NC + p.NA > cu_count()) return false;
+  const AttBwdLds L(E, C, Fh);
+  size_t fl = (size_t)L.total, gemm = 4 * 2 * 64 * 4 + (size_t)(4 * D / 16 + 1) * 256;
+  p.lds = (fl > gemm ? fl : gemm) * 4 + 16;
+  if (p.lds > 160 * 1024) return false;
+  size_t o = 128;
+  p.o_f1 = o; o += (size_t)p.NU * 128;
+  p.o_f2 = o; o += (size_t)p.NC * 128;
+  p.o_f4 = o; o += (size_t)p.NA * 128;
+  p.o_f5 = o; o += (size_t)p.NA * 128;
+  p.o_f6a = o; o += (size_t)p.NA * 128;
+  p.o_f6 = o; o += (size_t)p.NA * 128;
+  p.o_sc = o; o += (size_t)2 * B * p.NFR * 4; o = (o + 127) & ~(size_t)127;
+  p.o_pp = o; o += (size_t)2 * B * p.NFR * p.AP * 4; o = (o + 127) & ~(size_t)127;
+  p.o_dv = o; o += (size_t)L1 * B * T * C * 4;
+  p.ws = (o + 127) & ~(size_t)127;
+  return true;
+}
+
+LdsLimit g_dec_bwd_lim;
+}  // namespace
+
+extern "C" size_t re2e_dec_loop_bwd_workspace_bytes(int L1, int B, int T, int E, int D, int A, int C, int Fh) {
+  static const bool off = [] { const char* e = getenv("RE2E_DEC_PERSIST"); return e && (atoi(e) == 0 || atoi(e) == 2); }();      // 2: forward only
+  DecBwdPlan p;
+  if (off || !dec_bwd_plan(L1, B, T, E, D, A, C, Fh, p)) return 0;
+  return p.ws;
+}
+
+extern "C" int re2e_dec_loop_bwd(const float* pre, const float* enc, const float* cx, const float* z, const float* c, const float* w, const float* conv,
+                                 const float* dpj, const float* dZ, const int* hlens, const float* w_ctx, long ldw, const float* w_hh, const float* mlp_dec,
+                                 const float* w_att, const float* w_conv, const float* gvec, float* gates, float* d_cx_all, float* de_all, float* ddp,
+                                 float* partials, int partial_floats, int wconv_offset, int L1, int B, int T, int E, int D, int A, int C, int Fh,
+                                 void* ws, size_t ws_bytes, hipStream_t stream) {
+  DecBwdPlan p;
+  if (!dec_bwd_plan(L1, B, T, E, D, A, C, Fh, p)) {
+    re2e_set_error("re2e_dec_loop_bwd: shape outside the persistent loop's limits (L1=%d B=%d T=%d E=%d D=%d A=%d C=%d Fh=%d)", L1, B, T, E, D, A, C, Fh);
+    return RE2E_EUNSUPPORTED;
+  }
+  RE2E_CHECK_ARG(ws && ws_bytes >= p.ws, "workspace too small (re2e_dec_loop_bwd_workspace_bytes)");
+  RE2E_CHECK_ARG(!((reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(enc) | reinterpret_cast<uintptr_t>(gates) | reinterpret_cast<uintptr_t>(ddp) |
+                    reinterpret_cast<uintptr_t>(dpj) | reinterpret_cast<uintptr_t>(ws)) & 15), "operands must be 16-byte aligned");
+  char* base = reinterpret_cast<char*>(ws);
+  DecBwdArgs a;
+  a.pre = pre; a.enc = enc; a.cx = cx; a.z = z; a.c = c; a.w = w; a.conv = conv; a.dpj = dpj; a.dZ = dZ; a.hlens = hlens;
+  a.w_ctx = w_ctx; a.ldw = ldw; a.w_hh = w_hh; a.w_dec = mlp_dec; a.w_att = w_att; a.w_conv = w_conv; a.gvec = gvec;
+  a.gates = gates; a.d_cx = d_cx_all; a.de_all = de_all; a.ddp = ddp;
+  a.L1 = L1; a.B = B; a.T = T; a.E = E; a.D = D; a.A = A; a.C = C; a.Fh = Fh;
+  a.NU = p.NU; a.NC = p.NC; a.NFR = p.NFR; a.FR = p.FR; a.AP = p.AP; a.ARW = p.ARW;
+  a.err = reinterpret_cast<unsigned*>(base);
+  a.f1 = reinterpret_cast<unsigned*>(base + p.o_f1); a.f2 = reinterpret_cast<unsigned*>(base + p.o_f2);
+  a.f4 = reinterpret_cast<unsigned*>(base + p.o_f4); a.f5 = reinterpret_cast<unsigned*>(base + p.o_f5);
+  a.f6a = reinterpret_cast<unsigned*>(base + p.o_f6a); a.f6 = reinterpret_cast<unsigned*>(base + p.o_f6);
+  a.scal = reinterpret_cast<float*>(base + p.o_sc); a.ddpp = reinterpret_cast<float*>(base + p.o_pp);
+  a.d_conv = reinterpret_cast<float*>(base + p.o_dv);
+  (void)hipMemsetAsync(ws, 0, p.o_sc, stream);
+  const size_t lds = 160 * 1024;
+  g_dec_bwd_lim.ensure(reinterpret_cast<const void*>(&dec_loop_bwd_kernel), lds);
+  hipLaunchKernelGGL(dec_loop_bwd_kernel, dim3(p.NU + p.NC + p.NA), dim3(NT), lds, stream, a);
+  RE2E_LAUNCH_CHECK();
+  const size_t lds3 = (size_t)(((T + 2 * Fh + 7) & ~3) + T + 8) * sizeof(float);
+  hipLaunchKernelGGL(dwconv_all_kernel, dim3(B, C), dim3(NT), lds3, stream, w, hlens, (const float*)a.d_conv, L1, B, T, C, Fh, wconv_offset, partial_floats, partials);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}

@@ -1545,6 +1545,7 @@ class DecoderLoopFn(torch.autograd.Function):
                 gemm(z[i], Pm['w_hh'], gates[i], B, 4 * D, D, transb=True, beta=1.0)
                 call('re2e_lstm_cell_fwd', gates[i].data_ptr(), c[i].data_ptr(), c[i + 1].data_ptr(), z[i + 1].data_ptr(), B, D)
         ctx.Pm, ctx.ids, ctx.hlens = Pm, ids_tm, hlens_dev
+        ctx.persist = bool(lwsb)
         ctx.dims = (B, T, E, A, Dd, D, C, Fh, L1)
         ctx.save_for_backward(hmask, pre, emb, cx, z, c, w, gates, conv, dpj)
         ctx.mark_non_differentiable(w)
@@ -1574,7 +1575,15 @@ class DecoderLoopFn(torch.autograd.Function):
         dw_a, dw_b = empty((B, T), hmask), empty((B, T), hmask)
         have_dw = False
         fused = DECODER_FUSED and B <= 32
-        for i in range(L1 - 1, -1, -1):
+        # the whole reverse loop as ONE persistent launch (csrc/decloop.hip) when the forward took that form too (no sampled tokens)
+        bwsb = query('re2e_dec_loop_bwd_workspace_bytes', L1, B, T, E, D, A, C, Fh) if (ctx.persist and DECODER_PERSIST and fused) else 0
+        if bwsb:
+            bws = workspace(bwsb, dev, 'decloop_bwd')
+            call('re2e_dec_loop_bwd', pre.data_ptr(), hmask.data_ptr(), cx.data_ptr(), z.data_ptr(), c.data_ptr(), w.data_ptr(), conv.data_ptr(), dpj.data_ptr(),
+                 dZ.data_ptr(), ctx.hlens.data_ptr(), w_ctx, ldw, Pm['w_hh'].data_ptr(), Pm['mlp_dec'].data_ptr(), Pm['mlp_att'].data_ptr(),
+                 Pm['loc_conv'].data_ptr(), Pm['gvec_w'].data_ptr(), gates.data_ptr(), d_cx_all.data_ptr(), de_all.data_ptr(), ddp.data_ptr(),
+                 partials.data_ptr(), npart, A + 1 + A * C, L1, B, T, E, D, A, C, Fh, bws.data_ptr(), bwsb)
+        for i in range(L1 - 1 if not bwsb else -1, -1, -1):
             d_cx = d_cx_all[i]
             if fused:
                 # dh = carried dz + dZ[i] inside the cell kernel; d ctx and d z_{i-1} from the same dgates in one launch

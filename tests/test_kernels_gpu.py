@@ -925,6 +925,58 @@ def test_decoder_loop_persistent_vs_stepwise(B, T, L1, E, A, D, C, Fh):
         close(k, out['persist'][k], out['step'][k].cpu(), tol=2e-4)
 
 
+@pytest.mark.parametrize('B,T,L1,E,A,D,C,Fh', [(32, 200, 41, 512, 320, 300, 10, 100),     # config 4's decoder
+                                               (8, 750, 12, 512, 320, 300, 10, 100),      # config 5: 16 frame chunks per utterance
+                                               (32, 200, 4, 320, 320, 300, 10, 100),      # the reference's default widths
+                                               (5, 37, 6, 32, 24, 12, 3, 4),              # ragged everything
+                                               (3, 24, 7, 512, 320, 300, 10, 100),        # one chunk per utterance, fewer frames than filter taps
+                                               (3, 100, 4, 144, 68, 36, 12, 7)])
+def test_decoder_loop_backward_persistent_vs_stepwise(B, T, L1, E, A, D, C, Fh):
+    """csrc/decloop.hip's reverse loop (one persistent launch + one launch for d W_conv) against the launch-per-token backward: gradients
+    of the encoder states, of pre and of every decoder / attention parameter, from the same forward."""
+    ops, lib = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + T + 1)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(DEV)
+    hl = torch.randint(max(1, T // 2), T + 1, (B,), generator=g)
+    hl[0] = T
+    hmask0 = r(B, T, E)
+    for b in range(B):
+        hmask0[b, int(hl[b]):] = 0
+    pre0 = r(B, T, A)
+    P0 = dict(embed=r(50, D, scale=0.5), w_ih=r(4 * D, D + E, scale=0.08), w_hh=r(4 * D, D, scale=0.08), b_ih=r(4 * D, scale=0.1), b_hh=r(4 * D, scale=0.1),
+              mlp_dec=r(A, D, scale=0.1), mlp_att=r(A, C, scale=0.5), loc_conv=r(C, 1, 1, 2 * Fh + 1, scale=0.3), gvec_w=r(1, A, scale=0.3), gvec_b=r(1, scale=0.1))
+    ids = torch.randint(0, 50, (L1, B), generator=g).to(torch.int32).to(DEV)
+    hlens = hl.to(torch.int32).to(DEV)
+    gz = r(L1, B, D)
+    if lib.query('re2e_dec_loop_bwd_workspace_bytes', L1, B, T, E, D, A, C, Fh) == 0 or lib.query('re2e_dec_loop_workspace_bytes', L1, B, T, E, D, A, C, Fh) == 0:
+        pytest.skip('shape outside the persistent loop on this device')
+    out = {}
+    for name, flag in (('step', False), ('persist', True)):
+        hm, pr = hmask0.clone().requires_grad_(True), pre0.clone().requires_grad_(True)
+        Pm = {k: torch.nn.Parameter(v.clone()) for k, v in P0.items()}
+        ops.DECODER_PERSIST = True                      # the same (persistent) forward for both: what is compared is the backward
+        zs, w = ops.DecoderLoopFn.apply(hm, pr, ids, hlens, L1, Pm)
+        ops.DECODER_PERSIST = flag
+        try:
+            (zs * gz).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.DECODER_PERSIST = True
+        out[name] = dict(d_enc=hm.grad.clone(), d_pre=pr.grad.clone(), **{k: v.grad.clone() for k, v in Pm.items() if v.grad is not None})
+    assert lib.query('re2e_lstm_abort_count') == 0
+    assert set(out['persist']) == set(out['step'])
+    bad = []
+    for k in sorted(out['step']):
+        got, ref = out['persist'][k].float().cpu(), out['step'][k].float().cpu()
+        err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
+        print('%-10s max err %.3e  scale %.3e' % (k, err, scale))
+        # gvec_b: its true gradient is zero (softmax ignores a shift of the energies): both sides hold rounding noise of the sum of 260 000 terms
+        lim = 3e-4 * scale + 1e-7 if k != 'gvec_b' else 1e-5 * float(L1 * B)
+        if not (err <= lim):
+            bad.append(k)
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('M,K,N1,N2', [(32, 1200, 512, 300), (3, 56, 20, 14), (17, 40, 33, 1)])
 def test_gemm_skinny2(M, K, N1, N2):
     """re2e_gemm_skinny2: two products sharing the skinny left operand in one launch (decoder backward: d ctx and d z from
