@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 311
+#define RE2E_ABI_VERSION 312
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -328,17 +328,20 @@ int re2e_dec_loop_fwd(const float* pre, const float* enc, const int* hlens_dev, 
                       const float* gvec, const float* gvec_b, const float* w_ctx, long ldw, const float* w_hh, float* gates, float* z, float* c,
                       float* w, float* cx, float* conv, float* dpj, int L1, int B, int T, int E, int D, int A, int C, int Fh,
                       void* workspace, size_t workspace_bytes, re2e_stream_t stream);
-/* The loop's backward as ONE persistent launch (+ one launch for d W_conv of all tokens): the reverse of the above, token L1-1 .. 0.  On entry
- * gates holds the activated gates saved by the forward; on exit d(gates) (what the weight-gradient products read).  d_cx_all (L1,B,E),
- * de_all (L1,B,T), ddp (L1,B,A) = d dec_proj are written; partials (B, partial_floats) gets += d W_conv at float offset wconv_offset of each
- * row (layout of re2e_attloc_partial_floats).  dZ (L1,B,D): gradient of the decoder states.  0 bytes = shape outside the resident form
- * (also RE2E_DEC_PERSIST=0, or =2: forward only): the caller runs re2e_lstm_cell_bwd + re2e_gemm_skinny2 + re2e_attloc_bwd per token. */
+/* The loop's backward as ONE persistent launch: the reverse of the above, token L1-1 .. 0.  On entry gates holds the activated gates saved by
+ * the forward; on exit d(gates) (what the weight-gradient products read).  d_cx_all (L1,B,E), de_all (L1,B,T), ddp (L1,B,A) = d dec_proj and
+ * d_pre (B,T,A; may be NULL) are written; the d conv rows of every token stay in the workspace for re2e_dec_loop_dwconv, which adds d W_conv to
+ * partials (B, partial_floats) at float offset wconv_offset of each row (layout of re2e_attloc_partial_floats) -- a separate call so that it can
+ * run on a weight-gradient stream.  dZ (L1,B,D): gradient of the decoder states.  0 bytes = shape outside the resident form (also
+ * RE2E_DEC_PERSIST=0, or =2: forward only): the caller runs re2e_lstm_cell_bwd + re2e_gemm_skinny2 + re2e_attloc_bwd per token. */
 size_t re2e_dec_loop_bwd_workspace_bytes(int L1, int B, int T, int E, int D, int A, int C, int Fh);
 int re2e_dec_loop_bwd(const float* pre, const float* enc, const float* cx, const float* z, const float* c, const float* w, const float* conv,
                       const float* dpj, const float* dZ, const int* hlens_dev, const float* w_ctx, long ldw, const float* w_hh, const float* mlp_dec,
                       const float* w_att, const float* w_conv, const float* gvec, float* gates, float* d_cx_all, float* de_all, float* ddp,
-                      float* partials, int partial_floats, int wconv_offset, int L1, int B, int T, int E, int D, int A, int C, int Fh,
-                      void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+                      float* d_pre, int L1, int B, int T, int E, int D, int A, int C, int Fh, void* workspace, size_t workspace_bytes,
+                      re2e_stream_t stream);
+int re2e_dec_loop_dwconv(const float* w, const int* hlens_dev, const void* workspace, size_t workspace_bytes, float* partials, int partial_floats,
+                         int wconv_offset, int L1, int B, int T, int E, int D, int A, int C, int Fh, re2e_stream_t stream);
 /* Two skinny products that share A (M <= 32 rows) in one launch: C1 = A[M,K] B1[K,N1], C2 = A B2[K,N2] (B row-major (K,N));
  * the decoder's backward step: d ctx = dgates W_ih[:, Dd:], d z = dgates W_hh. */
 int re2e_gemm_skinny2(int M, int K, const float* A, long lda, const float* B1, long ldb1, int N1, float* C1, long ldc1,

@@ -600,7 +600,7 @@ struct DecBwdArgs {
   const int* hlens;
   const float *w_ctx; long ldw;
   const float *w_hh, *w_dec, *w_att, *w_conv, *gvec;
-  float *gates, *d_cx, *de_all, *ddp, *d_conv;
+  float *gates, *d_cx, *de_all, *ddp, *d_conv, *d_pre;
   int L1, B, T, E, D, A, C, Fh;
   int NU, NC, NFR, FR;              // unit / column workgroups, frame chunks per utterance, frames per chunk
   unsigned *err, *f1, *f2, *f4, *f5, *f6a, *f6;
@@ -825,6 +825,11 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
   const __amdgpu_buffer_rsrc_t pp_rs = __builtin_amdgcn_make_buffer_rsrc(a.ddpp, 0, (int)(2L * B * NFR * AP * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t dv_rs = __builtin_amdgcn_make_buffer_rsrc(a.d_conv, 0, (int)((long)L1 * B * T * C * 4), 0x00020000);
   const int arw = a.ARW;                                          // columns of d dec_proj this workgroup reduces
+  f32x4 dpa[TPA][ATW];                                             // d pre of the own frames: the sum of du over the tokens
+#pragma unroll
+  for (int j = 0; j < TPA; ++j)
+#pragma unroll
+    for (int qq = 0; qq < ATW; ++qq) dpa[j][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
   bool aborted = false;
   for (int it = 0; it < L1; ++it) {
     const int i = L1 - 1 - it, par = it & 1;
@@ -923,6 +928,7 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
         for (int qq = 0; qq < ATW; ++qq) {
           const f32x4 du = dtg[j][qq] * dej;
           dsum[qq] += du;
+          dpa[j][qq] += du;
 #pragma unroll
           for (int r = 0; r < 4; ++r) dcv[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wAT[qq][r], du[r], dcv[j], 0, 0, 0);
         }
@@ -1012,6 +1018,17 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
       __syncthreads();
     }
   }
+  if (a.d_pre) {
+#pragma unroll
+    for (int j = 0; j < TPA; ++j) {
+      const int f = 16 * j + m;
+#pragma unroll
+      for (int qq = 0; qq < ATW; ++qq) {
+        const int col = 16 * (wid + 4 * qq) + 4 * kq;
+        if (f < nt && col < A) *reinterpret_cast<f32x4*>(a.d_pre + ((long)b * T + t0 + f) * A + col) = dpa[j][qq];
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(NT) void dec_loop_bwd_kernel(DecBwdArgs a) {
@@ -1097,8 +1114,7 @@ extern "C" size_t re2e_dec_loop_bwd_workspace_bytes(int L1, int B, int T, int E,
 extern "C" int re2e_dec_loop_bwd(const float* pre, const float* enc, const float* cx, const float* z, const float* c, const float* w, const float* conv,
                                  const float* dpj, const float* dZ, const int* hlens, const float* w_ctx, long ldw, const float* w_hh, const float* mlp_dec,
                                  const float* w_att, const float* w_conv, const float* gvec, float* gates, float* d_cx_all, float* de_all, float* ddp,
-                                 float* partials, int partial_floats, int wconv_offset, int L1, int B, int T, int E, int D, int A, int C, int Fh,
-                                 void* ws, size_t ws_bytes, hipStream_t stream) {
+                                 float* d_pre, int L1, int B, int T, int E, int D, int A, int C, int Fh, void* ws, size_t ws_bytes, hipStream_t stream) {
   DecBwdPlan p;
   if (!dec_bwd_plan(L1, B, T, E, D, A, C, Fh, p)) {
     re2e_set_error("re2e_dec_loop_bwd: shape outside the persistent loop's limits (L1=%d B=%d T=%d E=%d D=%d A=%d C=%d Fh=%d)", L1, B, T, E, D, A, C, Fh);
@@ -1111,7 +1127,7 @@ extern "C" int re2e_dec_loop_bwd(const float* pre, const float* enc, const float
   DecBwdArgs a;
   a.pre = pre; a.enc = enc; a.cx = cx; a.z = z; a.c = c; a.w = w; a.conv = conv; a.dpj = dpj; a.dZ = dZ; a.hlens = hlens;
   a.w_ctx = w_ctx; a.ldw = ldw; a.w_hh = w_hh; a.w_dec = mlp_dec; a.w_att = w_att; a.w_conv = w_conv; a.gvec = gvec;
-  a.gates = gates; a.d_cx = d_cx_all; a.de_all = de_all; a.ddp = ddp;
+  a.gates = gates; a.d_cx = d_cx_all; a.de_all = de_all; a.ddp = ddp; a.d_pre = d_pre;
   a.L1 = L1; a.B = B; a.T = T; a.E = E; a.D = D; a.A = A; a.C = C; a.Fh = Fh;
   a.NU = p.NU; a.NC = p.NC; a.NFR = p.NFR; a.FR = p.FR; a.AP = p.AP; a.ARW = p.ARW;
   a.err = reinterpret_cast<unsigned*>(base);
@@ -1125,8 +1141,17 @@ extern "C" int re2e_dec_loop_bwd(const float* pre, const float* enc, const float
   g_dec_bwd_lim.ensure(reinterpret_cast<const void*>(&dec_loop_bwd_kernel), lds);
   hipLaunchKernelGGL(dec_loop_bwd_kernel, dim3(p.NU + p.NC + p.NA), dim3(NT), lds, stream, a);
   RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+extern "C" int re2e_dec_loop_dwconv(const float* w, const int* hlens, const void* ws, size_t ws_bytes, float* partials, int partial_floats, int wconv_offset,
+                                    int L1, int B, int T, int E, int D, int A, int C, int Fh, hipStream_t stream) {
+  DecBwdPlan p;
+  if (!dec_bwd_plan(L1, B, T, E, D, A, C, Fh, p)) { re2e_set_error("re2e_dec_loop_dwconv: shape outside the persistent loop's limits"); return RE2E_EUNSUPPORTED; }
+  RE2E_CHECK_ARG(w && hlens && ws && partials && ws_bytes >= p.ws, "bad args");
+  const float* d_conv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + p.o_dv);
   const size_t lds3 = (size_t)(((T + 2 * Fh + 7) & ~3) + T + 8) * sizeof(float);
-  hipLaunchKernelGGL(dwconv_all_kernel, dim3(B, C), dim3(NT), lds3, stream, w, hlens, (const float*)a.d_conv, L1, B, T, C, Fh, wconv_offset, partial_floats, partials);
+  hipLaunchKernelGGL(dwconv_all_kernel, dim3(B, C), dim3(NT), lds3, stream, w, hlens, d_conv, L1, B, T, C, Fh, wconv_offset, partial_floats, partials);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

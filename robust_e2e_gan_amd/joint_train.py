@@ -618,9 +618,11 @@ class JointTrainer(object):
                 b.copy_(s)
         saved = {k: os.environ.get(k) for k in ('RE2E_LSTM_PERSIST', 'RE2E_LSTM_PERSIST_BWD')}
         os.environ['RE2E_LSTM_PERSIST'] = os.environ['RE2E_LSTM_PERSIST_BWD'] = '0'
+        dec_persist, ops.DECODER_PERSIST = ops.DECODER_PERSIST, False        # ... and the launch-per-token decoder loop (csrc/decloop.hip counts with them)
         try:
             vals = self.to_floats({k: v for k, v in self.step(data, rate, cmvn).items() if k.startswith('train/') or k == 'grad_norm'})
         finally:
+            ops.DECODER_PERSIST = dec_persist
             for k, v in saved.items():
                 if v is None:
                     os.environ.pop(k, None)

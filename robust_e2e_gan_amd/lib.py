@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
-ABI_VERSION = 311      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
+ABI_VERSION = 312      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
@@ -96,7 +96,8 @@ SIGNATURES = {
     're2e_gemm_skinny2': (I, [I, I, P, L, P, L, I, P, L, P, L, I, P, L, P]),
     're2e_dec_loop_workspace_bytes': (Z, [I, I, I, I, I, I, I, I]),
     're2e_dec_loop_bwd_workspace_bytes': (Z, [I, I, I, I, I, I, I, I]),
-    're2e_dec_loop_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
+    're2e_dec_loop_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, Z, P]),
+    're2e_dec_loop_dwconv': (I, [P, P, P, Z, P, I, I, I, I, I, I, I, I, I, I, P]),
     're2e_dec_loop_fwd': (I, [P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, Z, P]),
     're2e_embedding_fwd': (I, [P, P, I, I, P, L, P]),
     're2e_embedding_bwd': (I, [P, L, P, I, I, I, P, F, P]),

@@ -1582,7 +1582,7 @@ class DecoderLoopFn(torch.autograd.Function):
             call('re2e_dec_loop_bwd', pre.data_ptr(), hmask.data_ptr(), cx.data_ptr(), z.data_ptr(), c.data_ptr(), w.data_ptr(), conv.data_ptr(), dpj.data_ptr(),
                  dZ.data_ptr(), ctx.hlens.data_ptr(), w_ctx, ldw, Pm['w_hh'].data_ptr(), Pm['mlp_dec'].data_ptr(), Pm['mlp_att'].data_ptr(),
                  Pm['loc_conv'].data_ptr(), Pm['gvec_w'].data_ptr(), gates.data_ptr(), d_cx_all.data_ptr(), de_all.data_ptr(), ddp.data_ptr(),
-                 partials.data_ptr(), npart, A + 1 + A * C, L1, B, T, E, D, A, C, Fh, bws.data_ptr(), bwsb)
+                 d_pre.data_ptr(), L1, B, T, E, D, A, C, Fh, bws.data_ptr(), bwsb)
         for i in range(L1 - 1 if not bwsb else -1, -1, -1):
             d_cx = d_cx_all[i]
             if fused:
@@ -1607,13 +1607,23 @@ class DecoderLoopFn(torch.autograd.Function):
             have_dw = True
             gemm(ddp[i], Pm['mlp_dec'], dz_carry, B, D, A, beta=1.0)
         call('re2e_attloc_denc', w.data_ptr(), d_cx_all.data_ptr(), L1, B, T, E, d_enc.data_ptr(), 0.0)
-        call('re2e_attloc_dpre', pre.data_ptr(), conv.data_ptr(), dpj.data_ptr(), de_all.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['gvec_w'].data_ptr(),
-             L1, B, T, A, C, Fh, d_pre.data_ptr(), partials.data_ptr(), aws.data_ptr(), awsb)
+        def dpre_into(d_pre_out):
+            aw = workspace(awsb, dev, 'attloc')
+            call('re2e_attloc_dpre', pre.data_ptr(), conv.data_ptr(), dpj.data_ptr(), de_all.data_ptr(), Pm['mlp_att'].data_ptr(), Pm['gvec_w'].data_ptr(),
+                 L1, B, T, A, C, Fh, d_pre_out.data_ptr(), partials.data_ptr(), aw.data_ptr(), awsb)
+        if not bwsb:
+            dpre_into(d_pre)
         M = L1 * B
         G2, zp2 = gates.view(M, 4 * D), z[:L1].reshape(M, D)
         # nothing downstream waits for the decoder's weight gradients (~0.4 ms of small GEMMs and reductions): weight-gradient stream
         if w_ih.requires_grad:
-            with param_grads(gates, z, emb, cx, ddp, partials):
+            with param_grads(gates, z, emb, cx, ddp, partials, *((bws, de_all, conv, dpj, pre, w) if bwsb else ())):
+                if bwsb:
+                    # the persistent loop has written d_pre itself: the weight-gradient sums of the energy backward (d gvec, d W_att, recomputed
+                    # from the saved rows) and d W_conv (from the d conv rows it left in its workspace) leave the critical stream
+                    dpre_into(empty((B, T, A), hmask))
+                    call('re2e_dec_loop_dwconv', w.data_ptr(), ctx.hlens.data_ptr(), bws.data_ptr(), bwsb, partials.data_ptr(), npart, A + 1 + A * C,
+                         L1, B, T, E, D, A, C, Fh)
                 with accumulate(w_ih) as (gw, beta):
                     gemm(G2, emb.view(M, Dd), gw, 4 * D, Dd, M, transa=True, ldc=ldw, beta=beta)                       # dW_ih[:, :Dd]
                     gemm(G2, cx.view(M, E), gw.data_ptr() + 4 * Dd, 4 * D, E, M, transa=True, ldc=ldw, beta=beta)      # dW_ih[:, Dd:]
