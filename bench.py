@@ -223,6 +223,44 @@ def chain_roofline(dev):
                                                             'mfma_floor_us': round(flop / (PEAK_FP32_MFMA_TFLOPS * 1e6), 2)},
                      'bwd': {'us_per_step': round(best[1], 2), 'handoff_floor_us': fl['bwd'],
                              'mfma_floor_us': round(flop / (PEAK_FP32_MFMA_TFLOPS * 1e6), 2)}}
+    # the third latency-bound chain of the step: the decoder's teacher-forced loop (csrc/decloop.hip), persistent against launch-per-token
+    try:
+        from robust_e2e_gan_amd import ops
+        B, T, L1, E, A, D, C, Fh = 32, 200, 41, 512, 320, 300, 10, 100
+        g = torch.Generator().manual_seed(7)
+        r = lambda *sh, scale=1.0: (torch.randn(*sh, generator=g) * scale).to(dev)
+        hmask, pre = r(B, T, E).requires_grad_(True), r(B, T, A).requires_grad_(True)
+        Pm = {k: torch.nn.Parameter(v) for k, v in dict(
+            embed=r(50, D, scale=0.5), w_ih=r(4 * D, D + E, scale=0.08), w_hh=r(4 * D, D, scale=0.08), b_ih=r(4 * D, scale=0.1), b_hh=r(4 * D, scale=0.1),
+            mlp_dec=r(A, D, scale=0.1), mlp_att=r(A, C, scale=0.5), loc_conv=r(C, 1, 1, 2 * Fh + 1, scale=0.3), gvec_w=r(1, A, scale=0.3), gvec_b=r(1, scale=0.1)).items()}
+        ids = torch.randint(0, 50, (L1, B), generator=g).to(torch.int32).to(dev)
+        hlens = torch.full((B,), T, dtype=torch.int32, device=dev)
+        res = {}
+        was = ops.DECODER_PERSIST
+        for label, flag in (('launch_per_token', False), ('persistent', True)):
+            ops.DECODER_PERSIST = flag
+            t = []
+            for bwd in (False, True):
+                for rep in range(13):
+                    if rep == 3:
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                    if bwd:
+                        z, w = ops.DecoderLoopFn.apply(hmask, pre, ids, hlens, L1, Pm)
+                        z.sum().backward()
+                    else:
+                        with torch.no_grad():
+                            z, w = ops.DecoderLoopFn.apply(hmask, pre, ids, hlens, L1, Pm)
+                torch.cuda.synchronize()
+                t.append((time.perf_counter() - t0) / 10 * 1e3)
+            res[label] = {'fwd_ms': round(t[0], 3), 'fwd_bwd_ms': round(t[1], 3), 'fwd_us_per_token': round(t[0] * 1e3 / L1, 1)}
+        ops.DECODER_PERSIST = was
+        res['tokens'] = L1
+        res['note'] = ('ops.DecoderLoopFn alone on the chip (B=32, T\'=200, E=512: this workload\'s decoder), forward and forward+backward incl. the batched GEMMs '
+                       'around the loop; per-token budgets from clock stamps: tools/dec_stamps.py')
+        out['decoder_loop'] = res
+    except Exception as e:                                   # (a measurement beside the metric: never fail the bench line)
+        out['decoder_loop'] = {'error': repr(e)}
     out['note'] = ('us_per_step: persistent bi-LSTM kernels alone on the chip, best of 3 sequences; handoff_floor_us: the same exchange with nothing '
                    'computed (profiles/r04_handoff_probe.txt); mfma_floor_us: step FLOPs / whole-chip fp32-MFMA peak')
     return out

@@ -587,6 +587,15 @@ extern "C" int re2e_dec_loop_fwd(const float* pre, const float* enc, const int* 
 // (transposed location conv) and one scalar per chunk (the softmax normaliser's w . d w term).  Same flagged hand-off as the forward.
 // Only what the recurrence needs is done per token; d W_conv is summed after the loop from the saved d conv rows (dwconv_all_kernel), d pre /
 // d W_att / d gvec by attloc_dpre, d enc by attloc_denc as before.
+#ifdef RE2E_EXPERIMENTS
+#define BWD_STAMP(ph)                                                                                                   \
+  do {                                                                                                                  \
+    if (a.stamps && threadIdx.x == 0 && it >= kStamp0 && it < kStamp0 + 16)                                             \
+      a.stamps[((long)blockIdx.x * 16 + (it - kStamp0)) * 16 + (ph)] = __builtin_amdgcn_s_memrealtime();                \
+  } while (0)
+#else
+#define BWD_STAMP(ph)
+#endif
 namespace {
 constexpr int FPA = 48;             // frames per attention workgroup (3 tiles of 16)
 constexpr int TPA = 3;
@@ -605,7 +614,9 @@ struct DecBwdArgs {
   int NU, NC, NFR, FR;              // unit / column workgroups, frame chunks per utterance, frames per chunk
   unsigned *err, *f1, *f2, *f4, *f5, *f6a, *f6;
   float *scal, *ddpp;               // [2][B][NFR], [2][B][NFR][AP]
+  float* xg;                        // [2][4 D / 16 + 1][32 utterances][16]: d(gates) in the order the gather reads it (one k-group = 2 KB contiguous)
   int AP, ARW;
+  unsigned long long* stamps;
 };
 
 __device__ __forceinline__ void store16f_sc1(float* p, const f32x4& v) {
@@ -623,16 +634,13 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // The product both GEMM roles run per token: out^T[col][b] = sum_k W[k][col] dgates[b][k] over this wave's quarter of the k-groups
 // (k = 16 g + 4 kq + j, g = wave + 4 gi: one 16-byte load of dgates per lane and four MFMAs).  acc[tile]: 16 utterances each.
-template <int NG_, class AOP>
-__device__ __forceinline__ void gather_mfma(const __amdgpu_buffer_rsrc_t rs, const unsigned row_b, const int K, const int wid, const int kq,
-                                            const int ntb, const bool ok0, const bool ok1, const AOP& aop, f32x4 (&acc)[2]) {
+template <int NG_, class AOP, class BOFF>
+__device__ __forceinline__ void gather_mfma(const __amdgpu_buffer_rsrc_t rs, const BOFF& boff, const int ntb, const AOP& aop, f32x4 (&acc)[2]) {
   f32x4 b0[NG_], b1[NG_];
 #pragma unroll
   for (int gi = 0; gi < NG_; ++gi) {
-    const int k = 16 * (wid + 4 * gi) + 4 * kq;
-    const unsigned off = k < K ? row_b + (unsigned)k * 4u : 0xFFFFFFF0u;
-    b0[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok0 ? off : 0xFFFFFFF0u, 0, 16));
-    b1[gi] = (ntb > 1) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok1 ? off + 16u * (unsigned)K * 4u : 0xFFFFFFF0u, 0, 16)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    b0[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, boff(gi, 0), 0, 16));
+    b1[gi] = (ntb > 1) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, boff(gi, 1), 0, 16)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int gi = 0; gi < NG_; ++gi) {
@@ -672,7 +680,8 @@ __device__ void bwd_unit_role(const DecBwdArgs& a, const int x, float* sm, const
   auto a_lds = [&](int gi) { const int g = wid + 4 * gi; return *reinterpret_cast<const f32x4*>(wl + (((g <= ngrp ? g : ngrp) * 4 + kq) * 16 + m) * 4); };
   auto a_reg = [&](int gi) { return wd[gi]; };
   f32x4* red = reinterpret_cast<f32x4*>(sm);                     // [4 waves][2 tiles][64 lanes]
-  const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(a.gates, 0, (int)((long)L1 * B * K * 4), 0x00020000);
+  const int XGP = (K / 16 + 1) * 32 * 16;                        // floats per parity of the packed d(gates)
+  const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, 2 * XGP * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t p_rs = __builtin_amdgcn_make_buffer_rsrc(a.ddp, 0, (int)((long)L1 * B * A * 4), 0x00020000);
   const bool ok0 = m < B, ok1 = 16 + m < B;
   const int NA = B * a.NFR;
@@ -684,6 +693,7 @@ __device__ void bwd_unit_role(const DecBwdArgs& a, const int x, float* sm, const
   bool aborted = false;
   for (int it = 0; it < L1; ++it) {
     const int i = L1 - 1 - it;
+    BWD_STAMP(0);
     if (!is_col) {
       // ---- (d) + (a): dz = dz' (in acc since the last token) + d dec_proj_{i+1} mlp_dec, then the cell backward ----
       float gv[2][4], cp[2], cc[2], dzo[2];
@@ -699,11 +709,18 @@ __device__ void bwd_unit_role(const DecBwdArgs& a, const int x, float* sm, const
       }
       if (it > 0) {
         if (!aborted && !wait_flags(a.f6, NA, (unsigned)it, a.err, lane)) aborted = true;
-        gather_mfma<GKA>(p_rs, (unsigned)((((long)(i + 1) * B + m) * A) * 4), A, wid, kq, ntb, ok0, ok1, a_reg, acc);
+        BWD_STAMP(1);
+        const unsigned row_b = (unsigned)((((long)(i + 1) * B + m) * A) * 4);
+        auto off_p = [&](int gi, int tl) {
+          const int k = 16 * (wid + 4 * gi) + 4 * kq;
+          return (k < A && (tl ? ok1 : ok0)) ? row_b + (unsigned)(k + 16 * tl * A) * 4u : 0xFFFFFFF0u;
+        };
+        gather_mfma<GKA>(p_rs, off_p, ntb, a_reg, acc);
       }
       red[(wid * 2 + 0) * 64 + lane] = acc[0];
       red[(wid * 2 + 1) * 64 + lane] = acc[1];
       __syncthreads();
+      BWD_STAMP(2);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int ul = jj + 8 * h, u = c0 + ul;
@@ -717,23 +734,37 @@ __device__ void bwd_unit_role(const DecBwdArgs& a, const int x, float* sm, const
           float d = dz + dzo[h];
           if (aborted) d = __uint_as_float(0x7fc00000u);
           const float dct = d * go * (1.f - tc * tc) + dcr[h];
-          float* gp = a.gates + ((long)i * B + bm) * K + u;
-          store4_sc1(gp, dct * gg * gi * (1.f - gi));
-          store4_sc1(gp + D, dct * cp[h] * gf * (1.f - gf));
-          store4_sc1(gp + 2L * D, dct * gi * (1.f - gg * gg));
-          store4_sc1(gp + 3L * D, d * tc * go * (1.f - go));
+          float* gp = a.gates + ((long)i * B + bm) * K + u;      // plain layout: what the weight-gradient products read after the loop
+          float* xp = a.xg + (long)(it & 1) * XGP;               // packed copy: what the gather of this token reads
+          const float dgv[4] = {dct * gg * gi * (1.f - gi), dct * cp[h] * gf * (1.f - gf), dct * gi * (1.f - gg * gg), d * tc * go * (1.f - go)};
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int k = g4 * D + u;
+            gp[(long)g4 * D] = dgv[g4];
+            store4_sc1(xp + ((k >> 4) * 32 + bm) * 16 + (k & 15), dgv[g4]);
+          }
           dcr[h] = dct * gf;
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      BWD_STAMP(3);
       if (tid == 0) __hip_atomic_store(a.f1 + (long)x * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (i == 0) break;                                           // nothing consumes dz of the initial state
     }
     // ---- (b): all of dgates_i, times this workgroup's 16 columns ----
     if (!aborted && !wait_flags(a.f1, a.NU, (unsigned)(it + 1), a.err, lane)) aborted = true;
-    gather_mfma<GKU>(g_rs, (unsigned)((((long)i * B + m) * K) * 4), K, wid, kq, ntb, ok0, ok1, a_lds, acc);
+    BWD_STAMP(4);
+    {
+      const unsigned pb = (unsigned)((it & 1) * XGP);
+      auto off_g = [&](int gi, int tl) {                        // k-group g of the packed copy: [g][utterance][16], lane (m, kq) -> 16 bytes at k = 4 kq
+        const int g = wid + 4 * gi;
+        return (g < ngrp && (tl ? ok1 : ok0)) ? (pb + (unsigned)((g * 32 + 16 * tl + m) * 16 + 4 * kq)) * 4u : 0xFFFFFFF0u;
+      };
+      gather_mfma<GKU>(g_rs, off_g, ntb, a_lds, acc);
+    }
+    BWD_STAMP(5);
     if (is_col) {
       red[(wid * 2 + 0) * 64 + lane] = acc[0];
       red[(wid * 2 + 1) * 64 + lane] = acc[1];
@@ -751,6 +782,7 @@ __device__ void bwd_unit_role(const DecBwdArgs& a, const int x, float* sm, const
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      BWD_STAMP(6);
       if (tid == 0) __hip_atomic_store(a.f2 + (long)(x) * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -773,7 +805,7 @@ struct AttBwdLds {
     o_dcw = o; o += 16 * W;                   // [channel][window] d conv rows of the frames within Fh of the own ones
     o_wcs = o; o += 16 * (2 * Fh + 1);        // [channel][tap]
     o_rc = o; o += 4 * TPA * 64 * 4;          // per-wave d conv partials
-    o_sc2 = o; o += 16 * 64;                  // [channel][frame] of the transposed conv
+    o_sc2 = o; o += 2 * 16 * 64;              // [tap half][channel][frame] of the transposed conv
     o_red = o; o += 32;
     total = o;
     (void)C;
@@ -819,6 +851,7 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
   }
   for (int idx = tid; idx < 16 * Kf; idx += NT) wcs[idx] = idx < C * Kf ? a.w_conv[idx] : 0.f;
   if (tid < 64) { dwl[tid] = 0.f; de[tid] = 0.f; wv[tid] = 0.f; }
+  for (int idx = tid; idx < 16 * W; idx += NT) dcw[idx] = 0.f;
   __syncthreads();
   const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(a.d_cx, 0, (int)((long)L1 * B * E * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t s_rs = __builtin_amdgcn_make_buffer_rsrc(a.scal, 0, (int)(2L * B * NFR * 4), 0x00020000);
@@ -833,6 +866,7 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
   bool aborted = false;
   for (int it = 0; it < L1; ++it) {
     const int i = L1 - 1 - it, par = it & 1;
+    BWD_STAMP(0);
     // ---- before d cx_i is needed: x = pre + dp + W_att conv_i recomputed from the saved conv rows, dtg = gvec (1 - tanh^2 x) ----
     f32x4 dtg[TPA][ATW];
     {
@@ -872,6 +906,7 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
           }
         }
     }
+    BWD_STAMP(1);
     // the normaliser's w . dw term: one scalar per chunk of the utterance, published at the end of the last token
     float sdot = 0.f;
     if (it > 0) {
@@ -881,7 +916,9 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
     }
     const float cx0 = tid < E ? a.cx[((long)i * B + b) * E + tid] : 0.f, cx1 = tid + NT < E ? a.cx[((long)i * B + b) * E + tid + NT] : 0.f;
     // ---- d cx_i[b] ----
+    BWD_STAMP(2);
     if (!aborted && !wait_flags(a.f2, a.NC, (unsigned)(it + 1), a.err, lane)) aborted = true;
+    BWD_STAMP(3);
     {
       const float d0v = tid < E ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (unsigned)((((long)i * B + b) * E + tid) * 4), 0, 16)) : 0.f;
       const float d1v = tid + NT < E ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rs, (unsigned)((((long)i * B + b) * E + tid + NT) * 4), 0, 16)) : 0.f;
@@ -889,6 +926,7 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
       if (tid + NT < E) dcs[tid + NT] = d1v;
       sdot += block_sum(d0v * cx0 + d1v * cx1, red);            // (its barriers publish dcs)
     }
+    BWD_STAMP(4);
     // g[f] = dc . enc[f]: thread = (frame f, quarter p of the columns), two batches of 16-byte reads
     {
       const int f = lane, p = wid, e4 = E / 16;                   // float4 per quarter
@@ -915,6 +953,7 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
       if (tid < nt) a.de_all[((long)i * B + b) * T + t0 + tid] = v;
     }
     __syncthreads();
+    BWD_STAMP(5);
     // ---- du = de dtg;  d dec_proj partial = sum over the own frames;  d conv^T = W_att^T du ----
     {
       f32x4 dsum[ATW], dcv[TPA];
@@ -943,6 +982,7 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
       }
     }
     __syncthreads();
+    BWD_STAMP(6);
     if (wid < TPA) {                                             // wave j sums the four waves' partials of tile j: lane (frame m, channels 4 kq + r)
       const f32x4 v = (rc[(0 * TPA + wid) * 64 + lane] + rc[(1 * TPA + wid) * 64 + lane]) + (rc[(2 * TPA + wid) * 64 + lane] + rc[(3 * TPA + wid) * 64 + lane]);
       const int f = 16 * wid + m;
@@ -955,12 +995,14 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    BWD_STAMP(7);
     if (tid == 0) {
       __hip_atomic_store(a.f6a + (long)q * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.f4 + (long)q * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- this workgroup's columns of d dec_proj_i: the sum of the utterance's chunk partials ----
     if (!aborted && !wait_flags(a.f6a + (long)b * NFR * 32, NFR, (unsigned)(it + 1), a.err, lane)) aborted = true;
+    BWD_STAMP(8);
     for (int cl = tid; cl < arw; cl += NT) {
       const int col = fr * arw + cl;
       float pv[NFRMAX];
@@ -975,36 +1017,64 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    BWD_STAMP(9);
     if (tid == 0) __hip_atomic_store(a.f6 + (long)q * 32, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i == 0) break;
     // ---- (off the critical path) d w_{i-1} of the own frames: transposed location conv over the d conv rows within Fh frames ----
     if (!aborted && !wait_flags(a.f4 + (long)b * NFR * 32, NFR, (unsigned)(it + 1), a.err, lane)) aborted = true;
+    BWD_STAMP(10);
     {
-      const int o = t0 - Fh, wn = nt + 2 * Fh;                    // window of frames [o, o + wn)
-      for (int idx = tid; idx < 16 * W; idx += NT) {
-        const int cch = idx / W, xw = idx % W, t = o + xw;
-        dcw[idx] = (cch < C && xw < wn && t >= 0 && t < T)
-                       ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dv_rs, (unsigned)(((((long)i * B + b) * T + t) * C + cch) * 4), 0, 16)) : 0.f;
+      // window of frames [o, o + wn) = [t0 - Fh, t0 + nt + Fh); its part inside [0, T) is one contiguous range of (frame, channel) floats: all of
+      // a thread's loads in flight together, transposed into LDS (the positions outside the range were zeroed once, before the loop)
+      const int o = t0 - Fh, tlo = o > 0 ? o : 0, thi = min(T, t0 + nt + Fh), nld = (thi - tlo) * C;
+      const unsigned gb0 = (unsigned)((((long)i * B + b) * T + tlo) * C * 4);
+      for (int u0 = 0; u0 < nld; u0 += 10 * NT) {
+        float tv[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+          const int idx = u0 + u * NT + tid;
+          tv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dv_rs, idx < nld ? gb0 + (unsigned)idx * 4u : 0xFFFFFFF0u, 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+          const int idx = u0 + u * NT + tid;
+          if (idx < nld) dcw[(idx % C) * W + (tlo - o) + idx / C] = tv[u];
+        }
       }
       __syncthreads();
-      // d w[t0 + f] = sum_c sum_k w_conv[c][k] d conv[t0 + f - k + Fh][c]: item = (channel, frame), frames along the lanes
-      for (int item = tid; item < C * 64; item += NT) {
-        const int cch = item >> 6, f = item & 63;
-        const float* qd = dcw + cch * W + (f < FPA ? f : 0) + 2 * Fh;      // qd[-k] = d conv[t0 + f - k + Fh][cch]
+      // d w[t0 + f] = sum_c sum_k w_conv[c][k] d conv[t0 + f - k + Fh][c]: item = (half of the taps, channel, 4 consecutive frames); four taps per
+      // round from 4 new window values (the other 3 of the 7 it touches stay in registers) and 4 taps
+      const int KH = (Kf + 1) / 2, nitem = 2 * C * (FPA / 4);
+      for (int item = tid; item < nitem; item += NT) {
+        const int h = item / (C * (FPA / 4)), rem = item % (C * (FPA / 4)), cch = rem / (FPA / 4), f0 = 4 * (rem % (FPA / 4));
+        const int k0 = h * KH, k1 = min(Kf, k0 + KH);
+        const float* bq = dcw + cch * W + f0 + 2 * Fh;                  // bq[j - k] = d conv[t0 + f0 + j - k + Fh][cch]
         const float* wk2 = wcs + cch * Kf;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int k = 0;
-        for (; k + 8 <= Kf; k += 8) {
-          a0 += wk2[k] * qd[-k] + wk2[k + 4] * qd[-k - 4]; a1 += wk2[k + 1] * qd[-k - 1] + wk2[k + 5] * qd[-k - 5];
-          a2 += wk2[k + 2] * qd[-k - 2] + wk2[k + 6] * qd[-k - 6]; a3 += wk2[k + 3] * qd[-k - 3] + wk2[k + 7] * qd[-k - 7];
+        int k = k0;
+        float v4 = bq[1 - k], v5 = bq[2 - k], v6 = bq[3 - k];            // v[m] = bq[-k - 3 + m]
+        for (; k + 4 <= k1; k += 4) {
+          const float v0 = bq[-k - 3], v1 = bq[-k - 2], v2 = bq[-k - 1], v3 = bq[-k];
+          const float w0 = wk2[k], w1 = wk2[k + 1], w2 = wk2[k + 2], w3 = wk2[k + 3];
+          // x_j(k + t) = v[j - t + 3]
+          a0 += w0 * v3 + w1 * v2 + w2 * v1 + w3 * v0;
+          a1 += w0 * v4 + w1 * v3 + w2 * v2 + w3 * v1;
+          a2 += w0 * v5 + w1 * v4 + w2 * v3 + w3 * v2;
+          a3 += w0 * v6 + w1 * v5 + w2 * v4 + w3 * v3;
+          v4 = v0; v5 = v1; v6 = v2;
         }
-        for (; k < Kf; ++k) a0 += wk2[k] * qd[-k];
-        sc2[cch * 64 + f] = (a0 + a1) + (a2 + a3);
+        for (; k < k1; ++k) {
+          const float w0 = wk2[k];
+          a0 += w0 * bq[-k]; a1 += w0 * bq[1 - k]; a2 += w0 * bq[2 - k]; a3 += w0 * bq[3 - k];
+        }
+        float* dst = sc2 + (h * 16 + cch) * 64 + f0;
+        dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
       }
       __syncthreads();
       if (tid < 64) {
         float s = 0.f;
-        for (int cch = 0; cch < C; ++cch) s += sc2[cch * 64 + tid];
+        if (tid < FPA)
+          for (int cch = 0; cch < C; ++cch) s += sc2[cch * 64 + tid] + sc2[(16 + cch) * 64 + tid];
         if (tid >= nt) s = 0.f;
         dwl[tid] = s;
         const float wprev = tid < nt ? a.w[((long)(i - 1) * B + b) * T + t0 + tid] : 0.f;
@@ -1016,6 +1086,7 @@ __device__ void bwd_att_role(const DecBwdArgs& a, const int q, float* sm) {
         }
       }
       __syncthreads();
+      BWD_STAMP(11);
     }
   }
   if (a.d_pre) {
@@ -1068,7 +1139,7 @@ __global__ __launch_bounds__(NT) void dwconv_all_kernel(const float* __restrict_
   if (tid < Kf) partials[(long)b * npart + off + c * Kf + tid] += acc;
 }
 
-struct DecBwdPlan { int NU, NC, NFR, FR, NA, AP, ARW; size_t lds, ws; size_t o_f1, o_f2, o_f4, o_f5, o_f6a, o_f6, o_sc, o_pp, o_dv; };
+struct DecBwdPlan { int NU, NC, NFR, FR, NA, AP, ARW; size_t lds, ws; size_t o_f1, o_f2, o_f4, o_f5, o_f6a, o_f6, o_sc, o_pp, o_xg, o_dv; };
 
 bool dec_bwd_plan(int L1, int B, int T, int E, int D, int A, int C, int Fh, DecBwdPlan& p) {
   if (L1 < 1 || B < 1 || B > 32 || T < 1 || E < 16 || D < 4 || A < 4 || C < 1 || C > 16 || Fh < 0) return false;
@@ -1096,6 +1167,7 @@ bool dec_bwd_plan(int L1, int B, int T, int E, int D, int A, int C, int Fh, DecB
   p.o_f6 = o; o += (size_t)p.NA * 128;
   p.o_sc = o; o += (size_t)2 * B * p.NFR * 4; o = (o + 127) & ~(size_t)127;
   p.o_pp = o; o += (size_t)2 * B * p.NFR * p.AP * 4; o = (o + 127) & ~(size_t)127;
+  p.o_xg = o; o += (size_t)2 * (4 * D / 16 + 1) * 32 * 16 * 4; o = (o + 127) & ~(size_t)127;
   p.o_dv = o; o += (size_t)L1 * B * T * C * 4;
   p.ws = (o + 127) & ~(size_t)127;
   return true;
@@ -1136,6 +1208,8 @@ extern "C" int re2e_dec_loop_bwd(const float* pre, const float* enc, const float
   a.f6a = reinterpret_cast<unsigned*>(base + p.o_f6a); a.f6 = reinterpret_cast<unsigned*>(base + p.o_f6);
   a.scal = reinterpret_cast<float*>(base + p.o_sc); a.ddpp = reinterpret_cast<float*>(base + p.o_pp);
   a.d_conv = reinterpret_cast<float*>(base + p.o_dv);
+  a.xg = reinterpret_cast<float*>(base + p.o_xg);
+  a.stamps = exp_env("RE2E_DEC_STAMPS") ? (unsigned long long*)strtoull(exp_env("RE2E_DEC_STAMPS"), nullptr, 16) : nullptr;
   (void)hipMemsetAsync(ws, 0, p.o_sc, stream);
   const size_t lds = 160 * 1024;
   g_dec_bwd_lim.ensure(reinterpret_cast<const void*>(&dec_loop_bwd_kernel), lds);

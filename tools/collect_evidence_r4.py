@@ -16,7 +16,8 @@ for src, dst in (('bench_default.json', 'r04_bench_default.json'), ('bench_kerne
                  ('step_bins_2ms.txt', 'r04_step_bins_2ms.txt'), ('bench_kernels.txt', 'r04_kernels_alone.txt'),
                  ('chain_rates_alone.txt', 'r04_chain_rates_alone.txt'), ('roofline_conv_kernel_stats.csv', 'r04_roofline_conv_kernel_stats.csv'),
                  ('step_pmc.json', 'r04_step_pmc.json'), ('pytest_gpu.log', 'r04_pytest_gpu.txt'), ('bench_config2.json', 'r04_bench_config2.json'),
-                 ('bench_config3.json', 'r04_bench_config3.json'), ('bench_config5.json', 'r04_bench_config5.json')):
+                 ('bench_config3.json', 'r04_bench_config3.json'), ('bench_config5.json', 'r04_bench_config5.json'),
+                 ('decoder_loop_alone.txt', 'r04_decoder_loop_alone.txt'), ('decoder_loop_budget.txt', 'r04_decoder_loop_budget.txt')):
     if os.path.exists(os.path.join(F, src)):
         shutil.copyfile(os.path.join(F, src), os.path.join(O, dst))
     else:

@@ -67,7 +67,53 @@ def main(B=32, T=200, L1=41, E=512, A=320, D=300, C=10, Fh=100):
     print(' skew of the attention workgroups at the top of a token: %.2f us' % float((att[:, :, 0].max(0).values - att[:, :, 0].min(0).values).mean()))
 
 
+UNIT = ['wait d dec_proj_{i+1} (all attention workgroups)', 'load it + MFMA mlp_dec + partials -> LDS + barrier', 'cell backward, d(gates) stores, drain, barrier (then the flag)',
+        'wait d(gates)_i (all unit workgroups)', 'gather d(gates)_i + MFMA W_hh']
+COL = ['(top)', '-', '-', 'wait d(gates)_i (all unit workgroups)', 'gather d(gates)_i + MFMA W_ctx', 'cross-wave sum, d cx stores, drain, barrier (then the flag)']
+ATTB = ['recompute u = pre + W_att conv_i (MFMA), tanh, dtg', 'wait the chunk scalars of the last token', 'wait d cx_i (all column workgroups)', 'load d cx_i[b], dc . cx (block sum)',
+        'g = dc . enc (LDS rows) + barrier, de, barrier', 'du, d dec_proj partial (row sums, stores), d conv^T (MFMA) -> LDS, barrier',
+        'd conv rows summed + stored, drain, barrier (then the flags)', 'wait the partials of utterance b', 'reduce own columns of d dec_proj, store, drain, barrier (then the flag)',
+        'wait the d conv rows of utterance b', 'window -> LDS, transposed location conv, d w, scalar, flag']
+
+
+def backward(B=32, T=200, L1=41, E=512, A=320, D=300, C=10, Fh=100):
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(DEV)
+    hmask, pre = r(B, T, E).requires_grad_(True), r(B, T, A).requires_grad_(True)
+    Pm = dict(embed=r(50, D, scale=0.5), w_ih=r(4 * D, D + E, scale=0.08), w_hh=r(4 * D, D, scale=0.08), b_ih=r(4 * D, scale=0.1), b_hh=r(4 * D, scale=0.1),
+              mlp_dec=r(A, D, scale=0.1), mlp_att=r(A, C, scale=0.5), loc_conv=r(C, 1, 1, 2 * Fh + 1, scale=0.3), gvec_w=r(1, A, scale=0.3), gvec_b=r(1, scale=0.1))
+    Pm = {k: torch.nn.Parameter(v) for k, v in Pm.items()}
+    ids = torch.randint(0, 50, (L1, B), generator=g).to(torch.int32).to(DEV)
+    hlens = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        z, w = ops.DecoderLoopFn.apply(hmask, pre, ids, hlens, L1, Pm)
+        torch.cuda.synchronize()
+        stamps.zero_()                                   # (the forward stamped too: keep the backward's only)
+        z.sum().backward()
+        torch.cuda.synchronize()
+    st = stamps.view(256, 16, 16).cpu().double() / 100.0
+    NU, NC = (D + 15) // 16, E // 16
+    nwg = int((st[:, 4, 0] > 0).sum())
+    if nwg == 0:
+        print('no stamps')
+        return
+    unit, col, att = st[:NU, 2:-2], st[NU:NU + NC, 2:-2], st[NU + NC:nwg, 2:-2]
+    step = float((att[:, -1, 0] - att[:, 0, 0]).mean() / (att.shape[1] - 1))
+    print('BACKWARD B=%d T=%d: %d unit + %d column + %d attention workgroups, %.2f us per token' % (B, T, NU, NC, nwg - NU - NC, step))
+    for name, x, names, seq in (('unit', unit, UNIT, [0, 1, 2, 3, 4, 5]), ('column', col, COL, [0, 4, 5, 6]), ('attention', att, ATTB, list(range(12)))):
+        print(' %s workgroup:' % name)
+        for a_, b_ in zip(seq[:-1], seq[1:]):
+            d = x[:, :, b_] - x[:, :, a_]
+            nm = names[a_] if name != 'column' else {0: COL[3], 4: COL[4], 5: COL[5]}[a_]
+            print('   %-92s mean %5.2f  max %5.2f us' % (nm, float(d.mean()), float(d.max())))
+        d = x[:, 1:, 0] - x[:, :-1, seq[-1]]
+        print('   %-92s mean %5.2f' % ('(flag store, loop back to the top)', float(d.mean())))
+
+
 if __name__ == '__main__':
+    if 'bwd' in sys.argv:
+        backward()
+        sys.exit(0)
     main()
     if len(sys.argv) > 1:
         main(B=8, T=750, L1=40)
