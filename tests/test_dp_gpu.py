@@ -243,3 +243,47 @@ def test_sync_batchnorm_equals_global_batch(monkeypatch):
     assert err(ba.grad + dzB.sum(0).float().to(DEV), br.grad) <= 1e-4 * float(br.grad.abs().max())
     # running statistics of the GLOBAL batch (unbiased variance over all P rows)
     assert err(rm, 0.1 * mean.float()) <= 1e-5 and err(rv, 0.9 + 0.1 * (var * P / (P - 1)).float()) <= 1e-4
+
+
+def test_occupied_cus_delay_the_persistent_decoder_loop_but_never_abort_it():
+    """The same disturbance for the decoder's persistent loop (csrc/decloop.hip: 198 forward / 211 backward workgroups that each ask for a whole
+    CU): occupiers that hold 64 CUs' LDS for 0.5 - 5 ms at a time, queued on a second stream while the loop's forward and backward run.  No
+    give-up, results bitwise equal to the undisturbed run."""
+    import random
+    from robust_e2e_gan_amd import lib, ops
+    B, T, L1, E, A, D, C, Fh = 32, 200, 41, 512, 320, 300, 10, 100
+    if lib.query('re2e_dec_loop_workspace_bytes', L1, B, T, E, D, A, C, Fh) == 0:
+        pytest.skip('shape outside the persistent loop on this device')
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(DEV)
+    hmask0, pre0 = r(B, T, E), r(B, T, A)
+    P0 = dict(embed=r(50, D, scale=0.5), w_ih=r(4 * D, D + E, scale=0.08), w_hh=r(4 * D, D, scale=0.08), b_ih=r(4 * D, scale=0.1), b_hh=r(4 * D, scale=0.1),
+              mlp_dec=r(A, D, scale=0.1), mlp_att=r(A, C, scale=0.5), loc_conv=r(C, 1, 1, 2 * Fh + 1, scale=0.3), gvec_w=r(1, A, scale=0.3), gvec_b=r(1, scale=0.1))
+    ids = torch.randint(0, 50, (L1, B), generator=g).to(torch.int32).to(DEV)
+    hlens = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    gz = r(L1, B, D)
+    side = torch.cuda.Stream()
+    base = lib.query('re2e_lstm_abort_count')
+    rnd = random.Random(7)
+
+    def run(disturb):
+        hm, pr = hmask0.clone().requires_grad_(True), pre0.clone().requires_grad_(True)
+        Pm = {k: torch.nn.Parameter(v.clone()) for k, v in P0.items()}
+        torch.cuda.synchronize()
+        if disturb:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    lib.call('re2e_debug_occupy', 64, 64 * 1024, rnd.choice((500, 1000, 2500, 5000)))
+                    lib.call('re2e_debug_occupy', 1, 1024, rnd.choice((200, 700, 1500)))
+        zs, w = ops.DecoderLoopFn.apply(hm, pr, ids, hlens, L1, Pm)
+        (zs * gz).sum().backward()
+        torch.cuda.synchronize()
+        return [zs.detach().clone(), w.clone(), hm.grad.clone(), pr.grad.clone()] + [v.grad.clone() for k, v in sorted(Pm.items()) if v.grad is not None]
+    run(False)
+    ref = run(False)
+    got = run(True)
+    assert lib.query('re2e_lstm_abort_count') == base, 'the persistent decoder loop gave up beside workgroups that only held CUs for a few ms'
+    assert len(ref) == len(got)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
