@@ -13,18 +13,21 @@
 //       step i:  acc  = z_i W_hh[rows]^T                         when z_i is complete        (off the critical path)
 //                acc += cx_i W_ctx[rows]^T                       when every context piece is there
 //                cell -> z_{i+1}, c_{i+1}, activated gates;  publish z_{i+1}[:, units]
-//   attention workgroup (b, ch, fc): utterance b, 64-column slice ch of the attention / projection dimension, frame chunk fc
-//       (<= 256 frames, one per thread).  Resident: pre[b, frames, slice] (registers), enc[b, frames, slice] (LDS), mlp_dec[slice, :]
-//       (registers), the conv / mlp_att / gvec weights (LDS).
-//       step i:  (before z_i arrives) location conv of w_{i-1} for its frames on the matrix core (Toeplitz operand from LDS,
-//                v_mfma_f32_16x16x4_f32), u = pre + W_att conv
+//   attention workgroup (b, ch, fc): utterance b, slice ch (64 columns of the attention dimension and the matching share of the projection
+//       columns), frame chunk fc (<= 256 frames).  Resident: pre[b, frames, slice] in registers IN THE ACCUMULATOR LAYOUT of v_mfma_f32_16x16x4 with
+//       the frames as N (lane = frame of a 16-frame tile and four columns of every 16-column block), enc[b, frames, slice] in LDS, mlp_dec[slice, :]
+//       and the W_att / gvec operands in registers, the conv taps in LDS.
+//       step i:  (before z_i arrives) location conv of w_{i-1} for its frames on the matrix core, TRANSPOSED (taps as the A operand, a Toeplitz B
+//                operand straight from LDS): its accumulators are the B operand of u^T = pre^T + W_att conv^T as they are; u stays in registers
 //                dp[slice] = W_dec[slice, :] z_i[b]              when z_i is complete
-//                e_part[t] = sum_{a in slice} gvec[a] tanh(u[t][a] + dp[a])  -> published; the slice axis is what is exchanged, so
-//                no workgroup needs another's dp
+//                e_part[t] = sum_{a in slice} gvec[a] tanh(u[t][a] + dp[a]): 16 columns per lane and tile, a frame's four lanes summed by two
+//                shuffles -> published; the slice axis is what is exchanged, so no workgroup needs another's dp
 //                e[t] = sum_ch e_part + gb, softmax over ALL T frames (every workgroup of b redundantly: no w exchange)
 //                cx_part[slice] = sum_{t in chunk} w[t] enc[t][slice] -> published
-// Per step the critical path is three hand-offs (z, e_part, cx_part) and ~3 us of arithmetic instead of four launches.
-// Workgroups ask for the whole CU's LDS (as the recurrences do): everything must be co-resident, spins are bounded, an abort poisons
+// One wave per SIMD hides no LDS or memory round trip, so every operand batch is fetched explicitly ahead of its use (first build, with the
+// compiler's load -> wait -> use per element: 24 us per token; this form: 18).
+// Per token the critical path is three hand-offs (z, e_part, cx_part: ~1 us each, measured) and the phases between them instead of four launches.
+// Everything must be co-resident (one workgroup per CU fits: checked against the CU count), spins are bounded, an abort poisons
 // z with NaN and is counted in re2e_lstm_abort_count.  Scheduled sampling (a data-dependent token per step) and shapes outside
 // re2e_dec_loop_workspace_bytes' limits stay on the launch-per-step path (ops.DecoderLoopFn), which is also the parity twin in
 // tests/test_kernels_gpu.py.
@@ -566,7 +569,10 @@ extern "C" int re2e_dec_loop_fwd(const float* pre, const float* enc, const int* 
   a.cxp = reinterpret_cast<float*>(base + p.o_cx);
   a.stamps = exp_env("RE2E_DEC_STAMPS") ? (unsigned long long*)strtoull(exp_env("RE2E_DEC_STAMPS"), nullptr, 16) : nullptr;
   (void)hipMemsetAsync(ws, 0, p.o_eb, stream);                    // error word and flags start at zero, every call
-  const size_t lds = 160 * 1024;                                  // the whole CU: nothing else is co-resident with a loop workgroup (see lstm.hip)
+  // Only the LDS it needs (104 of 160 KB at config 4): unlike the 64-workgroup recurrences (lstm.hip) the loop does not gain from owning its
+  // CUs -- what runs beside it are the CTC / CORAL heads, which the critical stream joins right behind the loop (step 52.1 -> 52.0, and
+  // 51.4 -> 51.2 with the recurrences' rule; RE2E_DEC_OWN_CU=1 in the experiments build asks for the whole CU)
+  const size_t lds = (exp_env("RE2E_DEC_OWN_CU") && atoi(exp_env("RE2E_DEC_OWN_CU")) == 1) ? (size_t)160 * 1024 : p.lds;
   g_dec_lim.ensure(reinterpret_cast<const void*>(&dec_loop_fwd_kernel), lds);
   hipLaunchKernelGGL(dec_loop_fwd_kernel, dim3(p.NG + p.NA), dim3(NT), lds, stream, a);
   RE2E_LAUNCH_CHECK();
@@ -1211,7 +1217,7 @@ extern "C" int re2e_dec_loop_bwd(const float* pre, const float* enc, const float
   a.xg = reinterpret_cast<float*>(base + p.o_xg);
   a.stamps = exp_env("RE2E_DEC_STAMPS") ? (unsigned long long*)strtoull(exp_env("RE2E_DEC_STAMPS"), nullptr, 16) : nullptr;
   (void)hipMemsetAsync(ws, 0, p.o_sc, stream);
-  const size_t lds = 160 * 1024;
+  const size_t lds = (exp_env("RE2E_DEC_OWN_CU") && atoi(exp_env("RE2E_DEC_OWN_CU")) == 1) ? (size_t)160 * 1024 : p.lds;
   g_dec_bwd_lim.ensure(reinterpret_cast<const void*>(&dec_loop_bwd_kernel), lds);
   hipLaunchKernelGGL(dec_loop_bwd_kernel, dim3(p.NU + p.NC + p.NA), dim3(NT), lds, stream, a);
   RE2E_LAUNCH_CHECK();

@@ -1167,14 +1167,15 @@ bool launch_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* w
   size_t lds = (size_t)UW * W * 32 * 33 * sizeof(float) + 16;
   dim3 grid(H / (8 * UW), cdiv(B, 32), 2);
   if ((long)grid.x * grid.y * grid.z > cu_count()) return false;          // every workgroup must be resident
-  // A chain (of any size up to the chip: RE2E_LSTM_OWN_CU_FRAC = 1; limited to a quarter of the chip the step was 75.5 ms, to half 75.1, and
-  // at the end of round 2 half 71.79 against whole 71.59 -- the 256-workgroup forward of the 512-wide layers then has the chip to itself)
+  // A chain of up to HALF the chip's CUs (RE2E_LSTM_OWN_CU_FRAC = 2 since the end of round 4; rounds 2-3 measured whole = half within 0.2 ms and
+  // shipped whole, with the decoder loop persistent the 256-workgroup chains of the 512-wide layers are better off NOT excluding the
+  // weight-gradient stream from the chip they only use 5-25 % of: 52.1 -> 51.4 ms, profiles/r04_own_cu_ab.txt; a quarter: 54.3)
   // asks for (almost) a whole CU's LDS per workgroup: nothing else can then be
   // co-resident on its CUs, so its MFMA pipe and memory queue are its own while the filler streams keep the other CUs.
   // (RE2E_LSTM_OWN_CU=0 turns it off, =n asks for n KB -- it has to be the whole CU: with 120 KB, which still admits a small filler
   // workgroup, the step is 74.2 instead of 71.8 ms.  Step 77.9 -> 75.2 ms when introduced: enhancer forward 13.6 -> 9.6, backward 16.7 -> 13.0 ms.)
   static const int hog = exp_env("RE2E_LSTM_OWN_CU") ? atoi(exp_env("RE2E_LSTM_OWN_CU")) : 160;
-  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 1;
+  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 2;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
   fwd_lim<W, QN, UW>().ensure(reinterpret_cast<const void*>(&lstm_fwd_persist<W, QN, UW>), lds);
   lstm_stamps_arm();
@@ -1195,7 +1196,7 @@ bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb,
   unsigned* flags = (unsigned*)((char*)flagmem + 16);
   static const int hog = exp_env("RE2E_LSTM_OWN_CU") ? atoi(exp_env("RE2E_LSTM_OWN_CU")) : 160;      // see launch_fwd_persist
   size_t lds = 0;
-  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 1;
+  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 2;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)(hog - 16) * 1024;       // + ~13 KB static
   bwd_lim<TPW, UW>().ensure(reinterpret_cast<const void*>(&lstm_bwd_persist<TPW, UW>), lds);
   hipLaunchKernelGGL((lstm_bwd_persist<TPW, UW>), grid, dim3(256), lds, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
@@ -1253,7 +1254,7 @@ bool launch_fwd2(bool persist, hipStream_t st, float* xg_f, float* xg_r, const f
   // mode 1 (default): poll one piece per producer, then sweep once.  mode 0: sweep right behind the publish and fall back to the poll when it
   // came too early -- within the run-to-run spread of mode 1 where a sweep is small (H = 256: 3.14 / 3.43 against 3.18 / 3.17 us per step in two
   // sessions), worse where it is not (H = 512, B = 64: 6.05 against 5.39)
-  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 1;
+  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 2;
   static const int mode_env = exp_env("RE2E_LSTM_FWD2_MODE") ? atoi(exp_env("RE2E_LSTM_FWD2_MODE")) : -1;
   const int mode = mode_env >= 0 ? mode_env : 1;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
@@ -1303,7 +1304,7 @@ bool launch_bwd3(hipStream_t st, float* g_f, float* g_r, const float* wb, const 
   unsigned* err = (unsigned*)flagmem;
   unsigned* flags = (unsigned*)((char*)flagmem + 16);
   static const int hog = exp_env("RE2E_LSTM_OWN_CU") ? atoi(exp_env("RE2E_LSTM_OWN_CU")) : 160;      // see launch_fwd_persist
-  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 1;
+  static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 2;
   size_t lds = hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac ? (size_t)(hog - 16) * 1024 : 0;     // + ~9 KB static
   bwd3_lim<UN, TPW>().ensure(reinterpret_cast<const void*>(&lstm_bwd3<UN, TPW>), lds);
   hipLaunchKernelGGL((lstm_bwd3<UN, TPW>), grid, dim3(256), lds, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
