@@ -117,7 +117,7 @@ class JointTrainer(object):
         if torch.cuda.is_available():
             # The step runs on its OWN stream, never on the legacy default stream (which synchronises implicitly with
             # the blocking CU-masked filler streams: 91 -> 140 ms).  It is a high-priority stream (RE2E_MAIN_PRIORITY,
-            # default -1): the launch-per-step chains gain from it (91.4 vs 92.4 ms).  A fifth, normal-priority stream for
+            # default -1; the device's range is (0, -1): there is no lower priority to give the fillers): the launch-per-step chains gain from it (91.4 vs 92.4 ms).  A fifth, normal-priority stream for
             # the persistent sequences (GPU_MAX_HW_QUEUES=8) changed nothing: what slows a resident chain beside the
             # fillers is two of its workgroups sharing a CU (tools/bench_fill_under_chain.py), not the queue it came from.
             try:

@@ -884,6 +884,8 @@ def test_dec_gates_cell_fused_vs_unfused(B, E, D):
                                                (8, 750, 12, 512, 320, 300, 10, 100),      # config 5: three frame chunks per utterance
                                                (32, 200, 5, 320, 320, 300, 10, 100),      # the reference's default widths
                                                (5, 37, 6, 20, 24, 12, 3, 4),              # ragged everything, partial slices
+                                               (1, 5, 1, 16, 4, 4, 1, 0),                 # one utterance, one token, a 1-tap filter
+                                               (2, 40, 3, 64, 64, 16, 12, 100),           # far more taps than frames, 12 channels
                                                (3, 300, 4, 132, 68, 36, 12, 7)])          # two chunks, E and A in different slice counts
 def test_decoder_loop_persistent_vs_stepwise(B, T, L1, E, A, D, C, Fh):
     """csrc/decloop.hip (the whole teacher-forced loop in one persistent launch) against the launch-per-step sequence it replaces
@@ -929,6 +931,8 @@ def test_decoder_loop_persistent_vs_stepwise(B, T, L1, E, A, D, C, Fh):
                                                (8, 750, 12, 512, 320, 300, 10, 100),      # config 5: 16 frame chunks per utterance
                                                (32, 200, 4, 320, 320, 300, 10, 100),      # the reference's default widths
                                                (5, 37, 6, 32, 24, 12, 3, 4),              # ragged everything
+                                               (1, 5, 1, 16, 4, 4, 1, 0),                 # one utterance, one token, a 1-tap filter
+                                               (2, 40, 3, 64, 64, 16, 12, 100),           # far more taps than frames, 12 channels
                                                (3, 24, 7, 512, 320, 300, 10, 100),        # one chunk per utterance, fewer frames than filter taps
                                                (3, 100, 4, 144, 68, 36, 12, 7)])
 def test_decoder_loop_backward_persistent_vs_stepwise(B, T, L1, E, A, D, C, Fh):
