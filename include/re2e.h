@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 312
+#define RE2E_ABI_VERSION 313
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -291,8 +291,18 @@ int re2e_lstm_abort_count(void);
  * counter above rises) without running -- what JointTrainer.fit's recovery path is tested with.  re2e_debug_occupy: a kernel of
  * `workgroups` x 256 threads that holds `lds_bytes` of LDS each and spins for `usec` microseconds on `stream`: what a ring
  * all-reduce waiting for a slow peer looks like to the workgroup scheduler. */
+/* Both hooks answer RE2E_EUNSUPPORTED unless RE2E_DEBUG_HOOKS=1 is in the environment (the tests set it). */
 int re2e_debug_force_abort(int n);
 int re2e_debug_occupy(int workgroups, int lds_bytes, int usec, re2e_stream_t stream);
+/* The trainer's step gate (joint_train.py:188-193 plus the give-up protocol above), one 1-thread kernel and no host round trip.
+ * base_dev: device int, the give-up count the trainer has acknowledged (ack != 0: set it to the current count first).  delta = count - *base_dev.
+ * hold_next (optional): 1.0 when delta == 0, NaN otherwise -- the next step multiplies its losses by it, so a step enqueued before the host
+ * repeated an aborted one applies nothing, on any replica.  stats_main (optional; the [norm, coef, finite | norm, 1, finite] of
+ * re2e_clip_coef): finite := 0 and norm := NaN when delta != 0 or *extra_sumsq (optional: another optimizer's gradient sum of squares) is not
+ * finite.  stats_d (optional): finite := 0 when delta != 0 or *d_requires (optional: another gate's finite flag) is 0.  delta_out (optional):
+ * delta as a float, for the step's meters. */
+int re2e_step_gate(int* base_dev, int ack, const float* extra_sumsq, float* stats_main, float* stats_d, const float* d_requires, float* hold_next,
+                   float* delta_out, re2e_stream_t stream);
 int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
                       const int* lens_dev, int T, int B, int H, void* workspace, size_t workspace_bytes,
                       re2e_stream_t stream);
@@ -318,7 +328,8 @@ int re2e_dec_gates_cell_fwd(const float* cx, const float* z_prev, const float* w
                             const float* c_prev, float* c_out, float* h_out, int B, int E, int D, re2e_stream_t stream);
 /* The whole teacher-forced decoder loop (e2e_decoder.py:113-152: AttLoc.forward e2e_attention.py:259-299 + LSTMCell per output token) as ONE
  * persistent launch (csrc/decloop.hip).  re2e_dec_loop_workspace_bytes returns 0 when the shape is outside the resident form's limits
- * (B <= 32, D, E <= 320 and multiples of 4, C <= 12, workgroups <= CUs, ...) or RE2E_DEC_PERSIST=0: the caller then runs the launch-per-step
+ * (forward: B <= 32, D <= 320, E <= 512, D, E, A multiples of 4, C <= 12, T <= 2048; backward: E <= 512 and a multiple of 16, C <= 16,
+ * 2*Fh+1 <= 255; both: every workgroup resident, one per CU -- csrc/decloop.hip dec_plan / dec_bwd_plan are the authority) or RE2E_DEC_PERSIST=0: the caller then runs the launch-per-step
  * sequence re2e_attloc_fwd + re2e_dec_gates_cell_fwd.  pre (B,T,A) = mlp_enc(enc), enc (B,T,E) masked encoder states, w_decT (D,A) = mlp_dec^T,
  * w_att (A,C), w_conv (C,2Fh+1), w_ctx = &W_ih[0][Dd] with row pitch ldw, w_hh (4D,D).  gates (L1,B,4D): embedding half of the input projection
  * + both biases on entry, activated gates on exit; z, c (L1+1,B,D) with block 0 = the initial state; w (L1,B,T), cx (L1,B,E),

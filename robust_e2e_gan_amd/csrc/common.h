@@ -149,5 +149,13 @@ void thin_wgrad(const ConvGeom& g, const float* dout, int Cout, float* slabs, in
 // chunk, taps walked in LDS).  Returns false when the geometry is not covered (the caller then uses the implicit GEMM).
 int gemm_kslices_tn(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st, int nolog = 0);
 int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st, int nolog = 0);   // igemm.hip
+// gemm_nt.hip: the x W^T product as an LDS-DMA pipelined kernel with a stream-K tail.  gemm_nt2 returns 1 when it launched the product,
+// 0 when the shape / alignment is left to igemm.hip's engine; gemm_nt2_workspace_bytes is what it needs for that shape (0: nothing).
+size_t gemm_nt2_workspace_bytes(int M, int N, int K);
+int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,
+             int act, float beta, const float* mul, float* mask_out, const int* lens, int T, void* ws, size_t wsb, hipStream_t st);
+size_t gemm_tn2_workspace_bytes(int M, int N, int K);      // the same kernel's dy^T x form (weight gradients)
+int gemm_tn2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,
+             int act, float beta, void* ws, size_t wsb, hipStream_t st);
 bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, const float* bias, int act, float beta, const float* mask,
                   hipStream_t st, float* pool_out = nullptr, unsigned char* pool_idx = nullptr);

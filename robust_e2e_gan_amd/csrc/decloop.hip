@@ -529,6 +529,11 @@ bool dec_plan(int L1, int B, int T, int E, int D, int A, int C, int Fh, DecPlan&
 LdsLimit g_dec_lim;
 }  // namespace
 
+const unsigned* re2e_dec_abort_counter_ptr_() {      // device address of the loop's give-up counter, for the step gate (lstm.hip)
+  static const unsigned* p = [] { void* q = nullptr; return hipGetSymbolAddress(&q, HIP_SYMBOL(g_dec_aborts)) == hipSuccess ? (const unsigned*)q : (const unsigned*)nullptr; }();
+  return p;
+}
+
 int re2e_dec_abort_count_() {
   unsigned n = 0;
   if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_dec_aborts), sizeof(n)) != hipSuccess) return -1;

@@ -773,6 +773,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* 
   float m = mean[c], v = var_b[c];
   save_mean[c] = m; save_invstd[c] = rsqrtf(v + eps);
   float unb = P > 1 ? v * ((float)P / (float)(P - 1)) : v;
+  // Batch statistics that are not finite (features poisoned by a persistent recurrence that gave up, csrc/lstm.hip) leave the running
+  // statistics alone: the trainer repeats such a step, and a NaN written here would outlive the repeat (torch would write it; with a
+  // finite batch the arithmetic is torch's)
+  if (!(fabsf(m) < 3.0e38f) || !(fabsf(unb) < 3.0e38f)) return;
   running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
   running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
 }

@@ -910,7 +910,10 @@ extern "C" int re2e_gemm_skinny2(int M, int K, const float* A, long lda, const f
 extern "C" size_t re2e_gemm_workspace_bytes(int transa, int transb, int M, int N, int K) {
   if (transa && transb) return 0;
   int s = gemm_splits(transa, transb, M, N, K);
-  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+  size_t b = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+  if (!transa && transb) { const size_t b2 = gemm_nt2_workspace_bytes(M, N, K); if (b2 > b) b = b2; }
+  if (transa && !transb) { const size_t b2 = gemm_tn2_workspace_bytes(M, N, K); if (b2 > b) b = b2; }
+  return b;
 }
 
 // bytes spanned by a (outer x inner) row-major view with leading dimension ld
@@ -1022,6 +1025,14 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
     else if (transb) hipLaunchKernelGGL((skinny_gemm_kernel<true, false>), g, t, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, bias, bias2, beta);
     else if (v) hipLaunchKernelGGL((skinny_gemm_kernel<false, true>), g, t, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, bias, bias2, beta);
     else hipLaunchKernelGGL((skinny_gemm_kernel<false, false>), g, t, 0, stream, A, lda, B, ldb, C, ldc, M, N, K, bias, bias2, beta);
+    RE2E_LAUNCH_CHECK();
+    return RE2E_OK;
+  }
+  if (!transa && transb && gemm_nt2(M, N, K, A, lda, B, ldb, C, ldc, bias, bias2, act, beta, mul, mask_out, lens_dev, T, workspace, workspace_bytes, stream)) {
+    RE2E_LAUNCH_CHECK();
+    return RE2E_OK;
+  }
+  if (transa && !transb && gemm_tn2(M, N, K, A, lda, B, ldb, C, ldc, bias, bias2, act, beta, workspace, workspace_bytes, stream)) {
     RE2E_LAUNCH_CHECK();
     return RE2E_OK;
   }

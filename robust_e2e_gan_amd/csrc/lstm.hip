@@ -14,6 +14,8 @@
 // each end remove every boundary special case (h_{-1}=c_{-1}=0, reverse start).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -1377,14 +1379,22 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
 // short jobs -- runs at the speed of the thousandth.
 // ---- test hooks -------------------------------------------------------------------------------------------------------------
 namespace {
-int g_force_abort = 0;                        // host side: persistent forward sequences still to be "given up" (re2e_debug_force_abort)
+std::atomic<int> g_force_abort{0};            // host side: persistent forward sequences still to be "given up" (re2e_debug_force_abort)
+// The two test hooks answer only when RE2E_DEBUG_HOOKS=1 is in the environment (tests/ set it): a shipped process cannot be told to
+// poison its own sequences or to park kernels on its CUs by a stray call.
+bool debug_hooks_enabled() {
+  static const bool on = [] { const char* e = getenv("RE2E_DEBUG_HOOKS"); return e && atoi(e) == 1; }();
+  return on;
+}
 __global__ void forced_abort_kernel(float* ybuf, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ybuf[i] = __uint_as_float(0x7fc00000u);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_persist_aborts, 1u);
 }
 bool forced_abort(hipStream_t st, float* ybuf, int T, int B, int H) {
-  if (g_force_abort <= 0) return false;
-  --g_force_abort;
+  int left = g_force_abort.load(std::memory_order_relaxed);
+  do {
+    if (left <= 0) return false;
+  } while (!g_force_abort.compare_exchange_weak(left, left - 1, std::memory_order_relaxed));
   const long n = (long)T * B * 2 * H;
   hipLaunchKernelGGL(forced_abort_kernel, dim3(1024), dim3(256), 0, st, ybuf + (long)B * 2 * H, n);
   return true;
@@ -1400,12 +1410,14 @@ __global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks, f
 
 extern "C" int re2e_debug_force_abort(int n) {
   RE2E_CHECK_ARG(n >= 0, "n must be >= 0");
-  g_force_abort = n;
+  if (!debug_hooks_enabled()) { re2e_set_error("re2e_debug_force_abort: test hook, needs RE2E_DEBUG_HOOKS=1 in the environment"); return RE2E_EUNSUPPORTED; }
+  g_force_abort.store(n, std::memory_order_relaxed);
   return RE2E_OK;
 }
 
 extern "C" int re2e_debug_occupy(int workgroups, int lds_bytes, int usec, hipStream_t stream) {
   RE2E_CHECK_ARG(workgroups > 0 && workgroups <= 4096 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && usec > 0 && usec <= 1000000, "bad argument");
+  if (!debug_hooks_enabled()) { re2e_set_error("re2e_debug_occupy: test hook, needs RE2E_DEBUG_HOOKS=1 in the environment"); return RE2E_EUNSUPPORTED; }
   static LdsLimit lim;
   lim.ensure(reinterpret_cast<const void*>(&occupy_kernel), (size_t)lds_bytes);
   hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, stream, (unsigned long long)usec * 100ull, (float*)nullptr);
@@ -1439,6 +1451,43 @@ extern "C" size_t re2e_lstm_workspace_bytes(int B, int H) {
 }
 
 int re2e_dec_abort_count_();      // decloop.hip: the persistent decoder loop's give-ups are counted with the recurrences'
+
+// ---- the trainer's step gate (joint_train.py:188-193 + the give-up protocol of the persistent kernels) ---------------------------------------
+// One 1-thread kernel at the end of a training step, no host round trip:
+//   delta     = give-ups counted on this device since the trainer's last acknowledgement (*base); ack != 0 first sets *base = the count
+//   hold_next = 1.0 if delta == 0, NaN otherwise: the NEXT step multiplies its losses by it, so a step that was enqueued before the host has
+//               repeated the aborted one computes NaN gradients (on every replica, through the gradient average) and applies nothing
+//   stats_main (the ASR optimizer's [norm, coef, finite | norm, 1, finite], re2e_clip_coef): the update is also refused -- finite := 0, norm :=
+//               NaN so that the host's one-step-late read-back sees it -- when delta != 0 or when extra_sumsq (the ENHANCER's gradient sum of
+//               squares: a give-up in its backward chain leaves the ASR norm finite) is not finite
+//   stats_d (the discriminator optimizer's triple): finite := 0 when delta != 0 (model NaNs alone do not stop D: upstream's D-step is independent),
+//               or when *d_requires (optional: another gate's finite flag) is 0 -- data-parallel runs pass the main gate's flag, which every
+//               replica agrees on, because delta is a per-device number
+const unsigned* re2e_dec_abort_counter_ptr_();      // decloop.hip
+namespace {
+__global__ void step_gate_kernel(const unsigned* dec_cnt, int* base, int ack, const float* extra_sumsq, float* stats_main, float* stats_d,
+                                 const float* d_requires, float* hold_next, float* delta_out) {
+  const int c = (int)(__hip_atomic_load(&g_persist_aborts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                      (dec_cnt ? __hip_atomic_load(dec_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u));
+  if (ack) *base = c;
+  const int delta = c - *base;
+  if (delta_out) *delta_out = (float)delta;
+  if (hold_next) *hold_next = delta == 0 ? 1.f : __uint_as_float(0x7fc00000u);
+  bool ok = delta == 0;
+  if (extra_sumsq) { const float e = *extra_sumsq; ok = ok && e == e && fabsf(e) < 3.0e38f; }
+  if (stats_main && !ok) { stats_main[2] = 0.f; stats_main[5] = 0.f; stats_main[0] = __uint_as_float(0x7fc00000u); stats_main[3] = stats_main[0]; }
+  if (stats_d && (delta != 0 || (d_requires && *d_requires == 0.f))) stats_d[2] = 0.f;
+}
+}  // namespace
+
+extern "C" int re2e_step_gate(int* base_dev, int ack, const float* extra_sumsq, float* stats_main, float* stats_d, const float* d_requires,
+                              float* hold_next, float* delta_out, hipStream_t stream) {
+  RE2E_CHECK_ARG(base_dev, "null base");
+  hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(1), 0, stream, re2e_dec_abort_counter_ptr_(), base_dev, ack, extra_sumsq, stats_main, stats_d,
+                     d_requires, hold_next, delta_out);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
 
 extern "C" int re2e_lstm_abort_count(void) {
   unsigned n = 0;

@@ -69,6 +69,11 @@ class JointTrainer(object):
                                                                                           gan_model if self.isGAN else None)
         self.criterionGAN = GANLoss(use_lsgan=not opt.no_lsgan) if self.isGAN else None
         self.asr_model.dec.return_acc_tensor = True
+        # Give-up protocol of the persistent kernels (csrc/lstm.hip re2e_step_gate; ``fit`` / ``recover_aborted_step``): device scalars,
+        # allocated at the first step -- the count of give-ups this trainer has acknowledged, the factor (1.0 or NaN) the losses of a step
+        # are multiplied by (two of them, alternating: step k reads one while its gate writes the other for step k + 1), the step's delta
+        self._gate = None
+        self._step_no = 0
         # Dropout masks (ops.dropout: counter-based Philox, nothing stored): one stream per process, keyed by (opt.seed, rank) so that
         # data-parallel replicas draw DIFFERENT masks, as upstream's per-process RNG would; the (seed, next mask index) pair is part
         # of ``state()`` and ``restore_dropout`` puts it back, so a resumed run continues the mask sequence instead of replaying
@@ -173,6 +178,7 @@ class JointTrainer(object):
         ops.WGRAD_STREAM = self.wgrad_stream if overlap else None
         ops.AUX_STREAM = self.side_stream if (overlap and lib.exp_env('RE2E_CTC_MAIN') != '1') else None
         main = torch.cuda.current_stream()
+        hold = self._hold_factor()
         clean_branch, d_real_part = None, None
         if overlap and getattr(self.asr_model, 'etype', '').startswith('vgg'):
             # the clean branch (fbank -> CMVN -> VGG conv stack) does not depend on the enhancer: enqueue it on the side
@@ -193,7 +199,7 @@ class JointTrainer(object):
                 # under the enhancer's forward chain instead of under the (already saturated) backward chain.  Enqueued
                 # AFTER the enhancer: its ~2.5 ms of host launches must not delay the start of that chain.
                 with torch.cuda.stream(side):
-                    d_real_part = self._d_real(clean_feat, enhance_cmvn)
+                    d_real_part = self._d_real(clean_feat, enhance_cmvn, hold)
             ops.mark_grad(enhance_out, 'enhance_out (fbank bwd done)')
             enhance_feat = self.feat_model(enhance_out)
             ops.mark_grad(enhance_feat, 'enhance_feat (VGG, D, L1 bwd done)')
@@ -247,6 +253,10 @@ class JointTrainer(object):
                 torch.cuda.current_stream().wait_stream(self.side_stream)
             loss = loss + gan_loss
             out['train/gan_loss'] = opt.gan_loss_lambda * gan_loss.detach()
+        out['train/loss'] = loss.detach()
+        # x 1.0 (exact) -- or x NaN while a step that a persistent kernel gave up on has not been repeated yet: this step was enqueued before
+        # the host could know, it must apply nothing (on any replica: the NaN travels through the gradient average), see ``fit``
+        loss = loss * hold
         self.enhance_optimizer.zero_grad()
         self.asr_optimizer.zero_grad()
         sync = GradSync()
@@ -308,8 +318,8 @@ class JointTrainer(object):
                 for t_ in (enhance_feat, clean_feat, enhance_cmvn):
                     if isinstance(t_, torch.Tensor) and t_.is_cuda:
                         t_.record_stream(side)
-                loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, wait_before_update=ev_bwd1,
-                                      d_fake=d_fake if reuse else None, fake_stats=fake_stats, fake_bn=fake_bn_layers, real_part=d_real_part)
+                loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, d_fake=d_fake if reuse else None, fake_stats=fake_stats,
+                                      fake_bn=fake_bn_layers, real_part=d_real_part, hold=hold)
             self._mark('D-step enqueued (side)')
             if self.marks is not None:
                 with torch.cuda.stream(side):
@@ -362,23 +372,58 @@ class JointTrainer(object):
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)      # deferred weight-gradient kernels
         sync.finish([self.enhance_optimizer] if armed else [self.asr_optimizer, self.enhance_optimizer])
         grad_norm = self.asr_optimizer.clip_grad_norm(opt.grad_clip)           # ASR params only (:188)
-        self.enhance_optimizer.step(self.asr_optimizer.gate_stats())           # unclipped, same NaN gate (:189-193)
+        # The NaN gate (:189-193), on the device.  Besides the ASR norm it refuses the update when the ENHANCER's gradients are not finite (a
+        # give-up in its backward chain leaves the ASR norm finite) or when a persistent kernel gave up anywhere in this step.
+        base, holds, delta = self._gate
+        dp = rdist.world_size() > 1
+        call_gate = lambda *a: lib.call('re2e_step_gate', base.data_ptr(), 0, *a)
+        call_gate(self.enhance_optimizer.grad_sumsq().data_ptr(), self.asr_optimizer.stats.data_ptr(), None, None, None, None)
+        self.enhance_optimizer.step(self.asr_optimizer.gate_stats())           # unclipped, same gate
         self.asr_optimizer.step()
+        nxt = holds[(self._step_no + 1) % 2]
         if self.isGAN:
             if loss_D is None:
                 loss_D = self._d_step(clean_feat, enhance_feat, enhance_cmvn, d_fake=d_fake if self.reuse_dfake else None,
-                                      fake_stats=fake_stats, fake_bn=fake_bn_layers)
+                                      fake_stats=fake_stats, fake_bn=fake_bn_layers, hold=hold)
             else:
                 torch.cuda.current_stream().wait_stream(self.side_stream)
+            # D's update (:211) is the step's LAST kernel, behind the gate: a step that a persistent kernel gave up on is repeated as a
+            # whole, so D must not have moved in it.  A NaN of the model's own does not stop D (upstream's D-step is independent of the G-step's
+            # gate) -- except in data-parallel runs, where the give-up count is a per-device number and the one thing every replica agrees
+            # on is the main gate's flag.
+            call_gate(None, None, self.gan_optimizer.stats.data_ptr(), self.asr_optimizer.stats.data_ptr() + 8 if dp else None, nxt.data_ptr(),
+                      delta.data_ptr())
+            self.gan_optimizer.step()
             out['train/loss_D'] = loss_D.detach()
-        out.update({'train/loss': loss.detach(), 'train/loss_ctc': loss_ctc.detach().view(()), 'train/acc': acc, 'train/loss_att': loss_att.detach(),
+        else:
+            call_gate(None, None, None, None, nxt.data_ptr(), delta.data_ptr())
+        self._step_no += 1
+        out.update({'train/loss_ctc': loss_ctc.detach().view(()), 'train/acc': acc, 'train/loss_att': loss_att.detach(),
                     'train/enhance_loss': enhance_loss.detach(), 'train/coral_loss': coral_loss.detach(),
-                    'grad_norm': grad_norm.clone()})     # a copy: the optimizer's stats buffer is rewritten by the next step
+                    'grad_norm': grad_norm.clone(),      # a copy: the optimizer's stats buffer is rewritten by the next step (NaN when the gate refused)
+                    'aborts': delta.clone()})            # give-ups of persistent kernels since the last acknowledgement, counted at the end of this step
         self.last = dict(enhance_out=enhance_out, enhance_feat=enhance_feat)
         self._mark('optimizers')
         return out
 
-    def _d_real(self, clean_feat, enhance_cmvn):
+    def _hold_factor(self):
+        """The device scalar this step's losses are multiplied by (see ``_step``); first call: allocate the gate's state and acknowledge
+        whatever earlier users of the process left in the give-up counters."""
+        if self._gate is None:
+            dev = next(self.enhance_model.parameters()).device
+            base = torch.zeros(1, dtype=torch.int32, device=dev)
+            holds = [torch.ones(1, dtype=torch.float32, device=dev) for _ in range(2)]
+            delta = torch.zeros(1, dtype=torch.float32, device=dev)
+            lib.call('re2e_step_gate', base.data_ptr(), 1, None, None, None, None, None, None)
+            self._gate = (base, holds, delta)
+        return self._gate[1][self._step_no % 2]
+
+    def _acknowledge_aborts(self):
+        """The host has seen the give-ups counted so far (it is about to repeat the step they spoilt): the next step's losses are whole again."""
+        base, holds, delta = self._gate
+        lib.call('re2e_step_gate', base.data_ptr(), 1, None, None, None, None, holds[self._step_no % 2].data_ptr(), delta.data_ptr())
+
+    def _d_real(self, clean_feat, enhance_cmvn, hold=None):
         """Real half of the discriminator update on the CURRENT stream, ahead of the G-step: forward of D(clean) with the
         BatchNorm running-statistics update deferred (upstream applies it AFTER the G-step's D(fake) pass; ``_d_step``
         replays it there), then the backward of 0.5 * loss_D_real into D's (freshly zeroed) gradient buffers -- the same
@@ -393,12 +438,12 @@ class JointTrainer(object):
             ops.BN_STATS_SINK, ops.BN_DEFER_RUNNING = None, False
         loss_D_real = self.criterionGAN(d_real, True)
         gan_params = [p for p in self.gan_model.parameters() if p.requires_grad]
-        torch.autograd.grad(loss_D_real * 0.5, gan_params, allow_unused=True)
+        torch.autograd.grad(loss_D_real * 0.5 if hold is None else loss_D_real * 0.5 * hold, gan_params, allow_unused=True)
         return loss_D_real.detach(), stats
 
-    def _d_step(self, clean_feat, enhance_feat, enhance_cmvn, wait_before_update=None, d_fake=None, fake_stats=None, fake_bn=None,
-                real_part=None):
-        """Discriminator update (joint_train.py:195-212) on the CURRENT stream.  ``d_fake``: D(enhance_feat) of the G-step
+    def _d_step(self, clean_feat, enhance_feat, enhance_cmvn, d_fake=None, fake_stats=None, fake_bn=None, real_part=None, hold=None):
+        """Discriminator step (joint_train.py:195-212) on the CURRENT stream up to and including the clipping of its gradients; the update
+        itself (``gan_optimizer.step()``) is the caller's, behind the step's gate (``_step``).  ``d_fake``: D(enhance_feat) of the G-step
         (same input, same weights as upstream's second evaluation) -- its graph is walked again for the parameter
         gradients instead of recomputing the forward; the BatchNorm running statistics get the update that forward would
         have applied (``fake_stats``), in upstream's order (after the D(real) pass)."""
@@ -417,18 +462,15 @@ class JointTrainer(object):
             loss_D_fake = self.criterionGAN(d_fake, False)
             loss_D = (loss_D_real + loss_D_fake) * 0.5
             gan_params = [p for p in self.gan_model.parameters() if p.requires_grad]
-            torch.autograd.grad(loss_D, gan_params, allow_unused=True)      # the fused ops accumulate the gradients themselves
+            torch.autograd.grad(loss_D if hold is None else loss_D * hold, gan_params, allow_unused=True)      # the fused ops accumulate the gradients themselves
         else:
             loss_D_fake = self.criterionGAN(self.gan_model(enhance_feat.detach(), enhance_cmvn), False)
             loss_D = (loss_D_real + loss_D_fake) * 0.5
-            loss_D.backward()
+            (loss_D if hold is None else loss_D * hold).backward()
         if ops.WGRAD_STREAM is not None:
             torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)
         GradSync().finish([self.gan_optimizer])
         self.gan_optimizer.clip_grad_norm(opt.grad_clip)
-        if wait_before_update is not None:     # the G-step backward still reads D's weights on the main stream
-            torch.cuda.current_stream().wait_event(wait_before_update)
-        self.gan_optimizer.step()
         return loss_D
 
     def validate(self, data, enhance_cmvn, want_attention=False):
@@ -498,29 +540,36 @@ class JointTrainer(object):
         writer = rdist.rank() == 0          # data parallel: one rank writes checkpoints / plots into exp_path
 
         def flush():
+            """Read back the meters of the step enqueued before the current one.  Returns True when that step had to be REPEATED because a
+            persistent kernel gave up in it: whatever was enqueued behind it was held on the device (its losses were multiplied by NaN,
+            ``_step``) and has to be run again by the caller."""
             nonlocal pending
+            repeated = False
             if pending is not None:
                 vals = self.to_floats(pending)
-                gn = vals.pop('grad_norm', 0.0)
+                gn, mine = vals.pop('grad_norm', 0.0), int(vals.pop('aborts', 0.0))
                 if not math.isfinite(gn):             # joint_train.py:189-193: the update was skipped on the device
-                    # ... either by non-finite numbers of the model's own (upstream: warn and go on), or because a persistent recurrence
-                    # gave up on a peer workgroup and poisoned its outputs: then the step is REPEATED with the launch-per-step kernels
-                    redo = self.recover_aborted_step(pending['_entry']) if pending.get('_entry') is not None else None
+                    # ... either by non-finite numbers of the model's own (upstream: warn and go on), or because a persistent kernel gave up
+                    # on a peer workgroup and poisoned its outputs: then the step is REPEATED with the launch-per-step kernels
+                    redo = self.recover_aborted_step(pending['_entry'], mine) if pending.get('_entry') is not None else None
                     if redo is None:
                         logging.warning('grad norm is nan. Do not update model.')
                     else:
-                        vals = redo
+                        vals, repeated = redo, True
+                elif mine:
+                    self.unexplained_aborts += mine   # a give-up that did NOT show up as a skipped update: raised at the next print boundary
                 visualizer.set_current_errors(vals)
                 pending = None
+            return repeated
 
         def check_recurrences():
-            # a persistent recurrence that gave up on a peer workgroup poisons its outputs with NaN, the NaN gate then skips the
-            # update; flush() repeats such a step.  What is left to check here is an abort that did NOT show up as a skipped update.
-            # (The query synchronises the device: only called where the loop reads the meters back anyway.)
-            n = rdist.any_rank(max(0, lib.query('re2e_lstm_abort_count') - self.aborts_seen))      # collective: all replicas fail together
+            # a persistent kernel that gave up on a peer workgroup poisons its outputs with NaN and the step gate refuses the update;
+            # flush() repeats such a step.  What is left to check here is a give-up that the gate counted in a step whose norm was finite
+            # all the same (collective: all replicas fail together).
+            n = rdist.any_rank(self.unexplained_aborts)
             if n != 0:
-                raise lib.Re2eError('%d recurrent sequences were aborted by a persistent LSTM kernel (a peer workgroup never '
-                                    'arrived) without a skipped update to show for it' % n)
+                raise lib.Re2eError('%d recurrent sequences were aborted by a persistent kernel (a peer workgroup never arrived) in a step whose '
+                                    'update was not refused' % n)
 
         for epoch in range(start_epoch, opt.epochs):
             if train_sampler is not None and epoch > opt.shuffle_epoch:
@@ -528,8 +577,13 @@ class JointTrainer(object):
             for data in loader():
                 entry = (data, sche_samp_rate, enhance_cmvn, self._bn_snapshot())
                 errors = self.step(data, sche_samp_rate, enhance_cmvn)
-                flush()                                   # previous step's meters, now that this step is queued
-                pending = {k: v for k, v in errors.items() if k.startswith('train/') or k == 'grad_norm'}
+                if flush():                               # previous step's meters, now that this step is queued
+                    # the previous step was repeated: THIS one ran behind the give-up and was held (it applied nothing; what it did to D's
+                    # running statistics was put back with the previous step's snapshot): run it again, on the repaired state
+                    self._uncount_step()
+                    entry = (data, sche_samp_rate, enhance_cmvn, self._bn_snapshot())
+                    errors = self.step(data, sche_samp_rate, enhance_cmvn)
+                pending = {k: v for k, v in errors.items() if k.startswith('train/') or k in ('grad_norm', 'aborts')}
                 pending['_entry'] = entry
                 iters += 1
                 if iters % opt.print_freq == 0:
@@ -590,37 +644,55 @@ class JointTrainer(object):
         flush()
         return iters, best_loss, best_acc
 
-    # ---- a persistent recurrence that gave up (csrc/lstm.hip: bounded spins, NaN outputs, re2e_lstm_abort_count) ----------------
-    aborts_seen = 0            # aborts of this process that a repeated step has made good
+    # ---- a persistent kernel that gave up (csrc/lstm.hip, csrc/decloop.hip: bounded spins, NaN outputs, counted on the device) ----------------
+    # Protocol (round 5).  The meters of step k are read one step late, when step k + 1 is already enqueued, so everything that must happen
+    # BEFORE the host knows is decided on the device by re2e_step_gate at the end of every step:
+    #   * the update of a step in which a kernel gave up is refused (also when the NaN did not reach the ASR norm: enhancer backward chain),
+    #     D's included -- D's optimizer step is the step's last kernel;
+    #   * BatchNorm running statistics are never moved by non-finite batch statistics (bn_finalize_kernel), so a snapshot taken before a
+    #     step is always clean;
+    #   * the step after it is HELD: its losses are multiplied by NaN (the factor the gate wrote), it applies nothing on any replica;
+    #   * the count of give-ups since the last acknowledgement travels with each step's meters, so a give-up is attributed to the step it
+    #     happened in, not to whatever the host had enqueued by the time it looked.
+    # The host then (``fit``): puts back the aborted step's BatchNorm snapshot (which also undoes the held step's forward), acknowledges the
+    # count, repeats the aborted step with the launch-per-step kernels and runs the held step again -- the updates land in the order of an
+    # undisturbed run.
     recovered_steps = 0
+    unexplained_aborts = 0
 
     def _bn_snapshot(self):
-        """D's BatchNorm running statistics (a few KB): an aborted step feeds them NaN features."""
+        """D's BatchNorm buffers (a few KB) before a step: what ``recover_aborted_step`` puts back before it repeats the step."""
         return [b.detach().clone() for b in self.gan_model.buffers()] if self.isGAN else []
 
-    def recover_aborted_step(self, entry):
-        """Called for a step whose update the device-side NaN gate skipped.  If a persistent recurrence gave up during it (on ANY replica: the
-        averaged gradients carried its NaN to all of them, so every replica is here and the agreement below is a collective all of them
-        reach), the step is repeated with the launch-per-step recurrences -- same arithmetic, no in-launch hand-off that can time out --
-        after D's BatchNorm running statistics have been put back.  Returns the repeated step's meters, or None if no recurrence was aborted
-        (the NaN was the model's own).  Raises if the repeated step is not finite either."""
+    def _uncount_step(self):
+        """A step whose update the gate refused because of a give-up is run again: it must not count twice (Adam's bias correction)."""
+        for o in (self.enhance_optimizer, self.asr_optimizer, self.gan_optimizer):
+            if o is not None:
+                o.step_count -= 1
+
+    def recover_aborted_step(self, entry, mine):
+        """Called for a step whose update the device-side gate refused.  ``mine``: give-ups counted on this device in it.  If there were any
+        (on ANY replica: the averaged gradients carried the NaN to all of them, so every replica is here and the agreement below is a
+        collective all of them reach), the step is repeated with the launch-per-step recurrences -- same arithmetic, no in-launch hand-off that
+        can time out -- on the state it first ran on.  Returns the repeated step's meters, or None if nothing gave up (the NaN was the
+        model's own).  Raises if the repeated step is not finite either."""
         data, rate, cmvn, bn = entry
-        mine = max(0, lib.query('re2e_lstm_abort_count') - self.aborts_seen)        # (synchronises the device)
-        if rdist.any_rank(mine) == 0:
+        if rdist.any_rank(max(0, int(mine))) == 0:
             return None
-        self.aborts_seen += mine
         if self.recovered_steps == 0:
-            logging.warning('a persistent recurrence gave up on a peer workgroup (%d sequence(s) on this rank): the step is repeated with the '
+            logging.warning('a persistent kernel gave up on a peer workgroup (%d sequence(s) on this rank): the step is repeated with the '
                             'launch-per-step kernels.  Further repeats are counted in JointTrainer.recovered_steps', mine)
         self.recovered_steps += 1
         if self.isGAN:
             for b, s in zip(self.gan_model.buffers(), bn):
                 b.copy_(s)
+        self._uncount_step()
+        self._acknowledge_aborts()
         saved = {k: os.environ.get(k) for k in ('RE2E_LSTM_PERSIST', 'RE2E_LSTM_PERSIST_BWD')}
         os.environ['RE2E_LSTM_PERSIST'] = os.environ['RE2E_LSTM_PERSIST_BWD'] = '0'
         dec_persist, ops.DECODER_PERSIST = ops.DECODER_PERSIST, False        # ... and the launch-per-token decoder loop (csrc/decloop.hip counts with them)
         try:
-            vals = self.to_floats({k: v for k, v in self.step(data, rate, cmvn).items() if k.startswith('train/') or k == 'grad_norm'})
+            vals = self.to_floats({k: v for k, v in self.step(data, rate, cmvn).items() if k.startswith('train/') or k in ('grad_norm', 'aborts')})
         finally:
             ops.DECODER_PERSIST = dec_persist
             for k, v in saved.items():
@@ -628,17 +700,23 @@ class JointTrainer(object):
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-        gn = vals.pop('grad_norm', 0.0)
-        again = max(0, lib.query('re2e_lstm_abort_count') - self.aborts_seen)
+        gn, again = vals.pop('grad_norm', 0.0), int(vals.pop('aborts', 0.0))
         if rdist.any_rank(1 if (again or not math.isfinite(gn)) else 0):
-            raise lib.Re2eError('a step that a persistent recurrence had aborted is not finite with the launch-per-step kernels either (grad norm %r)' % gn)
+            raise lib.Re2eError('a step that a persistent kernel had aborted is not finite with the launch-per-step kernels either (grad norm %r)' % gn)
         return vals
 
     @staticmethod
     def to_floats(errors):
+        """The meters as host floats: ONE device-to-host copy -- the only host synchronisation of a step.  The ragged-shard counters of
+        synchronised BatchNorm (ops._sync_rows_poison) ride along and raise here, on every rank in the same step."""
         keys = [k for k, v in errors.items() if isinstance(v, torch.Tensor)]      # (att_ws is a numpy array)
-        vals = torch.stack([errors[k].detach().float().reshape(()) for k in keys]).cpu().tolist()
-        return dict(zip(keys, vals))
+        if not keys:
+            return {}
+        flags = [f for f in ops.sync_bn_flags() if f.device == errors[keys[0]].device]
+        vals = torch.stack([errors[k].detach().double().reshape(()) for k in keys] + flags).cpu().tolist()
+        if flags:
+            ops.check_sync_bn(vals[len(keys):])
+        return dict(zip(keys, vals[:len(keys)]))
 
     def state(self, epoch, iters, best_loss=float('inf'), best_acc=0.0):
         """checkpoint dict with the reference's keys (joint_train.py:225-233)."""
@@ -668,8 +746,14 @@ class JointTrainer(object):
             ops.dropout_seed(int(ds[0]), int(ds[1]))
 
     def load_state(self, package):
-        """Counterpart of ``state()`` (upstream: the ``--joint_resume`` branch, joint_train.py:73-103): the networks' state_dicts, eps / lr
-        into ``opt``, and the dropout mask stream.  Returns (epoch, iters, best_loss, best_acc)."""
+        """Counterpart of ``state()`` (upstream: the ``--joint_resume`` branch, joint_train.py:98-111 and :127-140): the networks'
+        state_dicts, the dropout mask stream, and eps / lr -- into ``opt`` AND into every optimizer of the trainer, because upstream builds
+        its three optimizers AFTER reading the package (Adadelta(eps=package eps) / Adam(lr=package lr)): a resume after an
+        ``adadelta_eps_decay`` must train with the decayed eps.  As upstream, the optimizers' accumulators are NOT part of a checkpoint: they
+        restart from zero (``state()`` has no key for them), which is what a freshly constructed trainer has.
+        Returns (epoch, iters, best_loss, best_acc) with ``iters`` = the checkpoint's ``iters`` - 1, as upstream resumes
+        (joint_train.py:108: ``int(package.get('iters', 0)) - 1``; the 'latest' checkpoint is written at ``iters % print_freq == 0``, so the
+        resumed run reaches the next print / validation boundary one step later than the uninterrupted one would have)."""
         self.asr_model.load_state_dict(package['asr_state_dict'])
         self.feat_model.load_state_dict(package['fbank_state_dict'])
         self.enhance_model.load_state_dict(package['enhance_state_dict'])
@@ -678,8 +762,16 @@ class JointTrainer(object):
         for k in ('eps', 'lr'):
             if k in package:
                 setattr(self.opt, k, package[k])
+        for o in (self.enhance_optimizer, self.asr_optimizer, self.gan_optimizer):
+            if o is None:
+                continue
+            g = o.param_groups[0]
+            if o.kind == 'adadelta' and 'eps' in package:
+                g['eps'] = float(package['eps'])
+            if o.kind == 'adam' and 'lr' in package:
+                g['lr'] = float(package['lr'])
         self.restore_dropout(package)
-        return (int(package.get('epoch', 0)), int(package.get('iters', 0)), float(package.get('best_loss', float('inf'))),
+        return (int(package.get('epoch', 0)), int(package.get('iters', 0)) - 1, float(package.get('best_loss', float('inf'))),
                 float(package.get('best_acc', 0.0)))
 
 

@@ -147,10 +147,12 @@ def replay_running_stats(stats):
     therefore moves the running statistics twice."""
     with torch.no_grad():
         for rm, rv, mean, invstd, P, momentum, eps in stats:
-            var_b = 1.0 / (invstd * invstd) - eps
-            unb = var_b * (float(P) / float(P - 1)) if P > 1 else var_b
-            rm.mul_(1.0 - momentum).add_(mean, alpha=momentum)
-            rv.mul_(1.0 - momentum).add_(unb, alpha=momentum)
+            var_b = (1.0 / (invstd * invstd) - eps).contiguous()
+            # the forward's own finalize kernel (csrc/elementwise.hip bn_finalize_kernel): same arithmetic as the update it replays, and the
+            # same guard -- batch statistics that are not finite (a recurrence that gave up poisoned the features) move nothing
+            junk_m, junk_i = torch.empty_like(mean), torch.empty_like(mean)
+            lib.call('re2e_bn_sync_finalize', mean.data_ptr(), var_b.data_ptr(), int(P), mean.numel(), float(momentum), float(eps), rm.data_ptr(),
+                     rv.data_ptr(), junk_m.data_ptr(), junk_i.data_ptr())
 
 
 class GANLoss(torch.nn.Module):

@@ -891,24 +891,45 @@ def _sync_world():
     return rdist.world_size() if SYNC_BN else 1
 
 
-_SYNC_BN_CHECKED = set()
+_SYNC_BN_RAGGED = {}       # device -> fp64 scalar: BatchNorm calls of this process whose row count differed between the ranks
 
 
-def _sync_rows_checked(Pn, C, sums):
+def _sync_rows_poison(Pn, dev):
     """Synchronised BatchNorm takes the global row count as rows x world (no per-step host sync for a count): true for equal shards only.
-    The first all-reduce of a layer carries (rows, rows^2) of every rank behind its C sums -- the SAME collective on every rank whatever
-    each has seen before --, and the first time THIS rank meets a (rows, channels) shape it reads the two reduced numbers back (one host
-    sync per shape) and refuses ragged shards instead of normalising with wrong statistics."""
-    key = (Pn, C)
-    if key in _SYNC_BN_CHECKED:
-        return
+    Every call MAX-reduces the exact pair (rows, -rows) as fp64 -- the same tiny collective on every rank, whatever each rank has seen
+    before -- and everything is decided from the REDUCED pair alone, on the device: max rows != min rows adds 1 to a per-device counter and
+    returns NaN (0.0 otherwise), which the caller adds to the batch mean, so ragged shards can never produce an update: the NaN reaches the
+    gradient norm of every replica through the gradient average, the NaN gate skips the step everywhere, and ``check_sync_bn`` -- called
+    where the trainers read their meters back anyway (``JointTrainer.to_floats``) -- raises on EVERY rank in that same step.
+    (Round 4 carried rows and rows^2 in the fp32 sums and let each rank decide from its own history: rows^2 is not exact in fp32 beyond
+    4096 odd rows, and a rank that had seen its shape before skipped the check, so one rank raised alone and its peers hung.)"""
     from . import dist as rdist
-    world = rdist.world_size()
-    s1, s2 = sums.tolist()
-    if s1 != float(Pn) * world or s2 != float(Pn) * float(Pn) * world:
-        raise lib.Re2eError('synchronised BatchNorm needs the same number of rows on every rank (this rank %d, the ranks sum to %d over %d): '
-                            'shard equal utterance counts of equal padded length, or leave opt.sync_bn off' % (Pn, int(s1), world))
-    _SYNC_BN_CHECKED.add(key)
+    pair = rdist.allreduce_max_(torch.tensor([float(Pn), -float(Pn)], dtype=torch.float64).to(dev, non_blocking=True))
+    ragged = (pair[0] + pair[1]) != 0
+    cnt = _SYNC_BN_RAGGED.get(str(dev))
+    if cnt is None:
+        cnt = _SYNC_BN_RAGGED[str(dev)] = torch.zeros((), dtype=torch.float64, device=dev)
+    cnt.add_(ragged.to(torch.float64))
+    return torch.where(ragged, float('nan'), 0.0).to(torch.float32)
+
+
+def sync_bn_flags():
+    """The per-device counters of ``_sync_rows_poison`` (device scalars; empty when synchronised BatchNorm never ran)."""
+    return list(_SYNC_BN_RAGGED.values())
+
+
+def check_sync_bn(counts=None):
+    """Raise if a synchronised BatchNorm met ragged shards.  ``counts``: the counters' values if the caller has read them back already
+    (with its meters); otherwise they are read here (a host sync).  The counters hold REDUCED information, so all ranks raise together."""
+    if counts is None:
+        counts = [float(c.item()) for c in _SYNC_BN_RAGGED.values()]
+    n = int(sum(counts))
+    if n:
+        for c in _SYNC_BN_RAGGED.values():
+            c.zero_()
+        raise lib.Re2eError('synchronised BatchNorm needs the same number of rows on every rank (%d BatchNorm calls saw ranks with different '
+                            'row counts; their statistics were poisoned with NaN and no update was applied): shard equal utterance '
+                            'counts of equal padded length, or leave opt.sync_bn off' % n)
 
 
 class BnLreluFn(torch.autograd.Function):
@@ -931,13 +952,11 @@ class BnLreluFn(torch.autograd.Function):
         ctx.ptot = Pn
         if world > 1:
             from . import dist as rdist
-            acc = empty((C + 2,), x)                                          # C sums | rows, rows^2 of this rank (see _sync_rows_checked)
+            acc = empty((C,), x)
             call('re2e_bn_sync_partial', x.data_ptr(), Pn, C, None, 0, acc.data_ptr(), ws.data_ptr(), wsb)
-            acc[C:].copy_(torch.tensor([float(Pn), float(Pn) * float(Pn)]), non_blocking=True)
             rdist.allreduce_sum_(acc)
-            _sync_rows_checked(Pn, C, acc[C:])
             ptot = Pn * world                                                 # equal shards (bench.py --scaling strong): no host sync for a count
-            mean = (acc[:C] / float(ptot)).contiguous()
+            mean = (acc / float(ptot) + _sync_rows_poison(Pn, x.device)).contiguous()      # NaN when the shards are NOT equal (checked on the device)
             var = empty((C,), x)
             call('re2e_bn_sync_partial', x.data_ptr(), Pn, C, mean.data_ptr(), 1, var.data_ptr(), ws.data_ptr(), wsb)
             rdist.allreduce_sum_(var)

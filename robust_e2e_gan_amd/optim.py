@@ -62,6 +62,14 @@ class FlatOptimizer:
         call('re2e_clip_coef', self.sumsq.data_ptr(), float(max_norm), self.stats.data_ptr())
         return self.stats[0]
 
+    def grad_sumsq(self):
+        """Sum of squares of the flat gradient as a 1-element device tensor (no clipping, no host sync): the trainer's step gate reads it to
+        refuse an update whose OTHER optimizer's gradients are not finite (csrc/lstm.hip re2e_step_gate)."""
+        wsb = query('re2e_reduce_workspace_bytes', self.numel)
+        ws = workspace(wsb, self.grad.device, 'reduce')
+        call('re2e_sumsq', self.grad.data_ptr(), self.numel, self.sumsq.data_ptr(), ws.data_ptr(), wsb)
+        return self.sumsq
+
     def gate_stats(self):
         """View usable by ANOTHER optimizer: same NaN guard, clip coefficient 1 (joint_train.py:188-193)."""
         return self.stats[3:6]

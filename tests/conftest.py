@@ -8,6 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+os.environ.setdefault('RE2E_DEBUG_HOOKS', '1')      # re2e_debug_force_abort / re2e_debug_occupy answer only with this set (csrc/lstm.hip)
 
 
 def pytest_configure(config):

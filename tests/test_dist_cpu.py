@@ -143,24 +143,26 @@ def _sync_rows_worker(rank, world, port, q):
     out = {}
     t = rdist.allreduce_max_(torch.tensor([float(rank), -float(rank)]))
     out['max'] = t.tolist()
-    def reduced(pn):                                                        # what BnLreluFn's first all-reduce carries behind its C sums
-        return rdist.allreduce_sum_(torch.tensor([float(pn), float(pn) ** 2]))
-    ops._sync_rows_checked(96, 8, reduced(96))                              # equal rows on both ranks: passes, and is remembered
-    out['equal_ok'] = (96, 8) in ops._SYNC_BN_CHECKED
-    # ragged shards: rank 0 has seen its shape before, rank 1 has not -- the collective is the same on both, only rank 1 looks at it ...
-    pn = 96 + 16 * rank
+    dev = torch.device('cpu')
+    z = ops._sync_rows_poison(96, dev)                                      # equal rows on both ranks: no poison, nothing counted
+    out['equal_ok'] = float(z) == 0.0 and sum(float(c) for c in ops.sync_bn_flags()) == 0.0
+    ops.check_sync_bn()
+    # ragged shards: BOTH ranks get the NaN and count the call -- the decision comes from the reduced pair alone, not from what a rank has
+    # seen before (round 4: a rank that knew its own shape skipped the check and its peer raised alone) ...
+    z = ops._sync_rows_poison(96 + 16 * rank, dev)
+    out['ragged'] = 'poisoned' if z != z else 'clean'
+    # ... exact where fp32 sums of rows^2 were not: 3 utterances x 3069 rows = 9207 rows (odd part 9207 > 4096), equal on both ranks
+    z = ops._sync_rows_poison(9207, dev)
+    out['big_equal'] = float(z) == 0.0
+    z = ops._sync_rows_poison((1 << 30) + rank, dev)                        # and a difference of ONE row in 2^30 is seen
+    out['big_ragged'] = 'poisoned' if z != z else 'clean'
     try:
-        ops._sync_rows_checked(pn, 8, reduced(pn))
-        out['ragged'] = 'no error'
+        from robust_e2e_gan_amd.joint_train import JointTrainer as JT
+        JT.to_floats({'grad_norm': torch.tensor(1.0)})               # the trainers' one read-back per step carries the counters
+        out['raise'] = 'no error'
     except lib.Re2eError as e:
-        out['ragged'] = 'raised' if 'sum to 208' in str(e) else str(e)
-    # ... and a rank that meets a NEW shape beside a ragged peer raises too
-    pn2 = 48 + 16 * rank
-    try:
-        ops._sync_rows_checked(pn2, 8, reduced(pn2))
-        out['ragged2'] = 'no error'
-    except lib.Re2eError:
-        out['ragged2'] = 'raised'
+        out['raise'] = 'raised' if '2 BatchNorm calls' in str(e) else str(e)
+    out['cleared'] = sum(float(c) for c in ops.sync_bn_flags()) == 0.0
 
     # the dropout stream of a checkpoint written by rank 0 is re-derived per rank
     from robust_e2e_gan_amd.joint_train import JointTrainer
@@ -171,7 +173,7 @@ def _sync_rows_worker(rank, world, port, q):
 
 
 def test_sync_bn_row_check_and_per_rank_dropout_stream_world2():
-    """Round 4 (advisor findings): synchronised BatchNorm refuses ragged shards on every rank at once; a checkpoint's dropout state
+    """Round 4/5 (advisor findings): synchronised BatchNorm refuses ragged shards on every rank in the same step, exactly; a checkpoint's dropout state
     (base seed, mask index) gives each rank ITS stream back."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -185,5 +187,6 @@ def test_sync_bn_row_check_and_per_rank_dropout_stream_world2():
         assert p.exitcode == 0
     for rank in (0, 1):
         o = res[rank]
-        assert o['max'] == [1.0, 0.0] and o['equal_ok'] and o['ragged'] == ('raised' if rank == 1 else 'no error') and o['ragged2'] == 'raised', o
+        assert o['max'] == [1.0, 0.0] and o['equal_ok'] and o['ragged'] == 'poisoned' and o['big_equal'] and o['big_ragged'] == 'poisoned', o
+        assert o['raise'] == 'raised' and o['cleared'], o
         assert o['dropout'] == ((7 * 1000003 + rank) & 0xFFFFFFFFFFFF, 5)

@@ -221,20 +221,35 @@ def test_sync_batchnorm_equals_global_batch(monkeypatch):
 
     def fake_allreduce(t):
         o = other[len(calls)].float().to(t.device)
-        t[:o.numel()].add_(o)
-        if t.numel() == o.numel() + 2:                    # the first all-reduce also carries (rows, rows^2) of every rank
-            t[o.numel():].add_(torch.tensor([float(P - half), float(P - half) ** 2], device=t.device))
+        t.add_(o)
         calls.append(t.numel())
+        return t
+    maxes = []
+
+    def fake_allreduce_max(t):                            # the exact (rows, -rows) pair of every BatchNorm call: the other rank has the same rows
+        maxes.append((t.dtype, t.tolist()))
         return t
     monkeypatch.setattr(rdist, 'world_size', lambda: 2)
     monkeypatch.setattr(rdist, 'allreduce_sum_', fake_allreduce)
+    monkeypatch.setattr(rdist, 'allreduce_max_', fake_allreduce_max)
     monkeypatch.setattr(ops, 'SYNC_BN', True)
     xa = x[:N // 2].to(DEV).requires_grad_(True)
     ga, ba = torch.nn.Parameter(gamma.to(DEV)), torch.nn.Parameter(beta.to(DEV))
     rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     y = ops.bn_lrelu(xa, ga, ba, rm, rv, True, 0.1, eps, slope)
     (y * w[:N // 2].to(DEV)).sum().backward()
-    assert calls == [C + 2, C, 2 * C]
+    assert calls == [C, C, 2 * C]
+    assert maxes == [(torch.float64, [float(half), -float(half)])] and sum(float(f) for f in ops.sync_bn_flags()) == 0.0
+    # a peer with ONE row more: the batch mean is poisoned on the device and the next read-back of the meters raises
+    monkeypatch.setattr(rdist, 'allreduce_max_', lambda t: t.copy_(torch.tensor([float(half + 1), -float(half)], dtype=t.dtype)))
+    calls.clear()
+    y2 = ops.bn_lrelu(xa.detach(), ga, ba, rm.clone(), rv.clone(), True, 0.1, eps, slope)
+    assert bool(torch.isnan(y2).all())
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.lib import Re2eError
+    with pytest.raises(Re2eError, match='same number of rows'):
+        JointTrainer.to_floats({'grad_norm': y2.sum()})
+    assert sum(float(f) for f in ops.sync_bn_flags()) == 0.0
     err = lambda a, b: float((a.detach().cpu() - b.detach()).abs().max())
     assert err(y, yr[:N // 2]) <= 2e-5 * float(yr.detach().abs().max())
     assert err(xa.grad, xr.grad[:N // 2]) <= 2e-5 * float(xr.grad.abs().max())

@@ -165,6 +165,47 @@ def test_dropout_stream_is_checkpointed():
     assert seeds[0] == ((1234 * 1000003 + 0) & 0xFFFFFFFFFFFF, 41) and seeds[1] == ((1234 * 1000003 + 3) & 0xFFFFFFFFFFFF, 41)
 
 
+def test_trainer_state_round_trip_carries_the_decayed_eps():
+    """state() -> load_state() after an adadelta_eps_decay: upstream builds its optimizers from the package's eps / lr
+    (joint_train.py:98-111,127-140), so the resumed trainer's THREE optimizers must hold the decayed eps (round 4 wrote it to opt only),
+    the weights must be the checkpoint's, and iters comes back as the checkpoint's - 1 (:108)."""
+    import __graft_entry__ as g
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    from robust_e2e_gan_amd.utils.utils import adadelta_eps_decay
+
+    def trainer(seed, **over):
+        torch.manual_seed(seed)
+        opt = g._tiny_opt()
+        for k, v in over.items():
+            setattr(opt, k, v)
+        return JointTrainer(opt, EnhanceModel(opt), FbankModel(opt), ShareE2E(opt), GANModel(opt))
+    a = trainer(1)
+    a.opt.eps = adadelta_eps_decay(a.asr_optimizer, 0.01)
+    assert a.opt.eps == 1e-10
+    pkg = a.state(3, 100, 1.5, 0.7)
+    b = trainer(2)
+    assert b.asr_optimizer.param_groups[0]['eps'] == 1e-8
+    assert b.load_state(pkg) == (3, 99, 1.5, 0.7)
+    assert b.opt.eps == 1e-10
+    assert [o.param_groups[0]['eps'] for o in (b.enhance_optimizer, b.asr_optimizer, b.gan_optimizer)] == [1e-10] * 3
+    for ma, mb in ((a.asr_model, b.asr_model), (a.enhance_model, b.enhance_model), (a.gan_model, b.gan_model)):
+        for (k, va), (_, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert torch.equal(va, vb), k
+    # the flat optimizer buffers ARE the parameters' storage: load_state_dict must have written through them, not rebound the tensors
+    assert all(p.data_ptr() == b.asr_optimizer.flat[o:o + 1].data_ptr() for p, o in zip(b.asr_optimizer.params, b.asr_optimizer.offsets))
+    # Adam resumes with the package's lr
+    c = trainer(3, opt_type='adam', lr=0.005, beta1=0.5)
+    pkg2 = c.state(0, 10)
+    pkg2['lr'] = 0.00125
+    d = trainer(4, opt_type='adam', lr=0.005, beta1=0.5)
+    d.load_state(pkg2)
+    assert d.opt.lr == 0.00125 and [o.param_groups[0]['lr'] for o in (d.enhance_optimizer, d.asr_optimizer, d.gan_optimizer)] == [0.00125] * 3
+
+
 def test_filterbank_band_tables_rebuild_the_matrix():
     """band_from_matrix: the by-filter and the by-bin banded forms (forward / backward kernels of re2e_fbank_*) are both exact
     re-statements of the dense (257, 80) mel matrix."""

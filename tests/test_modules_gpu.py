@@ -71,7 +71,7 @@ def test_enhance_model(golden_dir):
     rel('l1_loss', loss.view(()), fx['l1_loss'])
     (loss + (out2 * torch.linspace(0.5, 1.5, 257).to(DEV)).mean()).backward()
     for k, p in m.named_parameters():
-        rel('g.' + k, p.grad, fx['g.' + k], tol=2e-3)
+        rel('g.' + k, p.grad, fx['g.' + k], tol=1.5e-3)
 
 
 def test_fbank_model(golden_dir):
@@ -114,6 +114,47 @@ def test_e2e(golden_dir):
     rel('dfeat', feat.grad, fx['dfeat'], tol=1.5e-3)
     for k, p in m.named_parameters():
         rel('g.' + k, p.grad, fx['g.' + k], tol=1.5e-3)
+
+
+@pytest.mark.parametrize('tag', ['a.', 'b.'])
+def test_persistent_decoder_loop_vs_reference(golden_dir, tag):
+    """The ONE-launch decoder loop (csrc/decloop.hip, forward and backward) against vectors from the reference's own Decoder + AttLoc
+    (tests/golden/make_fixtures_dec.py: dunits=16, eprojs=32, adim=20 -- every other reference fixture has dunits=14, which the resident
+    form declines, so those tests run the launch-per-token kernels).  Case b has T' = 300 > 256 frames: two frame chunks per utterance.
+    The test asserts that the resident form IS what runs (non-zero workspace request, both directions)."""
+    from robust_e2e_gan_amd import ops
+    from robust_e2e_gan_amd.lib import query
+    from robust_e2e_gan_amd.model.e2e_decoder import decoder_forward_hip
+    fx = _fx(golden_dir, 'dec_persist_tiny.npz')
+    hl, tl = fx[tag + 'hlens'].tolist(), fx[tag + 'tlens'].tolist()
+    pg = {}
+    for k, v in fx.items():
+        if k.startswith(tag + 'p.dec.'):
+            n = k[len(tag) + 2:]
+            pg[n[4:] if n.startswith('dec.att.') else n] = torch.nn.Parameter(torch.from_numpy(v).clone().to(DEV))
+    ys, o = [], 0
+    for n in tl:
+        ys.append(torch.from_numpy(fx[tag + 'ys'][o:o + n]))
+        o += n
+    B, T, E = fx[tag + 'hpad'].shape
+    D, A = pg['dec.decoder.0.weight_hh'].shape[1], pg['att.mlp_enc.weight'].shape[0]
+    C, Kf = pg['att.loc_conv.weight'].shape[0], pg['att.loc_conv.weight'].shape[3]
+    L1 = max(tl) + 1
+    assert ops.DECODER_PERSIST and ops.DECODER_FUSED
+    assert query('re2e_dec_loop_workspace_bytes', L1, B, T, E, D, A, C, (Kf - 1) // 2) > 0, 'the resident forward declines this shape: the test would pass on the stepwise kernels'
+    assert query('re2e_dec_loop_bwd_workspace_bytes', L1, B, T, E, D, A, C, (Kf - 1) // 2) > 0, 'the resident backward declines this shape'
+    from robust_e2e_gan_amd import lib
+    aborts = lib.query('re2e_lstm_abort_count')
+    hg = torch.from_numpy(fx[tag + 'hpad']).to(DEV).requires_grad_(True)
+    loss, acc, att = decoder_forward_hip(pg, hg, hl, ys, 11, return_att=True)
+    rel(tag + 'att_w', att, fx[tag + 'att_w'], tol=1e-3)
+    rel(tag + 'loss_att', loss.view(1), fx[tag + 'loss_att'], tol=1e-3)
+    assert abs(float(acc) - float(fx[tag + 'acc'])) < 1e-6
+    loss.backward()
+    rel(tag + 'd_hpad', hg.grad, fx[tag + 'd_hpad'], tol=1e-3)
+    for k, v in pg.items():
+        rel(tag + 'g.' + k, v.grad, fx[tag + 'g.dec.' + (k[4:] if k.startswith('dec.') else k)], tol=1e-3)
+    assert lib.query('re2e_lstm_abort_count') == aborts
 
 
 def test_gan(golden_dir):
@@ -334,7 +375,7 @@ def test_joint_step_ragged_shapes_vs_oracle(golden_dir, lens, tls):
     for pre, m, gd in (('enh', enh, ref['g_enh']), ('asr', asr, ref['g_asr']), ('gan', gan, ref['g_gan'])):
         for k, p in m.named_parameters():
             if k in gd:
-                rel(pre + '.' + k, p.grad, gd[k].numpy(), tol=2e-3, atol=1e-7)
+                rel(pre + '.' + k, p.grad, gd[k].numpy(), tol=1.5e-3, atol=1e-7)
 
 
 def test_instance_norm_discriminator_vs_torch():

@@ -89,6 +89,41 @@ def test_e2e(golden_dir):
         np.testing.assert_allclose(v.grad.numpy(), fx['g.' + k], rtol=5e-3, atol=2e-6, err_msg=k)
 
 
+def _dec_case(fx, tag):
+    """Parameters of a dec_persist_tiny case under the oracle's names (the attention module hangs off the decoder there)."""
+    p = {}
+    for k, v in fx.items():
+        if k.startswith(tag + 'p.dec.'):
+            n = k[len(tag) + 2:]
+            n = n[4:] if n.startswith('dec.att.') else n
+            p[n] = torch.from_numpy(v).clone().requires_grad_(True)
+    tl = fx[tag + 'tlens'].tolist()
+    ys, o = [], 0
+    for n in tl:
+        ys.append(torch.from_numpy(fx[tag + 'ys'][o:o + n]))
+        o += n
+    return p, ys
+
+
+def test_decoder_at_persistent_widths(golden_dir):
+    """Decoder + AttLoc alone at dunits=16 / eprojs=32 / adim=20 (make_fixtures_dec.py): the widths csrc/decloop.hip accepts, one case
+    with T' = 300 > 256 frames.  Attention weights of every step, loss, accuracy, d(hpad), every parameter gradient."""
+    fx = _load(golden_dir, 'dec_persist_tiny.npz')
+    for tag in ('a.', 'b.'):
+        p, ys = _dec_case(fx, tag)
+        hpad = torch.from_numpy(fx[tag + 'hpad']).requires_grad_(True)
+        loss, acc, att = nets.decoder_forward(p, hpad, fx[tag + 'hlens'].tolist(), ys, 11, return_att=True)
+        np.testing.assert_allclose(att.detach().numpy(), fx[tag + 'att_w'], rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(loss.detach().numpy().reshape(-1), fx[tag + 'loss_att'], rtol=1e-5)
+        assert abs(acc - float(fx[tag + 'acc'])) < 1e-9
+        loss.backward()
+        np.testing.assert_allclose(hpad.grad.numpy(), fx[tag + 'd_hpad'], rtol=2e-3, atol=1e-7)
+        for k, v in p.items():
+            ref = fx[tag + 'g.dec.' + (k[4:] if k.startswith('dec.') else k)]       # fixture keys: names inside the reference's Decoder module
+            err = np.abs(v.grad.numpy() - ref).max()
+            assert err <= 1e-4 * np.abs(ref).max() + 1e-7, (tag, k, err)
+
+
 def test_gan(golden_dir):
     fx = _load(golden_dir, 'gan_tiny.npz')
     full = _sub(fx, 'p.')

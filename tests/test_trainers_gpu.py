@@ -342,7 +342,7 @@ def test_blstmp_enhancer(golden_dir):
     rel('enhb.l1_loss', loss.view(1), fx['enhb.l1_loss'])
     (loss + (out2 * torch.linspace(0.5, 1.5, 257).to(DEV)).mean()).backward()
     for k, p in enh.named_parameters():
-        rel('enhb.g.' + k, p.grad, fx['enhb.g.' + k], tol=2e-3)
+        rel('enhb.g.' + k, p.grad, fx['enhb.g.' + k], tol=1.5e-3)
     spec = enh.calculate_all_specgram(t('mix'), t('mix_log'), lens)           # no length mask: padded rows = sigmoid(fc(tanh(bias)))
     assert spec.shape == out.shape and torch.isfinite(spec).all()
     assert torch.equal(spec[0, :int(fx['lens'][0])], out.detach()[0, :int(fx['lens'][0])])
@@ -438,7 +438,7 @@ def test_blstm_interlayer_dropout_vs_oracle(golden_dir):
     (out * torch.linspace(0.5, 1.5, 257).to(DEV)).mean().backward()
     (ref * torch.linspace(0.5, 1.5, 257)).mean().backward()
     for k, q in enh.named_parameters():
-        rel('g.' + k, q.grad, p[k].grad.numpy(), tol=2e-3)
+        rel('g.' + k, q.grad, p[k].grad.numpy(), tol=1.5e-3)
     enh.eval()
     with torch.no_grad():
         rel('eval: no dropout', enh(t('mix'), t('mix_log'), torch.IntTensor(lens)), fx['enhance_out'])
@@ -516,9 +516,11 @@ def test_fit_with_device_prefetcher_equals_collated_loader(tmp_path):
 
 
 def test_fit_repeats_a_step_whose_recurrence_was_aborted(tmp_path):
-    """A persistent recurrence that gives up poisons its outputs; the device-side NaN gate skips the update.  JointTrainer.fit must then
-    repeat that step with the launch-per-step recurrences (after putting D's BatchNorm running statistics back), count it, and end where
-    an undisturbed run ends: four steps on the same batch, the second one aborted by the test hook re2e_debug_force_abort."""
+    """A persistent recurrence that gives up poisons its outputs; the device-side step gate refuses the update (D's included) and HOLDS the
+    step that was enqueued behind it.  JointTrainer.fit must then repeat the aborted step with the launch-per-step recurrences on the state it
+    first ran on, run the held step again, count the repeat, and end where an undisturbed run ends -- BatchNorm running statistics included:
+    four steps on four DIFFERENT batches (an update applied out of order would show), the second one aborted by the test hook
+    re2e_debug_force_abort; then the same with the abort in the LAST step (nothing enqueued behind it) and with the step behind a repeat aborted too."""
     from robust_e2e_gan_amd import lib
     from robust_e2e_gan_amd.data.synthetic import make_batch
     from robust_e2e_gan_amd.joint_train import JointTrainer
@@ -539,35 +541,37 @@ def test_fit_repeats_a_step_whose_recurrence_was_aborted(tmp_path):
             setattr(opt, k, v)
         torch.manual_seed(11)
         enh, fb, asr, gan = (m.to(DEV).train() for m in (EnhanceModel(opt), FbankModel(opt), ShareE2E(opt), GANModel(opt)))
-        clean, mix, mix_log, targets, il, tl = make_batch(3, 40, 4, opt.odim, seed=5)
-        b = (['u%d' % i for i in range(3)], None, clean, None, mix, mix_log, None, targets, il, tl)
+        batches = []
+        for i in range(4):
+            clean, mix, mix_log, targets, il, tl = make_batch(3, 40, 4, opt.odim, seed=5 + i)
+            batches.append((['u%d' % j for j in range(3)], None, clean, None, mix, mix_log, None, targets, il, tl))
         tr = JointTrainer(opt, enh, fb, asr, gan)
-        base = lib.query('re2e_lstm_abort_count')
-        tr.aborts_seen = base                                  # (the counter is per process: earlier tests may have raised it)
+        base = lib.query('re2e_lstm_abort_count')             # (the counter is per process; the trainer acknowledges what it finds at its first step)
         n = [0]
         orig = tr.step
 
         def step(data, rate, cmvn):
             n[0] += 1
-            if n[0] == abort_at:
+            if n[0] in abort_at:
                 lib.query('re2e_debug_force_abort', 1)         # the next persistent forward sequence "gives up"
             return orig(data, rate, cmvn)
         tr.step = step
-        iters, _, _ = tr.fit([b, b, b, b], [], Quiet())
+        iters, _, _ = tr.fit(batches, [], Quiet())
         torch.cuda.synchronize()
         assert iters == 4
         state = {k: v.detach().clone() for m in (enh, asr, gan) for k, v in m.state_dict().items()}
         return tr, state, n[0], lib.query('re2e_lstm_abort_count') - base
     try:
-        _, ref, calls, aborts = run(None)
+        _, ref, calls, aborts = run(())
         assert calls == 4 and aborts == 0
-        tr, got, calls, aborts = run(2)
-        assert aborts == 1 and tr.recovered_steps == 1 and calls == 5          # four steps + the repeated one
-        for k in ref:
-            assert torch.isfinite(got[k].float()).all(), k
-            if 'running_' in k or 'num_batches' in k:
-                continue          # D's BatchNorm running statistics are an order-dependent moving average: put back, then fed steps 2', 4 instead of 2, 3, 4
-            rel(k, got[k].float(), ref[k].float().cpu().numpy(), tol=2e-4, atol=1e-6)
+        # (calls: the aborted step, the held one behind it, the repeat, the held one again)
+        for abort_at, want_calls, want_aborts, want_rec in (((2,), 6, 1, 1), ((4,), 5, 1, 1), ((2, 5), 8, 2, 2)):
+            tr, got, calls, aborts = run(abort_at)
+            assert aborts == want_aborts and tr.recovered_steps == want_rec and calls == want_calls, (abort_at, aborts, tr.recovered_steps, calls)
+            assert tr.unexplained_aborts == 0
+            for k in ref:
+                assert torch.isfinite(got[k].float()).all(), k
+                rel('%r %s' % (abort_at, k), got[k].float(), ref[k].float().cpu().numpy(), tol=2e-4, atol=1e-6)
     finally:
         lib.query('re2e_debug_force_abort', 0)
 
@@ -597,7 +601,7 @@ def test_instance_norm_discriminator_vs_reference(golden_dir):
     for k, p in gan.named_parameters():
         ref = fx['ind.g.' + k]
         err = float(np.abs(p.grad.detach().cpu().numpy() - ref).max())
-        assert err <= 3e-3 * max(float(np.abs(ref).max()), 1e-2 * gscale), (k, err)
+        assert err <= 1.5e-3 * max(float(np.abs(ref).max()), 1e-2 * gscale), (k, err)
 
 
 def test_instance_norm_unet_vs_reference(golden_dir):
@@ -624,6 +628,6 @@ def test_instance_norm_unet_vs_reference(golden_dir):
         if k.startswith('inu.g.'):
             g = named[k[len('inu.g.'):]].grad
             err = float(np.abs(g.detach().cpu().numpy() - fx[k]).max())
-            assert err <= 3e-3 * max(float(np.abs(fx[k]).max()), 1e-2 * gscale), (k, err)
+            assert err <= 1.5e-3 * max(float(np.abs(fx[k]).max()), 1e-2 * gscale), (k, err)
             n += 1
     assert n >= len(named) - 1          # (the reference leaves one parameter without a gradient: not in the fixture)

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Same-session A/B of the dense x W^T kernels: igemm.hip's engine (RE2E_NT2=0) against csrc/gemm_nt.hip's variants.
+
+Needs the experiments build (make -C robust_e2e_gan_amd/csrc EXPERIMENTS=1): RE2E_NT2 is re-read at every call there.
+    RE2E_EXPERIMENTS=1 RE2E_LIB=robust_e2e_gan_amd/libre2e_hip_exp.so python tools/bench_gemm2.py [variants] [--check-only]
+Every variant's output is compared with the old engine's (max |diff| / max |ref|); times are HIP events on the launch
+stream, best of 3 groups of `iters` back-to-back calls.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from robust_e2e_gan_amd import lib, ops
+
+DEV = 'cuda:0'
+
+# (M, N, K) of the step's x W^T products (profiles/r04_igemm_calls_nooverlap.txt), config 4; the last rows are config 5 / ragged cases
+SHAPES = [
+    (12800, 2560, 2048), (12288, 2048, 2560), (12800, 512, 2048), (12288, 2048, 512), (24576, 1024, 512), (25600, 512, 1024),
+    (12800, 1024, 512), (12800, 512, 1024), (24576, 1024, 260), (6400, 512, 4240), (5632, 4232, 512), (25600, 256, 512),
+    (25600, 512, 256), (6400, 320, 512), (6400, 512, 320), (25600, 256, 260), (1312, 4232, 300), (24000, 2048, 2560), (24000, 512, 2048),
+]
+
+
+# (M, N, K) of the step's dy^T x products; the last two are ragged (K tail, M / N edges)
+TN_SHAPES = [(2048, 512, 12800), (2048, 2560, 12800), (1024, 256, 25600), (1024, 512, 25600), (512, 1024, 12800), (1024, 260, 25600),
+             (4240, 512, 6400), (512, 512, 5452), (256, 512, 25600), (260, 256, 25600), (320, 512, 6400), (300, 1312, 4232), (516, 132, 1003)]
+
+
+def timeit(fn, iters, groups=3):
+    best = 1e9
+    for _ in range(groups):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e-3 / iters)
+    return best
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    variants = args[0].split(':') if args else ['0', '3,0', '3,2', '6,0', '6,2', '8,0', '8,2', '9,0', '1,2']
+    check_only = '--check-only' in sys.argv
+    skip_nt = '--tn-only' in sys.argv
+    torch.manual_seed(0)
+    print('%-22s %8s | %s' % ('M x N x K', 'engine', '  '.join('%9s' % v for v in variants)), flush=True)
+    for (M, N, K) in ([] if skip_nt else SHAPES):
+        A = torch.randn(M, K, device=DEV)
+        B = torch.randn(N, K, device=DEV)
+        bias = torch.randn(N, device=DEV)
+        C0 = torch.empty(M, N, device=DEV)
+        C1 = torch.empty(M, N, device=DEV)
+        fl = 2.0 * M * N * K
+        iters = max(3, min(40, int(3e-3 / (fl / 100e12))))
+
+        def runner(v, C):
+            def run():
+                os.environ['RE2E_NT2'] = v
+                ops.gemm(A, B, C, M, N, K, transb=True, bias=bias, act=lib.ACT_TANH)
+            return run
+        cfgs = ['old'] + variants
+        runs = [runner(v, C0 if v == 'old' else C1) for v in cfgs]
+        best = [1e9] * len(cfgs)
+        if not check_only:
+            for r in runs:
+                r()
+            for _ in range(3):                 # round-robin over the configurations: clocks / cache state drift hits all of them alike
+                for i, r in enumerate(runs):
+                    r()
+                    best[i] = min(best[i], timeit(r, iters, groups=1))
+        # fp64 truth on a sample of rows (first / last tile rows and a stride through the middle): both engines are judged against it --
+        # two fp32 summation orders differ by ~1e-4 of the tanh range at K ~ 4000 on N(0,1) operands, which is not an error
+        rows = torch.cat([torch.arange(0, min(M, 300)), torch.arange(max(0, M - 300), M), torch.arange(0, M, max(1, M // 257))]).unique().to(DEV)
+        truth = torch.tanh(A[rows].double() @ B.double().t() + bias.double())
+        runs[0]()
+        e0 = (C0[rows].double() - truth).abs().max().item()
+        cells = []
+        for i, v in enumerate(variants):
+            C1.fill_(float('nan'))
+            try:
+                if i == 0:
+                    os.environ['RE2E_NT2_LOG'] = '1'
+                runs[i + 1]()
+                os.environ.pop('RE2E_NT2_LOG', None)
+                torch.cuda.synchronize()
+                err = (C1[rows].double() - truth).abs().max().item()
+                bad = not (err <= 2.0 * e0 + 1e-6) or not bool(torch.isfinite(C1).all())
+                C2 = C1.clone()                # reproducible: a second call gives the same bits (the stream-K finisher is whoever arrives last)
+                runs[i + 1]()
+                torch.cuda.synchronize()
+                same = torch.equal(C1, C2)
+                t1 = best[i + 1]
+                cells.append('%6.1f%s%s' % (fl / t1 / 1e12 if not check_only else 0.0, '!' if bad else ' ', ' ' if same else '~') + ('(%.0e)' % err if bad else ''))
+            except Exception as e:     # noqa
+                cells.append('ERR %s' % str(e)[:40])
+        print('%-22s %8.1f | %s' % ('%dx%dx%d' % (M, N, K), fl / best[0] / 1e12 if not check_only else 0.0, '  '.join('%9s' % c for c in cells)), flush=True)
+    # accumulate / plain epilogues and a ragged everything case
+    for (M, N, K, act, beta) in [] if skip_nt else ((3000, 516, 200, lib.ACT_NONE, 1.0), (2049, 260, 36, lib.ACT_RELU, 0.0), (7777, 1028, 1000, lib.ACT_LRELU, 0.0),
+                                 (4100, 132, 2052, lib.ACT_SIGMOID, 0.0)):
+        A = torch.randn(M, K, device=DEV); B = torch.randn(N, K, device=DEV); b1 = torch.randn(N, device=DEV); b2 = torch.randn(N, device=DEV)
+        Cinit = torch.randn(M, N, device=DEV)
+        os.environ['RE2E_NT2'] = 'old'
+        C0 = Cinit.clone()
+        ops.gemm(A, B, C0, M, N, K, transb=True, bias=b1, bias2=b2, act=act, beta=beta)
+        out = []
+        for v in variants:
+            os.environ['RE2E_NT2'] = v
+            C1 = Cinit.clone()
+            ops.gemm(A, B, C1, M, N, K, transb=True, bias=b1, bias2=b2, act=act, beta=beta)
+            torch.cuda.synchronize()
+            out.append('%.1e' % ((C1 - C0).abs().max().item() / C0.abs().max().item()) if bool(torch.isfinite(C1).all()) else 'NAN')
+        print('edge %dx%dx%d act %d beta %.0f: rel err %s' % (M, N, K, act, beta, ' '.join(out)), flush=True)
+    # ---- dy^T x (weight gradients): C[M,N] += A[K,M]^T B[K,N] ----
+    tn_variants = [v for v in (args[1].split(':') if len(args) > 1 else ['0', '3,0', '3,2', '6,0', '6,2', '8,2'])]
+    print('%-22s %8s | %s' % ('TN  M x N x K', 'engine', '  '.join('%9s' % v for v in tn_variants)), flush=True)
+    for (M, N, K) in TN_SHAPES:
+        A = torch.randn(K, M, device=DEV)
+        B = torch.randn(K, N, device=DEV)
+        Cinit = torch.randn(M, N, device=DEV)
+        C0, C1 = Cinit.clone(), Cinit.clone()
+        fl = 2.0 * M * N * K
+        iters = max(3, min(40, int(3e-3 / (fl / 100e12))))
+
+        def runner(v, C, beta):
+            def run():
+                os.environ['RE2E_TN2'] = v
+                ops.gemm(A, B, C, M, N, K, transa=True, beta=beta)
+            return run
+        cfgs = ['old'] + tn_variants
+        best = [1e9] * len(cfgs)
+        runs = [runner(v, C0 if v == 'old' else C1, 0.0) for v in cfgs]
+        if not check_only:
+            for r in runs:
+                r()
+            for _ in range(3):
+                for i, r in enumerate(runs):
+                    r()
+                    best[i] = min(best[i], timeit(r, iters, groups=1))
+        truth = A.double().t() @ B.double() + Cinit.double()
+        C0.copy_(Cinit)
+        runner('old', C0, 1.0)()
+        e0 = (C0.double() - truth).abs().max().item()
+        cells = []
+        for i, v in enumerate(tn_variants):
+            C1.copy_(Cinit)
+            if i == 0:
+                os.environ['RE2E_NT2_LOG'] = '1'
+            runner(v, C1, 1.0)()
+            os.environ.pop('RE2E_NT2_LOG', None)
+            torch.cuda.synchronize()
+            err = (C1.double() - truth).abs().max().item()
+            bad = not (err <= 2.0 * e0 + 1e-6) or not bool(torch.isfinite(C1).all())
+            C2 = C1.clone()
+            C1.copy_(Cinit)
+            runner(v, C1, 1.0)()
+            torch.cuda.synchronize()
+            same = torch.equal(C1, C2)
+            cells.append('%6.1f%s%s' % (fl / best[i + 1] / 1e12 if not check_only else 0.0, '!' if bad else ' ', ' ' if same else '~') + ('(%.0e/%.0e)' % (err, e0) if bad else ''))
+        print('%-22s %8.1f | %s' % ('%dx%dx%d' % (M, N, K), fl / best[0] / 1e12 if not check_only else 0.0, '  '.join('%9s' % c for c in cells)), flush=True)
+    print('aborts', lib.query('re2e_lstm_abort_count') if hasattr(lib.load(), 're2e_lstm_abort_count') else 'n/a')
+
+
+if __name__ == '__main__':
+    main()
