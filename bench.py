@@ -17,6 +17,8 @@ Extra objects on the line:
   roofline     -- the dominant convolution (3x3 at the VGG conv1_2 shape of this workload, as the step launches it:
                   fused Winograd + ReLU + pool) timed live with HIP events on the launch stream; achieved / frac = EXECUTED
                   matrix-core FLOPs against the fp32-MFMA peak (<= 1), the direct-form figure is direct_equivalent_tflops
+  roofline_engine -- the fp32-MFMA engine measured live: the heaviest GEMM / convolution rows of one step, each timed alone with HIP events and
+                  weighted by its calls per step: executed TFLOP/s, fraction of the 157.3 peak, ms per step
   roofline_chain -- the latency-bound recurrent chains: us per step of the persistent bi-LSTM kernels alone on the chip, measured
                   live, next to the bare hand-off floor (tools/micro/handoff_probe.hip) and the MFMA floor
   other_configs -- configurations 2, 3 and 5 of BASELINE.json, 5 timed steps each in this same process (N = 1, --config 4)
@@ -130,10 +132,10 @@ def conv_roofline(dev, iters=20):
     ``re2e_conv3x3_wino`` with the fused ReLU + 2x2 max pool epilogue (csrc/winograd.hip: fused Winograd F(2x2,3x3); only the pooled
     tensor and the index bytes are written).
 
-    ``achieved`` follows the contract: ALGORITHMIC FLOPs (2*9*Cin*Cout per output pixel, the direct form) / launch time.
-    Winograd executes 1/2.25 of those multiply-adds on the matrix cores, so ``achieved`` can exceed the fp32-MFMA peak;
-    ``executed_*`` is what the matrix pipe really did (the figure to hold against the 157.3 TFLOP/s peak as a utilisation).  The
-    direct kernels of the same product (round 2's halo-patch kernel, fused with the pool and plain) are timed next to it."""
+    ``achieved`` = the FLOPs the matrix cores EXECUTE per launch (the Winograd form: 16 instead of 36 multiply-adds per 2x2 outputs, i.e. the
+    direct form's 2*9*Cin*Cout per output pixel / 2.25) / launch time, so ``frac`` <= 1 is a utilisation of the 157.3 TFLOP/s fp32-MFMA peak;
+    the direct-form (SURVEY 8(d) algorithmic) figure, which can exceed the peak, is ``direct_equivalent_tflops``.  The direct kernels of the
+    same product (round 2's halo-patch kernel, fused with the pool and plain) are timed next to it."""
     from robust_e2e_gan_amd import lib, ops
     N, H, W, C, K = 64, 800, 80, 64, 64
     x = torch.randn(N, H, W, C, device=dev)
@@ -180,6 +182,61 @@ def conv_roofline(dev, iters=20):
             'engine_avg_direct_equivalent_tflops': eng, 'engine_avg_source': esrc,
             'engine_avg_note': 'per-call table of one single-stream step over every GEMM / convolution call; executed = matrix-core FLOPs, '
                                'direct-equivalent counts Winograd calls with the FLOPs of the direct convolution they replace'}
+
+
+def engine_roofline(dev, iters=8):
+    """The fp32-MFMA engine's own roofline, measured LIVE: the heaviest GEMM / convolution calls of one config-4 step (the rows that make
+    up >= 85 % of the per-call table profiles/r0N_igemm_calls_nooverlap.txt), each timed alone with HIP events on the launch stream and
+    weighted by its calls per step.  ``executed_tflops`` = executed matrix-core FLOPs (Winograd rows: the FLOPs the transformed products
+    really run, not the direct convolution's) / time; ``frac`` against the 157.3 TFLOP/s peak; ``ms_per_step`` = the rows' time per step."""
+    from robust_e2e_gan_amd import lib, ops
+    r = lambda *sh: torch.randn(*sh, device=dev)
+    rows = []
+
+    def add(name, calls, exe_flop, fn):
+        sec = _time_launches(fn, iters)
+        rows.append({'row': name, 'calls_per_step': calls, 'ms': round(sec * 1e3, 4), 'executed_tflops': round(exe_flop / sec / 1e12, 1)})
+        return sec * calls, exe_flop * calls
+
+    tot_s = tot_f = 0.0
+    # dense x W^T (csrc/gemm_nt.hip) and dy^T x (csrc/igemm.hip): Linear forwards / input gradients, weight gradients
+    for (M, N, K, calls) in ((12800, 2560, 2048, 2), (12288, 2048, 2560, 2), (12800, 512, 2048, 4), (12288, 2048, 512, 4), (24576, 1024, 512, 3),
+                             (25600, 512, 1024, 2), (12800, 1024, 512, 3), (12800, 512, 1024, 3), (24576, 1024, 260, 3)):
+        A, B, C = r(M, K), r(N, K), torch.empty(M, N, device=dev)
+        t, f = add('x W^T %dx%dx%d' % (M, N, K), calls, 2.0 * M * N * K, lambda: ops.gemm(A, B, C, M, N, K, transb=True))
+        tot_s, tot_f = tot_s + t, tot_f + f
+    for (M, N, K, calls) in ((2048, 512, 12800, 10), (2048, 2560, 12800, 2), (1024, 256, 25600, 4), (1024, 512, 25600, 2), (512, 1024, 12800, 3)):
+        A, B, C = r(K, M), r(K, N), torch.empty(M, N, device=dev)
+        t, f = add('dy^T x %dx%dx%d' % (M, N, K), calls, 2.0 * M * N * K, lambda: ops.gemm(A, B, C, M, N, K, transa=True))
+        tot_s, tot_f = tot_s + t, tot_f + f
+    # discriminator 4x4 / stride-2 layers: forward and stride-2 data gradient (implicit GEMM on the same pipeline)
+    for (Nb, H, W, C, Kc, cf, cd) in ((32, 400, 40, 64, 128, 3, 3), (32, 200, 20, 128, 256, 2, 2)):
+        x, wt = r(Nb, H, W, C), r(Kc, C, 4, 4) * 0.05
+        OH, OW = H // 2, W // 2
+        wg = torch.empty(Kc, 4, 4, C, device=dev)
+        lib.call('re2e_conv_weight_gather', wt.data_ptr(), wg.data_ptr(), Kc, C, 4, 4, 0, 4, 4, 0, 0, 1)
+        y, dy = torch.empty(Nb, OH, OW, Kc, device=dev), r(Nb, OH, OW, Kc)
+        fl = 2.0 * 16 * C * Kc * Nb * OH * OW
+        t, f = add('D conv %d->%d 4x4/s2 fwd' % (C, Kc), cf, fl, lambda: lib.call('re2e_conv_igemm', x.data_ptr(), Nb, H, W, C, wg.data_ptr(), Kc, 4, 4, OH, OW, 2, 2,
+                                                                                 1, 1, -1, -1, y.data_ptr(), OH, OW, 1, 1, 0, 0, None, lib.ACT_LRELU, 0.0))
+        tot_s, tot_f = tot_s + t, tot_f + f
+        t, f = add('D conv %d->%d 4x4/s2 dgrad' % (C, Kc), cd, fl, lambda: ops.conv_dgrad(dy, wt, (Nb, H, W, C), 2, 1))
+        tot_s, tot_f = tot_s + t, tot_f + f
+    # VGG 3x3 layers: fused Winograd forward + data gradient (executed = direct / 2.25)
+    for (Nb, H, W, C, Kc) in ((64, 800, 80, 64, 64), (64, 400, 40, 64, 128), (64, 400, 40, 128, 128)):
+        x, wt, dy = r(Nb, H, W, C), r(Kc, C, 3, 3) * 0.04, r(Nb, H, W, Kc)
+        fl = 2.0 * 9 * C * Kc * Nb * H * W / 2.25
+        t, f = add('VGG conv %d->%d 3x3 fwd (Winograd)' % (C, Kc), 1, fl, lambda: ops.conv3x3_wino(x, wt, Kc))
+        tot_s, tot_f = tot_s + t, tot_f + f
+        if C % 64 == 0:
+            t, f = add('VGG conv %d->%d 3x3 dgrad (Winograd)' % (C, Kc), 1, fl, lambda: ops.conv3x3_wino(dy, wt, C, dgrad=True))
+            tot_s, tot_f = tot_s + t, tot_f + f
+        del x, dy
+    ach = tot_f / tot_s / 1e12
+    return {'bound': 'mfma', 'executed_tflops': round(ach, 1), 'peak': PEAK_FP32_MFMA_TFLOPS, 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            'ms_per_step': round(tot_s * 1e3, 2), 'rows': rows,
+            'note': 'each row alone on the chip, HIP events on the launch stream, %d launches after 3 warm-ups; weights = calls per config-4 step; the '
+                    'Winograd / F(2x2,4x4) weight gradients and the small products are not in the list' % iters}
 
 
 def chain_roofline(dev):
@@ -469,8 +526,12 @@ def time_other_config(cfg_id, dev, steps=5, warmup=2):
             f = torch.cat([fb(b[0].to(dev))[i, :l] for b in cmvn_batches for i, l in enumerate(b[4].tolist())], 0)
             cmvn = torch.stack([-f.mean(0), 1.0 / f.std(0)]).cpu()
     step, tr, _ = make_stepper(cfg_id, opt, (enh, fb, asr, gan), batch, cmvn.to(dev), dev)
+    host_ms = None
     for _ in range(warmup):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
         step()
+        host_ms = (time.perf_counter() - h0) * 1e3       # enqueue time of ONE step issued into an idle GPU (no back-pressure)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -479,7 +540,9 @@ def time_other_config(cfg_id, dev, steps=5, warmup=2):
     dt = time.perf_counter() - t0
     utt_s = B * steps / dt
     out = {'ms': round(dt / steps * 1e3, 3), 'utt_s': round(utt_s, 2), 'frac': round(utt_s * FLOP_PER_UTT[cfg_id] / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
-           'steps': steps, 'warmup': warmup, 'workload': '%s, B=%d, T=%d, L=%d' % (CONFIG_NAMES[cfg_id], B, T, L)}
+           'steps': steps, 'warmup': warmup, 'workload': '%s, B=%d, T=%d, L=%d' % (CONFIG_NAMES[cfg_id], B, T, L),
+           'host_enqueue_ms': round(host_ms, 2) if host_ms is not None else None,
+           'host_bound': bool(host_ms is not None and dt / steps * 1e3 < 1.3 * host_ms)}
     del step, tr, enh, fb, asr, gan
     torch.cuda.empty_cache()
     return out
@@ -664,6 +727,7 @@ def main():
         line['input_side'] = input_side
     if not a.no_roofline:
         line['roofline'] = conv_roofline(dev)
+        line['roofline_engine'] = engine_roofline(dev)
         line['roofline_chain'] = chain_roofline(dev)
     if world == 1 and a.config == 4 and default_shape and not a.no_other_configs:
         # step_mfma_frac of the other configurations, measured by THIS run (5 timed steps each): `frac` = utt/s x SURVEY 8(d) FLOP / fp32-MFMA peak

@@ -154,8 +154,13 @@ int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const fl
 size_t gemm_nt2_workspace_bytes(int M, int N, int K);
 int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,
              int act, float beta, const float* mul, float* mask_out, const int* lens, int T, void* ws, size_t wsb, hipStream_t st);
+int gemm_nt2_kslices(int M, int N, int Ks, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st, int nolog);
 size_t gemm_tn2_workspace_bytes(int M, int N, int K);      // the same kernel's dy^T x form (weight gradients)
 int gemm_tn2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,
              int act, float beta, void* ws, size_t wsb, hipStream_t st);
+// ... and its implicit-GEMM convolution form (forward / data gradient; ncls = 4: the output parity classes of a stride-2 data gradient)
+int conv_nt2(const ConvGeom& g, int M, const float* wg, int Cout, float* out, long ldc, const float* bias, int act, float beta, int ncls,
+             const int* cls_oy0, const int* cls_ox0, long cls_wstride, int remap, int OHF, int OWF, int osy, int osx, const int* ooy, const int* oox,
+             hipStream_t st);
 bool halo_conv3x3(const ConvGeom& g, const float* wg, int Cout, float* out, const float* bias, int act, float beta, const float* mask,
                   hipStream_t st, float* pool_out = nullptr, unsigned char* pool_idx = nullptr);

@@ -59,6 +59,16 @@ struct NtArgs {
   float* slabs;      // [g_sk][2][BM*BN] partial accumulators of cut tiles
   int* counters;     // [ntm*ntn - n_dp] arrival tickets: zero on entry, put back to zero by each tile's last arriver
   int nomem;
+  // MODE 2 (implicit-GEMM convolution; csrc/common.h ConvGeom semantics).  A = the NHWC image, M = pixels of ONE class, K = KH*KW*C.
+  int cH, cW, cC, cPH, cPW, cKH, cKW, cSY, cSX, cDY, cDX;
+  int ncls;                       // 1, or 4 output parity classes: tile index / (ntm*ntn) = class
+  int cOY0[4], cOX0[4];           // per class: input row / column of tap (0,0) at pixel (0,0)
+  long cls_wstride;               // per class: float offset of its weight set in B
+  int remap, OHF, OWF, osy, osx, ooy[4], oox[4];      // output row of pixel (n,py,px): ((n*OHF + py*osy+ooy)*OWF + px*osx+oox)*ldc ; remap = 0: m*ldc
+  unsigned a_shift;               // bytes the image descriptor starts in FRONT of the tensor (so that every per-lane offset is >= 0)
+  // MODE 0, K-sliced batch (gemm_kslices: Winograd F(2x2,4x4) positions): ncls slices, slice z contracts k in [z*batch_k, (z+1)*batch_k) and writes
+  // C + z*batch_c; K = batch_k, tiles count over the slices like the convolution's classes
+  int batch_k; long batch_c;
 };
 
 template <int N>
@@ -85,8 +95,13 @@ __device__ __forceinline__ int xcd_chunk(int orig, int n) {
 //   straight out of it: the lane that supplies "row lr" of the x-side operand reads the TM CONSECUTIVE floats m = TM*lr + a of k-row 2s + lh with
 //   one ds_read (they are its values for the wave's TM tiles, whose rows are interleaved), the dy-side operand is a ds_read_b32 per tile;
 //   every read is conflict-free.  Same pipeline, schedule, hand-off and epilogue.
-template <class CF, bool TNF>
+// MODE 2: MODE 0 with the A operand gathered from an NHWC image (implicit GEMM: rows = output pixels, k = (tap, channel), a k-tile = BK channels
+//   of ONE tap = 64 contiguous bytes of a pixel): the per-lane offset is the pixel (a tile constant), the tap + channel position goes through the
+//   scalar offset, the halo through a per-lane bit mask over the taps (invalid -> out-of-range offset: zeros, no traffic).  Tiles count over the
+//   output parity classes of a stride-2 data gradient (re2e_conv_dgrad_s2): class = own input offsets, weight set and output positions.
+template <class CF, int MODE>
 __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p) {
+  constexpr bool TNF = MODE == 1, CONV = MODE == 2;
   constexpr int BM = CF::BM, BN = CF::BN, BK = CF::BK, ST = CF::ST, TM = CF::TM, TN = CF::TN, NW = CF::NW, TH = CF::THREADS;
   constexpr int NPW = CF::NPW, NPA = CF::NPA, NQ = CF::NQ, STAGE = CF::STAGE, CPR = CF::CPR, RPL = CF::RPL, RPP = CF::RPP;
   extern __shared__ __attribute__((aligned(1024))) float smem[];     // the ONE LDS object of the kernel (a second one makes hipcc drain vmcnt before every ds_read)
@@ -145,7 +160,9 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
     const int trel = (int)(u0 / nkt);
     const int kb = (int)(u0 - (long)trel * nkt);
     const int ke = (int)min((long)nkt, kb + (u1 - u0));
-    const int tile = tile_base + trel;
+    int tile = tile_base + trel;
+    int cls = 0;
+    if (CONV || p.ncls > 1) { const int tpc = p.ntm * p.ntn; cls = tile / tpc; tile -= cls * tpc; }
     int tile_m, tile_n;
     {
       const int GROUP = 8, per_group = GROUP * p.ntn;
@@ -160,6 +177,26 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       const bool isA = i < NPA;
+      if constexpr (CONV) {
+        if (isA) {
+          // pixel of this lane's row, the position of its tap (0,0) moved to the most negative tap so that scalar tap offsets are >= 0
+          const int row = m0 + prow_t[i];
+          const int px = row % p.cPW, t2 = row / p.cPW, py = t2 % p.cPH, n = t2 / p.cPH;
+          const int iy0 = py * p.cSY + p.cOY0[cls], ix0 = px * p.cSX + p.cOX0[cls];
+          const int ylo = p.cDY < 0 ? (p.cKH - 1) * p.cDY : 0, xlo = p.cDX < 0 ? (p.cKW - 1) * p.cDX : 0;
+          unsigned mask = 0;
+          if (row < p.M) {
+#pragma unroll 1
+            for (int t = 0; t < p.cKH * p.cKW; ++t) {
+              const int iy = iy0 + (t / p.cKW) * p.cDY, ix = ix0 + (t % p.cKW) * p.cDX;
+              if ((unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW) mask |= 1u << t;
+            }
+          }
+          voff[i] = (unsigned)((((long)n * p.cH + iy0 + ylo) * p.cW + ix0 + xlo) * p.cC * 4 + (long)p.a_shift) + pc16[i];
+          voff_t[i] = mask;       // (MODE 2 has no ragged k: C % BK == 0)
+          continue;
+        }
+      }
       if constexpr (!TNF) {
         const int row = (isA ? m0 : n0) + prow_t[i];
         const bool ok = row < (isA ? p.M : p.N);
@@ -176,11 +213,22 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
       const bool dead = kt >= ke;
       const bool tail = ragged_k && kt == nkt - 1;
       const unsigned kb4 = dead ? 0u : (unsigned)kt * (unsigned)(BK * 4);
-      const unsigned soffA = TNF ? kb4 * (unsigned)p.lda : kb4, soffB = TNF ? kb4 * (unsigned)p.ldb : kb4;
+      unsigned soffA = TNF ? kb4 * (unsigned)p.lda : kb4, soffB = TNF ? kb4 * (unsigned)p.ldb : kb4;
+      if constexpr (MODE == 0) { const unsigned zk = (unsigned)(cls * p.batch_k) * 4u; soffA += zk; soffB += zk; }
+      unsigned tapbit = 0;
+      if constexpr (CONV) {
+        const int cpt = p.cC / BK, tap = dead ? 0 : kt / cpt, c0 = dead ? 0 : (kt - tap * cpt) * BK;       // scalar
+        const int a = tap / p.cKW, b = tap - a * p.cKW;
+        const int ya = a * p.cDY - (p.cDY < 0 ? (p.cKH - 1) * p.cDY : 0), xb = b * p.cDX - (p.cDX < 0 ? (p.cKW - 1) * p.cDX : 0);      // >= 0
+        soffA = (unsigned)(((ya * p.cW + xb) * p.cC + c0) * 4);
+        soffB += (unsigned)(cls * p.cls_wstride * 4);
+        tapbit = 1u << tap;
+      }
       float* base = smem + slot * STAGE + wid * 256;
 #pragma unroll
       for (int i = 0; i < NPW; ++i) {
-        const unsigned v = dead ? OOB : (tail ? voff_t[i] : voff[i]);
+        unsigned v = dead ? OOB : (tail ? voff_t[i] : voff[i]);
+        if constexpr (CONV) { if (i < NPA) v = (!dead && (voff_t[i] & tapbit)) ? voff[i] : OOB; }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(i < NPA ? rsA : rsB, (__attribute__((address_space(3))) void*)(base + i * NW * 256), 16, v,
                                                  i < NPA ? soffA : soffB, 0, 0);
       }
@@ -313,9 +361,25 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
     // constant, the tile / run position goes through the instruction's scalar offset (excluded from the range check), and only
     // edge tiles pay a select per store (invalid -> out-of-range offset, dropped by the hardware). ----
     if (finish) {
-      const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFF0u, 0x00020000);     // below OOB; the scalar offset is not range-checked
+      const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + (MODE == 0 ? cls * p.batch_c : 0L), 0, 0x7FFFFFF0u, 0x00020000);     // below OOB; the scalar offset is not range-checked
       const unsigned vlane = ((unsigned)(TNF ? TM * lr : lr) * (unsigned)p.ldc + 4u * (unsigned)lh) * 4u;
-      const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
+      const bool interior = !CONV && m0 + BM <= p.M && n0 + BN <= p.N;
+      unsigned vrow[TM];
+      if constexpr (CONV) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          const int row = m0 + (wm * TM + a) * 32 + lr;
+          bool ok = row < p.M;
+          long off = (long)row * p.ldc;
+          if (p.remap) {
+            const int px = row % p.cPW, t2 = row / p.cPW, py = t2 % p.cPH, n = t2 / p.cPH;
+            const int oy = py * p.osy + p.ooy[cls], ox = px * p.osx + p.oox[cls];
+            ok = ok && oy < p.OHF && ox < p.OWF;
+            off = (((long)n * p.OHF + oy) * p.OWF + ox) * p.ldc;
+          }
+          vrow[a] = ok ? (unsigned)((off + 4 * lh) * 4) : OOB;
+        }
+      }
       const bool has_bias = p.bias != nullptr, has_bias2 = p.bias2 != nullptr;
       const int act = p.act;
       const bool acc_old = p.beta != 0.f;
@@ -331,8 +395,9 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
 #pragma unroll
           for (int a = 0; a < TM; ++a) {
             const int rowq = TNF ? m0 + wm * TM * 32 + a : m0 + (wm * TM + a) * 32;      // scalar; this lane's row is rowq + lr (dy^T x: + TM * lr)
-            const unsigned soff = ((unsigned)rowq * (unsigned)p.ldc + (unsigned)colq) * 4u;
-            const unsigned vo = (interior || (col_ok && rowq + (TNF ? TM * lr : lr) < p.M)) ? vlane : OOB;
+            unsigned soff = ((unsigned)rowq * (unsigned)p.ldc + (unsigned)colq) * 4u;
+            unsigned vo = (interior || (col_ok && rowq + (TNF ? TM * lr : lr) < p.M)) ? vlane : OOB;
+            if constexpr (CONV) { soff = (unsigned)colq * 4u; vo = col_ok ? vrow[a] : OOB; }
             f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
             v += bq;
             if (act == RE2E_ACT_TANH) {
@@ -415,13 +480,14 @@ NtPlan nt2_plan_variant(const NtVariant& v, int M, int N, int K, int sk) {
 // RE2E_NT2 (experiments build, read at every call so that one process can compare variants):
 //   "old" = the engine of igemm.hip;  "<variant>[,<sk>]": variant id of the table above (0 = choose), sk = 0 whole tiles only, 1 stream-K
 //   tail where the model says it pays (default), 2 stream-K tail wherever there is a partial round
-NtPlan nt2_plan(int M, int N, int K, bool filler, bool tn = false) {
+NtPlan nt2_plan(int M, int N, int K, bool filler, bool tn = false, int sk_override = -1) {
   int variant = 0, sk = 1;
   if (const char* e = exp_env(tn ? "RE2E_TN2" : "RE2E_NT2")) {
     if (e[0] == 'o') { NtPlan none; memset(&none, 0, sizeof(none)); return none; }
     variant = atoi(e);
     if (const char* c = strchr(e, ',')) sk = atoi(c + 1);
   }
+  if (sk_override >= 0) sk = sk_override;
   NtPlan best;
   memset(&best, 0, sizeof(best));
   for (const NtVariant& v : VARIANTS) {
@@ -454,15 +520,15 @@ int* ticket_slice() {
   return pool[dev] + (size_t)(next[dev]++ % POOL_SLICES) * POOL_SLICE_INTS;
 }
 
-template <class CF, bool TNF>
+template <class CF, int MODE>
 void nt2_launch(const NtArgs& a, const NtPlan& pl, hipStream_t st) {
   static LdsLimit lim;
   size_t lds = CF::LDS_BYTES;
   // residency is set through the LDS request: exactly wg_per_cu workgroups fit a CU's 160 KB
   const size_t want = (size_t)(160 * 1024) / (pl.wg_per_cu + 1) + 1024;
   if (lds < want) lds = want;
-  lim.ensure(reinterpret_cast<const void*>(&gemm_nt2_kernel<CF, TNF>), lds);
-  hipLaunchKernelGGL((gemm_nt2_kernel<CF, TNF>), dim3(pl.n_dp + pl.g_sk), dim3(CF::THREADS), lds, st, a);
+  lim.ensure(reinterpret_cast<const void*>(&gemm_nt2_kernel<CF, MODE>), lds);
+  hipLaunchKernelGGL((gemm_nt2_kernel<CF, MODE>), dim3(pl.n_dp + pl.g_sk), dim3(CF::THREADS), lds, st, a);
 }
 
 }  // namespace
@@ -473,7 +539,103 @@ size_t gemm_nt2_workspace_bytes(int M, int N, int K) {
   return a > b ? a : b;
 }
 
+// Implicit-GEMM convolution forward / data gradient on the same pipeline (MODE 2).  g: geometry of ONE class (g.in = the image); ncls = 1, or 4 with
+// per-class offsets / weight sets / output positions (stride-2 data gradient).  Returns 1 when launched here, 0 when left to igemm.hip's gather engine.
+int conv_nt2(const ConvGeom& g, int M, const float* wg, int Cout, float* out, long ldc, const float* bias, int act, float beta, int ncls,
+             const int* cls_oy0, const int* cls_ox0, long cls_wstride, int remap, int OHF, int OWF, int osy, int osx, const int* ooy, const int* oox,
+             hipStream_t st) {
+  if (const char* e = exp_env("RE2E_CONV_NT2")) { if (atoi(e) == 0) return 0; }      // (experiments build, read per call: same-session A/B against igemm.hip's gather engine)
+  const int K = g.KH * g.KW * g.C;
+  if (g.C % 16 || Cout % 4 || g.KH * g.KW > 32 || g.KH * g.KW < 2 || ncls < 1 || ncls > 4) return 0;
+  if ((reinterpret_cast<uintptr_t>(g.in) & 15) || (reinterpret_cast<uintptr_t>(wg) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) || ldc % 4) return 0;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return 0;
+  if (act == RE2E_ACT_SIGMOID_MASK_MUL || (long)M * ncls > 0x7FFFFFFFL || M < 256) return 0;
+  // the most negative tap position over all classes fixes how far in front of the tensor the descriptor starts
+  const int ylo = g.DY < 0 ? (g.KH - 1) * g.DY : 0, xlo = g.DX < 0 ? (g.KW - 1) * g.DX : 0;
+  int pady = 0, padx = 0;
+  for (int c = 0; c < ncls; ++c) {
+    const int oy = (cls_oy0 ? cls_oy0[c] : g.OY0) + ylo, ox = (cls_ox0 ? cls_ox0[c] : g.OX0) + xlo;
+    if (-oy > pady) pady = -oy;
+    if (-ox > padx) padx = -ox;
+  }
+  const long shift = ((long)pady * g.W + padx) * g.C * 4;
+  const long in_bytes = (long)g.NI * g.H * g.W * g.C * 4;
+  // rows past the last pixel (phantom rows of the last tile) carry an empty tap mask; their offsets may be anything, but stay 31-bit
+  if (in_bytes + shift + (long)(g.KH * g.W + g.KW) * g.C * 4 * 4 >= 0x7FFFFFF0L) return 0;
+  if ((long)ncls * Cout * K * 4 >= 0x7FFFFFF0L) return 0;
+  // whole tiles only (the convolution entry points carry no workspace for partial slabs; the step's shapes fill their rounds: 500 / 250 / 4000 tiles)
+  NtPlan q = nt2_plan(M, Cout, K, re2e_stream_is_filler(st), false, 0);
+  if (!q.variant || g.C % q.bk) return 0;
+  q.n_dp = ncls * q.ntm * q.ntn; q.g_sk = 0;
+  NtArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.in) - shift); a.B = wg; a.C = out;
+  a.a_bytes = (unsigned)(in_bytes + shift); a.b_bytes = (unsigned)((long)ncls * Cout * K * 4);
+  a.lda = 0; a.ldb = K; a.ldc = ldc; a.M = M; a.N = Cout; a.K = K;
+  a.bias = bias; a.act = act; a.beta = beta;
+  a.ntm = q.ntm; a.ntn = q.ntn; a.n_dp = q.n_dp; a.g_sk = q.g_sk; a.nkt = q.nkt;
+  a.cH = g.H; a.cW = g.W; a.cC = g.C; a.cPH = g.PH; a.cPW = g.PW; a.cKH = g.KH; a.cKW = g.KW; a.cSY = g.SY; a.cSX = g.SX; a.cDY = g.DY; a.cDX = g.DX;
+  a.ncls = ncls; a.cls_wstride = cls_wstride; a.remap = remap; a.OHF = OHF; a.OWF = OWF; a.osy = osy; a.osx = osx;
+  for (int c = 0; c < 4; ++c) {
+    a.cOY0[c] = cls_oy0 ? cls_oy0[c < ncls ? c : 0] : g.OY0; a.cOX0[c] = cls_ox0 ? cls_ox0[c < ncls ? c : 0] : g.OX0;
+    a.ooy[c] = ooy ? ooy[c < ncls ? c : 0] : 0; a.oox[c] = oox ? oox[c < ncls ? c : 0] : 0;
+  }
+  a.a_shift = (unsigned)shift;
+  static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;
+  if (log_calls)
+    fprintf(stderr, "[igemm] A=ConvK B=DenseK tile=%dx%dx%d vec=1 M=%d N=%d K=%d splits=%d\n", q.bm, q.bn, q.bk, M * ncls, Cout, K, q.g_sk ? -q.g_sk : 1);
+  if (exp_env("RE2E_NT2_LOG")) fprintf(stderr, "[conv2] %dx%dx%d cls %d variant %d tiles %ld dp %d sk %d\n", M, Cout, K, ncls, q.variant, (long)ncls * q.ntm * q.ntn, q.n_dp, q.g_sk);
+  const NtPlan& pl2 = q;
+  switch (pl2.variant) {
+    case 1: nt2_launch<N256x128k32s3, 2>(a, pl2, st); break;
+    case 3: nt2_launch<N256x128k16s3, 2>(a, pl2, st); break;
+    case 5: nt2_launch<N128x128k32s2, 2>(a, pl2, st); break;
+    case 6: nt2_launch<N128x128k16s3, 2>(a, pl2, st); break;
+    case 8: nt2_launch<N128x64k16s4, 2>(a, pl2, st); break;
+    case 9: nt2_launch<N256x64k16s3, 2>(a, pl2, st); break;
+    default: return 0;
+  }
+  return 1;
+}
+
+// K-sliced batch of x W^T products (igemm.hip gemm_kslices; wino44.hip's 25 positions): out[z][M][N] = A[:, z*Ks : (z+1)*Ks] . B[:, same]^T, whole tiles.
+int gemm_nt2_kslices(int M, int N, int Ks, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st, int nolog) {
+  if (const char* e = exp_env("RE2E_NT2")) { if (e[0] == 'o') return 0; }
+  if (Ks % 16 || lda % 4 || ldb % 4 || N % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return 0;
+  const long K = (long)Ks * ns;
+  if (((long)(M - 1) * lda + K) * 4 >= 0x7FFFFFF0L || ((long)(N - 1) * ldb + K) * 4 >= 0x7FFFFFF0L || (long)M * N * 4 >= 0x7FFFFFF0L || M < 256 || ns > 4096) return 0;
+  NtPlan q = nt2_plan(M, N, Ks, re2e_stream_is_filler(st), false, 0);
+  if (!q.variant) return 0;
+  q.n_dp = ns * q.ntm * q.ntn; q.g_sk = 0;
+  NtArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.B = B; a.C = out;
+  a.a_bytes = (unsigned)(((long)(M - 1) * lda + K) * 4); a.b_bytes = (unsigned)(((long)(N - 1) * ldb + K) * 4);
+  a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = N; a.M = M; a.N = N; a.K = Ks;
+  a.act = RE2E_ACT_NONE;
+  a.ntm = q.ntm; a.ntn = q.ntn; a.n_dp = q.n_dp; a.g_sk = 0; a.nkt = q.nkt;
+  a.ncls = ns; a.batch_k = Ks; a.batch_c = (long)M * N;
+  static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;
+  if (log_calls && !nolog)
+    fprintf(stderr, "[igemm] A=DenseK B=DenseK tile=%dx%dx%d vec=1 M=%d N=%d K=%ld splits=%d\n", q.bm, q.bn, q.bk, M, N, K, ns);
+  switch (q.variant) {
+    case 1: nt2_launch<N256x128k32s3, 0>(a, q, st); break;
+    case 3: nt2_launch<N256x128k16s3, 0>(a, q, st); break;
+    case 5: nt2_launch<N128x128k32s2, 0>(a, q, st); break;
+    case 6: nt2_launch<N128x128k16s3, 0>(a, q, st); break;
+    case 8: nt2_launch<N128x64k16s4, 0>(a, q, st); break;
+    case 9: nt2_launch<N256x64k16s3, 0>(a, q, st); break;
+    default: return 0;
+  }
+  return 1;
+}
+
+// The dy^T x form is NOT what the shipped library runs: measured against igemm.hip's transposing-stage kernel + split-K it ties at best
+// (profiles/r05_gemm_tn_variants.txt: 2048x2560x12800 124 vs 123 TFLOP/s, 2048x512x12800 103 vs 116) -- with few output tiles the whole
+// product is the stream-K tail, one workgroup per CU, and a 4-wave workgroup alone on a CU does not cover its LDS latency.  Kept behind
+// RE2E_TN2 in the experiments build.
 size_t gemm_tn2_workspace_bytes(int M, int N, int K) {
+  if (!exp_env("RE2E_TN2")) return 0;
   if (M % 4 || N % 4) return 0;
   const size_t a = nt2_plan(M, N, K, false, true).bytes, b = nt2_plan(M, N, K, true, true).bytes;
   return a > b ? a : b;
@@ -482,6 +644,7 @@ size_t gemm_tn2_workspace_bytes(int M, int N, int K) {
 // C[M,N] = A[K,M]^T B[K,N] (+ beta C): the weight-gradient form.  Returns 1 when launched here, 0 when left to igemm.hip.
 int gemm_tn2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,
              int act, float beta, void* ws, size_t wsb, hipStream_t st) {
+  if (!exp_env("RE2E_TN2")) return 0;
   if (M % 4 || N % 4 || lda % 4 || ldb % 4 || ldc % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
       (reinterpret_cast<uintptr_t>(C) & 15))
     return 0;
@@ -510,9 +673,9 @@ int gemm_tn2(int M, int N, int K, const float* A, long lda, const float* B, long
     fprintf(stderr, "[igemm] A=DenseM B=DenseM tile=%dx%dx%d vec=1 M=%d N=%d K=%d splits=%d\n", pl.bm, pl.bn, pl.bk, M, N, K, pl.g_sk ? -pl.g_sk : 1);
   if (exp_env("RE2E_NT2_LOG")) fprintf(stderr, "[tn2] %dx%dx%d variant %d tiles %ld dp %d sk %d est %.1f us\n", M, N, K, pl.variant, (long)pl.ntm * pl.ntn, pl.n_dp, pl.g_sk, pl.est * 1e6);
   switch (pl.variant) {
-    case 3: nt2_launch<T256x128k16s3, true>(a, pl, st); break;
-    case 6: nt2_launch<N128x128k16s3, true>(a, pl, st); break;
-    case 8: nt2_launch<N128x64k16s4, true>(a, pl, st); break;
+    case 3: nt2_launch<T256x128k16s3, 1>(a, pl, st); break;
+    case 6: nt2_launch<N128x128k16s3, 1>(a, pl, st); break;
+    case 8: nt2_launch<N128x64k16s4, 1>(a, pl, st); break;
     default: return 0;
   }
   return 1;
@@ -549,12 +712,12 @@ int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long
     fprintf(stderr, "[igemm] A=DenseK B=DenseK tile=%dx%dx%d vec=1 M=%d N=%d K=%d splits=%d\n", pl.bm, pl.bn, pl.bk, M, N, K, pl.g_sk ? -pl.g_sk : 1);
   if (exp_env("RE2E_NT2_LOG")) fprintf(stderr, "[nt2] %dx%dx%d variant %d tiles %ld dp %d sk %d est %.1f us\n", M, N, K, pl.variant, (long)pl.ntm * pl.ntn, pl.n_dp, pl.g_sk, pl.est * 1e6);
   switch (pl.variant) {
-    case 1: nt2_launch<N256x128k32s3, false>(a, pl, st); break;
-    case 3: nt2_launch<N256x128k16s3, false>(a, pl, st); break;
-    case 5: nt2_launch<N128x128k32s2, false>(a, pl, st); break;
-    case 6: nt2_launch<N128x128k16s3, false>(a, pl, st); break;
-    case 8: nt2_launch<N128x64k16s4, false>(a, pl, st); break;
-    case 9: nt2_launch<N256x64k16s3, false>(a, pl, st); break;
+    case 1: nt2_launch<N256x128k32s3, 0>(a, pl, st); break;
+    case 3: nt2_launch<N256x128k16s3, 0>(a, pl, st); break;
+    case 5: nt2_launch<N128x128k32s2, 0>(a, pl, st); break;
+    case 6: nt2_launch<N128x128k16s3, 0>(a, pl, st); break;
+    case 8: nt2_launch<N128x64k16s4, 0>(a, pl, st); break;
+    case 9: nt2_launch<N256x64k16s3, 0>(a, pl, st); break;
     default: return 0;
   }
   return 1;

@@ -978,6 +978,7 @@ int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const fl
     re2e_set_error("gemm_kslices: unsupported slicing (M=%d N=%d K=%d ns=%d)", M, N, K, ns);
     return RE2E_EUNSUPPORTED;
   }
+  if (gemm_nt2_kslices(M, N, K / ns, ns, A, lda, B, ldb, out, st, nolog)) return RE2E_OK;      // gemm_nt.hip: the LDS-DMA pipeline, tiles counted over the slices
   Epi ep;
   memset(&ep, 0, sizeof(ep));
   ep.C = out; ep.ldc = N; ep.M = M; ep.N = N; ep.act = RE2E_ACT_NONE; ep.ws = out; ep.nsplit = ns; ep.nolog = nolog;
@@ -1132,6 +1133,13 @@ static int conv_igemm_impl(const float* in, int NI, int H, int W, int C, const f
     RE2E_LAUNCH_CHECK();
     return RE2E_OK;
   }
+  if (!mask) {
+    const int oy0[1] = {OY0}, ox0[1] = {OX0}, oo_y[1] = {ooy}, oo_x[1] = {oox};
+    if (conv_nt2(g, M, wg, Cout, out, Cout, bias, act, beta, 1, oy0, ox0, 0, ep.remap, OHF, OWF, osy, osx, oo_y, oo_x, stream)) {
+      RE2E_LAUNCH_CHECK();
+      return RE2E_OK;
+    }
+  }
   if (C % 4 == 0 && aligned16(in) && aligned16(wg)) conv_dispatch<true>(g, M, K, wg, Cout, ep, stream);
   else conv_dispatch<false>(g, M, K, wg, Cout, ep, stream);
   if (mask) {
@@ -1197,6 +1205,15 @@ extern "C" int re2e_conv_dgrad_s2(const float* dz, int N, int OH, int OW, int Co
   for (int p = 0; p < 2; ++p) {   // oh = (2i + p + pad - kh)/2 = i + (p + pad - kh0)/2 - a
     const int k0 = (p + pad) & 1;
     ep.cls_oy0[p] = (p + pad - k0) / 2; ep.cls_ox0[p] = ep.cls_oy0[p];
+  }
+  {
+    // class (ph, pw) = cls >> 1, cls & 1: input offsets cls_oy0[ph] / cls_ox0[pw], output positions (2i + ph, 2j + pw)
+    int oy0[4], ox0[4], oo_y[4], oo_x[4];
+    for (int c = 0; c < 4; ++c) { oy0[c] = ep.cls_oy0[c >> 1]; ox0[c] = ep.cls_ox0[c & 1]; oo_y[c] = c >> 1; oo_x[c] = c & 1; }
+    if (conv_nt2(g, M, wt_ws, Cin, dx, Cin, nullptr, RE2E_ACT_NONE, 0.f, 4, oy0, ox0, wtot, 1, H, Wd, 2, 2, oo_y, oo_x, stream)) {
+      RE2E_LAUNCH_CHECK();
+      return RE2E_OK;
+    }
   }
   if (Cout % 4 == 0 && aligned16(dz) && aligned16(wt_ws)) conv_dispatch<true>(g, M, K, wt_ws, Cin, ep, stream);
   else conv_dispatch<false>(g, M, K, wt_ws, Cin, ep, stream);

@@ -521,31 +521,43 @@ def _wino_note(kind, N, H, Wd, C, Cout):
 
 def _wino_ok(N, H, Wd, C, Cout, k, stride, pad):
     """3x3 / stride-1 / pad-1 layers the fused Winograd F(2x2,3x3) kernel covers (re2e_conv3x3_wino: C % 8 == 0, Cout / 64 a power of
-    two -- 192 or 320 output channels stay with the direct engine --, tensors < 2 GiB)."""
+    two -- 192 or 320 output channels stay with the direct engine).  The kernels address with 31-bit offsets; a tensor of 2 GiB or more
+    (a per-GPU batch of 64: 128 images x 800 x 80 x 64 channels) is cut along the image axis by the callers (``_wino_images``)."""
     g = Cout // 64
     if not (WINOGRAD and k == (3, 3) and stride == 1 and pad == 1 and C % 8 == 0 and Cout % 64 == 0 and g & (g - 1) == 0):
         return False
-    if N * H * Wd * max(C, Cout) * 4 >= 2 ** 31 - 256:
+    if H * Wd * max(C, Cout) * 4 >= 2 ** 31 - 256:            # one image alone is too large
         _wino_note('3x3', N, H, Wd, C, Cout)
         return False
     return True
 
 
+def _wino_images(N, H, Wd, C, Cout):
+    """Images per launch of the fused Winograd kernels: all of them, or as many as keep both tensors under 2 GiB."""
+    return max(1, min(N, (2 ** 31 - 256) // (H * Wd * max(C, Cout) * 4)))
+
+
 def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool=False):
     """re2e_conv3x3_wino on NHWC ``x`` with the layer's weight ``W`` in PyTorch layout: forward (dgrad=False: bias / ReLU / fused
-    2x2 max pool -> (pooled, index bytes)) or data gradient (dgrad=True: ``x`` is dy; ``mask``: the ReLU output in front)."""
+    2x2 max pool -> (pooled, index bytes)) or data gradient (dgrad=True: ``x`` is dy; ``mask``: the ReLU output in front).  Tensors of
+    2 GiB or more run as several launches over slices of the image axis (same stream, same workspace: the launches are ordered)."""
     N, H, Wd, C = x.shape
     wsb = query('re2e_conv3x3_wino_workspace_bytes', C, Cout)
     ws = workspace(wsb, x.device, 'wino')
+    nb = _wino_images(N, H, Wd, C, Cout)
     if pool:
         yp = empty((N, (H + 1) // 2, (Wd + 1) // 2, Cout), x)
         idx = torch.empty(yp.shape, dtype=torch.uint8, device=x.device)
-        call('re2e_conv3x3_wino', x.data_ptr(), N, H, Wd, C, W.data_ptr(), Cout, 0, ptr(bias), 1, None, None, yp.data_ptr(), idx.data_ptr(),
-             ws.data_ptr(), wsb)
+        for i in range(0, N, nb):
+            n = min(nb, N - i)
+            call('re2e_conv3x3_wino', x[i:i + n].data_ptr(), n, H, Wd, C, W.data_ptr(), Cout, 0, ptr(bias), 1, None, None, yp[i:i + n].data_ptr(),
+                 idx[i:i + n].data_ptr(), ws.data_ptr(), wsb)
         return yp, idx
     y = empty((N, H, Wd, Cout), x)
-    call('re2e_conv3x3_wino', x.data_ptr(), N, H, Wd, C, W.data_ptr(), Cout, int(bool(dgrad)), ptr(bias), int(bool(relu)), ptr(mask), y.data_ptr(),
-         None, None, ws.data_ptr(), wsb)
+    for i in range(0, N, nb):
+        n = min(nb, N - i)
+        call('re2e_conv3x3_wino', x[i:i + n].data_ptr(), n, H, Wd, C, W.data_ptr(), Cout, int(bool(dgrad)), ptr(bias), int(bool(relu)),
+             None if mask is None else mask[i:i + n].data_ptr(), y[i:i + n].data_ptr(), None, None, ws.data_ptr(), wsb)
     return y
 
 
@@ -643,10 +655,14 @@ class Conv2dFn(torch.autograd.Function):
             if need_w and WINO_WGRAD and _wino_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and Cin % 64 == 0 and x.is_contiguous() \
                     and dz.is_contiguous():
                 # 3x3 / stride-1 VGG layers: the sum over pixels in the Winograd domain (re2e_conv3x3_wino_wgrad), 2.25x fewer matrix FLOPs
-                wsb = query('re2e_conv3x3_wino_wgrad_workspace_bytes', N, H, Wd, Cin, Cout)
+                nb = _wino_images(N, H, Wd, Cin, Cout)                # tensors of 2 GiB or more: slices of the image axis, accumulated
+                wsb = query('re2e_conv3x3_wino_wgrad_workspace_bytes', nb, H, Wd, Cin, Cout)
                 ws = workspace(wsb, x.device, 'winow')
                 with accumulate(W) as (gw, beta):
-                    call('re2e_conv3x3_wino_wgrad', x.data_ptr(), N, H, Wd, Cin, dz.data_ptr(), Cout, gw.data_ptr(), beta, ws.data_ptr(), wsb)
+                    for i in range(0, N, nb):
+                        n = min(nb, N - i)
+                        call('re2e_conv3x3_wino_wgrad', x[i:i + n].data_ptr(), n, H, Wd, Cin, dz[i:i + n].data_ptr(), Cout, gw.data_ptr(),
+                             beta if i == 0 else 1.0, ws.data_ptr(), wsb)
             elif need_w and _wino44_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and x.is_contiguous() and dz.is_contiguous():
                 wsb = query('re2e_conv4x4_wino_wgrad_workspace_bytes', N, H, Wd, Cin, Cout, pad)
                 ws = workspace(wsb, x.device, 'wino44w')

@@ -162,6 +162,41 @@ def main():
             same = torch.equal(C1, C2)
             cells.append('%6.1f%s%s' % (fl / best[i + 1] / 1e12 if not check_only else 0.0, '!' if bad else ' ', ' ' if same else '~') + ('(%.0e/%.0e)' % (err, e0) if bad else ''))
         print('%-22s %8.1f | %s' % ('%dx%dx%d' % (M, N, K), fl / best[0] / 1e12 if not check_only else 0.0, '  '.join('%9s' % c for c in cells)), flush=True)
+    # ---- implicit-GEMM convolutions (MODE 2 of the same kernel) against igemm.hip's gather engine: forward and stride-2 data gradient ----
+    print('conv: N x H x W x C -> K, k s p   TFLOP/s of: old engine | new auto | variants 1 3 5 6 8 9 (whole tiles)   (max |new - old| / max |old|)', flush=True)
+    for (Nb, H, W, C, Kc, k, st, pd) in ((32, 400, 40, 64, 128, 4, 2, 1), (32, 200, 20, 128, 256, 4, 2, 1), (3, 37, 21, 16, 20, 4, 2, 1), (2, 33, 18, 32, 24, 3, 1, 1),
+                                          (5, 64, 32, 16, 64, 4, 2, 1)):
+        x = torch.randn(Nb, H, W, C, device=DEV)
+        wt = torch.randn(Kc, C, k, k, device=DEV) * 0.05
+        bias = torch.randn(Kc, device=DEV)
+        OH, OW = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+        wg = torch.empty(Kc, k, k, C, device=DEV)
+        lib.call('re2e_conv_weight_gather', wt.data_ptr(), wg.data_ptr(), Kc, C, k, k, 0, k, k, 0, 0, 1)
+        dy = torch.randn(Nb, OH, OW, Kc, device=DEV)
+        fl = 2.0 * k * k * C * Kc * Nb * OH * OW
+        ys, ds, tf, td = [], [], [], []
+        modes = [('0', 'old')] + [('1', v) for v in ('0', '1,0', '3,0', '5,0', '6,0', '8,0', '9,0')]
+        for mode, var in modes:
+            os.environ['RE2E_CONV_NT2'] = mode
+            os.environ['RE2E_NT2'] = var
+            y = torch.full((Nb, OH, OW, Kc), float('nan'), device=DEV)
+            fwd = lambda: lib.call('re2e_conv_igemm', x.data_ptr(), Nb, H, W, C, wg.data_ptr(), Kc, k, k, OH, OW, st, st, 1, 1, -pd, -pd, y.data_ptr(), OH, OW,
+                                   1, 1, 0, 0, bias.data_ptr(), lib.ACT_LRELU, 0.0)
+            fwd()
+            tf.append(timeit(fwd, 10))
+            ys.append(y.clone())
+            if st == 2:
+                dg = lambda: ops.conv_dgrad(dy, wt, (Nb, H, W, C), st, pd)
+                d = dg()
+                td.append(timeit(dg, 10))
+                ds.append(d.clone())
+        e_f = max((yy - ys[0]).abs().max().item() for yy in ys[1:]) / ys[0].abs().max().item()
+        e_d = max((dd - ds[0]).abs().max().item() for dd in ds[1:]) / ds[0].abs().max().item() if ds else 0.0
+        print('%-34s fwd %s | dgrad %s (%.1e, %.1e)%s' % ('%dx%dx%dx%d -> %d, %d %d %d' % (Nb, H, W, C, Kc, k, st, pd), ' '.join('%6.1f' % (fl / t / 1e12) for t in tf),
+              ' '.join('%6.1f' % (fl / t / 1e12) for t in td), e_f, e_d,
+              '' if (e_f < 1e-5 and e_d < 1e-5 and all(bool(torch.isfinite(yy).all()) for yy in ys)) else '   <-- MISMATCH'), flush=True)
+    os.environ.pop('RE2E_NT2', None)
+    os.environ.pop('RE2E_CONV_NT2', None)
     print('aborts', lib.query('re2e_lstm_abort_count') if hasattr(lib.load(), 're2e_lstm_abort_count') else 'n/a')
 
 
