@@ -92,9 +92,10 @@ __device__ __forceinline__ int xcd_chunk(int orig, int n) {
 // TNF = false: C = A[M,K] . B[N,K]^T, both operands k-major (x W^T).
 // TNF = true:  C = A[K,M]^T . B[K,N], both operands ROW-major along the contraction (dy^T x, the weight gradient): a k-row of a tile is
 //   contiguous, so the LDS image [BK][BM] | [BK][BN] is the memory image (no swizzle, no transposing stage) and the matrix-core operands come
-//   straight out of it: the lane that supplies "row lr" of the x-side operand reads the TM CONSECUTIVE floats m = TM*lr + a of k-row 2s + lh with
-//   one ds_read (they are its values for the wave's TM tiles, whose rows are interleaved), the dy-side operand is a ds_read_b32 per tile;
-//   every read is conflict-free.  Same pipeline, schedule, hand-off and epilogue.
+//   straight out of it: the wave's TM x TN tiles are INTERLEAVED in both directions -- lane lr of the A operand stands for rows m = TM*lr + a,
+//   lane lr of the B operand for columns n = TN*lr + b -- so ONE ds_read of TM (TN) consecutive floats of k-row 2s + lh is the lane's operand for
+//   all its tiles (first form: a ds_read_b32 per B tile -- 12 LDS instructions per 16 MFMAs instead of 4 -- lost 15 % to instruction issue).
+//   The MFMAs run un-swapped: a lane holds, per tile row, the TN consecutive columns of its lr: the store is TN floats wide.  Conflict-free reads.
 // MODE 2: MODE 0 with the A operand gathered from an NHWC image (implicit GEMM: rows = output pixels, k = (tap, channel), a k-tile = BK channels
 //   of ONE tap = 64 contiguous bytes of a pixel): the per-lane offset is the pixel (a tile constant), the tap + channel position goes through the
 //   scalar offset, the halo through a per-lane bit mask over the taps (invalid -> out-of-range offset: zeros, no traffic).  Tiles count over the
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
     }
   }
   const int xs = lh ^ ((lr / RPL) % CPR);
-  const int a_row0 = TNF ? wm * TM * 32 + TM * lr : (wm * TM) * 32 + lr, b_row0 = (wn * TN) * 32 + lr;
+  const int a_row0 = TNF ? wm * TM * 32 + TM * lr : (wm * TM) * 32 + lr, b_row0 = TNF ? wn * TN * 32 + TN * lr : (wn * TN) * 32 + lr;
   const bool ragged_k = (p.K % BK) != 0;
   const int krem_bytes = (p.K - (nkt - 1) * BK) * 4;          // valid bytes of a row in the last k-tile (x W^T); / 4 = its valid k-rows (dy^T x)
 
@@ -253,14 +254,16 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
         for (int b = 0; b < TN; ++b) fb[buf][b] = *reinterpret_cast<const f32x4*>(S + BM * BK + (b_row0 + b * 32) * BK + co);
       } else {
         typedef float fTM __attribute__((ext_vector_type(TM)));
+        typedef float fTN __attribute__((ext_vector_type(TN)));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int k = 8 * q + 2 * j + lh;
           const fTM av = *reinterpret_cast<const fTM*>(S + k * BM + a_row0);
+          const fTN bv = *reinterpret_cast<const fTN*>(S + BK * BM + k * BN + b_row0);
 #pragma unroll
           for (int a = 0; a < TM; ++a) fa[buf][a][j] = av[a];
 #pragma unroll
-          for (int b = 0; b < TN; ++b) fb[buf][b][j] = S[BK * BM + k * BN + b_row0 + b * 32];
+          for (int b = 0; b < TN; ++b) fb[buf][b][j] = bv[b];
         }
       }
     };
@@ -270,7 +273,9 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[buf][b][j], fa[buf][a][j], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = TNF ? __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][a][j], fb[buf][b][j], acc[a][b], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x2f32(fb[buf][b][j], fa[buf][a][j], acc[a][b], 0, 0, 0);
     };
 
     // ---- pipeline ----
@@ -360,6 +365,47 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
     // row (lr) and four runs of 4 consecutive output columns (8g + 4lh ..): every store is 16 bytes, its per-lane offset is a kernel
     // constant, the tile / run position goes through the instruction's scalar offset (excluded from the range check), and only
     // edge tiles pay a select per store (invalid -> out-of-range offset, dropped by the hardware). ----
+    if constexpr (TNF) {
+      // dy^T x: acc[a][b][r] = C[m0 + wm*TM*32 + TM*rho + a][n0 + wn*TN*32 + TN*lr + b], rho = (r & 3) + 8 (r >> 2) + 4 lh: per (a, r) ONE store of
+      // the lane's TN consecutive columns (32 lanes = TN*128 contiguous bytes of a row)
+      if (finish) {
+        static_assert(!TNF || TN == 4 || TN == 2, "store width");
+        typedef float fTN __attribute__((ext_vector_type(TN)));
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFF0u, 0x00020000);
+        const int col = n0 + wn * TN * 32 + TN * lr;
+        const bool col_ok = col < p.N;                                 // N % 4 == 0 and TN | 4: a run is whole or absent
+        const unsigned vlane = col_ok ? ((unsigned)(TM * 4 * lh) * (unsigned)p.ldc + (unsigned)col) * 4u : OOB;
+        fTN bq;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bq[b] = 0.f;
+        if (col_ok) {
+          if (p.bias) bq += *reinterpret_cast<const fTN*>(p.bias + col);
+          if (p.bias2) bq += *reinterpret_cast<const fTN*>(p.bias2 + col);
+        }
+        const bool rows_in = m0 + BM <= p.M;
+        const bool acc_old = p.beta != 0.f;
+        const int act = p.act;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rowq = m0 + wm * TM * 32 + TM * ((r & 3) + 8 * (r >> 2)) + a;     // scalar; the lane's row is rowq + TM * 4 * lh
+            const unsigned soff = (unsigned)rowq * (unsigned)p.ldc * 4u;
+            const unsigned vo = (rows_in || rowq + TM * 4 * lh < p.M) ? vlane : OOB;
+            fTN v;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) v[b] = apply_act(acc[a][b][r] + bq[b], act);
+            if constexpr (TN == 4) {
+              if (acc_old) v += __builtin_bit_cast(fTN, __builtin_amdgcn_raw_buffer_load_b128(rsC, vo, soff, 0));
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsC, vo, soff, 0);
+            } else {
+              typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+              if (acc_old) v += __builtin_bit_cast(fTN, __builtin_amdgcn_raw_buffer_load_b64(rsC, vo, soff, 0));
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), rsC, vo, soff, 0);
+            }
+          }
+      }
+    } else
     if (finish) {
       const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + (MODE == 0 ? cls * p.batch_c : 0L), 0, 0x7FFFFFF0u, 0x00020000);     // below OOB; the scalar offset is not range-checked
       const unsigned vlane = ((unsigned)(TNF ? TM * lr : lr) * (unsigned)p.ldc + 4u * (unsigned)lh) * 4u;
@@ -429,12 +475,14 @@ using N128x128k32s2 = NtCfg<2, 2, 2, 2, 32, 2, 2>;    // 4 waves, 64 KB: two per
 using N128x128k16s3 = NtCfg<2, 2, 2, 2, 16, 3, 3>;    // 4 waves, 48 KB: three per CU
 using N128x64k16s4 = NtCfg<2, 2, 2, 1, 16, 4, 3>;     // 4 waves of 64x32, 48 KB: three per CU (few-column products: 320 columns = 5 tiles, not 2.5)
 using N256x64k16s3 = NtCfg<4, 1, 2, 2, 16, 3, 2>;     // 4 waves of 64x64, 60 KB: two per CU
-using T256x128k16s3 = NtCfg<2, 2, 4, 2, 16, 3, 2>;    // dy^T x: 4 waves of 128x64 (one ds_read_b128 = a lane's x values for its four row-interleaved tiles), 72 KB: two per CU
+using T128x256k16s3 = NtCfg<2, 2, 2, 4, 16, 3, 2>;    // dy^T x: 4 waves of 64x128 (ds_read_b64 + ds_read_b128 per k-step for 8 MFMAs), 72 KB: two per CU
+using T128x128k16s3 = NtCfg<2, 2, 2, 2, 16, 3, 3>;    // dy^T x: 4 waves of 64x64
 
 struct NtVariant { int id, bm, bn, bk, wg_per_cu; double tflops; };
 // tflops: what the variant sustains on a chip-filling product with whole rounds (tools/bench_gemm2.py, MI355X), the cost model's rate
 const NtVariant VARIANTS[] = {{1, 256, 128, 32, 1, 130.0}, {3, 256, 128, 16, 2, 138.0}, {5, 128, 128, 32, 2, 130.0},
-                              {6, 128, 128, 16, 3, 137.0}, {8, 128, 64, 16, 3, 136.0},  {9, 256, 64, 16, 2, 128.0}};
+                              {6, 128, 128, 16, 3, 137.0}, {8, 128, 64, 16, 3, 136.0},  {9, 256, 64, 16, 2, 128.0},
+                              {7, 128, 256, 16, 2, 130.0}};      // 7: the dy^T x form only
 
 struct NtPlan { int variant; int wg_per_cu; int bm, bn, bk; int ntm, ntn, nkt, n_dp, g_sk; size_t bytes; double est; };
 
@@ -491,7 +539,8 @@ NtPlan nt2_plan(int M, int N, int K, bool filler, bool tn = false, int sk_overri
   NtPlan best;
   memset(&best, 0, sizeof(best));
   for (const NtVariant& v : VARIANTS) {
-    if (variant ? v.id != variant : (v.id == 1 || v.id == 5 || v.id == 9)) continue;      // candidates of the automatic choice: 3, 6, 8
+    if (variant ? v.id != variant : (tn ? (v.id != 6 && v.id != 7) : (v.id == 1 || v.id == 5 || v.id == 9 || v.id == 7))) continue;      // candidates of the automatic choice: 3, 6, 8 (dy^T x: 6, 7)
+    if (v.id == 7 && !tn) continue;
     // on a FILLER stream (work that runs beside resident recurrences, core.hip re2e_stream_role) only 4-wave tiles: they fit the registers
     // and LDS a recurrence workgroup leaves free on its CU
     if (!variant && filler && v.id == 3) continue;
@@ -525,7 +574,10 @@ void nt2_launch(const NtArgs& a, const NtPlan& pl, hipStream_t st) {
   static LdsLimit lim;
   size_t lds = CF::LDS_BYTES;
   // residency is set through the LDS request: exactly wg_per_cu workgroups fit a CU's 160 KB
-  const size_t want = (size_t)(160 * 1024) / (pl.wg_per_cu + 1) + 1024;
+  // (RE2E_NT2_MAXWG, experiments build: fewer -- what a co-resident persistent recurrence workgroup needs is registers: 240 per SIMD for the 512-wide chains)
+  int per_cu = pl.wg_per_cu;
+  if (const char* e = exp_env("RE2E_NT2_MAXWG")) { const int m = atoi(e); if (m >= 1 && m < per_cu) per_cu = m; }
+  const size_t want = (size_t)(160 * 1024) / (per_cu + 1) + 1024;
   if (lds < want) lds = want;
   lim.ensure(reinterpret_cast<const void*>(&gemm_nt2_kernel<CF, MODE>), lds);
   hipLaunchKernelGGL((gemm_nt2_kernel<CF, MODE>), dim3(pl.n_dp + pl.g_sk), dim3(CF::THREADS), lds, st, a);
@@ -630,10 +682,12 @@ int gemm_nt2_kslices(int M, int N, int Ks, int ns, const float* A, long lda, con
   return 1;
 }
 
-// The dy^T x form is NOT what the shipped library runs: measured against igemm.hip's transposing-stage kernel + split-K it ties at best
-// (profiles/r05_gemm_tn_variants.txt: 2048x2560x12800 124 vs 123 TFLOP/s, 2048x512x12800 103 vs 116) -- with few output tiles the whole
-// product is the stream-K tail, one workgroup per CU, and a 4-wave workgroup alone on a CU does not cover its LDS latency.  Kept behind
-// RE2E_TN2 in the experiments build.
+// The dy^T x form (MODE 1) is NOT what the shipped library runs.  Measured against igemm.hip's transposing-stage kernel + split-K + reduce launch
+// (profiles/r05_gemm_tn_variants.txt: first form, a ds_read_b32 per B tile; profiles/r05_gemm_tn_variants_v2.txt: both operands one wide read):
+// 2048x2560x12800 128 vs 122 TFLOP/s, but 2048x512x12800 104 vs 110 and everything with fewer tiles far behind -- a weight gradient has few output
+// tiles and a long K, so the WHOLE product is the stream-K tail: 4 to 32 parts per tile, summed by one last arriver each, where the old path's
+// reduce launch spreads that sum over the chip.  Compiled only into the experiments build (RE2E_TN2 selects it there).
+#ifdef RE2E_EXPERIMENTS
 size_t gemm_tn2_workspace_bytes(int M, int N, int K) {
   if (!exp_env("RE2E_TN2")) return 0;
   if (M % 4 || N % 4) return 0;
@@ -673,13 +727,17 @@ int gemm_tn2(int M, int N, int K, const float* A, long lda, const float* B, long
     fprintf(stderr, "[igemm] A=DenseM B=DenseM tile=%dx%dx%d vec=1 M=%d N=%d K=%d splits=%d\n", pl.bm, pl.bn, pl.bk, M, N, K, pl.g_sk ? -pl.g_sk : 1);
   if (exp_env("RE2E_NT2_LOG")) fprintf(stderr, "[tn2] %dx%dx%d variant %d tiles %ld dp %d sk %d est %.1f us\n", M, N, K, pl.variant, (long)pl.ntm * pl.ntn, pl.n_dp, pl.g_sk, pl.est * 1e6);
   switch (pl.variant) {
-    case 3: nt2_launch<T256x128k16s3, 1>(a, pl, st); break;
-    case 6: nt2_launch<N128x128k16s3, 1>(a, pl, st); break;
-    case 8: nt2_launch<N128x64k16s4, 1>(a, pl, st); break;
+    case 6: nt2_launch<T128x128k16s3, 1>(a, pl, st); break;
+    case 7: nt2_launch<T128x256k16s3, 1>(a, pl, st); break;
     default: return 0;
   }
   return 1;
 }
+
+#else
+size_t gemm_tn2_workspace_bytes(int, int, int) { return 0; }
+int gemm_tn2(int, int, int, const float*, long, const float*, long, float*, long, const float*, const float*, int, float, void*, size_t, hipStream_t) { return 0; }
+#endif
 
 // returns 1 when the product was launched here, 0 when the shape / alignment is left to igemm.hip
 int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,

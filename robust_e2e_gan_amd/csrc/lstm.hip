@@ -1357,6 +1357,11 @@ bool try_fwd_persist(hipStream_t st, float* xg_f, float* xg_r, const float* wfra
   // needs 130 registers per lane, 2 more than 1024 threads leave)
   static const int uw = exp_env("RE2E_LSTM_FWD_UW") ? atoi(exp_env("RE2E_LSTM_FWD_UW")) : 1;
   if (NX == 64 && uw == 2) return launch_fwd_persist<8, 8, 2>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
+#ifdef RE2E_EXPERIMENTS
+  // 256-wide layers on HALF the workgroups (32 instead of 64 owned CUs for the enhancer's forward chains): RE2E_LSTM_FWD_UW256=2
+  static const int uw256 = exp_env("RE2E_LSTM_FWD_UW256") ? atoi(exp_env("RE2E_LSTM_FWD_UW256")) : 1;
+  if (NX == 32 && uw256 == 2) return launch_fwd_persist<8, 4, 2>(st, xg_f, xg_r, wfrag, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
+#endif
   // 512-wide layers, 8 units per workgroup: 8 wavefronts x 8 k-groups (140 registers, 2 waves per SIMD = 288 of a SIMD's 512) rather than
   // 16 x 4 (94 registers, 4 waves per SIMD = 384).  Its 256 workgroups sit on every CU of the chip for the whole sequence, and what
   // they leave free decides which filler workgroups can be co-resident: 224 registers per SIMD admit a 4-wave engine tile (152),

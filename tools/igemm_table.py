@@ -5,7 +5,8 @@ Run on the GPU box:
         python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline 2> OUT/log.txt
     python3 tools/igemm_table.py OUT/log.txt OUT/*/*_kernel_trace.csv
 
-The k-th "[igemm]" log line is the k-th igemm_kernel launch (single stream => launch order = trace order).
+The k-th "[igemm]" log line is the k-th engine launch (igemm_kernel, gemm_nt2_kernel, the halo / Winograd kernels; single stream => launch
+order = trace order).  spl < 0: the product ran with a stream-K tail of -spl workgroups (csrc/gemm_nt.hip).
 """
 import csv
 import re
@@ -16,13 +17,13 @@ from collections import defaultdict
 def main(log_path, trace_path):
     calls = []
     for line in open(log_path, errors="replace"):
-        m = re.search(r"\[igemm\] A=(\w+) B=(\w+) tile=(\d+)x(\d+)x(\d+) vec=(\d) M=(\d+) N=(\d+) K=(\d+) splits=(\d+)", line)
+        m = re.search(r"\[igemm\] A=(\w+) B=(\w+) tile=(\d+)x(\d+)x(\d+) vec=(\d) M=(\d+) N=(\d+) K=(\d+) splits=(-?\d+)", line)
         if m:
             a, b = m.group(1), m.group(2)
             calls.append((a, b) + tuple(int(x) for x in m.groups()[2:]))
     kern = []
     for r in csv.DictReader(open(trace_path)):
-        if "igemm_kernel" in r["Kernel_Name"] or "conv3x3_halo_kernel" in r["Kernel_Name"] or "conv3x3_wgrad_kernel" in r["Kernel_Name"] or "wino_conv3x3_kernel" in r["Kernel_Name"] or "wino_wgrad_kernel" in r["Kernel_Name"]:
+        if "igemm_kernel" in r["Kernel_Name"] or "gemm_nt2_kernel" in r["Kernel_Name"] or "conv3x3_halo_kernel" in r["Kernel_Name"] or "conv3x3_wgrad_kernel" in r["Kernel_Name"] or "wino_conv3x3_kernel" in r["Kernel_Name"] or "wino_wgrad_kernel" in r["Kernel_Name"]:
             kern.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     kern.sort()
     if len(kern) != len(calls):
