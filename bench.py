@@ -114,7 +114,7 @@ def engine_average():
     table (tools/igemm_table.py over a RE2E_NO_OVERLAP=1 rocprofv3 kernel trace of this script): (direct-equivalent, executed, source).
     Direct-equivalent counts a Winograd call with the FLOPs of the direct convolution it replaces; executed is what the matrix cores did."""
     import re
-    for n in ('r04_igemm_calls_nooverlap.txt', 'r03_igemm_calls_nooverlap.txt'):
+    for n in ('r05_igemm_calls_nooverlap.txt', 'r04_igemm_calls_nooverlap.txt', 'r03_igemm_calls_nooverlap.txt'):
         try:
             txt = open(os.path.join(ROOT, 'profiles', n)).read()
             m = re.search(r'total .*?([\d.]+) TFLOP/s average', txt)
@@ -157,7 +157,7 @@ def conv_roofline(dev, iters=20):
     ach = exe / sec_wino / 1e12
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
     # kernel and shape, tools/roofline_conv.py); a counter pass cannot run inside this process.
-    pj, tsrc = _profile_json(['r04_conv1_2_wino_pmc_traffic.json', 'r03_conv1_2_wino_pmc_traffic.json'])
+    pj, tsrc = _profile_json(['r05_conv1_2_wino_pmc_traffic.json', 'r04_conv1_2_wino_pmc_traffic.json', 'r03_conv1_2_wino_pmc_traffic.json'])
     pj2, tsrc2 = _profile_json(['r03_conv1_2_pmc_traffic.json', 'r02_conv1_2_pmc_traffic.json'])
     eng, eng_exe, esrc = engine_average()
     pk = PEAK_FP32_MFMA_TFLOPS

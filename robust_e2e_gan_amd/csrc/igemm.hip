@@ -199,6 +199,7 @@ struct Epi {
   // gathered-weight sets (re2e_conv_dgrad_s2)
   int ncls; int cls_oy0[2], cls_ox0[2]; long cls_wstride;
   int nomem;
+  int zx;           // split-K: map K slices to XCDs (see the kernel)
   int nolog;        // the caller prints its own RE2E_IGEMM_LOG line (wino44.hip: direct-equivalent shape of the whole convolution)
 };
 
@@ -226,11 +227,25 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   // so give every XCD a contiguous chunk of the tile sequence (bijective remap), and walk the
   // sequence in groups of 8 M-tiles so that co-resident workgroups share A and B panels in L2.
   int tile_m, tile_n;
+  int zsplit = blockIdx.z;
   {
     const int ntm = gridDim.x, ntn = gridDim.y, nwg = ntm * ntn;
     const int orig = blockIdx.y * ntm + blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    int pid;
+    if (ep.zx) {
+      // split-K with a multiple of 8 slices (weight gradients): XCD = K slice.  Workgroups are dealt round-robin over the 8 XCDs in launch
+      // order, so workgroup L of the launch (z-major) sits on XCD L % 8: give it slice (L % 8) + 8 * ((L / 8) / nwg) and tile (L / 8) % nwg.
+      // All tiles of a slice then share one L2 and walk the same k-rows at the same time: every k-row of both operands is fetched once per
+      // slice, i.e. once in all (the plain order keeps a TILE on one XCD for all slices: each XCD pulls its tiles' operand panels over the
+      // whole K, 3-4x the operands' bytes in all).
+      const int L = (int)blockIdx.z * nwg + orig;
+      const int idx = L >> 3;
+      zsplit = (L & 7) + 8 * (idx / nwg);
+      pid = idx % nwg;
+    } else {
+      const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+      pid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    }
     const int GROUP = 8;
     const int per_group = GROUP * ntn;
     const int gid = pid / per_group;
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   // NB: the by-value kernel arguments (la, lb, ep) are never written: a modified argument struct is demoted
   // to scratch memory.  Per-class values live in scalars instead.
-  int zsplit = blockIdx.z, ooy = ep.ooy, oox = ep.oox, cls_dy = 0, cls_dx = 0;
+  int ooy = ep.ooy, oox = ep.oox, cls_dy = 0, cls_dx = 0;
   const float* pB = lb.p;
   if constexpr (LA::IS_CONVK) {
     if (ep.ncls) {
@@ -636,6 +651,10 @@ int launch_igemm(const LA& la, const LB& lb, Epi ep, int K, hipStream_t st) {
   dim3 grid(cdiv(ep.M, CF::BM), cdiv(ep.N, CF::BN), ep.ncls ? ep.ncls : ep.nsplit);
   static const bool nomem = exp_env("RE2E_IGEMM_NOMEM") != nullptr;
   ep.nomem = nomem ? 1 : 0;
+  {
+    const char* zx = exp_env("RE2E_TN_XCD_KSLICE");      // experiments build: 0 = tiles keep their XCD for all slices (rounds 1-4)
+    ep.zx = (ep.nsplit > 1 && (ep.nsplit & 7) == 0 && !ep.ncls && !(zx && atoi(zx) == 0)) ? 1 : 0;
+  }
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
   if (log_calls && !ep.nolog)
     fprintf(stderr, "[igemm] A=%s B=%s tile=%dx%dx%d vec=%d M=%d N=%d K=%d splits=%d\n", LA::NAME, LB::NAME, CF::BM, CF::BN,

@@ -1153,6 +1153,53 @@ def test_conv3x3_wino_above_2gib_runs_in_image_slices():
     close('wgrad over image slices', Wp.grad, want.cpu(), tol=1e-5)
 
 
+def test_step_gate_kernel():
+    """re2e_step_gate (csrc/lstm.hip): the device half of the trainer's NaN gate and of the give-up protocol, case by case -- nothing refused when
+    nothing happened; a non-finite ENHANCER sum of squares refuses the main update and makes the reported norm NaN; a give-up (counted by the
+    test hook re2e_debug_force_abort through one forced sequence) refuses main and D, writes NaN as the next step's loss factor and reports
+    delta; the data-parallel form refuses D from the main gate's flag; an acknowledgement puts everything back."""
+    ops, lib = _ops()
+    i32 = lambda v: torch.tensor([v], dtype=torch.int32, device=DEV)
+    f = lambda *v: torch.tensor(list(v), dtype=torch.float32, device=DEV)
+    base, hold, delta = i32(0), f(7.0), f(7.0)
+    gate = lambda ack, es, sm, sd, dr, h, d: lib.call('re2e_step_gate', base.data_ptr(), ack, ptr_(es), ptr_(sm), ptr_(sd), ptr_(dr), ptr_(h), ptr_(d))
+    ptr_ = lambda t: None if t is None else t.data_ptr()
+    gate(1, None, None, None, None, hold, delta)                       # acknowledge whatever earlier tests left
+    assert hold.item() == 1.0 and delta.item() == 0.0
+    sm, sd = f(3.0, 0.5, 1.0, 3.0, 1.0, 1.0), f(2.0, 1.0, 1.0, 2.0, 1.0, 1.0)
+    gate(0, f(12.5), sm, sd, None, hold, delta)
+    assert sm.tolist() == [3.0, 0.5, 1.0, 3.0, 1.0, 1.0] and sd.tolist()[2] == 1.0 and hold.item() == 1.0
+    gate(0, f(float('nan')), sm, sd, None, hold, delta)                # the enhancer's gradients are not finite: main refused, D untouched
+    got = sm.tolist()
+    assert got[2] == 0.0 and got[5] == 0.0 and got[0] != got[0] and got[3] != got[3] and sd.tolist()[2] == 1.0 and hold.item() == 1.0
+    sm = f(3.0, 0.5, 1.0, 3.0, 1.0, 1.0)
+    gate(0, f(float('inf')), sm, None, None, None, None)
+    assert sm.tolist()[2] == 0.0
+    # data-parallel form: D follows the main gate's flag
+    sm0, sd = f(3.0, 0.5, 0.0, 3.0, 1.0, 0.0), f(2.0, 1.0, 1.0, 2.0, 1.0, 1.0)
+    lib.call('re2e_step_gate', base.data_ptr(), 0, None, None, sd.data_ptr(), sm0.data_ptr() + 8, None, None)
+    assert sd.tolist()[2] == 0.0
+    # a give-up: one forced persistent forward sequence raises the counter
+    T, B, H = 4, 2, 16
+    wsb = lib.query('re2e_lstm_workspace_bytes', B, H)
+    ws = torch.empty(wsb // 4 + 16, device=DEV)
+    xg = [torch.zeros(T * B, 4 * H, device=DEV) for _ in range(2)]
+    whh = [torch.zeros(4 * H, H, device=DEV) for _ in range(2)]
+    ybuf, cbuf = torch.zeros(T + 2, B, 2 * H, device=DEV), torch.zeros(T + 2, B, 2 * H, device=DEV)
+    lens = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    lib.query('re2e_debug_force_abort', 1)
+    try:
+        lib.call('re2e_lstm_seq_fwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), ybuf.data_ptr(), cbuf.data_ptr(),
+                 lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+    finally:
+        lib.query('re2e_debug_force_abort', 0)
+    sm, sd = f(3.0, 0.5, 1.0, 3.0, 1.0, 1.0), f(2.0, 1.0, 1.0, 2.0, 1.0, 1.0)
+    gate(0, f(1.0), sm, sd, None, hold, delta)
+    assert delta.item() == 1.0 and hold.item() != hold.item() and sm.tolist()[2] == 0.0 and sd.tolist()[2] == 0.0
+    gate(1, None, None, None, None, hold, delta)                       # acknowledged: the next step is whole again
+    assert delta.item() == 0.0 and hold.item() == 1.0
+
+
 def test_device_prefetcher_equals_host_collate():
     """data.prefetch.DevicePrefetcher (pinned staging slots reused every third batch, H2D + re2e_pack_pad on a copy stream, event
     hand-off) against the host collate the reference defines (data/mix_data_loader.py:264-302), bit for bit, over more batches
