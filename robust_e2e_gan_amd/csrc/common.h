@@ -34,7 +34,7 @@ bool re2e_stream_is_filler(hipStream_t stream);     // core.hip: re2e_stream_rol
     }                                                                              \
   } while (0)
 
-// Experiment switches.  The shipped library reads seven environment variables, each covered by a parity test or result-neutral:
+// Experiment switches.  The shipped library reads eight environment variables, each covered by a parity test or result-neutral:
 //   RE2E_LSTM_PERSIST / RE2E_LSTM_PERSIST_BWD = 0  launch-per-step recurrences (tests/test_kernels_gpu.py: persistent vs stepwise)
 //   RE2E_LSTM_FWD2 / RE2E_LSTM_BWD3 = 0            the round-1..3 recurrence kernels instead of the round-4 forms (same test; they
 //                                                  also serve the hidden sizes the round-4 forms are not built for)
@@ -42,6 +42,7 @@ bool re2e_stream_is_filler(hipStream_t stream);     // core.hip: re2e_stream_rol
 //   RE2E_DEC_PERSIST = 0 | 2                       launch-per-token decoder loop (2: only its backward) instead of csrc/decloop.hip (same file:
 //                                                  decoder loop persistent vs stepwise, forward and backward)
 //   RE2E_IGEMM_LOG                                 one stderr line per engine call (tools/igemm_table.py), no effect on results
+//   RE2E_DEBUG_HOOKS = 1                           lets re2e_debug_force_abort / re2e_debug_occupy answer (tests/conftest.py sets it)
 // Everything else -- tile variants, occupancy probes, rejected forms kept for A/B measurements -- is compiled in only with
 // -DRE2E_EXPERIMENTS (make EXPERIMENTS=1 -> libre2e_hip_exp.so, used by tools/ through RE2E_LIB) and answers "unset" otherwise.
 #ifdef RE2E_EXPERIMENTS

@@ -475,14 +475,12 @@ using N128x128k32s2 = NtCfg<2, 2, 2, 2, 32, 2, 2>;    // 4 waves, 64 KB: two per
 using N128x128k16s3 = NtCfg<2, 2, 2, 2, 16, 3, 3>;    // 4 waves, 48 KB: three per CU
 using N128x64k16s4 = NtCfg<2, 2, 2, 1, 16, 4, 3>;     // 4 waves of 64x32, 48 KB: three per CU (few-column products: 320 columns = 5 tiles, not 2.5)
 using N256x64k16s3 = NtCfg<4, 1, 2, 2, 16, 3, 2>;     // 4 waves of 64x64, 60 KB: two per CU
-using T128x256k16s3 = NtCfg<2, 2, 2, 4, 16, 3, 2>;    // dy^T x: 4 waves of 64x128 (ds_read_b64 + ds_read_b128 per k-step for 8 MFMAs), 72 KB: two per CU
 using T128x128k16s3 = NtCfg<2, 2, 2, 2, 16, 3, 3>;    // dy^T x: 4 waves of 64x64
 
 struct NtVariant { int id, bm, bn, bk, wg_per_cu; double tflops; };
 // tflops: what the variant sustains on a chip-filling product with whole rounds (tools/bench_gemm2.py, MI355X), the cost model's rate
 const NtVariant VARIANTS[] = {{1, 256, 128, 32, 1, 130.0}, {3, 256, 128, 16, 2, 138.0}, {5, 128, 128, 32, 2, 130.0},
-                              {6, 128, 128, 16, 3, 137.0}, {8, 128, 64, 16, 3, 136.0},  {9, 256, 64, 16, 2, 128.0},
-                              {7, 128, 256, 16, 2, 130.0}};      // 7: the dy^T x form only
+                              {6, 128, 128, 16, 3, 137.0}, {8, 128, 64, 16, 3, 136.0},  {9, 256, 64, 16, 2, 128.0}};
 
 struct NtPlan { int variant; int wg_per_cu; int bm, bn, bk; int ntm, ntn, nkt, n_dp, g_sk; size_t bytes; double est; };
 
@@ -510,7 +508,10 @@ NtPlan nt2_plan_variant(const NtVariant& v, int M, int N, int K, int sk) {
   pl.est = (double)cdiv(T, cus) * (t_tile + t_over);
   if (sk && R != 0) {
     const long U = R * pl.nkt;
+    // one unit range per CU -- except when the WHOLE product is the tail and the workgroup has 4 waves (RE2E_NT2_TAILWG, experiments: a lone
+    // 4-wave workgroup leaves three quarters of a CU's wave slots empty for the whole launch): then two per CU
     long g = cus;
+    if (T == R && v.bm * v.bn <= 128 * 256) { const char* e = exp_env("RE2E_NT2_TAILWG"); g = cus * (e ? atoi(e) : 1); }
     const long min_units = 128 / pl.bk;                  // a workgroup's share of the tail: at least 128 k
     if (U / g < min_units) g = U / min_units;
     if (g >= 8) g &= ~7L;                                // whole rounds of XCDs (the whole-tile workgroups behind keep blockIdx % 8 = XCD)
@@ -539,8 +540,7 @@ NtPlan nt2_plan(int M, int N, int K, bool filler, bool tn = false, int sk_overri
   NtPlan best;
   memset(&best, 0, sizeof(best));
   for (const NtVariant& v : VARIANTS) {
-    if (variant ? v.id != variant : (tn ? (v.id != 6 && v.id != 7) : (v.id == 1 || v.id == 5 || v.id == 9 || v.id == 7))) continue;      // candidates of the automatic choice: 3, 6, 8 (dy^T x: 6, 7)
-    if (v.id == 7 && !tn) continue;
+    if (variant ? v.id != variant : (tn ? v.id != 6 : (v.id == 1 || v.id == 5 || v.id == 9))) continue;      // candidates of the automatic choice: 3, 6, 8 (dy^T x: 6)
     // on a FILLER stream (work that runs beside resident recurrences, core.hip re2e_stream_role) only 4-wave tiles: they fit the registers
     // and LDS a recurrence workgroup leaves free on its CU
     if (!variant && filler && v.id == 3) continue;
@@ -686,7 +686,10 @@ int gemm_nt2_kslices(int M, int N, int Ks, int ns, const float* A, long lda, con
 // (profiles/r05_gemm_tn_variants.txt: first form, a ds_read_b32 per B tile; profiles/r05_gemm_tn_variants_v2.txt: both operands one wide read):
 // 2048x2560x12800 128 vs 122 TFLOP/s, but 2048x512x12800 104 vs 110 and everything with fewer tiles far behind -- a weight gradient has few output
 // tiles and a long K, so the WHOLE product is the stream-K tail: 4 to 32 parts per tile, summed by one last arriver each, where the old path's
-// reduce launch spreads that sum over the chip.  Compiled only into the experiments build (RE2E_TN2 selects it there).
+// reduce launch spreads that sum over the chip.  Compiled only into the experiments build (RE2E_TN2 selects it there), 128x128 tile only: the
+// 128x256 tile (four interleaved column tiles per wave, 232 registers) reached 134 TFLOP/s on 2048x2560x12800 but returned wrong, non-repeatable
+// sums on products with many parts per tile (tools/stress_gemm_nt_tail.py, profiles/r05_stress_streamk_tail.txt: every x W^T variant and the
+// 128x128 dy^T x form pass it, bitwise repeatable, 1-3 unit ranges per CU beside an unevenly loaded chip) -- not run down, removed.
 #ifdef RE2E_EXPERIMENTS
 size_t gemm_tn2_workspace_bytes(int M, int N, int K) {
   if (!exp_env("RE2E_TN2")) return 0;
@@ -728,7 +731,6 @@ int gemm_tn2(int M, int N, int K, const float* A, long lda, const float* B, long
   if (exp_env("RE2E_NT2_LOG")) fprintf(stderr, "[tn2] %dx%dx%d variant %d tiles %ld dp %d sk %d est %.1f us\n", M, N, K, pl.variant, (long)pl.ntm * pl.ntn, pl.n_dp, pl.g_sk, pl.est * 1e6);
   switch (pl.variant) {
     case 6: nt2_launch<T128x128k16s3, 1>(a, pl, st); break;
-    case 7: nt2_launch<T128x256k16s3, 1>(a, pl, st); break;
     default: return 0;
   }
   return 1;

@@ -57,6 +57,42 @@ def test_gemm_nt_nn(M, N, K):
     close('nn relu', c, torch.relu(A @ Bm.t()))
 
 
+# x W^T on csrc/gemm_nt.hip (LDS-DMA pipeline + stream-K tail).  The shapes pick, on a 256-CU chip: whole rounds only (768 tiles of 256x128);
+# a tail behind whole tiles (800 tiles of 128x64: 32 tiles cut into 256 unit ranges; 12800 x 512: 144 tiles behind 256); a product that is ALL tail
+# (100 tiles) with a long K; K tails (260 = 16 k-tiles + 4, 36 = 2 + 4, 20); ragged M and N edges; 4-column N; one k-tile.
+@pytest.mark.parametrize('M,N,K', [(12288, 2048, 64), (12800, 512, 260), (6400, 512, 4240), (12800, 1024, 512), (2049, 260, 36), (7777, 1028, 1000),
+                                   (300, 516, 200), (4100, 4, 20), (256, 64, 16), (25600, 256, 260)])
+def test_gemm_nt_pipeline_and_stream_k(M, N, K):
+    ops, lib = _ops()
+    assert lib.query('re2e_gemm_workspace_bytes', 0, 1, M, N, K) >= 0
+    A, Bm, b1, b2, C0 = rnd(M, K + 4), rnd(N, K + 8, seed=1), rnd(N, seed=2), rnd(N, seed=3), rnd(M, N + 12, seed=4)
+    a, b = A.to(DEV), Bm.to(DEV)
+    want = A[:, :K].double() @ Bm[:, :K].double().t()                      # leading dimensions larger than the widths, fp64 truth
+    c = C0.to(DEV).clone()
+    ops.gemm(a, b, c, M, N, K, transb=True, lda=K + 4, ldb=K + 8, ldc=N + 12, bias=b1.to(DEV), bias2=b2.to(DEV), act=lib.ACT_TANH)
+    close('nt2 tanh', c[:, :N], torch.tanh(want + b1.double() + b2.double()).float(), tol=2e-5)
+    assert torch.equal(c[:, N:].cpu(), C0[:, N:]), 'wrote beyond the N columns'
+    c2 = C0.to(DEV).clone()
+    ops.gemm(a, b, c2, M, N, K, transb=True, lda=K + 4, ldb=K + 8, ldc=N + 12, bias=b1.to(DEV), bias2=b2.to(DEV), act=lib.ACT_TANH)
+    assert torch.equal(c, c2), 'the stream-K finisher is whoever arrives last: the sum must not depend on it'
+    for act, fn in ((lib.ACT_NONE, lambda v: v), (lib.ACT_RELU, torch.relu), (lib.ACT_LRELU, lambda v: F.leaky_relu(v, 0.2)), (lib.ACT_SIGMOID, torch.sigmoid)):
+        c = C0.to(DEV).clone()
+        ops.gemm(a, b, c, M, N, K, transb=True, lda=K + 4, ldb=K + 8, ldc=N + 12, act=act, beta=1.0)
+        close('nt2 act %d beta' % act, c[:, :N], (fn(want) + C0[:, :N].double()).float(), tol=2e-5)
+    # the tiles a FILLER stream gets (4-wave only) give the same numbers up to the summation order of a cut tile
+    st = torch.cuda.Stream()
+    lib.set_stream_role(st, True)
+    try:
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            c = torch.empty(M, N, device=DEV)
+            ops.gemm(a, b, c, M, N, K, transb=True, lda=K + 4, ldb=K + 8)
+        st.synchronize()
+    finally:
+        lib.set_stream_role(st, False)
+    close('nt2 filler stream', c, want.float(), tol=2e-5)
+
+
 @pytest.mark.parametrize('M,N,K', [(64, 96, 5000), (257, 130, 77), (1200, 812, 1312), (8, 4, 40000)])
 def test_gemm_tn_splitk(M, N, K):
     ops, lib = _ops()

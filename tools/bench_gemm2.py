@@ -116,7 +116,7 @@ def main():
             out.append('%.1e' % ((C1 - C0).abs().max().item() / C0.abs().max().item()) if bool(torch.isfinite(C1).all()) else 'NAN')
         print('edge %dx%dx%d act %d beta %.0f: rel err %s' % (M, N, K, act, beta, ' '.join(out)), flush=True)
     # ---- dy^T x (weight gradients): C[M,N] += A[K,M]^T B[K,N] ----
-    tn_variants = [v for v in (args[1].split(':') if len(args) > 1 else ['0', '3,0', '3,2', '6,0', '6,2', '8,2'])]
+    tn_variants = [v for v in (args[1].split(':') if len(args) > 1 else ['0', '6,0', '6,2'])]
     print('%-22s %8s | %s' % ('TN  M x N x K', 'engine', '  '.join('%9s' % v for v in tn_variants)), flush=True)
     for (M, N, K) in TN_SHAPES:
         A = torch.randn(K, M, device=DEV)

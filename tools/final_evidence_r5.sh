@@ -43,7 +43,7 @@ python3 tools/trace_bins.py $DB 2 > $O/step_bins_2ms.txt 2>&1
 rm -rf $O/t
 RE2E_TIMELINE=1 python3 tools/step_timeline.py 2>&1 | grep -v amdgpu.ids > $O/step_timeline.txt
 python tools/bench_kernels.py 2>&1 | grep -v amdgpu.ids > $O/bench_kernels.txt
-RE2E_EXPERIMENTS=1 RE2E_LIB=$R/robust_e2e_gan_amd/libre2e_hip_exp.so timeout 900 python tools/bench_gemm2.py 0:3,0:3,2:6,0:6,2:8,0:8,2 0:6,2:7,2 2>/dev/null > $O/gemm_nt_variants.txt
+RE2E_EXPERIMENTS=1 RE2E_LIB=$R/robust_e2e_gan_amd/libre2e_hip_exp.so timeout 900 python tools/bench_gemm2.py 0:3,0:3,2:6,0:6,2:8,0:8,2 0:6,2 2>/dev/null > $O/gemm_nt_variants.txt
 python tools/bench_chain.py --all 2>&1 | grep -v amdgpu.ids > $O/chain_rates_alone.txt
 python tools/bench_decoder.py 2>&1 | grep -v amdgpu.ids > $O/decoder_loop_alone.txt
 RE2E_EXPERIMENTS=1 RE2E_LIB=$R/robust_e2e_gan_amd/libre2e_hip_exp.so python tools/dec_stamps.py 2>&1 | grep -v amdgpu.ids > $O/decoder_loop_budget.txt
