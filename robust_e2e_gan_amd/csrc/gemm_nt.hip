@@ -308,6 +308,9 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
     bool finish = true;
     if (!whole) {
       float* slab = p.slabs + ((long)my_sk * 2 + (u0 == range0 ? 0 : 1)) * (BM * BN);
+      // the stores below are inline asm (write-through form): hipcc pads no hazard for them, and an MFMA result needs its passes before a
+      // vector-memory instruction may read it -- the barrier above usually covers that, these wait states always do
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll

@@ -53,6 +53,7 @@ def gemm(A, B, C, M, N, K, transa=False, transb=False, lda=None, ldb=None, ldc=N
 
 
 NT_INPUT_GRAD = lib.exp_env('RE2E_NO_NT_INPUT_GRAD') is None
+CHAIN_WAITS_WGRAD = lib.exp_env('RE2E_CHAIN_WAITS_WGRAD', '0') == '1'
 INLINE_LAST_WGRAD = lib.exp_env('RE2E_NO_INLINE_LAST_WGRAD') is None
 
 
@@ -1133,6 +1134,10 @@ class BiLstmFn(torch.autograd.Function):
         dc = empty((B, 2 * H), dy)
         wsb = query('re2e_lstm_workspace_bytes', B, H)
         ws = workspace(wsb, dy.device, 'lstm')
+        if CHAIN_WAITS_WGRAD and MULTI_STREAM and WGRAD_STREAM is not None and H >= 512:
+            # experiment (RE2E_CHAIN_WAITS_WGRAD=1): a 256-workgroup backward chain starts only when the weight-gradient stream has drained, so its
+            # workgroups are placed at once instead of one by one as the long-lived weight-gradient tiles end
+            torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
         call('re2e_lstm_seq_bwd', g_f.data_ptr(), g_r.data_ptr(), w[1].data_ptr(), w[5].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
              cbuf.data_ptr(), dc.data_ptr(), ctx.lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
         dG = (g_f, g_r)
@@ -1500,6 +1505,7 @@ def dropout(x, p):
 
 
 DECODER_FUSED = lib.exp_env('RE2E_NO_DECODER_FUSION', '0') != '1'     # fused LSTMCell step kernels (A/B switch)
+_DECLOOP_BWS_READ = {}     # workspace address -> event behind the last re2e_dec_loop_dwconv that read it (DecoderLoopFn.backward)
 DECODER_PERSIST = os.environ.get('RE2E_DEC_PERSIST', '1') != '0'     # the teacher-forced loop as one persistent launch (csrc/decloop.hip)
 
 
@@ -1614,6 +1620,12 @@ class DecoderLoopFn(torch.autograd.Function):
         bwsb = query('re2e_dec_loop_bwd_workspace_bytes', L1, B, T, E, D, A, C, Fh) if (ctx.persist and DECODER_PERSIST and fused) else 0
         if bwsb:
             bws = workspace(bwsb, dev, 'decloop_bwd')
+            # the grow-only workspace is read once more by re2e_dec_loop_dwconv on the weight-gradient stream (below): a second backward on this
+            # stream before the trainer has joined that stream (two decoder passes in one graph, gradient accumulation) must not memset / rewrite
+            # the d conv rows under it (record_stream does nothing for a buffer that is never freed)
+            ev_prev = _DECLOOP_BWS_READ.pop(bws.data_ptr(), None)
+            if ev_prev is not None:
+                torch.cuda.current_stream().wait_event(ev_prev)
             call('re2e_dec_loop_bwd', pre.data_ptr(), hmask.data_ptr(), cx.data_ptr(), z.data_ptr(), c.data_ptr(), w.data_ptr(), conv.data_ptr(), dpj.data_ptr(),
                  dZ.data_ptr(), ctx.hlens.data_ptr(), w_ctx, ldw, Pm['w_hh'].data_ptr(), Pm['mlp_dec'].data_ptr(), Pm['mlp_att'].data_ptr(),
                  Pm['loc_conv'].data_ptr(), Pm['gvec_w'].data_ptr(), gates.data_ptr(), d_cx_all.data_ptr(), de_all.data_ptr(), ddp.data_ptr(),
@@ -1659,6 +1671,9 @@ class DecoderLoopFn(torch.autograd.Function):
                     dpre_into(empty((B, T, A), hmask))
                     call('re2e_dec_loop_dwconv', w.data_ptr(), ctx.hlens.data_ptr(), bws.data_ptr(), bwsb, partials.data_ptr(), npart, A + 1 + A * C,
                          L1, B, T, E, D, A, C, Fh)
+                    ev_read = torch.cuda.Event()
+                    ev_read.record()                         # (on the stream the call above ran on)
+                    _DECLOOP_BWS_READ[bws.data_ptr()] = ev_read
                 with accumulate(w_ih) as (gw, beta):
                     gemm(G2, emb.view(M, Dd), gw, 4 * D, Dd, M, transa=True, ldc=ldw, beta=beta)                       # dW_ih[:, :Dd]
                     gemm(G2, cx.view(M, E), gw.data_ptr() + 4 * Dd, 4 * D, E, M, transa=True, ldc=ldw, beta=beta)      # dW_ih[:, Dd:]

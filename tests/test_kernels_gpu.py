@@ -70,7 +70,8 @@ def test_gemm_nt_pipeline_and_stream_k(M, N, K):
     want = A[:, :K].double() @ Bm[:, :K].double().t()                      # leading dimensions larger than the widths, fp64 truth
     c = C0.to(DEV).clone()
     ops.gemm(a, b, c, M, N, K, transb=True, lda=K + 4, ldb=K + 8, ldc=N + 12, bias=b1.to(DEV), bias2=b2.to(DEV), act=lib.ACT_TANH)
-    close('nt2 tanh', c[:, :N], torch.tanh(want + b1.double() + b2.double()).float(), tol=2e-5)
+    # tanh's slope is <= 1: the output may be off by what the fp32 sum is allowed below (2e-5 of the largest pre-activation), not by 2e-5 of tanh's own range
+    close('nt2 tanh', c[:, :N], torch.tanh(want + b1.double() + b2.double()).float(), tol=0.0, atol=2e-5 * want.abs().max().item())
     assert torch.equal(c[:, N:].cpu(), C0[:, N:]), 'wrote beyond the N columns'
     c2 = C0.to(DEV).clone()
     ops.gemm(a, b, c2, M, N, K, transb=True, lda=K + 4, ldb=K + 8, ldc=N + 12, bias=b1.to(DEV), bias2=b2.to(DEV), act=lib.ACT_TANH)
