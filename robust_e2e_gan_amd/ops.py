@@ -53,7 +53,6 @@ def gemm(A, B, C, M, N, K, transa=False, transb=False, lda=None, ldb=None, ldc=N
 
 
 NT_INPUT_GRAD = lib.exp_env('RE2E_NO_NT_INPUT_GRAD') is None
-CHAIN_WAITS_WGRAD = lib.exp_env('RE2E_CHAIN_WAITS_WGRAD', '0') == '1'
 INLINE_LAST_WGRAD = lib.exp_env('RE2E_NO_INLINE_LAST_WGRAD') is None
 
 
@@ -1134,10 +1133,6 @@ class BiLstmFn(torch.autograd.Function):
         dc = empty((B, 2 * H), dy)
         wsb = query('re2e_lstm_workspace_bytes', B, H)
         ws = workspace(wsb, dy.device, 'lstm')
-        if CHAIN_WAITS_WGRAD and MULTI_STREAM and WGRAD_STREAM is not None and H >= 512:
-            # experiment (RE2E_CHAIN_WAITS_WGRAD=1): a 256-workgroup backward chain starts only when the weight-gradient stream has drained, so its
-            # workgroups are placed at once instead of one by one as the long-lived weight-gradient tiles end
-            torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
         call('re2e_lstm_seq_bwd', g_f.data_ptr(), g_r.data_ptr(), w[1].data_ptr(), w[5].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
              cbuf.data_ptr(), dc.data_ptr(), ctx.lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
         dG = (g_f, g_r)
