@@ -181,7 +181,12 @@ def conv_roofline(dev, iters=20):
             'engine_avg_executed_tflops': eng_exe, 'engine_avg_executed_frac': round(eng_exe / pk, 4) if eng_exe else None,
             'engine_avg_direct_equivalent_tflops': eng, 'engine_avg_source': esrc,
             'engine_avg_note': 'per-call table of one single-stream step over every GEMM / convolution call; executed = matrix-core FLOPs, '
-                               'direct-equivalent counts Winograd calls with the FLOPs of the direct convolution they replace'}
+                               'direct-equivalent counts Winograd calls with the FLOPs of the direct convolution they replace',
+            # why frac cannot reach 1 for THIS kernel (a model from committed measurements, not timed in this run): vector-ALU instructions never run
+            # beside fp32 MFMAs on a SIMD (tools/micro/mfma_coissue.hip: every v_* costs the matrix stream 4-8 cycles), and the fused transforms /
+            # output stage of this kernel are 3.4 of them per MFMA (SQ counters)
+            'issue_model': {'valu_per_mfma': 3.4, 'cycles_per_mfma': 64, 'cycles_per_valu': 5.0, 'bound_frac': round(64.0 / (64.0 + 3.4 * 5.0), 3),
+                            'sources': ['profiles/r05_conv1_2_wino_pmc_sq.json', 'profiles/r05_mfma_coissue.txt', 'DESIGN.md 4.2']}}
 
 
 def engine_roofline(dev, iters=8):
