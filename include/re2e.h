@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 313
+#define RE2E_ABI_VERSION 314
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -76,6 +76,16 @@ int re2e_gemm(int transa, int transb, int M, int N, int K, const float* A, long 
               float* C, long ldc, const float* bias, const float* bias2, int act, float beta, const float* mul,
               float* mask_out, const int* lens_dev, int T, void* workspace, size_t workspace_bytes,
               re2e_stream_t stream);
+/* x W^T over the VALID rows of a ragged time-major batch (the reference packs its sequences: e2e_encoder.py:129-131, enhance_model.py:120-123):
+ *   C[map[r]][:] = act(A[map[r]][:] . B[N,K]^T + bias + bias2) + beta C[map[r]][:]   for r < Mv,
+ * A (phys_rows x K, lda) and C (phys_rows x N, ldc) in the padded layout, rowmap[Mv] the physical rows with t < len_b.  Rows outside the map are
+ * not touched (re2e_fill_rows).  Workspace as re2e_gemm(0, 1, Mv, N, K).  RE2E_EUNSUPPORTED when the shape is not one the LDS-DMA pipeline
+ * takes (K, N, lda, ldb, ldc multiples of 4, 16-byte aligned operands, Mv >= 256): the caller runs re2e_gemm over all rows instead. */
+int re2e_gemm_nt_rows(int Mv, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias,
+                      const float* bias2, int act, float beta, const int* rowmap, int phys_rows, void* workspace, size_t workspace_bytes,
+                      re2e_stream_t stream);
+/* C[rows[i]][0 .. N) = value, i < nrows (N, ldc multiples of 4) */
+int re2e_fill_rows(float* C, long ldc, int N, const int* rows, int nrows, float value, re2e_stream_t stream);
 
 /* ---- K5/K9 convolution as implicit GEMM over NHWC (nn.Conv2d: e2e_encoder.py:234-237,
  * gan_model.py:63-90).  `wg` is the gathered weight [Cout][KH][KW][C] from

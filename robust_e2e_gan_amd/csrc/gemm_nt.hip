@@ -58,6 +58,9 @@ struct NtArgs {
   int nkt;           // k-tiles per tile
   float* slabs;      // [g_sk][2][BM*BN] partial accumulators of cut tiles
   int* counters;     // [ntm*ntn - n_dp] arrival tickets: zero on entry, put back to zero by each tile's last arriver
+  // MODE 0, row map (re2e_gemm_nt_rows): logical row r of the product is physical row rowmap[r] of BOTH A and C (M counts logical rows; the
+  // bounds a_bytes / ldc cover the physical tensors).  Time-major (T, B, .) activations of ragged batches: only the (t, b) with t < len_b.
+  const int* rowmap;
   int nomem;
   // MODE 2 (implicit-GEMM convolution; csrc/common.h ConvGeom semantics).  A = the NHWC image, M = pixels of ONE class, K = KH*KW*C.
   int cH, cW, cC, cPH, cPW, cKH, cKW, cSY, cSX, cDY, cDX;
@@ -199,8 +202,9 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
         }
       }
       if constexpr (!TNF) {
-        const int row = (isA ? m0 : n0) + prow_t[i];
+        int row = (isA ? m0 : n0) + prow_t[i];
         const bool ok = row < (isA ? p.M : p.N);
+        if constexpr (MODE == 0) { if (isA && ok && p.rowmap) row = p.rowmap[row]; }
         voff[i] = ok ? (unsigned)row * (unsigned)(isA ? p.lda : p.ldb) * 4u + pc16[i] : OOB;
         voff_t[i] = (ok && (int)pc16[i] < krem_bytes) ? voff[i] : OOB;
       } else {
@@ -418,6 +422,16 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
       const unsigned vlane = ((unsigned)(TNF ? TM * lr : lr) * (unsigned)p.ldc + 4u * (unsigned)lh) * 4u;
       const bool interior = !CONV && m0 + BM <= p.M && n0 + BN <= p.N;
       unsigned vrow[TM];
+      const bool mapped = MODE == 0 && p.rowmap != nullptr;
+      if constexpr (MODE == 0) {
+        if (mapped) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a) {
+            const int row = m0 + (wm * TM + a) * 32 + lr;
+            vrow[a] = row < p.M ? (unsigned)(((long)p.rowmap[row] * p.ldc + 4 * lh) * 4) : OOB;
+          }
+        }
+      }
       if constexpr (CONV) {
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -451,6 +465,7 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
             unsigned soff = ((unsigned)rowq * (unsigned)p.ldc + (unsigned)colq) * 4u;
             unsigned vo = (interior || (col_ok && rowq + (TNF ? TM * lr : lr) < p.M)) ? vlane : OOB;
             if constexpr (CONV) { soff = (unsigned)colq * 4u; vo = col_ok ? vrow[a] : OOB; }
+            if constexpr (MODE == 0) { if (mapped) { soff = (unsigned)colq * 4u; vo = col_ok ? vrow[a] : OOB; } }
             f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
             v += bq;
             if (act == RE2E_ACT_TANH) {
@@ -750,13 +765,16 @@ int gemm_tn2(int, int, int, const float*, long, const float*, long, float*, long
 #endif
 
 // returns 1 when the product was launched here, 0 when the shape / alignment is left to igemm.hip
+// rowmap / phys_rows (optional): M logical rows, row r = physical row rowmap[r] < phys_rows of A and of C (see NtArgs)
 int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,
-             int act, float beta, const float* mul, float* mask_out, const int* lens, int T, void* ws, size_t wsb, hipStream_t st) {
+             int act, float beta, const float* mul, float* mask_out, const int* lens, int T, void* ws, size_t wsb, hipStream_t st,
+             const int* rowmap, int phys_rows) {
+  const int Mp = rowmap ? phys_rows : M;           // rows the bounds are taken over
   if (K % 4 || lda % 4 || ldb % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 0;
-  if (((long)(M - 1) * lda + K) * 4 >= 0x7FFFFFF0L || ((long)(N - 1) * ldb + K) * 4 >= 0x7FFFFFF0L) return 0;     // 31-bit offsets: OOB is bit 31
-  if (M < 256 || act == RE2E_ACT_SIGMOID_MASK_MUL) return 0;
+  if (((long)(Mp - 1) * lda + K) * 4 >= 0x7FFFFFF0L || ((long)(N - 1) * ldb + K) * 4 >= 0x7FFFFFF0L) return 0;     // 31-bit offsets: OOB is bit 31
+  if (M < 256 || Mp < M || act == RE2E_ACT_SIGMOID_MASK_MUL) return 0;
   (void)mul; (void)mask_out; (void)lens; (void)T;
-  if (N % 4 || ldc % 4 || (reinterpret_cast<uintptr_t>(C) & 15) || ((long)(M - 1) * ldc + N) * 4 >= 0x7FFFFFF0L) return 0;      // 16-byte stores of 4 output columns
+  if (N % 4 || ldc % 4 || (reinterpret_cast<uintptr_t>(C) & 15) || ((long)(Mp - 1) * ldc + N) * 4 >= 0x7FFFFFF0L) return 0;      // 16-byte stores of 4 output columns
   if ((bias && (reinterpret_cast<uintptr_t>(bias) & 15)) || (bias2 && (reinterpret_cast<uintptr_t>(bias2) & 15))) return 0;
   const NtPlan pl = nt2_plan(M, N, K, re2e_stream_is_filler(st));
   if (!pl.variant) return 0;
@@ -769,10 +787,11 @@ int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long
     a.slabs = (float*)ws;
   }
   a.A = A; a.B = B; a.C = C;
-  a.a_bytes = (unsigned)(((long)(M - 1) * lda + K) * 4); a.b_bytes = (unsigned)(((long)(N - 1) * ldb + K) * 4);
+  a.a_bytes = (unsigned)(((long)(Mp - 1) * lda + K) * 4); a.b_bytes = (unsigned)(((long)(N - 1) * ldb + K) * 4);
   a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias = bias; a.bias2 = bias2; a.act = act; a.beta = beta;
   a.ntm = pl.ntm; a.ntn = pl.ntn; a.n_dp = pl.n_dp; a.g_sk = pl.g_sk; a.nkt = pl.nkt;
+  a.rowmap = rowmap;
   static const bool nomem = exp_env("RE2E_IGEMM_NOMEM") != nullptr;
   a.nomem = nomem ? 1 : 0;
 
@@ -790,4 +809,48 @@ int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long
     default: return 0;
   }
   return 1;
+}
+
+// ---- x W^T over the VALID rows of a ragged time-major batch ------------------------------------------------------------------------------
+// C[map[r]][:] = act(A[map[r]][:] . B^T + bias + bias2) + beta C[map[r]][:]  for r < Mv: the product runs over Mv logical rows that sit at
+// physical rows map[r] (ascending or not) of A (phys_rows x K, lda) and C (phys_rows x N, ldc).  The reference packs its sequences
+// (pack_padded_sequence, e2e_encoder.py:129-131, enhance_model.py:120-123) and never computes the padded (t, b) rows; in the padded (T, B, .)
+// layout the recurrences run on, those rows are 15 % of a config-4 batch (lengths 0.7 T .. T).  The per-lane row offsets of the LDS-DMA
+// pipeline make the gather free: a lane's offset is map[row] * lda instead of row * lda, once per tile.  Rows not in the map are not touched:
+// re2e_fill_rows puts zeros there where a consumer reads all rows.  RE2E_EUNSUPPORTED when the pipeline does not take the shape (the caller
+// then runs the product over all physical rows).
+extern "C" int re2e_gemm_nt_rows(int Mv, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias,
+                                 const float* bias2, int act, float beta, const int* rowmap, int phys_rows, void* workspace, size_t workspace_bytes,
+                                 hipStream_t stream) {
+  RE2E_CHECK_ARG(Mv > 0 && N > 0 && K > 0 && phys_rows >= Mv, "bad sizes");
+  RE2E_CHECK_ARG(A && B && C && rowmap, "null operand");
+  RE2E_CHECK_ARG(beta == 0.f || beta == 1.f, "beta must be 0 or 1");
+  RE2E_CHECK_ARG(act >= 0 && act < RE2E_ACT_SIGMOID_MASK_MUL, "bad activation");
+  if (!gemm_nt2(Mv, N, K, A, lda, B, ldb, C, ldc, bias, bias2, act, beta, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes, stream, rowmap,
+                phys_rows)) {
+    re2e_set_error("re2e_gemm_nt_rows: shape not taken by the pipeline (Mv=%d N=%d K=%d)", Mv, N, K);
+    return RE2E_EUNSUPPORTED;
+  }
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+namespace {
+__global__ void fill_rows_kernel(float* __restrict__ C, long ldc, int N4, const int* __restrict__ rows, int nrows, float value) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nrows * N4) return;
+  const int r = (int)(i / N4), c = (int)(i - (long)r * N4);
+  *reinterpret_cast<f32x4*>(C + (long)rows[r] * ldc + 4 * c) = f32x4{value, value, value, value};
+}
+}  // namespace
+
+// C[rows[i]][0 .. N) = value for i < nrows (N % 4 == 0, 16-byte aligned rows): the padded rows of a ragged batch behind re2e_gemm_nt_rows
+extern "C" int re2e_fill_rows(float* C, long ldc, int N, const int* rows, int nrows, float value, hipStream_t stream) {
+  RE2E_CHECK_ARG(C && (rows || nrows == 0) && nrows >= 0 && N > 0, "bad argument");
+  RE2E_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0, "rows must be 16-byte aligned multiples of 4 floats");
+  if (nrows == 0) return RE2E_OK;
+  const long tot = (long)nrows * (N / 4);
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, C, ldc, N / 4, rows, nrows, value);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
 }

@@ -14,10 +14,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
-ABI_VERSION = 313      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
+ABI_VERSION = 314      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
+EUNSUPPORTED = -2      # RE2E_EUNSUPPORTED
 STREAM_DEFAULT, STREAM_FILLER = 0, 1
 
 P, I, L, F, Z = c_void_p, c_int, c_long, c_float, c_size_t
@@ -31,6 +32,8 @@ SIGNATURES = {
     're2e_stream_role': (I, [P, I]),
     're2e_gemm_workspace_bytes': (Z, [I, I, I, I, I]),
     're2e_gemm': (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, I, F, P, P, P, I, P, Z, P]),
+    're2e_gemm_nt_rows': (I, [I, I, I, P, L, P, L, P, L, P, P, I, F, P, I, P, Z, P]),
+    're2e_fill_rows': (I, [P, L, I, P, I, F, P]),
     're2e_conv_igemm': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, I, F, P]),
     're2e_conv3x3_relu_pool': (I, [P, I, I, I, I, P, I, P, P, P, P]),
     're2e_conv_igemm_masked': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, P]),
@@ -189,6 +192,17 @@ def call(name, *args):
     rc = getattr(lib, name)(*args, stream())
     if rc != 0:
         raise Re2eError('%s failed (%d): %s' % (name, rc, lib.re2e_last_error().decode()))
+
+
+def call_supported(name, *args):
+    """``call`` for entry points that may decline a shape: False on RE2E_EUNSUPPORTED (nothing was launched), raises on any other error."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream())
+    if rc == EUNSUPPORTED:
+        return False
+    if rc != 0:
+        raise Re2eError('%s failed (%d): %s' % (name, rc, lib.re2e_last_error().decode()))
+    return True
 
 
 def set_stream_role(torch_stream, filler=True):

@@ -70,20 +70,21 @@ def host_to_dev(values, device, dtype=torch.int32):
 
 
 _LENS_CACHE = {}
+LENS_HOST = {}        # data_ptr of a cached length tensor -> the host tuple it was made from (ops.row_maps: the valid rows of a ragged batch)
 
 
-def lens_dev(lens, device):
-    """int32 device copy of a length list; the same lists recur many times per step, so uploads are cached.  An entry
-    remembers the stream its (non-blocking) upload was enqueued on and an event behind that copy: a user on ANOTHER
-    stream (the CTC branch on the aux stream, the decoder on main) waits for the event and tells the caching allocator
-    about its use, so neither a read ahead of the copy nor a reuse of the block under a late reader can happen."""
-    key = (tuple(lens_list(lens)), str(device))
+def dev_cached(key, make, device):
+    """Device copy of a small host array ``make()`` (int32), cached under ``key``.  An entry remembers the stream its
+    (non-blocking) upload was enqueued on and an event behind that copy: a user on ANOTHER stream (the CTC branch on the
+    aux stream, the decoder on main) waits for the event and tells the caching allocator about its use, so neither a read
+    ahead of the copy nor a reuse of the block under a late reader can happen."""
     ent = _LENS_CACHE.get(key)
     cuda = torch.device(device).type == 'cuda'
     if ent is None:
         if len(_LENS_CACHE) >= 256:
             _LENS_CACHE.clear()
-        t = host_to_dev(np.asarray(key[0], np.int32), device)
+            LENS_HOST.clear()
+        t = host_to_dev(np.asarray(make(), np.int32), device)
         if cuda:
             ev = torch.cuda.Event()
             ev.record()
@@ -99,6 +100,14 @@ def lens_dev(lens, device):
             cur.wait_event(ev)
             t.record_stream(cur)
             seen.add(cur.cuda_stream)
+    return t
+
+
+def lens_dev(lens, device):
+    """int32 device copy of a length list; the same lists recur many times per step, so uploads are cached (``dev_cached``)."""
+    key = (tuple(lens_list(lens)), str(device))
+    t = dev_cached(key, lambda: key[0], device)
+    LENS_HOST[t.data_ptr()] = key[0]
     return t
 
 

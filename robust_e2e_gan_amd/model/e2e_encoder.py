@@ -86,7 +86,8 @@ class BLSTMP(torch.nn.Module):
                 cur = [i // sub for i in cur]
                 lens_d = lens_dev(cur, y.device)
             bt = getattr(self, 'bt%d' % l)
-            x_tm = ops.linear(y, bt.weight, bt.bias, 'tanh')      # applied to padded rows too (:145-147)
+            # (upstream applies it to the padded rows too, :145-147: tanh(bias) there, which nothing downstream reads -- here those rows are 0)
+            x_tm = ops.linear(y, bt.weight, bt.bias, 'tanh', maps=ops.row_maps(lens_d, y.shape[0], y.shape[1]))
         return (x_tm, cur) if lens is not None else x_tm
 
     def forward(self, xpad, ilens):

@@ -68,6 +68,80 @@ def gemm_input_grad(dz, W, dx, M, K, N, beta=0.0):
     return gemm(dz, W, dx, M, K, N, beta=beta)
 
 
+# ---------------------------------------------------------------------------------------------
+# Ragged time-major batches: products over the VALID rows only (re2e_gemm_nt_rows)
+# ---------------------------------------------------------------------------------------------
+# The reference packs its sequences (pack_padded_sequence) and never computes a padded (t, b) row; the recurrences here run on the padded
+# (T, B, .) layout, where a config-4 batch (lengths 0.7 T .. T) is 15 % padding.  ``row_maps(lens_dev, T, B)`` gives the physical rows t * B + b
+# with t < len_b (and the others): the x W^T products around the recurrences then run over those rows only, gathered / scattered through the
+# per-lane offsets of the LDS-DMA pipeline.  RE2E_NO_ROW_MAPS=1 (experiments): all rows, as rounds 1-5 did.
+ROW_MAPS = lib.exp_env('RE2E_NO_ROW_MAPS') is None
+ROW_MAPS_MIN_PAD = 0.04      # below this share of padded rows the maps are not worth their per-tile lookups
+
+
+class RowMaps(object):
+    __slots__ = ('valid', 'invalid', 'nv', 'ni', 'rows')
+
+    def __init__(self, valid, invalid, nv, ni, rows):
+        self.valid, self.invalid, self.nv, self.ni, self.rows = valid, invalid, nv, ni, rows
+
+
+_ROW_MAPS = {}
+
+
+def row_maps(lens_d, T, B):
+    """RowMaps of a (T, B, .) time-major tensor whose utterance lengths are the cached length tensor ``lens_d`` (model.e2e_common.lens_dev), or
+    None: maps off, lengths not known on the host, too little padding, too few rows."""
+    if not ROW_MAPS or lens_d is None:
+        return None
+    from .model import e2e_common as ec
+    lens = ec.LENS_HOST.get(lens_d.data_ptr())
+    if lens is None or len(lens) != B:
+        return None
+    key = (lens, T, B, str(lens_d.device))
+    hit = _ROW_MAPS.get(key)
+    if hit is None:
+        import numpy as np
+        ln = np.minimum(np.asarray(lens, np.int64), T)
+        ok = (np.arange(T, dtype=np.int64)[:, None] < ln[None, :]).reshape(-1)
+        idx = np.arange(T * B, dtype=np.int32)
+        hit = (idx[ok], idx[~ok])
+        if len(_ROW_MAPS) >= 64:
+            _ROW_MAPS.clear()
+        _ROW_MAPS[key] = hit
+    v, iv = hit
+    if v.size < 256 or iv.size < ROW_MAPS_MIN_PAD * T * B:
+        return None
+    dev = lens_d.device
+    return RowMaps(ec.dev_cached(('rows_v',) + key, lambda: v, dev), ec.dev_cached(('rows_i',) + key, lambda: iv, dev), int(v.size), int(iv.size), T * B)
+
+
+def gemm_rows(A, B, C, N, K, maps, lda=None, ldb=None, ldc=None, bias=None, bias2=None, act=lib.ACT_NONE, beta=0.0, fill=False):
+    """C[r] = act(A[r] B^T + bias + bias2) + beta C[r] over the rows r of ``maps.valid`` (B stored (N, K): x W^T); ``fill``: zeros in the other
+    rows of C (only with beta = 0).  Falls back to the product over all rows when the pipeline declines the shape."""
+    lda = lda if lda is not None else K
+    ldb = ldb if ldb is not None else K
+    ldc = ldc if ldc is not None else N
+    wsb = query('re2e_gemm_workspace_bytes', 0, 1, maps.nv, N, K)
+    ws = workspace(wsb, A.device, 'gemm') if wsb else None
+    _p = lambda t: t if isinstance(t, int) else t.data_ptr()
+    if lib.call_supported('re2e_gemm_nt_rows', maps.nv, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, ptr(bias), ptr(bias2), act, float(beta),
+                          maps.valid.data_ptr(), maps.rows, ptr(ws), wsb):
+        if fill and N % 4 == 0 and ldc % 4 == 0:
+            call('re2e_fill_rows', _p(C), ldc, N, maps.invalid.data_ptr(), maps.ni, 0.0)
+        return C
+    return gemm(A, B, C, maps.rows, N, K, transb=True, lda=lda, ldb=ldb, ldc=ldc, bias=bias, bias2=bias2, act=act, beta=beta)
+
+
+def gemm_input_grad_rows(dz, W, dx, K, N, maps, beta=0.0, fill=False):
+    """``gemm_input_grad`` over the valid rows: dx[r] = dz[r] W (+ beta dx[r]); ``fill``: zeros in the padded rows of dx."""
+    if K % 4 == 0 and N % 4 == 0 and W.is_contiguous():
+        wt = empty((K, N), dz)
+        call('re2e_conv_weight_gather', W.data_ptr(), wt.data_ptr(), N, K, 1, 1, 1, 1, 1, 0, 0, 1)       # wt[k][n] = W[n][k]
+        return gemm_rows(dz, wt, dx, K, N, maps, beta=beta, fill=fill)
+    return gemm_input_grad(dz, W, dx, maps.rows, K, N, beta=beta)
+
+
 def colsum_into(A2d, M, N, out, beta, lda=None):
     wsb = query('re2e_colsum_workspace_bytes', M, N)
     ws = workspace(wsb, A2d.device, 'colsum')
@@ -232,18 +306,25 @@ def _linear_backward_padded(ctx, dy, x2, W, b, M, K, N, Np, need_w, need_b):
         if b is not None and need_b:
             with accumulate(b) as (gb, beta):
                 colsum_into(dzp, M, N, gb, beta, lda=Np)
-    return dx, None, None, None
+    return dx, None, None, None, None
 
 
 class LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, act):
+    def forward(ctx, x, W, b, act, maps=None):
         _need_gpu(x)
         x2 = _f32(x).view(-1, x.shape[-1])
         M, K = x2.shape
         N = W.shape[0]
         y = empty((M, N), x)
-        gemm(x2, W, y, M, N, K, transb=True, bias=b, act=act)
+        if maps is not None and maps.rows == M and W.is_contiguous() and N % 4 == 0:
+            # ragged time-major rows: the valid (t, b) only, zeros in the padded rows (upstream they hold act(b), which nothing reads:
+            # the next recurrence packs them away, attention and CTC mask them)
+            gemm_rows(x2, W, y, N, K, maps, bias=b, act=act, fill=True)
+        else:
+            maps = None
+            gemm(x2, W, y, M, N, K, transb=True, bias=b, act=act)
+        ctx.maps = maps
         ctx.act, ctx.W, ctx.b = act, W, b
         ctx.save_for_backward(x2, y if act != lib.ACT_NONE else None)
         ctx.xshape = x.shape
@@ -267,7 +348,10 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = empty((M, K), x2)
-            gemm_input_grad(dz, W, dx, M, K, N)            # dx = dz[M,N] * W[N,K]
+            if ctx.maps is not None and K % 4 == 0:
+                gemm_input_grad_rows(dz, W, dx, K, N, ctx.maps, fill=True)      # (dz is zero in the padded rows: so is dx)
+            else:
+                gemm_input_grad(dz, W, dx, M, K, N)            # dx = dz[M,N] * W[N,K]
             dx = dx.view(ctx.xshape)
         with param_grads(dz, x2):
             if need_w:
@@ -276,11 +360,12 @@ class LinearFn(torch.autograd.Function):
             if b is not None and need_b and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, M, N, gb, beta)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def linear(x, W, b=None, act=None):
-    return LinearFn.apply(x, W, b, ACT[act] if not isinstance(act, int) else act)
+def linear(x, W, b=None, act=None, maps=None):
+    """``maps``: RowMaps of a ragged time-major ``x`` (T, B, .): the product runs over its valid rows only (see ``row_maps``)."""
+    return LinearFn.apply(x, W, b, ACT[act] if not isinstance(act, int) else act, maps)
 
 
 class Transpose01Fn(torch.autograd.Function):
@@ -1092,6 +1177,10 @@ class BiLstmFn(torch.autograd.Function):
         T, B, I = x.shape
         H = w[1].shape[1]
         x2 = x.view(T * B, I)
+        # the input projections over the valid (t, b) rows only: the recurrence never uses a pre-activation with t >= len_b (it selects zeros
+        # there), so those rows of xg stay unwritten
+        maps = row_maps(lens_dev, T, B)
+        ctx.maps = maps
         xg = [empty((T * B, 4 * H), x), empty((T * B, 4 * H), x)]
         Ip = (I + 3) & ~3
         if Ip != I and T * B >= 1024 and lib.exp_env('RE2E_NO_PAD_INPUT') != '1':
@@ -1102,11 +1191,17 @@ class BiLstmFn(torch.autograd.Function):
             for d in range(2):
                 wp = zeros((4 * H, Ip), x)
                 wp[:, :I].copy_(w[4 * d].detach())
-                gemm(x2p, wp, xg[d], T * B, 4 * H, Ip, transb=True, bias=w[4 * d + 2], bias2=w[4 * d + 3])
+                if maps is not None:
+                    gemm_rows(x2p, wp, xg[d], 4 * H, Ip, maps, bias=w[4 * d + 2], bias2=w[4 * d + 3])
+                else:
+                    gemm(x2p, wp, xg[d], T * B, 4 * H, Ip, transb=True, bias=w[4 * d + 2], bias2=w[4 * d + 3])
             x2 = x2p
         else:
             for d in range(2):
-                gemm(x2, w[4 * d], xg[d], T * B, 4 * H, I, transb=True, bias=w[4 * d + 2], bias2=w[4 * d + 3])
+                if maps is not None and w[4 * d].is_contiguous():
+                    gemm_rows(x2, w[4 * d], xg[d], 4 * H, I, maps, bias=w[4 * d + 2], bias2=w[4 * d + 3])
+                else:
+                    gemm(x2, w[4 * d], xg[d], T * B, 4 * H, I, transb=True, bias=w[4 * d + 2], bias2=w[4 * d + 3])
         # blocks 1..T are written in full by the recurrence (zeros beyond an utterance's length); only the two border blocks -- the
         # state before the first / after the last frame -- have to be cleared (2 x 64 KB instead of 2 x 52 MB for the enhancer)
         ybuf = empty((T + 2, B, 2 * H), x)
@@ -1140,8 +1235,13 @@ class BiLstmFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = empty((M, I), dy)
-            gemm_input_grad(dG[0], w[0], dx, M, I, 4 * H)
-            gemm_input_grad(dG[1], w[4], dx, M, I, 4 * H, beta=1.0)
+            if ctx.maps is not None and I % 4 == 0:
+                # d(gates) is zero in the padded rows (the recurrence wrote them): so is dx there -- written as zeros, not computed
+                gemm_input_grad_rows(dG[0], w[0], dx, I, 4 * H, ctx.maps, fill=True)
+                gemm_input_grad_rows(dG[1], w[4], dx, I, 4 * H, ctx.maps, beta=1.0)
+            else:
+                gemm_input_grad(dG[0], w[0], dx, M, I, 4 * H)
+                gemm_input_grad(dG[1], w[4], dx, M, I, 4 * H, beta=1.0)
             dx = dx.view(T, B, I)
         # A layer whose input needs no gradient is the bottom of its network: its backward recurrence is the LAST link of the
         # chain on this stream (the enhancer's first layer ends the training step's backward), so nothing waits behind its weight

@@ -495,6 +495,96 @@ def test_bilstm(B, T, I, H, lens):
             i += 1
 
 
+def _poison_free_blocks(nbytes):
+    """NaN in the caching allocator's free blocks: what the next ``torch.empty`` of that size class hands out."""
+    junk = [torch.full((nbytes // 4,), float('nan'), device=DEV) for _ in range(3)]
+    torch.cuda.synchronize()
+    del junk
+
+
+# x W^T over the valid rows of a ragged time-major batch (re2e_gemm_nt_rows + re2e_fill_rows; ops.row_maps / gemm_rows): rows outside the map are
+# not touched (or zero-filled), rows inside equal the product over all rows.  Shapes: the enhancer's and the BLSTMP's row spaces, a K tail, ragged
+# N edge, a stream-K tail, beta = 1.
+@pytest.mark.parametrize('T,B,N,K,act', [(800, 32, 1024, 260, 'none'), (200, 64, 512, 1024, 'tanh'), (97, 24, 260, 36, 'relu'), (400, 16, 2048, 512, 'none')])
+def test_gemm_nt_rows(T, B, N, K, act):
+    ops, lib = _ops()
+    from robust_e2e_gan_amd.model.e2e_common import lens_dev
+    lens = [max(1, int(round(T * (1 - 0.3 * i / (B - 1))))) for i in range(B)]
+    maps = ops.row_maps(lens_dev(lens, DEV), T, B)
+    assert maps is not None and maps.nv == sum(lens) and maps.nv + maps.ni == T * B
+    ok = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).reshape(-1)
+    assert torch.equal(maps.valid.cpu().long(), torch.nonzero(ok).flatten()) and torch.equal(maps.invalid.cpu().long(), torch.nonzero(~ok).flatten())
+    A, W, b1, b2, C0 = rnd(T * B, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(N, seed=3), rnd(T * B, N, seed=4)
+    a, w = A.to(DEV), W.to(DEV)
+    fn = {'none': lambda v: v, 'tanh': torch.tanh, 'relu': torch.relu}[act]
+    want = fn(A.double() @ W.double().t() + b1.double() + b2.double())
+    c = C0.to(DEV).clone()
+    ops.gemm_rows(a, w, c, N, K, maps, bias=b1.to(DEV), bias2=b2.to(DEV), act=ops.ACT[None if act == 'none' else act])
+    scale = (A.double() @ W.double().t()).abs().max().item()
+    close('valid rows', c.cpu()[ok], want.float()[ok], tol=0.0, atol=2e-5 * scale)
+    assert torch.equal(c.cpu()[~ok], C0[~ok]), 'rows outside the map were touched'
+    c2 = C0.to(DEV).clone()
+    ops.gemm_rows(a, w, c2, N, K, maps, act=ops.ACT[None if act == 'none' else act], fill=True)
+    if N % 4 == 0:
+        assert float(c2.cpu()[~ok].abs().max()) == 0.0
+    c3 = C0.to(DEV).clone()
+    ops.gemm_rows(a, w, c3, N, K, maps, beta=1.0)
+    close('beta', c3.cpu()[ok], (A.double() @ W.double().t() + C0.double()).float()[ok], tol=0.0, atol=2e-5 * scale)
+    assert torch.equal(c3.cpu()[~ok], C0[~ok])
+    c4 = C0.to(DEV).clone()
+    ops.gemm_rows(a, w, c4, N, K, maps, beta=1.0)
+    assert torch.equal(c3, c4), 'bitwise repeatable'
+
+
+@pytest.mark.parametrize('B,T,I,H', [(32, 40, 260, 256), (64, 30, 512, 512), (16, 64, 257, 64)])
+def test_bilstm_and_projection_over_valid_rows_only(B, T, I, H):
+    """ops.bilstm + the BLSTMP projection with row maps (lengths registered through ``lens_dev``): the padded (t, b) rows of the input projections
+    are never written -- here they hold NaN (poisoned allocator blocks) -- and neither results nor gradients may notice; against a packed
+    nn.LSTM + Linear + tanh on the CPU, and against the same ops with the maps switched off."""
+    ops, lib = _ops()
+    from robust_e2e_gan_amd.model.e2e_common import lens_dev
+    lens = [max(1, int(round(T * (1 - 0.45 * i / (B - 1))))) for i in range(B)]
+    lstm = torch.nn.LSTM(I, H, 1, batch_first=True, bidirectional=True)
+    lin = torch.nn.Linear(2 * H, 128)
+    x = rnd(B, T, I)
+    for b, l in enumerate(lens):
+        x[b, l:] = 0
+    xr = x.clone().requires_grad_(True)
+    pk = torch.nn.utils.rnn.pack_padded_sequence(xr, torch.tensor(lens), batch_first=True)
+    yr, _ = torch.nn.utils.rnn.pad_packed_sequence(lstm(pk)[0], batch_first=True, total_length=T)
+    pr = torch.tanh(lin(yr))
+    msk = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).float()[:, :, None]
+    go = rnd(B, T, 128, seed=9) * msk                       # nothing reads the padded rows of the projection
+    (pr * go).sum().backward()
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+
+    def run(with_maps):
+        ws = [torch.nn.Parameter(getattr(lstm, n + sfx).data.clone().to(DEV)) for sfx in ('', '_reverse') for n in names]
+        Wp, bp = torch.nn.Parameter(lin.weight.data.clone().to(DEV)), torch.nn.Parameter(lin.bias.data.clone().to(DEV))
+        xg = x.to(DEV).requires_grad_(True)
+        ld = lens_dev(lens, DEV) if with_maps else torch.tensor(lens, dtype=torch.int32, device=DEV)
+        maps = ops.row_maps(ld, T, B) if with_maps else None
+        assert (maps is not None) == with_maps
+        _poison_free_blocks(T * B * 4 * H * 4)
+        y = ops.bilstm(ops.transpose01(xg), ld, ws)
+        p_ = ops.linear(y, Wp, bp, 'tanh', maps=maps)
+        (p_ * go.transpose(0, 1).contiguous().to(DEV)).sum().backward()
+        return y, p_, xg.grad, [w.grad for w in ws] + [Wp.grad, bp.grad]
+    y, p_, dx, gs = run(True)
+    close('y', y.transpose(0, 1), yr, tol=1e-4)
+    close('proj (valid rows)', p_.transpose(0, 1) * msk.to(DEV), pr * msk, tol=1e-4)
+    assert float((p_.detach().transpose(0, 1) * (1 - msk.to(DEV))).abs().max()) == 0.0, 'padded rows of the projection are zero'
+    close('dx', dx, xr.grad, tol=2e-4)
+    refs = [getattr(lstm, n + sfx).grad for sfx in ('', '_reverse') for n in names] + [lin.weight.grad, lin.bias.grad]
+    for i, (g, r) in enumerate(zip(gs, refs)):
+        close('grad %d' % i, g, r, tol=3e-4)
+    y0, p0, dx0, gs0 = run(False)
+    close('y vs all rows', y, y0, tol=1e-6)
+    close('dx vs all rows', dx, dx0, tol=2e-5)
+    for i, (g, r) in enumerate(zip(gs, gs0)):
+        close('grad %d vs all rows' % i, g, r, tol=2e-5)
+
+
 def _fwd2_runs(B, H):
     """csrc/lstm.hip fwd2_config: the round-4 forward serves <= 16 utterances and wide layers (multiples of 64 units)."""
     return H % 64 == 0 and H // 64 in (1, 2, 4, 5, 8) and (B <= 16 or H >= 384)
