@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 314
+#define RE2E_ABI_VERSION 315
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -84,6 +84,10 @@ int re2e_gemm(int transa, int transb, int M, int N, int K, const float* A, long 
 int re2e_gemm_nt_rows(int Mv, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias,
                       const float* bias2, int act, float beta, const int* rowmap, int phys_rows, void* workspace, size_t workspace_bytes,
                       re2e_stream_t stream);
+/* The weight gradient over the same rows: C[M,N] = sum_{r < Kv} A[map[r]][:M]^T B[map[r]][:N] + beta C, A (dy) and B (x) padded
+ * (phys_rows x ., lda / ldb).  Workspace as re2e_gemm(1, 0, M, N, Kv).  RE2E_EUNSUPPORTED unless both operands are 16-byte loadable. */
+int re2e_gemm_tn_rows(int M, int N, int Kv, const float* A, long lda, const float* B, long ldb, float* C, long ldc, float beta,
+                      const int* rowmap, int phys_rows, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 /* C[rows[i]][0 .. N) = value, i < nrows (N, ldc multiples of 4) */
 int re2e_fill_rows(float* C, long ldc, int N, const int* rows, int nrows, float value, re2e_stream_t stream);
 

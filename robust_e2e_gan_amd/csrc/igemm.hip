@@ -69,6 +69,32 @@ struct DenseM {   // X[k*ld + row]
   }
 };
 
+// DenseM over a ROW MAP (re2e_gemm_tn_rows): logical k-row k is physical row map[k] of the tensor -- the contraction of a weight gradient
+// runs over the valid (t, b) rows of a ragged time-major batch only.  The physical row of the NEXT k-tile is fetched one tile ahead (a load
+// per thread and k-tile that has a whole MFMA block to land), so the operand loads never wait for the table.
+struct DenseMG {   // X[map[k]*ld + row]
+  static constexpr bool KMAJ = false;
+  static constexpr const char* NAME = "DenseMG";
+  static constexpr bool IS_CONVK = false;
+  const float* p; unsigned nbytes; long ld; int rows, K; const int* map;
+  struct Row { int r0; };
+  struct Kst { int k; unsigned koff; int nxt; };
+  __device__ void init_row(Row& r, int row0) const { r.r0 = row0; }
+  __device__ void init_k(Kst& s, int k) const {
+    s.k = k;
+    s.koff = k < K ? (unsigned)((long)map[k] * ld * 4) : 0u;
+    s.nxt = k + 16 < K ? map[k + 16] : 0;               // the engine's k-tile of these products is 16 (BKD)
+  }
+  __device__ void advance(Kst& s, int bk) const {
+    s.k += bk;
+    s.koff = (unsigned)((long)s.nxt * ld * 4);
+    s.nxt = s.k + bk < K ? map[s.k + bk] : 0;
+  }
+  __device__ unsigned off(const Row& r, const Kst& s, int j) const {
+    return (s.k < K && r.r0 + j < rows) ? s.koff + (unsigned)(r.r0 + j) * 4u : nbytes;
+  }
+};
+
 // Conv loaders keep their addresses as 32-bit BYTE offsets split into a row part and a k part that are each
 // updated incrementally, so the per-load work of the 16-byte path is one add, two bound checks and a select
 // (tensors are < 4 GiB, checked by the callers; the split parts wrap mod 2^32 and their sum is exact whenever
@@ -692,7 +718,7 @@ template <class LA, class LB, bool V, bool WIDE>
 void launch_big(const LA& la, const LB& lb, Epi& ep, int K, hipStream_t st) {
   if constexpr (V) {
     int v = igemm_variant();
-    if (v == 1) { launch_igemm<LA, LB, C128b, V>(la, lb, ep, K, st); return; }
+    if (v == 1 && !std::is_same<LA, DenseMG>::value) { launch_igemm<LA, LB, C128b, V>(la, lb, ep, K, st); return; }      // (DenseMG looks 16 k-rows ahead)
     bool wide = v == 2 ? true : (v == 3 ? false : (WIDE && ep.M >= 2048 && wide_allowed(st)));
     if (wide) { launch_igemm<LA, LB, C256x128, V>(la, lb, ep, K, st); return; }
   }
@@ -1075,6 +1101,40 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
     long tot = (long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s,
                        M, N, C, ldc, beta, 0, 0, 0, bias, bias2, act);
+  }
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+// ---- weight gradient over the valid rows of a ragged time-major batch ------------------------------------------------------------------
+// C[M,N] = sum_{r < Kv} A[map[r]][:M]^T B[map[r]][:N] + beta C: A (dy) and B (x) in the padded (phys_rows x .) layout, the contraction over
+// the rows of the map only (the padded rows of dy are zero: the sum is the same, 15 % shorter for a config-4 batch).  16-byte-loadable
+// operands only (RE2E_EUNSUPPORTED otherwise: the caller contracts over all rows).  Workspace as re2e_gemm(1, 0, M, N, Kv).
+extern "C" int re2e_gemm_tn_rows(int M, int N, int Kv, const float* A, long lda, const float* B, long ldb, float* C, long ldc, float beta,
+                                 const int* rowmap, int phys_rows, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(M > 0 && N > 0 && Kv > 0 && phys_rows >= Kv, "bad sizes");
+  RE2E_CHECK_ARG(A && B && C && rowmap, "null operand");
+  RE2E_CHECK_ARG(beta == 0.f || beta == 1.f, "beta must be 0 or 1");
+  RE2E_CHECK_ARG(fits32(phys_rows, lda, M) && fits32(phys_rows, ldb, N), "operand larger than 4 GiB");
+  if (!(aligned16(A) && lda % 4 == 0 && M % 4 == 0 && aligned16(B) && ldb % 4 == 0 && N % 4 == 0) || Kv < 64) {
+    re2e_set_error("re2e_gemm_tn_rows: operands not 16-byte loadable (M=%d N=%d Kv=%d)", M, N, Kv);
+    return RE2E_EUNSUPPORTED;
+  }
+  Epi ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.C = C; ep.ldc = ldc; ep.M = M; ep.N = N; ep.act = RE2E_ACT_NONE; ep.beta = beta; ep.nsplit = 1;
+  const int s = gemm_splits(1, 0, M, N, Kv);
+  if (s > 1) {
+    RE2E_CHECK_ARG(workspace && workspace_bytes >= (size_t)s * M * N * sizeof(float), "workspace too small");
+    ep.ws = (float*)workspace; ep.nsplit = s;
+  }
+  DenseMG la{A, kbytes(phys_rows, lda, M), lda, M, Kv, rowmap};
+  DenseMG lb{B, kbytes(phys_rows, ldb, N), ldb, N, Kv, rowmap};
+  launch_big<DenseMG, DenseMG, true, true>(la, lb, ep, Kv, stream);
+  if (s > 1) {
+    const long tot = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, stream, (const float*)workspace, s, M, N, C, ldc, beta, 0, 0, 0,
+                       (const float*)nullptr, (const float*)nullptr, (int)RE2E_ACT_NONE);
   }
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;

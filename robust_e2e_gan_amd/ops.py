@@ -76,6 +76,7 @@ def gemm_input_grad(dz, W, dx, M, K, N, beta=0.0):
 # with t < len_b (and the others): the x W^T products around the recurrences then run over those rows only, gathered / scattered through the
 # per-lane offsets of the LDS-DMA pipeline.  RE2E_NO_ROW_MAPS=1 (experiments): all rows, as rounds 1-5 did.
 ROW_MAPS = lib.exp_env('RE2E_NO_ROW_MAPS') is None
+TN_ROW_MAPS = lib.exp_env('RE2E_NO_TN_ROW_MAPS') is None      # (experiments) the weight gradients over all rows
 ROW_MAPS_MIN_PAD = 0.04      # below this share of padded rows the maps are not worth their per-tile lookups
 
 
@@ -140,6 +141,24 @@ def gemm_input_grad_rows(dz, W, dx, K, N, maps, beta=0.0, fill=False):
         call('re2e_conv_weight_gather', W.data_ptr(), wt.data_ptr(), N, K, 1, 1, 1, 1, 1, 0, 0, 1)       # wt[k][n] = W[n][k]
         return gemm_rows(dz, wt, dx, K, N, maps, beta=beta, fill=fill)
     return gemm_input_grad(dz, W, dx, maps.rows, K, N, beta=beta)
+
+
+def gemm_tn_rows(A, B, C, M, N, maps, beta=0.0, lda=None, ldb=None, ldc=None):
+    """C[M,N] = sum over the rows r of ``maps.valid`` of A[r][:M]^T B[r][:N] + beta C (the weight gradient dy^T x of a ragged time-major batch:
+    dy is zero in the padded rows, so the sum over the valid rows is the whole sum).  Falls back to the contraction over all rows."""
+    lda = lda if lda is not None else M
+    ldb = ldb if ldb is not None else N
+    ldc = ldc if ldc is not None else N
+    wsb = query('re2e_gemm_workspace_bytes', 1, 0, M, N, maps.nv)
+    ws = workspace(wsb, A.device if not isinstance(A, int) else C.device, 'gemm') if wsb else None
+    _p = lambda t: t if isinstance(t, int) else t.data_ptr()
+    if TN_ROW_MAPS and lib.call_supported('re2e_gemm_tn_rows', M, N, maps.nv, _p(A), lda, _p(B), ldb, _p(C), ldc, float(beta), maps.valid.data_ptr(), maps.rows,
+                          ptr(ws), wsb):
+        return C
+    wsb = query('re2e_gemm_workspace_bytes', 1, 0, M, N, maps.rows)
+    ws = workspace(wsb, C.device, 'gemm') if wsb else None
+    call('re2e_gemm', 1, 0, M, N, maps.rows, _p(A), lda, _p(B), ldb, _p(C), ldc, None, None, lib.ACT_NONE, float(beta), None, None, None, 0, ptr(ws), wsb)
+    return C
 
 
 def colsum_into(A2d, M, N, out, beta, lda=None):
@@ -356,7 +375,10 @@ class LinearFn(torch.autograd.Function):
         with param_grads(dz, x2):
             if need_w:
                 with accumulate(W) as (gw, beta):
-                    gemm(dz, x2, gw, N, K, M, transa=True, beta=beta)   # dW = dz^T x
+                    if ctx.maps is not None:
+                        gemm_tn_rows(dz, x2, gw, N, K, ctx.maps, beta=beta)       # dW = dz^T x over the valid rows (dz is zero in the others)
+                    else:
+                        gemm(dz, x2, gw, N, K, M, transa=True, beta=beta)   # dW = dz^T x
             if b is not None and need_b and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, M, N, gb, beta)
@@ -1258,9 +1280,13 @@ class BiLstmFn(torch.autograd.Function):
                 for d in range(2):
                     w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
                     n_ih, n_hh, n_bi, n_bh = needs[2 + 4 * d:6 + 4 * d]
+                    mp = ctx.maps
                     if n_ih and x2.shape[1] != I:              # padded input copy (see forward): full-width product, then the real columns
                         tmp = empty((4 * H, x2.shape[1]), dy)
-                        gemm(dG[d], x2, tmp, 4 * H, x2.shape[1], M, transa=True)
+                        if mp is not None:
+                            gemm_tn_rows(dG[d], x2, tmp, 4 * H, x2.shape[1], mp)
+                        else:
+                            gemm(dG[d], x2, tmp, 4 * H, x2.shape[1], M, transa=True)
                         with accumulate(w_ih) as (gw, beta):
                             if beta == 0.0:
                                 gw.copy_(tmp[:, :I])
@@ -1268,12 +1294,18 @@ class BiLstmFn(torch.autograd.Function):
                                 gw.add_(tmp[:, :I])
                     elif n_ih:
                         with accumulate(w_ih) as (gw, beta):
-                            gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
+                            if mp is not None:
+                                gemm_tn_rows(dG[d], x2, gw, 4 * H, I, mp, beta=beta)       # d(gates) is zero in the padded rows: the valid ones are the sum
+                            else:
+                                gemm(dG[d], x2, gw, 4 * H, I, M, transa=True, beta=beta)
                     if n_hh:
                         # h_{t-1}: forward direction = ybuf block t (y[t-1]); reverse = ybuf block t+2 (y[t+1])
                         hprev = yflat[(0 if d == 0 else 2 * B):, d * H:]
                         with accumulate(w_hh) as (gw, beta):
-                            call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
+                            if mp is not None:
+                                gemm_tn_rows(dG[d], hprev.data_ptr(), gw, 4 * H, H, mp, beta=beta, lda=4 * H, ldb=2 * H)
+                            else:
+                                call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
                     if n_bi and n_bh:                         # the same column sums: ONE pass over d(gates) (105 MB per direction and layer)
                         csum = empty((4 * H,), dy)
                         colsum_into(dG[d], M, 4 * H, csum, 0.0)

@@ -536,6 +536,34 @@ def test_gemm_nt_rows(T, B, N, K, act):
     assert torch.equal(c3, c4), 'bitwise repeatable'
 
 
+# dy^T x over the valid rows (re2e_gemm_tn_rows: the contraction walks a row map, one table look-up per thread and k-tile, a tile ahead): equal to the
+# sum over all rows when dy is zero in the others, and it must not READ the others (NaN there).  Shapes: split-K with the K slice = XCD order, one
+# slice, ragged M / N edges, a strided x operand (the h_{t-1} view of a recurrent layer), beta = 1.
+@pytest.mark.parametrize('T,B,M,N,ldb', [(800, 32, 1024, 260, None), (200, 64, 2048, 512, None), (97, 24, 132, 68, 72), (300, 16, 512, 256, 512)])
+def test_gemm_tn_rows(T, B, M, N, ldb):
+    ops, lib = _ops()
+    from robust_e2e_gan_amd.model.e2e_common import lens_dev
+    lens = [max(1, int(round(T * (1 - 0.3 * i / (B - 1))))) for i in range(B)]
+    maps = ops.row_maps(lens_dev(lens, DEV), T, B)
+    assert maps is not None
+    ok = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).reshape(-1)
+    ldb = ldb or N
+    A, X, C0 = rnd(T * B, M), rnd(T * B, ldb, seed=1), rnd(M, N, seed=2)
+    want = A[ok].double().t() @ X[ok][:, :N].double()
+    A[~ok] = float('nan')
+    X[~ok] = float('nan')
+    a, x = A.to(DEV), X.to(DEV)
+    c = torch.empty(M, N, device=DEV)
+    ops.gemm_tn_rows(a, x, c, M, N, maps, ldb=ldb)
+    close('dy^T x over the map', c, want.float(), tol=2e-5)
+    c2 = C0.to(DEV).clone()
+    ops.gemm_tn_rows(a, x, c2, M, N, maps, beta=1.0, ldb=ldb)
+    close('beta', c2, (want + C0.double()).float(), tol=2e-5)
+    c3 = C0.to(DEV).clone()
+    ops.gemm_tn_rows(a, x, c3, M, N, maps, beta=1.0, ldb=ldb)
+    assert torch.equal(c2, c3), 'bitwise repeatable'
+
+
 @pytest.mark.parametrize('B,T,I,H', [(32, 40, 260, 256), (64, 30, 512, 512), (16, 64, 257, 64)])
 def test_bilstm_and_projection_over_valid_rows_only(B, T, I, H):
     """ops.bilstm + the BLSTMP projection with row maps (lengths registered through ``lens_dev``): the padded (t, b) rows of the input projections
