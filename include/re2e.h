@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 315
+#define RE2E_ABI_VERSION 316
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -135,6 +135,20 @@ int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, const float*
 size_t re2e_conv3x3_wino_wgrad_workspace_bytes(int NI, int H, int W, int C, int Cout);
 int re2e_conv3x3_wino_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, float* gw, float beta,
                             void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+
+/* The three over a RAGGED image batch (the VGG front end convolves zero-padded utterances and cuts each at its pooled length afterwards,
+ * e2e_encoder.py:259-278: what it computes further beyond an utterance's end than the stack reaches is never read).  row_lim[n], int32 on
+ * the device: output rows y >= row_lim[n] of image n (full-resolution rows, also with the fused pool) are neither computed nor written by
+ * re2e_conv3x3_wino_rows -- patches of 8 / 16 rows that START there are skipped, so limits are multiples of 16; the weight gradient skips
+ * the patches that start there (its dout is zero there: the caller's promise).  re2e_fill_image_rows writes `value` into rows
+ * r >= ceil(lim[n] / div) of a (N, H, row_floats) tensor (div = 2: the pooled output of a layer whose limits count full-resolution rows);
+ * max_tail_rows bounds H - lim / div over the batch.  The caller keeps the limits of consecutive layers consistent (VGG2L.conv_stack). */
+int re2e_conv3x3_wino_rows(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int dgrad, const float* bias, int relu,
+                           const float* mask, float* out, float* pool_out, unsigned char* pool_idx, const int* row_lim, void* workspace,
+                           size_t workspace_bytes, re2e_stream_t stream);
+int re2e_conv3x3_wino_wgrad_rows(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, float* gw, float beta,
+                                 const int* row_lim, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+int re2e_fill_image_rows(float* t, int N, int H, long row_floats, const int* lim, int div, int max_tail_rows, float value, re2e_stream_t stream);
 
 /* 4x4 / stride-1 convolution as Winograd F(2x2,4x4) (csrc/wino44.hip; the discriminator's conv4, model/networks.py NLayerDiscriminator
  * `nn.Conv2d(ndf*4, ndf*8, kernel_size=4, stride=1, padding=1)`, and its data gradient): filter / input transform, ONE K-sliced launch

@@ -29,6 +29,7 @@ struct WwArgs {
   int NI, H, W, C, Cout;
   int px, py, npatch, nsplit, ncb, nblk;   // patches per image row / column, total, patch ranges, channel blocks, (c,o) blocks
   unsigned x_bytes, dy_bytes;
+  const int* row_lim;   // optional, per image: patches that start at a row >= row_lim[n] are skipped (dy is zero there: re2e_conv3x3_wino_wgrad_rows)
   int flat;     // RE2E_EXPERIMENTS builds (RE2E_WW_FLAT=1): workgroup order of rounds 3-5
   int dbg;      // RE2E_EXPERIMENTS builds (RE2E_WW_DBG): 1 = every patch load re-reads the range's first patch (cache hits), 2 = only the first patch is loaded
 };
@@ -108,6 +109,10 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(WwArgs p) {
       for (int r = 0; r < 16; ++r) acc[j][ct][r] = 0.f;
 
   for (int pi = pbeg; pi < pend; ++pi) {
+    if (p.row_lim) {                       // ragged batch: a patch in rows where dy is zero adds nothing (uniform over the workgroup)
+      const int n = pi / (p.py * p.px), pyi = (pi - n * (p.py * p.px)) / p.px;
+      if (pyi * PH >= p.row_lim[n]) continue;
+    }
     load_patch(pi);
     store_patch();
     __syncthreads();
@@ -452,8 +457,8 @@ extern "C" size_t re2e_conv3x3_wino_wgrad_workspace_bytes(int NI, int H, int W, 
   return ww_plan(NI, H, W, C, Cout).bytes;
 }
 
-extern "C" int re2e_conv3x3_wino_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, float* gw, float beta, void* workspace,
-                                       size_t workspace_bytes, hipStream_t stream) {
+static int ww_impl(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, float* gw, float beta, const int* row_lim, void* workspace,
+                   size_t workspace_bytes, hipStream_t stream) {
   RE2E_CHECK_ARG(in && dout && gw && workspace, "null operand");
   RE2E_CHECK_ARG(NI > 0 && H > 0 && W > 0 && C > 0 && Cout > 0, "bad geometry");
   RE2E_CHECK_ARG(beta == 0.f || beta == 1.f, "beta must be 0 or 1");
@@ -468,6 +473,7 @@ extern "C" int re2e_conv3x3_wino_wgrad(const float* in, int NI, int H, int W, in
   a.NI = NI; a.H = H; a.W = W; a.C = C; a.Cout = Cout;
   a.px = q.px; a.py = q.py; a.npatch = q.npatch; a.nsplit = q.nsplit; a.ncb = q.ncb; a.nblk = q.nblk;
   a.x_bytes = (unsigned)x_bytes; a.dy_bytes = (unsigned)dy_bytes;
+  a.row_lim = row_lim;
   a.dbg = exp_env("RE2E_WW_DBG") ? atoi(exp_env("RE2E_WW_DBG")) : 0;
   a.flat = exp_env("RE2E_WW_FLAT") ? atoi(exp_env("RE2E_WW_FLAT")) : 0;
   static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;   // tools/igemm_table.py joins this with a kernel trace
@@ -480,4 +486,17 @@ extern "C" int re2e_conv3x3_wino_wgrad(const float* in, int NI, int H, int W, in
   hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3((unsigned)cdiv((long)C * Cout, 256)), dim3(256), 0, stream, red, 1, C, Cout, gw, beta);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
+}
+
+extern "C" int re2e_conv3x3_wino_wgrad(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, float* gw, float beta, void* workspace,
+                                       size_t workspace_bytes, hipStream_t stream) {
+  return ww_impl(in, NI, H, W, C, dout, Cout, gw, beta, nullptr, workspace, workspace_bytes, stream);
+}
+
+// The weight gradient of a RAGGED image batch: dout is zero in rows y >= row_lim[n] of image n (the caller's promise), patches that start there
+// are skipped -- neither operand is read there.
+extern "C" int re2e_conv3x3_wino_wgrad_rows(const float* in, int NI, int H, int W, int C, const float* dout, int Cout, float* gw, float beta,
+                                            const int* row_lim, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(row_lim, "null row limits");
+  return ww_impl(in, NI, H, W, C, dout, Cout, gw, beta, row_lim, workspace, workspace_bytes, stream);
 }

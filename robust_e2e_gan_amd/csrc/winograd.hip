@@ -53,6 +53,7 @@ struct WinoArgs {
   int dbg;                                    // RE2E_EXPERIMENTS builds only: 1 = weight loads always hit the same 2 KB, 2 = pixel loads always read chunk 0
   unsigned in_bytes, u_bytes, out_bytes, pool_bytes;
   int total, ipw;                             // pipelined form: work items of the launch (per_image * NI) and consecutive items per workgroup
+  const int* row_lim;                         // optional, per image: output rows >= row_lim[n] are not computed (patches that start there exit at once)
 };
 
 // U[g][chunk][pos][nt][lane][e] = sum_{a,b} G[i][a] G[j][b] k[o][c][a][b],  pos = 4i + j, o = 64 g + 32 nt + (lane & 31),
@@ -185,6 +186,8 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
 
   WSTAMP(0);
   Geo cur = geo_of(item);
+  // ragged image batches (re2e_conv3x3_wino_rows): rows the caller never reads (beyond an utterance's end + the stack's reach) are left alone
+  if (p.row_lim && cur.y0 >= p.row_lim[n]) return;
   set_item(cur);
   // (same issue order as in the loop -- pixels first, then the weights position by position -- or the wait at the loop's head
   // has to cover the prologue's order as well and degenerates to vmcnt(0))
@@ -675,9 +678,9 @@ extern "C" size_t re2e_conv3x3_wino_workspace_bytes(int C, int Cout) {
   return C > 0 && Cout > 0 ? (size_t)16 * C * Cout * sizeof(float) : 0;
 }
 
-extern "C" int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int dgrad, const float* bias, int relu,
-                                 const float* mask, float* out, float* pool_out, unsigned char* pool_idx, void* workspace,
-                                 size_t workspace_bytes, hipStream_t stream) {
+static int wino_impl(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int dgrad, const float* bias, int relu,
+                     const float* mask, float* out, float* pool_out, unsigned char* pool_idx, const int* row_lim, void* workspace,
+                     size_t workspace_bytes, hipStream_t stream) {
   RE2E_CHECK_ARG(in && w && workspace && (out || pool_out), "null operand");
   RE2E_CHECK_ARG(NI > 0 && H > 0 && W > 0 && C > 0 && Cout > 0, "bad geometry");
   RE2E_CHECK_ARG(!pool_out || (pool_idx && relu && !mask && !dgrad), "pool_out needs pool_idx, relu = 1, no mask, forward direction");
@@ -698,6 +701,7 @@ extern "C" int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, c
   WinoArgs a;
   a.in = in; a.ufrag = uf; a.out = out; a.bias = bias; a.mask = mask; a.pool_out = pool_out; a.pool_idx = pool_idx;
   a.NI = NI; a.H = H; a.W = W; a.C = C; a.Cout = Cout; a.relu = relu;
+  a.row_lim = row_lim;
   const int ngn = Cout / WNT;
   if (ngn & (ngn - 1)) { re2e_set_error("re2e_conv3x3_wino: Cout / 64 must be a power of two (got Cout = %d)", Cout); return RE2E_EUNSUPPORTED; }
   a.ngn_shift = 0;
@@ -739,6 +743,48 @@ extern "C" int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, c
   }
 #endif
   if (wide) launch_wino<8>(a, stream); else launch_wino<4>(a, stream);
+  RE2E_LAUNCH_CHECK();
+  return RE2E_OK;
+}
+
+extern "C" int re2e_conv3x3_wino(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int dgrad, const float* bias, int relu,
+                                 const float* mask, float* out, float* pool_out, unsigned char* pool_idx, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+  return wino_impl(in, NI, H, W, C, w, Cout, dgrad, bias, relu, mask, out, pool_out, pool_idx, nullptr, workspace, workspace_bytes, stream);
+}
+
+// The same over a RAGGED image batch: output rows y >= row_lim[n] of image n (full-resolution rows, also with the fused pool) are not computed
+// and not written -- patches that start at or beyond the limit exit at once, a patch that straddles it is computed whole.  The VGG front end
+// convolves zero-padded utterances and cuts every one at its pooled length afterwards (e2e_encoder.py:259-278): what it computes more than
+// the stack's reach beyond an utterance's end is never read.  The caller owns the limits' consistency (VGG2L.conv_stack) and puts zeros where a
+// consumer reads all rows (re2e_fill_image_rows).
+extern "C" int re2e_conv3x3_wino_rows(const float* in, int NI, int H, int W, int C, const float* w, int Cout, int dgrad, const float* bias, int relu,
+                                      const float* mask, float* out, float* pool_out, unsigned char* pool_idx, const int* row_lim, void* workspace,
+                                      size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(row_lim, "null row limits");
+  return wino_impl(in, NI, H, W, C, w, Cout, dgrad, bias, relu, mask, out, pool_out, pool_idx, row_lim, workspace, workspace_bytes, stream);
+}
+
+namespace {
+__global__ void fill_image_rows_kernel(float* __restrict__ t, int H, long row_f4, const int* __restrict__ lim, int div, float value) {
+  const int n = blockIdx.y;
+  int r0 = (lim[n] + div - 1) / div;
+  if (r0 >= H) return;
+  const long tot = (long)(H - r0) * row_f4;
+  f32x4* base = reinterpret_cast<f32x4*>(t) + ((long)n * H + r0) * row_f4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)gridDim.x * blockDim.x) base[i] = f32x4{value, value, value, value};
+}
+}  // namespace
+
+// t: (N, H, row_floats) images; rows r >= ceil(lim[n] / div) of image n = value (div = 2: t is the 2x2-pooled tensor of a layer whose limits
+// count full-resolution rows).  max_tail_rows: an upper bound of H - lim / div over the batch (the host knows the lengths): sizes the launch.
+extern "C" int re2e_fill_image_rows(float* t, int N, int H, long row_floats, const int* lim, int div, int max_tail_rows, float value, hipStream_t stream) {
+  RE2E_CHECK_ARG(t && lim && N > 0 && H > 0 && row_floats > 0 && (div == 1 || div == 2), "bad argument");
+  RE2E_CHECK_ARG(row_floats % 4 == 0 && (reinterpret_cast<uintptr_t>(t) & 15) == 0, "rows must be whole float4s");
+  if (max_tail_rows <= 0) return RE2E_OK;
+  long blocks = ((long)max_tail_rows * (row_floats / 4) + 1023) / 1024;       // 4 float4 per thread
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_image_rows_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0, stream, t, H, row_floats / 4, lim, div, value);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

@@ -190,7 +190,7 @@ class JointTrainer(object):
                     clean_feat = self.feat_model(clean_inputs)
                 ev_cf = torch.cuda.Event()
                 ev_cf.record()
-                clean_branch = self.asr_model.encode_clean(clean_feat, enhance_cmvn)
+                clean_branch = self.asr_model.encode_clean(clean_feat, enhance_cmvn, input_sizes)
             self._mark('clean branch enqueued (side)')
             enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
             self._mark('enhancer fwd')

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
-ABI_VERSION = 315      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
+ABI_VERSION = 316      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
@@ -42,6 +42,9 @@ SIGNATURES = {
     're2e_conv3x3_wino': (I, [P, I, I, I, I, P, I, I, P, I, P, P, P, P, P, Z, P]),
     're2e_conv3x3_wino_wgrad_workspace_bytes': (Z, [I, I, I, I, I]),
     're2e_conv3x3_wino_wgrad': (I, [P, I, I, I, I, P, I, P, F, P, Z, P]),
+    're2e_conv3x3_wino_rows': (I, [P, I, I, I, I, P, I, I, P, I, P, P, P, P, P, P, Z, P]),
+    're2e_conv3x3_wino_wgrad_rows': (I, [P, I, I, I, I, P, I, P, F, P, P, Z, P]),
+    're2e_fill_image_rows': (I, [P, I, I, L, P, I, I, F, P]),
     're2e_conv4x4_wino_workspace_bytes': (Z, [I, I, I, I, I, I]),
     're2e_conv4x4_wino': (I, [P, I, I, I, I, P, I, I, I, P, P, Z, P]),
     're2e_conv4x4_wino_wgrad_workspace_bytes': (Z, [I, I, I, I, I, I]),

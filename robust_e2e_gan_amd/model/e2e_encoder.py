@@ -97,6 +97,9 @@ class BLSTMP(torch.nn.Module):
         return ops.transpose01(y), nl
 
 
+ROW_LIMITS = lib.exp_env('RE2E_NO_VGG_ROW_LIMITS') is None      # (experiments) every row of every image, as rounds 1-5 did
+
+
 class VGG2L(torch.nn.Module):
     def __init__(self, in_channel=1):
         super(VGG2L, self).__init__()
@@ -106,11 +109,40 @@ class VGG2L(torch.nn.Module):
         self.conv2_2 = ConvParams(128, 128, 3, stride=1, padding=1)
         self.in_channel = in_channel
 
-    def conv_stack(self, xs):
-        """(B,T,idim) batch-first -> pooled NHWC (B, ceil(ceil(T/2)/2), ceil(ceil(idim/2)/2), 128)  (e2e_encoder.py:259-266)"""
+    def row_limits(self, ilens, T, device):
+        """Per-layer row limits of a ragged batch for ``conv_stack`` -> (lims of conv1_2, conv2_1, conv2_2) or None.
+
+        Upstream convolves the whole zero-padded (B, 1, Tmax, idim) batch and cuts every utterance at its pooled length afterwards (:272-278):
+        a pooled frame p reads input rows < 4 p + 10, so rows further than the stack's reach beyond an utterance's end are computed and never read.
+        With P pooled frames, conv2_2 is needed in rows < 2 P, conv2_1 in < 2 P + 1, pool1 in < 2 P + 2, conv1_2 in < 4 P + 4, conv1_1 in < 4 P + 5,
+        and the gradients are exactly zero beyond the same rows.  The limits below nest with two rows to spare per layer and are multiples of 16 (the
+        kernels skip whole 8- / 16-row patches); what lies beyond is zero wherever a kernel reads all rows (ops.RowLims).  Config 4 (lengths
+        0.7 .. 1.0 Tmax): 9-11 % of the three Winograd layers' rows, forward, data and weight gradient."""
+        lens = lens_list(ilens)
+        H1, H2 = T, (T + 1) // 2
+        a16 = lambda v: (v + 15) // 16 * 16
+        P = self.pooled_lens(lens)
+        L22 = [min(H2, a16(2 * p + 2)) for p in P]
+        L21 = [min(H2, a16(l + 2)) for l in L22]
+        L12 = [min(H1, a16(2 * (l + 2))) for l in L21]
+        L11 = [min(H1, a16(l + 2)) for l in L12]
+        Lp1 = [(l + 1) // 2 for l in L12]                       # pooled rows of conv1_2's output = conv2_1's input
+        saved = sum(H1 - l for l in L12) / float(max(1, len(lens)) * H1)
+        if saved < 0.03:
+            return None
+        dv = lambda v: lens_dev(v, device)
+        tail = lambda v, H: max(H - min(v), 0)
+        return (ops.RowLims(dv(L12), dv(L11), tail(L12, H1), tail(L11, H1)), ops.RowLims(dv(L21), dv(Lp1), tail(L21, H2), tail(Lp1, H2)),
+                ops.RowLims(dv(L22), dv(L21), tail(L22, H2), tail(L21, H2)))
+
+    def conv_stack(self, xs, ilens=None):
+        """(B,T,idim) batch-first -> pooled NHWC (B, ceil(ceil(T/2)/2), ceil(ceil(idim/2)/2), 128)  (e2e_encoder.py:259-266).
+        ``ilens``: the utterance lengths -- rows the cut + re-pad of :272-278 never reads are then not computed (``row_limits``)."""
         if self.in_channel != 1:
             raise Re2eError('VGG2L with in_channel != 1 is not on the hot path')
         B, T, Fd = xs.shape
+        lm = self.row_limits(ilens, T, xs.device) if (ilens is not None and ROW_LIMITS and FUSE_CONV_POOL) else None
+        l12, l21, l22 = lm if lm is not None else (None, None, None)
         h = xs.contiguous().view(B, T, Fd, 1)                                     # NCHW (B,1,T,F) == NHWC (B,T,F,1)
         # No ReLU-backward pass anywhere in the stack: conv -> ReLU -> conv takes the data gradient of the second convolution through
         # the ReLU in that kernel's epilogue (x_is_relu_out), conv -> ReLU -> pool folds the ReLU's mask into the pool's index
@@ -118,9 +150,9 @@ class VGG2L(torch.nn.Module):
         fp, fc = FUSE_RELU_POOL_BWD, FUSE_RELU_CONV_BWD
         h = ops.conv2d(h, self.conv1_1.weight, self.conv1_1.bias, 1, 1, 'relu', relu_bwd_in_next=fc)
         if FUSE_CONV_POOL:          # conv -> ReLU -> pool in one launch: the full-resolution activation is never written
-            h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu', x_is_relu_out=fc, pool=True)
-            h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu', relu_bwd_in_next=fc)
-            return ops.conv2d(h, self.conv2_2.weight, self.conv2_2.bias, 1, 1, 'relu', x_is_relu_out=fc, pool=True)
+            h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu', x_is_relu_out=fc, pool=True, lims=l12)
+            h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu', relu_bwd_in_next=fc, lims=l21)
+            return ops.conv2d(h, self.conv2_2.weight, self.conv2_2.bias, 1, 1, 'relu', x_is_relu_out=fc, pool=True, lims=l22)
         h = ops.conv2d(h, self.conv1_2.weight, self.conv1_2.bias, 1, 1, 'relu', relu_bwd_in_pool=fp, x_is_relu_out=fc)
         h = ops.maxpool2(h, relu_in=fp)
         h = ops.conv2d(h, self.conv2_1.weight, self.conv2_1.bias, 1, 1, 'relu', relu_bwd_in_next=fc)
@@ -141,7 +173,7 @@ class VGG2L(torch.nn.Module):
 
     def forward_tm(self, xs, ilens):
         """(B,T,idim) batch-first -> time-major (T',B,128*F')."""
-        return self.pack_tm([self.conv_stack(xs)], [ilens])
+        return self.pack_tm([self.conv_stack(xs, ilens)], [ilens])
 
     def forward(self, xs, ilens):
         y, nl = self.forward_tm(xs, ilens)

@@ -103,14 +103,14 @@ class ShareE2E(E2E):
     one 2B batch, losses come from the enhanced branch exactly as E2E.forward, contexts are the
     encoder states of the valid frames of each branch."""
 
-    def encode_clean(self, clean_feat, cmvn):
+    def encode_clean(self, clean_feat, cmvn, input_sizes=None):
         """Clean-branch CMVN + VGG conv stack, to be enqueued on a SIDE stream while the enhancer's recurrent chain
         occupies the main stream (the clean branch does not depend on the enhancer).  Returns a handle for
         ``forward(..., clean_branch=handle)``."""
         cln = to_cuda(self, clean_feat)
         if cmvn is not None:
             cln = ops.cmvn_pair(cln, None, to_cuda(self, cmvn).float().contiguous())
-        h = self.enc.enc1.conv_stack(cln)
+        h = self.enc.enc1.conv_stack(cln, input_sizes)
         ev = torch.cuda.Event()
         ev.record()
         return h, ev
@@ -127,7 +127,7 @@ class ShareE2E(E2E):
             # the two branches share only the recurrent stack: conv stacks separately (possibly on different streams),
             # then ONE (T', 2B, .) tensor for the BLSTMP so that the sequential chain is paid once
             h_cln, ev = clean_branch
-            h_enh = self.enc.enc1.conv_stack(ops.cmvn_pair(enh, None, cm) if cm is not None else enh)
+            h_enh = self.enc.enc1.conv_stack(ops.cmvn_pair(enh, None, cm) if cm is not None else enh, ilens)
             torch.cuda.current_stream().wait_event(ev)
             h_cln.record_stream(torch.cuda.current_stream())
             if torch.is_grad_enabled() and h_cln.requires_grad:

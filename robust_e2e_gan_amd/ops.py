@@ -644,7 +644,24 @@ def _wino_images(N, H, Wd, C, Cout):
     return max(1, min(N, (2 ** 31 - 256) // (H * Wd * max(C, Cout) * 4)))
 
 
-def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool=False):
+class RowLims(object):
+    """Row limits of one 3x3 layer of a ragged image batch (VGG2L.conv_stack): ``out`` / ``inp`` = int32 device tensors, per image, of the rows
+    of the layer's output / input that are computed (the rest is zero where someone reads it), ``out_tail`` / ``inp_tail`` = the largest
+    number of rows beyond them in the batch (sizes the fill launches)."""
+    __slots__ = ('out', 'inp', 'out_tail', 'inp_tail')
+
+    def __init__(self, out, inp, out_tail, inp_tail):
+        self.out, self.inp, self.out_tail, self.inp_tail = out, inp, out_tail, inp_tail
+
+
+def fill_image_rows(t, lim, div, max_tail):
+    """zeros in rows >= ceil(lim[n] / div) of the NHWC tensor ``t`` (see re2e_fill_image_rows)."""
+    N, H = t.shape[0], t.shape[1]
+    if max_tail > 0:
+        call('re2e_fill_image_rows', t.data_ptr(), N, H, t.shape[2] * t.shape[3], lim.data_ptr(), div, int(max_tail), 0.0)
+
+
+def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool=False, row_lim=None):
     """re2e_conv3x3_wino on NHWC ``x`` with the layer's weight ``W`` in PyTorch layout: forward (dgrad=False: bias / ReLU / fused
     2x2 max pool -> (pooled, index bytes)) or data gradient (dgrad=True: ``x`` is dy; ``mask``: the ReLU output in front).  Tensors of
     2 GiB or more run as several launches over slices of the image axis (same stream, same workspace: the launches are ordered)."""
@@ -657,14 +674,22 @@ def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool
         idx = torch.empty(yp.shape, dtype=torch.uint8, device=x.device)
         for i in range(0, N, nb):
             n = min(nb, N - i)
-            call('re2e_conv3x3_wino', x[i:i + n].data_ptr(), n, H, Wd, C, W.data_ptr(), Cout, 0, ptr(bias), 1, None, None, yp[i:i + n].data_ptr(),
-                 idx[i:i + n].data_ptr(), ws.data_ptr(), wsb)
+            if row_lim is not None:
+                call('re2e_conv3x3_wino_rows', x[i:i + n].data_ptr(), n, H, Wd, C, W.data_ptr(), Cout, 0, ptr(bias), 1, None, None,
+                     yp[i:i + n].data_ptr(), idx[i:i + n].data_ptr(), row_lim.data_ptr() + 4 * i, ws.data_ptr(), wsb)
+            else:
+                call('re2e_conv3x3_wino', x[i:i + n].data_ptr(), n, H, Wd, C, W.data_ptr(), Cout, 0, ptr(bias), 1, None, None, yp[i:i + n].data_ptr(),
+                     idx[i:i + n].data_ptr(), ws.data_ptr(), wsb)
         return yp, idx
     y = empty((N, H, Wd, Cout), x)
     for i in range(0, N, nb):
         n = min(nb, N - i)
-        call('re2e_conv3x3_wino', x[i:i + n].data_ptr(), n, H, Wd, C, W.data_ptr(), Cout, int(bool(dgrad)), ptr(bias), int(bool(relu)),
-             None if mask is None else mask[i:i + n].data_ptr(), y[i:i + n].data_ptr(), None, None, ws.data_ptr(), wsb)
+        if row_lim is not None:
+            call('re2e_conv3x3_wino_rows', x[i:i + n].data_ptr(), n, H, Wd, C, W.data_ptr(), Cout, int(bool(dgrad)), ptr(bias), int(bool(relu)),
+                 None if mask is None else mask[i:i + n].data_ptr(), y[i:i + n].data_ptr(), None, None, row_lim.data_ptr() + 4 * i, ws.data_ptr(), wsb)
+        else:
+            call('re2e_conv3x3_wino', x[i:i + n].data_ptr(), n, H, Wd, C, W.data_ptr(), Cout, int(bool(dgrad)), ptr(bias), int(bool(relu)),
+                 None if mask is None else mask[i:i + n].data_ptr(), y[i:i + n].data_ptr(), None, None, ws.data_ptr(), wsb)
     return y
 
 
@@ -690,7 +715,7 @@ class Conv2dFn(torch.autograd.Function):
     """x: (N,H,W,Cin) NHWC; W: (Cout,Cin,KH,KW) PyTorch layout; returns (N,OH,OW,Cout)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, stride, pad, act, act_bwd_done=False, x_is_relu_out=False, pool=False):
+    def forward(ctx, x, W, b, stride, pad, act, act_bwd_done=False, x_is_relu_out=False, pool=False, lims=None):
         _need_gpu(x)
         x = _f32(x)
         N, H, Wd, Cin = x.shape
@@ -700,13 +725,21 @@ class Conv2dFn(torch.autograd.Function):
         ctx.x_is_relu_out = bool(x_is_relu_out)        # x = ReLU output of the layer in front: dx is taken through that ReLU (dx = 0 where x <= 0)
         ctx.pool = bool(pool)                          # the result is maxpool2(relu(conv)), 2x2 / stride 2 / ceil mode
         ctx.W, ctx.b, ctx.cfg = W, b, (stride, pad, act)
+        ctx.lims = None
         if act in (lib.ACT_NONE, lib.ACT_RELU) and _wino_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and W.is_contiguous():
             # 3x3 / stride-1 VGG layers: fused Winograd F(2x2,3x3), 2.25x fewer matrix instructions than the direct kernels below
+            # ``lims`` (RowLims, ragged image batches): rows beyond an utterance's reach are not computed; zeros where a later kernel reads all rows
+            ctx.lims = lims
+            lo = lims.out if lims is not None else None
             if pool:
-                yp, idx = conv3x3_wino(x, W, Cout, bias=b, relu=True, pool=True)
+                yp, idx = conv3x3_wino(x, W, Cout, bias=b, relu=True, pool=True, row_lim=lo)
+                if lims is not None:
+                    fill_image_rows(yp, lims.out, 2, (lims.out_tail + 1) // 2)
                 ctx.save_for_backward(x, idx)
                 return yp
-            y = conv3x3_wino(x, W, Cout, bias=b, relu=act == lib.ACT_RELU)
+            y = conv3x3_wino(x, W, Cout, bias=b, relu=act == lib.ACT_RELU, row_lim=lo)
+            if lims is not None:
+                fill_image_rows(y, lims.out, 1, lims.out_tail)
             ctx.save_for_backward(x, y if (act != lib.ACT_NONE and not ctx.act_bwd_done) else None)
             return y
         if act == lib.ACT_NONE and b is None and not pool and _wino44_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and W.is_contiguous():
@@ -756,8 +789,11 @@ class Conv2dFn(torch.autograd.Function):
         dz, bias_done = act_bwd_bias(_f32(dy).reshape(N * OH * OW, Cout), y, act, b, need_b)
         dz = dz.view(N, OH, OW, Cout)
         dx = None
+        lims = ctx.lims
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad, relu_out=x if ctx.x_is_relu_out else None)
+            dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad, relu_out=x if ctx.x_is_relu_out else None, row_lim=lims.inp if lims is not None else None)
+            if lims is not None and lims.inp is not None:
+                fill_image_rows(dx, lims.inp, 1, lims.inp_tail)         # the gradient is zero there: written, not computed
         with param_grads(dz, x):
             if need_w and WINO_WGRAD and _wino_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and Cin % 64 == 0 and x.is_contiguous() \
                     and dz.is_contiguous():
@@ -768,8 +804,12 @@ class Conv2dFn(torch.autograd.Function):
                 with accumulate(W) as (gw, beta):
                     for i in range(0, N, nb):
                         n = min(nb, N - i)
-                        call('re2e_conv3x3_wino_wgrad', x[i:i + n].data_ptr(), n, H, Wd, Cin, dz[i:i + n].data_ptr(), Cout, gw.data_ptr(),
-                             beta if i == 0 else 1.0, ws.data_ptr(), wsb)
+                        if lims is not None:      # dz is zero in rows >= lims.out: patches there are skipped
+                            call('re2e_conv3x3_wino_wgrad_rows', x[i:i + n].data_ptr(), n, H, Wd, Cin, dz[i:i + n].data_ptr(), Cout, gw.data_ptr(),
+                                 beta if i == 0 else 1.0, lims.out.data_ptr() + 4 * i, ws.data_ptr(), wsb)
+                        else:
+                            call('re2e_conv3x3_wino_wgrad', x[i:i + n].data_ptr(), n, H, Wd, Cin, dz[i:i + n].data_ptr(), Cout, gw.data_ptr(),
+                                 beta if i == 0 else 1.0, ws.data_ptr(), wsb)
             elif need_w and _wino44_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and x.is_contiguous() and dz.is_contiguous():
                 wsb = query('re2e_conv4x4_wino_wgrad_workspace_bytes', N, H, Wd, Cin, Cout, pad)
                 ws = workspace(wsb, x.device, 'wino44w')
@@ -784,17 +824,17 @@ class Conv2dFn(torch.autograd.Function):
             if b is not None and need_b and not bias_done:
                 with accumulate(b) as (gb, beta):
                     colsum_into(dz, N * OH * OW, Cout, gb, beta)
-        return dx, None, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None
 
 
-def conv_dgrad(dz, W, xshape, stride, pad, relu_out=None):
+def conv_dgrad(dz, W, xshape, stride, pad, relu_out=None, row_lim=None):
     """Data gradient of an NHWC convolution (see re2e_conv_igemm).  ``relu_out`` (stride 1): the convolution's input, which was
     the ReLU output of the layer in front -- the gradient is taken through that ReLU as well (re2e_conv_igemm_masked)."""
     N, H, Wd, Cin = xshape
     Cout, _, KH, KW = W.shape
     OH, OW = dz.shape[1], dz.shape[2]
     if stride == 1 and _wino_ok(N, H, Wd, Cout, Cin, (KH, KW), stride, pad) and (OH, OW) == (H, Wd) and W.is_contiguous():
-        return conv3x3_wino(_f32(dz), W, Cin, dgrad=True, mask=relu_out)
+        return conv3x3_wino(_f32(dz), W, Cin, dgrad=True, mask=relu_out, row_lim=row_lim)
     if relu_out is None and _wino44_ok(N, OH, OW, Cout, Cin, (KH, KW), stride, pad) and (OH, OW) == (H - 1, Wd - 1) and W.is_contiguous():
         return conv4x4_wino(_f32(dz).contiguous(), W, Cin, 3 - pad, dgrad=True)
     if stride == 1:
@@ -835,7 +875,7 @@ def conv_dgrad(dz, W, xshape, stride, pad, relu_out=None):
     return dx
 
 
-def conv2d(x, W, b=None, stride=1, pad=1, act=None, relu_bwd_in_pool=False, relu_bwd_in_next=False, x_is_relu_out=False, pool=False):
+def conv2d(x, W, b=None, stride=1, pad=1, act=None, relu_bwd_in_pool=False, relu_bwd_in_next=False, x_is_relu_out=False, pool=False, lims=None):
     """``relu_bwd_in_pool`` / ``relu_bwd_in_next``: act is 'relu' and the result goes ONLY into ``maxpool2(y, relu_in=True)`` /
     ``conv2d(y, ..., x_is_relu_out=True)``, whose backward applies the ReLU's derivative (a pooled maximum <= 0 passes nothing back;
     the next convolution's data gradient is masked by its input > 0 in the kernel's epilogue): this convolution's backward then
@@ -849,7 +889,7 @@ def conv2d(x, W, b=None, stride=1, pad=1, act=None, relu_bwd_in_pool=False, relu
         raise lib.Re2eError('x_is_relu_out needs stride 1')
     if pool and act != 'relu':
         raise lib.Re2eError('pool=True is conv -> ReLU -> maxpool2: act must be "relu"')
-    return Conv2dFn.apply(x, W, b, stride, pad, ACT[act], relu_bwd_in_pool or relu_bwd_in_next, x_is_relu_out, pool)
+    return Conv2dFn.apply(x, W, b, stride, pad, ACT[act], relu_bwd_in_pool or relu_bwd_in_next, x_is_relu_out, pool, lims)
 
 
 class ConvTranspose2dFn(torch.autograd.Function):

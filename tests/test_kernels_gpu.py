@@ -613,6 +613,46 @@ def test_bilstm_and_projection_over_valid_rows_only(B, T, I, H):
         close('grad %d vs all rows' % i, g, r, tol=2e-5)
 
 
+@pytest.mark.parametrize('B,T,F_', [(12, 208, 80), (6, 333, 40)])
+def test_vgg_conv_stack_row_limits(B, T, F_):
+    """VGG2L.conv_stack over a ragged batch with per-image row limits (re2e_conv3x3_wino_rows / _wgrad_rows / re2e_fill_image_rows): rows beyond
+    an utterance's reach are not computed -- they hold NaN here (poisoned allocator blocks) -- and the packed output, the input gradient and every
+    parameter gradient equal those of the stack that computes every row."""
+    ops, lib = _ops()
+    from robust_e2e_gan_amd.model import e2e_encoder as enc
+    torch.manual_seed(3)
+    vgg = enc.VGG2L(1).to(DEV)
+    for p_ in vgg.parameters():
+        p_.data.normal_(0, 0.2 if p_.dim() > 1 else 0.05)
+    lens = [max(8, int(round(T * (1 - 0.45 * i / (B - 1))))) for i in range(B)]
+    x = rnd(B, T, F_)
+    for b, l in enumerate(lens):
+        x[b, l:] = 0
+    assert vgg.row_limits(lens, T, DEV) is not None
+    res = []
+    for on in (True, False):
+        enc.ROW_LIMITS = on
+        try:
+            for p_ in vgg.parameters():
+                p_.grad = None
+            xg = x.to(DEV).requires_grad_(True)
+            if on:
+                _poison_free_blocks(B * T * F_ * 64 * 4)
+                _poison_free_blocks(B * (T // 2) * (F_ // 2) * 128 * 4)
+            y, nl = vgg.forward_tm(xg, lens)
+            g = rnd(*y.shape, seed=5).to(DEV)
+            (y * g).sum().backward()
+            res.append((y.detach().clone(), xg.grad.clone(), [p_.grad.clone() for p_ in vgg.parameters()], nl))
+        finally:
+            enc.ROW_LIMITS = True
+    (y1, dx1, gs1, nl1), (y0, dx0, gs0, nl0) = res
+    assert nl1 == nl0
+    close('packed output', y1, y0, tol=1e-6)
+    close('dx', dx1, dx0, tol=2e-5)
+    for i, (a, b) in enumerate(zip(gs1, gs0)):
+        close('grad %d' % i, a, b, tol=2e-5)
+
+
 def _fwd2_runs(B, H):
     """csrc/lstm.hip fwd2_config: the round-4 forward serves <= 16 utterances and wide layers (multiples of 64 units)."""
     return H % 64 == 0 and H // 64 in (1, 2, 4, 5, 8) and (B <= 16 or H >= 384)
