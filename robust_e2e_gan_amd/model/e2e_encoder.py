@@ -115,17 +115,18 @@ class VGG2L(torch.nn.Module):
         Upstream convolves the whole zero-padded (B, 1, Tmax, idim) batch and cuts every utterance at its pooled length afterwards (:272-278):
         a pooled frame p reads input rows < 4 p + 10, so rows further than the stack's reach beyond an utterance's end are computed and never read.
         With P pooled frames, conv2_2 is needed in rows < 2 P, conv2_1 in < 2 P + 1, pool1 in < 2 P + 2, conv1_2 in < 4 P + 4, conv1_1 in < 4 P + 5,
-        and the gradients are exactly zero beyond the same rows.  The limits below nest with two rows to spare per layer and are multiples of 16 (the
-        kernels skip whole 8- / 16-row patches); what lies beyond is zero wherever a kernel reads all rows (ops.RowLims).  Config 4 (lengths
-        0.7 .. 1.0 Tmax): 9-11 % of the three Winograd layers' rows, forward, data and weight gradient."""
+        and the gradients are exactly zero beyond the same rows.  Every limit is its layer's need rounded up to 16 (the kernels skip whole 8- /
+        16-row patches).  A layer's rows between its need and its limit are computed from whatever the layer in front holds there -- real values
+        below that layer's limit, zeros beyond it (ops.RowLims: zero-filled wherever a kernel reads all rows) -- finite, unneeded, multiplied
+        by zero gradients.  Config 4 (lengths 0.7 .. 1.0 Tmax): 12-14 % of the three Winograd layers' rows, forward, data and weight gradient."""
         lens = lens_list(ilens)
         H1, H2 = T, (T + 1) // 2
         a16 = lambda v: (v + 15) // 16 * 16
         P = self.pooled_lens(lens)
-        L22 = [min(H2, a16(2 * p + 2)) for p in P]
-        L21 = [min(H2, a16(l + 2)) for l in L22]
-        L12 = [min(H1, a16(2 * (l + 2))) for l in L21]
-        L11 = [min(H1, a16(l + 2)) for l in L12]
+        L22 = [min(H2, a16(2 * p)) for p in P]
+        L21 = [min(H2, a16(2 * p + 1)) for p in P]
+        L12 = [min(H1, a16(4 * p + 4)) for p in P]
+        L11 = [min(H1, a16(4 * p + 5)) for p in P]
         Lp1 = [(l + 1) // 2 for l in L12]                       # pooled rows of conv1_2's output = conv2_1's input
         saved = sum(H1 - l for l in L12) / float(max(1, len(lens)) * H1)
         if saved < 0.03:
