@@ -1,5 +1,6 @@
 """Helpers that fix padding / init / freezing semantics (mirror of model/e2e_common.py)."""
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -107,8 +108,14 @@ def lens_dev(lens, device):
     """int32 device copy of a length list; the same lists recur many times per step, so uploads are cached (``dev_cached``)."""
     key = (tuple(lens_list(lens)), str(device))
     t = dev_cached(key, lambda: key[0], device)
-    LENS_HOST[t.data_ptr()] = key[0]
+    LENS_HOST[t.data_ptr()] = (key[0], weakref.ref(t))
     return t
+
+
+def host_lens_of(lens_d):
+    """The host tuple a cached length tensor was made from, or None for any other tensor (also one that merely reuses a cached tensor's address)."""
+    ent = LENS_HOST.get(lens_d.data_ptr())
+    return ent[0] if ent is not None and ent[1]() is lens_d else None
 
 
 def lecun_normal_init_parameters(module):

@@ -38,7 +38,9 @@ class BLSTM(torch.nn.Module):
             # tensor is the same arithmetic on the valid frames.
             if self.dropout and self.training and l + 1 < self.elayers:
                 x_tm = ops.dropout(x_tm, self.dropout)
-        return ops.linear(x_tm, self.l_last.weight, self.l_last.bias, 'tanh')
+        # (upstream applies it to the padded rows too, :173-176: tanh(bias) there, which nothing downstream reads -- the mask layer and the
+        #  attention select by length -- here the product runs over the valid rows and the padded ones are 0)
+        return ops.linear(x_tm, self.l_last.weight, self.l_last.bias, 'tanh', maps=ops.row_maps(lens_d, x_tm.shape[0], x_tm.shape[1]))
 
     def forward(self, xpad, ilens):
         lens = lens_list(ilens)

@@ -77,6 +77,7 @@ def gemm_input_grad(dz, W, dx, M, K, N, beta=0.0):
 # per-lane offsets of the LDS-DMA pipeline.  RE2E_NO_ROW_MAPS=1 (experiments): all rows, as rounds 1-5 did.
 ROW_MAPS = lib.exp_env('RE2E_NO_ROW_MAPS') is None
 TN_ROW_MAPS = lib.exp_env('RE2E_NO_TN_ROW_MAPS') is None      # (experiments) the weight gradients over all rows
+ROW_MAPS_MIN_K = 384
 ROW_MAPS_MIN_PAD = 0.04      # below this share of padded rows the maps are not worth their per-tile lookups
 
 
@@ -96,7 +97,7 @@ def row_maps(lens_d, T, B):
     if not ROW_MAPS or lens_d is None:
         return None
     from .model import e2e_common as ec
-    lens = ec.LENS_HOST.get(lens_d.data_ptr())
+    lens = ec.host_lens_of(lens_d)
     if lens is None or len(lens) != B:
         return None
     key = (lens, T, B, str(lens_d.device))
@@ -123,6 +124,10 @@ def gemm_rows(A, B, C, N, K, maps, lda=None, ldb=None, ldc=None, bias=None, bias
     lda = lda if lda is not None else K
     ldb = ldb if ldb is not None else K
     ldc = ldc if ldc is not None else N
+    if K < ROW_MAPS_MIN_K and not fill:
+        # a short contraction is over before the per-tile row lookups have paid (25600 x 1024 x 260: 141 us mapped against 131 over all rows,
+        # profiles/r05_rows_alone.txt): all rows
+        return gemm(A, B, C, maps.rows, N, K, transb=True, lda=lda, ldb=ldb, ldc=ldc, bias=bias, bias2=bias2, act=act, beta=beta)
     wsb = query('re2e_gemm_workspace_bytes', 0, 1, maps.nv, N, K)
     ws = workspace(wsb, A.device, 'gemm') if wsb else None
     _p = lambda t: t if isinstance(t, int) else t.data_ptr()
