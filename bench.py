@@ -713,7 +713,10 @@ def main():
         'config': {'workload': '%s, B=%d %s, T=%d, F=257->80, L=%d, V=4233%s' % (
                        CONFIG_NAMES[a.config], B, 'per GPU' if a.scaling == 'weak' else 'GLOBAL (rank r keeps utterances r::N)', T, L,
                        ', enhancer 2xBLSTM-256, VGG+3xBLSTMP-512, loc-attention decoder 300, D basic ndf64, Adadelta' if joint else ''),
-                   'global_batch': global_b, 'per_rank_batch': local_b, 'parallelism': 'dp%d' % world, 'coral_loss_lambda': opt.coral_loss_lambda},
+                   'global_batch': global_b, 'per_rank_batch': local_b, 'parallelism': 'dp%d' % world, 'coral_loss_lambda': opt.coral_loss_lambda,
+                   # the synthetic batch is ragged like a collated one (data/synthetic.py: lengths T .. 0.7 T, sorted): the reference packs its
+                   # sequences and cuts its VGG output, and so do the products around the recurrences and the VGG stack here
+                   'utterance_lengths': '%d..%d frames (mean %.0f of T=%d)' % (int(batch[4].min()), int(batch[4].max()), float(batch[4].float().mean()), T)},
         # whole-step fraction of the fp32-MFMA roofline: utterances/s x SURVEY 8(d) FLOP per utterance / (N x 157.3 TFLOP/s); the FLOP
         # count holds for the configuration's own (T, L) whatever the batch, so it is given for weak and strong scaling alike
         'step_mfma_frac': round(value * FLOP_PER_UTT[a.config] / (world * PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if (T, L) == CONFIG_SHAPES[a.config][1:] else None,

@@ -506,9 +506,15 @@ def _poison_free_blocks(nbytes):
 # not touched (or zero-filled), rows inside equal the product over all rows.  Shapes: the enhancer's and the BLSTMP's row spaces, a K tail, ragged
 # N edge, a stream-K tail, beta = 1.
 @pytest.mark.parametrize('T,B,N,K,act', [(800, 32, 1024, 260, 'none'), (200, 64, 512, 1024, 'tanh'), (97, 24, 260, 36, 'relu'), (400, 16, 2048, 512, 'none')])
-def test_gemm_nt_rows(T, B, N, K, act):
+def test_gemm_nt_rows(T, B, N, K, act, monkeypatch):
     ops, lib = _ops()
     from robust_e2e_gan_amd.model.e2e_common import lens_dev
+    if K < ops.ROW_MAPS_MIN_K:
+        # short contractions stay on all rows in the step (ops.ROW_MAPS_MIN_K: the per-tile row lookups do not pay); the kernel takes them all the same
+        a0, w0, c0 = torch.zeros(T * B, K, device=DEV), torch.zeros(N, K, device=DEV), torch.ones(T * B, N, device=DEV)
+        ops.gemm_rows(a0, w0, c0, N, K, ops.row_maps(lens_dev([max(1, int(round(T * (1 - 0.3 * i / (B - 1))))) for i in range(B)], DEV), T, B))
+        assert float(c0.abs().max()) == 0.0, 'below ROW_MAPS_MIN_K the product runs over all rows'
+        monkeypatch.setattr(ops, 'ROW_MAPS_MIN_K', 0)
     lens = [max(1, int(round(T * (1 - 0.3 * i / (B - 1))))) for i in range(B)]
     maps = ops.row_maps(lens_dev(lens, DEV), T, B)
     assert maps is not None and maps.nv == sum(lens) and maps.nv + maps.ni == T * B
