@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 316
+#define RE2E_ABI_VERSION 317
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -80,14 +80,16 @@ int re2e_gemm(int transa, int transb, int M, int N, int K, const float* A, long 
  *   C[map[r]][:] = act(A[map[r]][:] . B[N,K]^T + bias + bias2) + beta C[map[r]][:]   for r < Mv,
  * A (phys_rows x K, lda) and C (phys_rows x N, ldc) in the padded layout, rowmap[Mv] the physical rows with t < len_b.  Rows outside the map are
  * not touched (re2e_fill_rows).  Workspace as re2e_gemm(0, 1, Mv, N, K).  RE2E_EUNSUPPORTED when the shape is not one the LDS-DMA pipeline
- * takes (K, N, lda, ldb, ldc multiples of 4, 16-byte aligned operands, Mv >= 256): the caller runs re2e_gemm over all rows instead. */
+ * takes (K, N, lda, ldb, ldc multiples of 4, 16-byte aligned operands, Mv >= 256): the caller runs re2e_gemm over all rows instead.
+ * ident_rows (0 .. Mv, both entry points): the caller's promise that rowmap[r] == r for r < ident_rows (every utterance is at least that long:
+ * min(len) * B rows of a time-major batch) -- tiles / k-tiles below it skip the table; 0 is always correct. */
 int re2e_gemm_nt_rows(int Mv, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias,
-                      const float* bias2, int act, float beta, const int* rowmap, int phys_rows, void* workspace, size_t workspace_bytes,
-                      re2e_stream_t stream);
+                      const float* bias2, int act, float beta, const int* rowmap, int ident_rows, int phys_rows, void* workspace,
+                      size_t workspace_bytes, re2e_stream_t stream);
 /* The weight gradient over the same rows: C[M,N] = sum_{r < Kv} A[map[r]][:M]^T B[map[r]][:N] + beta C, A (dy) and B (x) padded
  * (phys_rows x ., lda / ldb).  Workspace as re2e_gemm(1, 0, M, N, Kv).  RE2E_EUNSUPPORTED unless both operands are 16-byte loadable. */
 int re2e_gemm_tn_rows(int M, int N, int Kv, const float* A, long lda, const float* B, long ldb, float* C, long ldc, float beta,
-                      const int* rowmap, int phys_rows, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+                      const int* rowmap, int ident_rows, int phys_rows, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 /* C[rows[i]][0 .. N) = value, i < nrows (N, ldc multiples of 4) */
 int re2e_fill_rows(float* C, long ldc, int N, const int* rows, int nrows, float value, re2e_stream_t stream);
 

@@ -155,7 +155,7 @@ int gemm_kslices(int M, int N, int K, int ns, const float* A, long lda, const fl
 size_t gemm_nt2_workspace_bytes(int M, int N, int K);
 int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,
              int act, float beta, const float* mul, float* mask_out, const int* lens, int T, void* ws, size_t wsb, hipStream_t st,
-             const int* rowmap = nullptr, int phys_rows = 0);
+             const int* rowmap = nullptr, int phys_rows = 0, int ident_rows = 0);
 int gemm_nt2_kslices(int M, int N, int Ks, int ns, const float* A, long lda, const float* B, long ldb, float* out, hipStream_t st, int nolog);
 size_t gemm_tn2_workspace_bytes(int M, int N, int K);      // the same kernel's dy^T x form (weight gradients)
 int gemm_tn2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,

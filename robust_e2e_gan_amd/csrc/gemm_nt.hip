@@ -61,6 +61,7 @@ struct NtArgs {
   // MODE 0, row map (re2e_gemm_nt_rows): logical row r of the product is physical row rowmap[r] of BOTH A and C (M counts logical rows; the
   // bounds a_bytes / ldc cover the physical tensors).  Time-major (T, B, .) activations of ragged batches: only the (t, b) with t < len_b.
   const int* rowmap;
+  int ident_rows;    // rowmap[r] == r for r < ident_rows (every utterance is at least that long): tiles below need no look-up
   int nomem;
   // MODE 2 (implicit-GEMM convolution; csrc/common.h ConvGeom semantics).  A = the NHWC image, M = pixels of ONE class, K = KH*KW*C.
   int cH, cW, cC, cPH, cPW, cKH, cKW, cSY, cSX, cDY, cDX;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
       if constexpr (!TNF) {
         int row = (isA ? m0 : n0) + prow_t[i];
         const bool ok = row < (isA ? p.M : p.N);
-        if constexpr (MODE == 0) { if (isA && ok && p.rowmap) row = p.rowmap[row]; }
+        if constexpr (MODE == 0) { if (isA && ok && p.rowmap && m0 + BM > p.ident_rows) row = p.rowmap[row]; }
         voff[i] = ok ? (unsigned)row * (unsigned)(isA ? p.lda : p.ldb) * 4u + pc16[i] : OOB;
         voff_t[i] = (ok && (int)pc16[i] < krem_bytes) ? voff[i] : OOB;
       } else {
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
       const unsigned vlane = ((unsigned)(TNF ? TM * lr : lr) * (unsigned)p.ldc + 4u * (unsigned)lh) * 4u;
       const bool interior = !CONV && m0 + BM <= p.M && n0 + BN <= p.N;
       unsigned vrow[TM];
-      const bool mapped = MODE == 0 && p.rowmap != nullptr;
+      const bool mapped = MODE == 0 && p.rowmap != nullptr && m0 + BM > p.ident_rows;       // (a tile of identity rows stores like an unmapped one)
       if constexpr (MODE == 0) {
         if (mapped) {
 #pragma unroll
@@ -768,7 +769,7 @@ int gemm_tn2(int, int, int, const float*, long, const float*, long, float*, long
 // rowmap / phys_rows (optional): M logical rows, row r = physical row rowmap[r] < phys_rows of A and of C (see NtArgs)
 int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,
              int act, float beta, const float* mul, float* mask_out, const int* lens, int T, void* ws, size_t wsb, hipStream_t st,
-             const int* rowmap, int phys_rows) {
+             const int* rowmap, int phys_rows, int ident_rows) {
   const int Mp = rowmap ? phys_rows : M;           // rows the bounds are taken over
   if (K % 4 || lda % 4 || ldb % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return 0;
   if (((long)(Mp - 1) * lda + K) * 4 >= 0x7FFFFFF0L || ((long)(N - 1) * ldb + K) * 4 >= 0x7FFFFFF0L) return 0;     // 31-bit offsets: OOB is bit 31
@@ -791,7 +792,7 @@ int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long
   a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias = bias; a.bias2 = bias2; a.act = act; a.beta = beta;
   a.ntm = pl.ntm; a.ntn = pl.ntn; a.n_dp = pl.n_dp; a.g_sk = pl.g_sk; a.nkt = pl.nkt;
-  a.rowmap = rowmap;
+  a.rowmap = rowmap; a.ident_rows = rowmap ? ident_rows : 0;
   static const bool nomem = exp_env("RE2E_IGEMM_NOMEM") != nullptr;
   a.nomem = nomem ? 1 : 0;
 
@@ -820,14 +821,14 @@ int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long
 // re2e_fill_rows puts zeros there where a consumer reads all rows.  RE2E_EUNSUPPORTED when the pipeline does not take the shape (the caller
 // then runs the product over all physical rows).
 extern "C" int re2e_gemm_nt_rows(int Mv, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias,
-                                 const float* bias2, int act, float beta, const int* rowmap, int phys_rows, void* workspace, size_t workspace_bytes,
-                                 hipStream_t stream) {
-  RE2E_CHECK_ARG(Mv > 0 && N > 0 && K > 0 && phys_rows >= Mv, "bad sizes");
+                                 const float* bias2, int act, float beta, const int* rowmap, int ident_rows, int phys_rows, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(Mv > 0 && N > 0 && K > 0 && phys_rows >= Mv && ident_rows >= 0 && ident_rows <= Mv, "bad sizes");
   RE2E_CHECK_ARG(A && B && C && rowmap, "null operand");
   RE2E_CHECK_ARG(beta == 0.f || beta == 1.f, "beta must be 0 or 1");
   RE2E_CHECK_ARG(act >= 0 && act < RE2E_ACT_SIGMOID_MASK_MUL, "bad activation");
   if (!gemm_nt2(Mv, N, K, A, lda, B, ldb, C, ldc, bias, bias2, act, beta, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes, stream, rowmap,
-                phys_rows)) {
+                phys_rows, ident_rows)) {
     re2e_set_error("re2e_gemm_nt_rows: shape not taken by the pipeline (Mv=%d N=%d K=%d)", Mv, N, K);
     return RE2E_EUNSUPPORTED;
   }

@@ -77,18 +77,20 @@ struct DenseMG {   // X[map[k]*ld + row]
   static constexpr const char* NAME = "DenseMG";
   static constexpr bool IS_CONVK = false;
   const float* p; unsigned nbytes; long ld; int rows, K; const int* map;
+  int ident;      // map[k] == k for k < ident (every utterance is at least that long): no look-up there
   struct Row { int r0; };
   struct Kst { int k; unsigned koff; int nxt; };
+  __device__ int phys(int k) const { return k < ident ? k : (k < K ? map[k] : 0); }
   __device__ void init_row(Row& r, int row0) const { r.r0 = row0; }
   __device__ void init_k(Kst& s, int k) const {
     s.k = k;
-    s.koff = k < K ? (unsigned)((long)map[k] * ld * 4) : 0u;
-    s.nxt = k + 16 < K ? map[k + 16] : 0;               // the engine's k-tile of these products is 16 (BKD)
+    s.koff = (unsigned)((long)phys(k) * ld * 4);
+    s.nxt = phys(k + 16);                               // the engine's k-tile of these products is 16 (BKD)
   }
   __device__ void advance(Kst& s, int bk) const {
     s.k += bk;
     s.koff = (unsigned)((long)s.nxt * ld * 4);
-    s.nxt = s.k + bk < K ? map[s.k + bk] : 0;
+    s.nxt = phys(s.k + bk);
   }
   __device__ unsigned off(const Row& r, const Kst& s, int j) const {
     return (s.k < K && r.r0 + j < rows) ? s.koff + (unsigned)(r.r0 + j) * 4u : nbytes;
@@ -1111,7 +1113,8 @@ extern "C" int re2e_gemm(int transa, int transb, int M, int N, int K, const floa
 // the rows of the map only (the padded rows of dy are zero: the sum is the same, 15 % shorter for a config-4 batch).  16-byte-loadable
 // operands only (RE2E_EUNSUPPORTED otherwise: the caller contracts over all rows).  Workspace as re2e_gemm(1, 0, M, N, Kv).
 extern "C" int re2e_gemm_tn_rows(int M, int N, int Kv, const float* A, long lda, const float* B, long ldb, float* C, long ldc, float beta,
-                                 const int* rowmap, int phys_rows, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                                 const int* rowmap, int ident_rows, int phys_rows, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  RE2E_CHECK_ARG(ident_rows >= 0 && ident_rows <= Kv, "ident_rows out of range");
   RE2E_CHECK_ARG(M > 0 && N > 0 && Kv > 0 && phys_rows >= Kv, "bad sizes");
   RE2E_CHECK_ARG(A && B && C && rowmap, "null operand");
   RE2E_CHECK_ARG(beta == 0.f || beta == 1.f, "beta must be 0 or 1");
@@ -1128,8 +1131,8 @@ extern "C" int re2e_gemm_tn_rows(int M, int N, int Kv, const float* A, long lda,
     RE2E_CHECK_ARG(workspace && workspace_bytes >= (size_t)s * M * N * sizeof(float), "workspace too small");
     ep.ws = (float*)workspace; ep.nsplit = s;
   }
-  DenseMG la{A, kbytes(phys_rows, lda, M), lda, M, Kv, rowmap};
-  DenseMG lb{B, kbytes(phys_rows, ldb, N), ldb, N, Kv, rowmap};
+  DenseMG la{A, kbytes(phys_rows, lda, M), lda, M, Kv, rowmap, ident_rows};
+  DenseMG lb{B, kbytes(phys_rows, ldb, N), ldb, N, Kv, rowmap, ident_rows};
   launch_big<DenseMG, DenseMG, true, true>(la, lb, ep, Kv, stream);
   if (s > 1) {
     const long tot = (long)M * N;

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
-ABI_VERSION = 316      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
+ABI_VERSION = 317      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
@@ -32,8 +32,8 @@ SIGNATURES = {
     're2e_stream_role': (I, [P, I]),
     're2e_gemm_workspace_bytes': (Z, [I, I, I, I, I]),
     're2e_gemm': (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, I, F, P, P, P, I, P, Z, P]),
-    're2e_gemm_nt_rows': (I, [I, I, I, P, L, P, L, P, L, P, P, I, F, P, I, P, Z, P]),
-    're2e_gemm_tn_rows': (I, [I, I, I, P, L, P, L, P, L, F, P, I, P, Z, P]),
+    're2e_gemm_nt_rows': (I, [I, I, I, P, L, P, L, P, L, P, P, I, F, P, I, I, P, Z, P]),
+    're2e_gemm_tn_rows': (I, [I, I, I, P, L, P, L, P, L, F, P, I, I, P, Z, P]),
     're2e_fill_rows': (I, [P, L, I, P, I, F, P]),
     're2e_conv_igemm': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, I, F, P]),
     're2e_conv3x3_relu_pool': (I, [P, I, I, I, I, P, I, P, P, P, P]),

@@ -77,15 +77,17 @@ def gemm_input_grad(dz, W, dx, M, K, N, beta=0.0):
 # per-lane offsets of the LDS-DMA pipeline.  RE2E_NO_ROW_MAPS=1 (experiments): all rows, as rounds 1-5 did.
 ROW_MAPS = lib.exp_env('RE2E_NO_ROW_MAPS') is None
 TN_ROW_MAPS = lib.exp_env('RE2E_NO_TN_ROW_MAPS') is None      # (experiments) the weight gradients over all rows
+ROW_IDENT = lib.exp_env('RE2E_NO_ROW_IDENT') is None           # (experiments) every tile looks its rows up
 ROW_MAPS_MIN_K = 384
 ROW_MAPS_MIN_PAD = 0.04      # below this share of padded rows the maps are not worth their per-tile lookups
 
 
 class RowMaps(object):
-    __slots__ = ('valid', 'invalid', 'nv', 'ni', 'rows')
+    """``ident``: valid[r] == r for r < ident (the first padded physical row: about min(len) * B of a time-major batch): tiles of those rows skip the table."""
+    __slots__ = ('valid', 'invalid', 'nv', 'ni', 'rows', 'ident')
 
-    def __init__(self, valid, invalid, nv, ni, rows):
-        self.valid, self.invalid, self.nv, self.ni, self.rows = valid, invalid, nv, ni, rows
+    def __init__(self, valid, invalid, nv, ni, rows, ident):
+        self.valid, self.invalid, self.nv, self.ni, self.rows, self.ident = valid, invalid, nv, ni, rows, ident
 
 
 _ROW_MAPS = {}
@@ -107,15 +109,18 @@ def row_maps(lens_d, T, B):
         ln = np.minimum(np.asarray(lens, np.int64), T)
         ok = (np.arange(T, dtype=np.int64)[:, None] < ln[None, :]).reshape(-1)
         idx = np.arange(T * B, dtype=np.int32)
-        hit = (idx[ok], idx[~ok])
+        v_ = idx[ok]
+        neq = np.nonzero(v_ != idx[:v_.size])[0]
+        hit = (v_, idx[~ok], int(neq[0]) if neq.size else int(v_.size))
         if len(_ROW_MAPS) >= 64:
             _ROW_MAPS.clear()
         _ROW_MAPS[key] = hit
-    v, iv = hit
+    v, iv, ident = hit
     if v.size < 256 or iv.size < ROW_MAPS_MIN_PAD * T * B:
         return None
     dev = lens_d.device
-    return RowMaps(ec.dev_cached(('rows_v',) + key, lambda: v, dev), ec.dev_cached(('rows_i',) + key, lambda: iv, dev), int(v.size), int(iv.size), T * B)
+    return RowMaps(ec.dev_cached(('rows_v',) + key, lambda: v, dev), ec.dev_cached(('rows_i',) + key, lambda: iv, dev), int(v.size), int(iv.size), T * B,
+                   ident if ROW_IDENT else 0)
 
 
 def gemm_rows(A, B, C, N, K, maps, lda=None, ldb=None, ldc=None, bias=None, bias2=None, act=lib.ACT_NONE, beta=0.0, fill=False):
@@ -132,7 +137,7 @@ def gemm_rows(A, B, C, N, K, maps, lda=None, ldb=None, ldc=None, bias=None, bias
     ws = workspace(wsb, A.device, 'gemm') if wsb else None
     _p = lambda t: t if isinstance(t, int) else t.data_ptr()
     if lib.call_supported('re2e_gemm_nt_rows', maps.nv, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, ptr(bias), ptr(bias2), act, float(beta),
-                          maps.valid.data_ptr(), maps.rows, ptr(ws), wsb):
+                          maps.valid.data_ptr(), maps.ident, maps.rows, ptr(ws), wsb):
         if fill and N % 4 == 0 and ldc % 4 == 0:
             call('re2e_fill_rows', _p(C), ldc, N, maps.invalid.data_ptr(), maps.ni, 0.0)
         return C
@@ -157,8 +162,8 @@ def gemm_tn_rows(A, B, C, M, N, maps, beta=0.0, lda=None, ldb=None, ldc=None):
     wsb = query('re2e_gemm_workspace_bytes', 1, 0, M, N, maps.nv)
     ws = workspace(wsb, A.device if not isinstance(A, int) else C.device, 'gemm') if wsb else None
     _p = lambda t: t if isinstance(t, int) else t.data_ptr()
-    if TN_ROW_MAPS and lib.call_supported('re2e_gemm_tn_rows', M, N, maps.nv, _p(A), lda, _p(B), ldb, _p(C), ldc, float(beta), maps.valid.data_ptr(), maps.rows,
-                          ptr(ws), wsb):
+    if TN_ROW_MAPS and lib.call_supported('re2e_gemm_tn_rows', M, N, maps.nv, _p(A), lda, _p(B), ldb, _p(C), ldc, float(beta), maps.valid.data_ptr(), maps.ident,
+                          maps.rows, ptr(ws), wsb):
         return C
     wsb = query('re2e_gemm_workspace_bytes', 1, 0, M, N, maps.rows)
     ws = workspace(wsb, C.device, 'gemm') if wsb else None

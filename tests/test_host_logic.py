@@ -253,7 +253,7 @@ def test_row_maps_and_vgg_row_limits_host_logic():
     valid = [t * B + b for t in range(T) for b in range(B) if t < lens[b]]
     pad = [t * B + b for t in range(T) for b in range(B) if t >= lens[b]]
     assert mp is not None and mp.nv == len(valid) == sum(lens) and mp.ni == len(pad) and mp.rows == T * B
-    assert mp.valid.tolist() == valid and mp.invalid.tolist() == pad
+    assert mp.valid.tolist() == valid and mp.invalid.tolist() == pad and mp.ident == pad[0]
     assert ops.row_maps(torch.tensor(lens, dtype=torch.int32), T, B) is None             # not a registered length tensor
     assert ops.row_maps(ld, T, B + 1) is None                                            # not this batch
     assert ops.row_maps(lens_dev([T] * B, 'cpu'), T, B) is None                          # nothing to skip
