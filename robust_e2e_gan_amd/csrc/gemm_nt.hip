@@ -777,7 +777,9 @@ int gemm_nt2(int M, int N, int K, const float* A, long lda, const float* B, long
   (void)mul; (void)mask_out; (void)lens; (void)T;
   if (N % 4 || ldc % 4 || (reinterpret_cast<uintptr_t>(C) & 15) || ((long)(Mp - 1) * ldc + N) * 4 >= 0x7FFFFFF0L) return 0;      // 16-byte stores of 4 output columns
   if ((bias && (reinterpret_cast<uintptr_t>(bias) & 15)) || (bias2 && (reinterpret_cast<uintptr_t>(bias2) & 15))) return 0;
-  const NtPlan pl = nt2_plan(M, N, K, re2e_stream_is_filler(st));
+  // (mapped products: the 4-wave tiles only -- their row counts are whatever the batch's lengths give, and on such counts the cost model's
+  //  256x128 choices miss: 21760 x 1024 x 512 ran 236 us on the 8-wave tile with a stream-K tail it priced at 196, 182 on 128x128 tiles)
+  const NtPlan pl = nt2_plan(M, N, K, re2e_stream_is_filler(st) || rowmap != nullptr);
   if (!pl.variant) return 0;
   NtArgs a;
   memset(&a, 0, sizeof(a));
