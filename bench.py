@@ -114,7 +114,7 @@ def engine_average():
     table (tools/igemm_table.py over a RE2E_NO_OVERLAP=1 rocprofv3 kernel trace of this script): (direct-equivalent, executed, source).
     Direct-equivalent counts a Winograd call with the FLOPs of the direct convolution it replaces; executed is what the matrix cores did."""
     import re
-    for n in ('r05_igemm_calls_nooverlap.txt', 'r04_igemm_calls_nooverlap.txt', 'r03_igemm_calls_nooverlap.txt'):
+    for n in ('r06_igemm_calls_nooverlap.txt', 'r05_igemm_calls_nooverlap.txt', 'r04_igemm_calls_nooverlap.txt', 'r03_igemm_calls_nooverlap.txt'):
         try:
             txt = open(os.path.join(ROOT, 'profiles', n)).read()
             m = re.search(r'total .*?([\d.]+) TFLOP/s average', txt)
@@ -157,7 +157,7 @@ def conv_roofline(dev, iters=20):
     ach = exe / sec_wino / 1e12
     # HBM-side bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
     # kernel and shape, tools/roofline_conv.py); a counter pass cannot run inside this process.
-    pj, tsrc = _profile_json(['r05_conv1_2_wino_pmc_traffic.json', 'r04_conv1_2_wino_pmc_traffic.json', 'r03_conv1_2_wino_pmc_traffic.json'])
+    pj, tsrc = _profile_json(['r06_conv1_2_wino_pmc_traffic.json', 'r05_conv1_2_wino_pmc_traffic.json', 'r04_conv1_2_wino_pmc_traffic.json', 'r03_conv1_2_wino_pmc_traffic.json'])
     pj2, tsrc2 = _profile_json(['r03_conv1_2_pmc_traffic.json', 'r02_conv1_2_pmc_traffic.json'])
     eng, eng_exe, esrc = engine_average()
     pk = PEAK_FP32_MFMA_TFLOPS
@@ -182,11 +182,18 @@ def conv_roofline(dev, iters=20):
             'engine_avg_direct_equivalent_tflops': eng, 'engine_avg_source': esrc,
             'engine_avg_note': 'per-call table of one single-stream step over every GEMM / convolution call; executed = matrix-core FLOPs, '
                                'direct-equivalent counts Winograd calls with the FLOPs of the direct convolution they replace',
-            # why frac cannot reach 1 for THIS kernel (a model from committed measurements, not timed in this run): vector-ALU instructions never run
-            # beside fp32 MFMAs on a SIMD (tools/micro/mfma_coissue.hip: every v_* costs the matrix stream 4-8 cycles), and the fused transforms /
-            # output stage of this kernel are 3.4 of them per MFMA (SQ counters)
-            'issue_model': {'valu_per_mfma': 3.4, 'cycles_per_mfma': 64, 'cycles_per_valu': 5.0, 'bound_frac': round(64.0 / (64.0 + 3.4 * 5.0), 3),
-                            'sources': ['profiles/r05_conv1_2_wino_pmc_sq.json', 'profiles/r05_mfma_coissue.txt', 'DESIGN.md 4.2']}}
+            # what the committed SQ counter passes of THIS kernel say (read from the file, nothing modelled): matrix-pipe utilisation in shader
+            # cycles, the clock the kernel really ran at (the 157.3 TFLOP/s peak assumes 2.4 GHz), vector instructions per MFMA
+            'counters': _wino_counters()}
+
+
+def _wino_counters():
+    pj, src = _profile_json(['r06_conv1_2_wino_pmc_sq.json', 'r05_conv1_2_wino_pmc_sq.json'])
+    if not pj:
+        return None
+    d = pj.get('derived', {})
+    return {'source': src, 'mfma_pipe_utilisation': d.get('mfma_pipe_utilisation'), 'vector_instructions_per_mfma': d.get('other_vector_instructions_per_mfma'),
+            'shader_clock_ghz': d.get('shader_clock_ghz'), 'wave_cycles_split': d.get('wave_cycles_split')}
 
 
 def engine_roofline(dev, iters=8):
@@ -686,6 +693,13 @@ def main():
         raise SystemExit('bench: %d recurrent sequences were aborted by a persistent kernel (rank %d)' % (aborts, rank))
     if not all(v == v and abs(v) != float('inf') for v in losses.values()):
         raise SystemExit('bench: non-finite losses after the timed region: %r' % (losses,))
+    # ONE more, untimed step under the host-side FLOP meter (robust_e2e_gan_amd/flops.py): the matrix-core FLOPs the launches of a step really
+    # execute -- valid rows of the ragged batch, row-limited Winograd heights, Winograd-reduced products -- and their direct-form equivalent
+    from robust_e2e_gan_amd import flops as rflops
+    with rflops.meter() as fmeter:
+        step()
+    torch.cuda.synchronize()
+    exe_flop, direct_flop = rflops.totals(fmeter)
     replicas_identical = None
     rccl_ranks = torch.distributed.get_world_size() if (world > 1 and torch.distributed.is_initialized()) else 1
     if world > 1:
@@ -720,6 +734,18 @@ def main():
         # whole-step fraction of the fp32-MFMA roofline: utterances/s x SURVEY 8(d) FLOP per utterance / (N x 157.3 TFLOP/s); the FLOP
         # count holds for the configuration's own (T, L) whatever the batch, so it is given for weak and strong scaling alike
         'step_mfma_frac': round(value * FLOP_PER_UTT[a.config] / (world * PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if (T, L) == CONFIG_SHAPES[a.config][1:] else None,
+        # ... and the honest twin of it (round 6): the FLOP count above prices every padded row of the (B, Tmax) box, while the step no longer
+        # computes them (products over the valid rows, row-limited VGG launches).  step_executed_* = matrix-core FLOPs of the launches one step
+        # of THIS rank really made (host-side meter over lib.call, robust_e2e_gan_amd/flops.py: valid rows, row-limited heights, Winograd-reduced
+        # products) over the measured step time; flop_per_utt_valid_rows = the direct-form equivalent of those launches per utterance (what
+        # SURVEY 8(d)'s figure becomes when padding is not counted); step_valid_rows_frac = utt/s x that / peak
+        'step_executed_tflop': round(exe_flop / 1e12, 4),
+        'step_executed_tflops': round(exe_flop / (dt / a.steps) / 1e12, 2),
+        'step_executed_frac': round(exe_flop / (dt / a.steps) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+        'flop_per_utt_valid_rows': round(direct_flop / max(local_b, 1) / 1e9, 2),
+        'flop_per_utt_valid_rows_unit': 'GFLOP (direct form, padded rows not counted; SURVEY 8(d) with padding: %.2f)' % (FLOP_PER_UTT[a.config] / 1e9),
+        'step_valid_rows_frac': round(direct_flop / (dt / a.steps) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+        'step_executed_by_entry_point_gflop': {k: round(v / 1e9, 1) for k, v in sorted(fmeter.items(), key=lambda kv: -kv[1]) if k != rflops.DIRECT},
         'default_shape': default_shape,
         'final_losses': {k: round(v, 5) for k, v in losses.items()}, 'persistent_kernel_aborts': aborts,
         'rccl_ranks': rccl_ranks, 'replicas_identical': replicas_identical, 'self_spawned': os.environ.get('RE2E_BENCH_SPAWNED') == '1',

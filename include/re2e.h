@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 317
+#define RE2E_ABI_VERSION 318
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -90,8 +90,10 @@ int re2e_gemm_nt_rows(int Mv, int N, int K, const float* A, long lda, const floa
  * (phys_rows x ., lda / ldb).  Workspace as re2e_gemm(1, 0, M, N, Kv).  RE2E_EUNSUPPORTED unless both operands are 16-byte loadable. */
 int re2e_gemm_tn_rows(int M, int N, int Kv, const float* A, long lda, const float* B, long ldb, float* C, long ldc, float beta,
                       const int* rowmap, int ident_rows, int phys_rows, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
-/* C[rows[i]][0 .. N) = value, i < nrows (N, ldc multiples of 4) */
-int re2e_fill_rows(float* C, long ldc, int N, const int* rows, int nrows, float value, re2e_stream_t stream);
+/* C[rows[i]][0 .. N) = row_vec ? act(row_vec[0 .. N)) : value, i < nrows (N, ldc multiples of 4; row_vec 16-byte aligned, act one of
+ * RE2E_ACT_NONE .. RE2E_ACT_SIGMOID).  With row_vec = the product's bias the padded rows hold what the reference's Linear + activation over
+ * zero-padded frames leaves there: tanh(bias), e2e_encoder.py:145-147,173-176. */
+int re2e_fill_rows(float* C, long ldc, int N, const int* rows, int nrows, float value, const float* row_vec, int act, re2e_stream_t stream);
 
 /* ---- K5/K9 convolution as implicit GEMM over NHWC (nn.Conv2d: e2e_encoder.py:234-237,
  * gan_model.py:63-90).  `wg` is the gathered weight [Cout][KH][KW][C] from

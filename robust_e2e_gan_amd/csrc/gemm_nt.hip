@@ -335,6 +335,16 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt2_kernel(NtArgs p
       const long t0 = (long)trel * nkt, t1 = t0 + nkt;
       const int g_first = (int)(((t0 + 1) * p.g_sk - 1) / U), g_last = (int)((t1 * p.g_sk - 1) / U);
       const int nparts = g_last - g_first + 1;
+      // Ordering of the hand-off (why the ticket can be a RELAXED agent-scope add, with no buffer_wbl2 / buffer_inv around it -- a write-back of
+      // the XCD's whole L2 per cut tile would cost more than the tail saves):
+      //   release side: every byte a finisher will read was written by an sc1 (write-through) store; the s_waitcnt vmcnt(0) above returns only
+      //     when those stores are acknowledged by the memory side, every wave of the workgroup has passed that wait before the barrier
+      //     releases lane 0, and only then is the add issued -- it cannot be observed before the data it announces;
+      //   acquire side: the finisher's slab reads are issued after the add has RETURNED (its value decides the branch they sit in) and are sc1
+      //     loads, served by the memory side, never by this XCD's L2 or a CU's vector cache: there is no stale copy they could hit;
+      //   the add itself executes at the memory side (agent scope), so the tickets of the parts of a tile are totally ordered.
+      // tests/test_kernels_gpu.py::test_gemm_nt_stream_k_tail_under_load and tools/stress_gemm_nt_tail.py (many parts per tile, a busy second
+      // stream, mapped rows) check sums and bitwise repeatability.
       if (tid == 0) {
         const int old = __hip_atomic_fetch_add(p.counters + trel, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         reinterpret_cast<volatile int*>(smem)[0] = old;
@@ -714,52 +724,7 @@ int gemm_nt2_kslices(int M, int N, int Ks, int ns, const float* A, long lda, con
 // sums on products with many parts per tile (tools/stress_gemm_nt_tail.py, profiles/r05_stress_streamk_tail.txt: every x W^T variant and the
 // 128x128 dy^T x form pass it, bitwise repeatable, 1-3 unit ranges per CU beside an unevenly loaded chip) -- not run down, removed.
 #ifdef RE2E_EXPERIMENTS
-size_t gemm_tn2_workspace_bytes(int M, int N, int K) {
-  if (!exp_env("RE2E_TN2")) return 0;
-  if (M % 4 || N % 4) return 0;
-  const size_t a = nt2_plan(M, N, K, false, true).bytes, b = nt2_plan(M, N, K, true, true).bytes;
-  return a > b ? a : b;
-}
-
-// C[M,N] = A[K,M]^T B[K,N] (+ beta C): the weight-gradient form.  Returns 1 when launched here, 0 when left to igemm.hip.
-int gemm_tn2(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const float* bias, const float* bias2,
-             int act, float beta, void* ws, size_t wsb, hipStream_t st) {
-  if (!exp_env("RE2E_TN2")) return 0;
-  if (M % 4 || N % 4 || lda % 4 || ldb % 4 || ldc % 4 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
-      (reinterpret_cast<uintptr_t>(C) & 15))
-    return 0;
-  if (((long)(K - 1) * lda + M) * 4 >= 0x7FFFFFF0L || ((long)(K - 1) * ldb + N) * 4 >= 0x7FFFFFF0L || ((long)(M - 1) * ldc + N) * 4 >= 0x7FFFFFF0L) return 0;
-  if (M < 64 || N < 64 || K < 256 || act == RE2E_ACT_SIGMOID_MASK_MUL) return 0;
-  if ((bias && (reinterpret_cast<uintptr_t>(bias) & 15)) || (bias2 && (reinterpret_cast<uintptr_t>(bias2) & 15))) return 0;
-  const NtPlan pl = nt2_plan(M, N, K, re2e_stream_is_filler(st), true);
-  if (!pl.variant) return 0;
-  NtArgs a;
-  memset(&a, 0, sizeof(a));
-  if (pl.g_sk) {
-    if (!ws || wsb < pl.bytes || (long)pl.ntm * pl.ntn - pl.n_dp > POOL_SLICE_INTS) return 0;
-    a.counters = ticket_slice();
-    if (!a.counters) return 0;
-    a.slabs = (float*)ws;
-  }
-  a.A = A; a.B = B; a.C = C;
-  a.a_bytes = (unsigned)(((long)(K - 1) * lda + M) * 4); a.b_bytes = (unsigned)(((long)(K - 1) * ldb + N) * 4);
-  a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
-  a.bias = bias; a.bias2 = bias2; a.act = act; a.beta = beta;
-  a.ntm = pl.ntm; a.ntn = pl.ntn; a.n_dp = pl.n_dp; a.g_sk = pl.g_sk; a.nkt = pl.nkt;
-  static const bool nomem = exp_env("RE2E_IGEMM_NOMEM") != nullptr;
-  a.nomem = nomem ? 1 : 0;
-
-  static const bool log_calls = getenv("RE2E_IGEMM_LOG") != nullptr;
-  if (log_calls)
-    fprintf(stderr, "[igemm] A=DenseM B=DenseM tile=%dx%dx%d vec=1 M=%d N=%d K=%d splits=%d\n", pl.bm, pl.bn, pl.bk, M, N, K, pl.g_sk ? -pl.g_sk : 1);
-  if (exp_env("RE2E_NT2_LOG")) fprintf(stderr, "[tn2] %dx%dx%d variant %d tiles %ld dp %d sk %d est %.1f us\n", M, N, K, pl.variant, (long)pl.ntm * pl.ntn, pl.n_dp, pl.g_sk, pl.est * 1e6);
-  switch (pl.variant) {
-    case 6: nt2_launch<T128x128k16s3, 1>(a, pl, st); break;
-    default: return 0;
-  }
-  return 1;
-}
-
+#include "experiments/gemm_tn2.hip"     // RE2E_TN2: the rejected dy^T x launcher, experiments build only
 #else
 size_t gemm_tn2_workspace_bytes(int, int, int) { return 0; }
 int gemm_tn2(int, int, int, const float*, long, const float*, long, float*, long, const float*, const float*, int, float, void*, size_t, hipStream_t) { return 0; }
@@ -839,21 +804,31 @@ extern "C" int re2e_gemm_nt_rows(int Mv, int N, int K, const float* A, long lda,
 }
 
 namespace {
-__global__ void fill_rows_kernel(float* __restrict__ C, long ldc, int N4, const int* __restrict__ rows, int nrows, float value) {
+__global__ void fill_rows_kernel(float* __restrict__ C, long ldc, int N4, const int* __restrict__ rows, int nrows, float value,
+                                 const float* __restrict__ row_vec, int act) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)nrows * N4) return;
   const int r = (int)(i / N4), c = (int)(i - (long)r * N4);
-  *reinterpret_cast<f32x4*>(C + (long)rows[r] * ldc + 4 * c) = f32x4{value, value, value, value};
+  f32x4 v = {value, value, value, value};
+  if (row_vec) {
+    // what x W^T + b with the activation leaves in a row whose x is zero: act(b) -- the same device function as the product's epilogue
+    const f32x4 b = *reinterpret_cast<const f32x4*>(row_vec + 4 * c);
+    v = f32x4{apply_act(b[0], act), apply_act(b[1], act), apply_act(b[2], act), apply_act(b[3], act)};
+  }
+  *reinterpret_cast<f32x4*>(C + (long)rows[r] * ldc + 4 * c) = v;
 }
 }  // namespace
 
-// C[rows[i]][0 .. N) = value for i < nrows (N % 4 == 0, 16-byte aligned rows): the padded rows of a ragged batch behind re2e_gemm_nt_rows
-extern "C" int re2e_fill_rows(float* C, long ldc, int N, const int* rows, int nrows, float value, hipStream_t stream) {
+// C[rows[i]][0 .. N) = row_vec ? act(row_vec[0 .. N)) : value  for i < nrows (N % 4 == 0, 16-byte aligned rows): the padded rows of a ragged batch
+// behind re2e_gemm_nt_rows.  With row_vec = the bias of the product they hold what the reference's Linear + activation over the zero-padded
+// frames leaves there (e2e_encoder.py:145-147,173-176: tanh(bias)).
+extern "C" int re2e_fill_rows(float* C, long ldc, int N, const int* rows, int nrows, float value, const float* row_vec, int act, hipStream_t stream) {
   RE2E_CHECK_ARG(C && (rows || nrows == 0) && nrows >= 0 && N > 0, "bad argument");
   RE2E_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0, "rows must be 16-byte aligned multiples of 4 floats");
+  RE2E_CHECK_ARG(!row_vec || ((reinterpret_cast<uintptr_t>(row_vec) & 15) == 0 && act >= 0 && act <= RE2E_ACT_SIGMOID), "row_vec must be 16-byte aligned, act a plain activation");
   if (nrows == 0) return RE2E_OK;
   const long tot = (long)nrows * (N / 4);
-  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, C, ldc, N / 4, rows, nrows, value);
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, C, ldc, N / 4, rows, nrows, value, row_vec, act);
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

@@ -75,6 +75,7 @@ struct DenseM {   // X[k*ld + row]
 struct DenseMG {   // X[map[k]*ld + row]
   static constexpr bool KMAJ = false;
   static constexpr const char* NAME = "DenseMG";
+  static constexpr int LOOKAHEAD = 16;   // init_k fetches the physical row LOOKAHEAD k-rows ahead: the kernel's k-tile must be exactly this (static_assert there)
   static constexpr bool IS_CONVK = false;
   const float* p; unsigned nbytes; long ld; int rows, K; const int* map;
   int ident;      // map[k] == k for k < ident (every utterance is at least that long): no look-up there
@@ -85,7 +86,7 @@ struct DenseMG {   // X[map[k]*ld + row]
   __device__ void init_k(Kst& s, int k) const {
     s.k = k;
     s.koff = (unsigned)((long)phys(k) * ld * 4);
-    s.nxt = phys(k + 16);                               // the engine's k-tile of these products is 16 (BKD)
+    s.nxt = phys(k + LOOKAHEAD);                        // = the k-tile advance() is called with
   }
   __device__ void advance(Kst& s, int bk) const {
     s.k += bk;
@@ -312,6 +313,8 @@ __global__ __launch_bounds__(CF::THREADS) void igemm_kernel(LA la, LB lb, Epi ep
   constexpr int AIT = BM * KQ / TH, BIT = BN * KQ / TH;
   static_assert(AIT >= 1 && BIT >= 1 && (BM * KQ) % TH == 0 && (BN * KQ) % TH == 0, "tile / thread-count mismatch");
   static_assert(TH % KQ == 0 && TH % BK == 0, "per-thread k state must be item-invariant");
+  static_assert((!std::is_same<LA, DenseMG>::value && !std::is_same<LB, DenseMG>::value) || BK == DenseMG::LOOKAHEAD,
+                "DenseMG prefetches the physical row of the next k-tile: the tile must advance by DenseMG::LOOKAHEAD");
   static_assert(AKL || TH % (BM / 4) == 0, "per-thread row state of a row-major A tile must be item-invariant");
   static_assert(BKL || TH % (BN / 4) == 0, "per-thread row state of a row-major B tile must be item-invariant");
   constexpr int NRA = AKL ? AIT : 1, NKA = AKL ? 1 : AIT;               // k-major staging: per-item rows + ONE k state per thread
@@ -720,7 +723,9 @@ template <class LA, class LB, bool V, bool WIDE>
 void launch_big(const LA& la, const LB& lb, Epi& ep, int K, hipStream_t st) {
   if constexpr (V) {
     int v = igemm_variant();
-    if (v == 1 && !std::is_same<LA, DenseMG>::value) { launch_igemm<LA, LB, C128b, V>(la, lb, ep, K, st); return; }      // (DenseMG looks 16 k-rows ahead)
+    if constexpr (!std::is_same<LA, DenseMG>::value && !std::is_same<LB, DenseMG>::value) {      // (DenseMG looks one 16-row k-tile ahead: BK 16 only)
+      if (v == 1) { launch_igemm<LA, LB, C128b, V>(la, lb, ep, K, st); return; }
+    }
     bool wide = v == 2 ? true : (v == 3 ? false : (WIDE && ep.M >= 2048 && wide_allowed(st)));
     if (wide) { launch_igemm<LA, LB, C256x128, V>(la, lb, ep, K, st); return; }
   }

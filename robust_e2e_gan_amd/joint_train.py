@@ -5,6 +5,7 @@
 order of operations (Appendix A.12-14): freeze toggling, clip on the ASR net only, NaN guard
 gating both G optimizers, D clipped separately.  Every rank runs it on its own utterance shard;
 gradients are averaged by dist.GradSync (RCCL) before clipping."""
+import copy
 import logging
 import math
 import os
@@ -21,6 +22,28 @@ from .model.gan_model import CORAL, GANLoss, replay_running_stats
 from .optim import FlatOptimizer
 
 _LOSS_KIND = {'L2': lib.LOSS_L2, 'L1': lib.LOSS_L1, 'smooth_L1': lib.LOSS_SMOOTH_L1}
+
+
+class stepwise_kernels(object):
+    """``with stepwise_kernels():`` the launch-per-step recurrences and the launch-per-token decoder loop instead of the persistent kernels --
+    same arithmetic, no in-launch hand-off that can time out (what a step / pass is repeated with after a persistent kernel gave up)."""
+    _KEYS = ('RE2E_LSTM_PERSIST', 'RE2E_LSTM_PERSIST_BWD')
+
+    def __enter__(self):
+        self.saved = {k: os.environ.get(k) for k in self._KEYS}
+        for k in self._KEYS:
+            os.environ[k] = '0'
+        self.dec, ops.DECODER_PERSIST = ops.DECODER_PERSIST, False        # (csrc/decloop.hip counts its give-ups with the recurrences')
+        return self
+
+    def __exit__(self, *exc):
+        ops.DECODER_PERSIST = self.dec
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False
 
 
 def compute_cmvn_epoch(opt, train_loader, enhance_model, feat_model):
@@ -423,6 +446,38 @@ class JointTrainer(object):
         base, holds, delta = self._gate
         lib.call('re2e_step_gate', base.data_ptr(), 1, None, None, None, None, holds[self._step_no % 2].data_ptr(), delta.data_ptr())
 
+    def _giveups_since_ack(self):
+        """Give-ups of persistent kernels on THIS device since the last acknowledgement, read through the gate (no acknowledgement, nothing
+        refused): for work that has no step gate of its own -- the validation pass, the CMVN estimate.  Synchronises with the device."""
+        self._hold_factor()
+        base = self._gate[0]
+        out = torch.zeros(1, dtype=torch.float32, device=base.device)
+        lib.call('re2e_step_gate', base.data_ptr(), 0, None, None, None, None, None, out.data_ptr())
+        return int(out.item())
+
+    guarded_repeats = 0
+
+    def run_guarded(self, fn, snapshot, restore, what):
+        """Non-training work runs the same persistent recurrences / decoder loop as a step but behind no step gate: ``fn()`` is run, the
+        replicas agree (collective) whether a persistent kernel gave up in it on ANY of them, and if so every replica puts ``snapshot()``'s state
+        back (``restore``), acknowledges and runs ``fn`` again with the launch-per-step kernels -- before the next training step is enqueued, whose
+        gate would otherwise refuse its update on the one replica that counted the give-up and let the others apply it.  Raises on every
+        replica if the repeated pass gives up as well."""
+        self._hold_factor()          # (the gate's first use acknowledges what earlier users of the process left: before fn, not after)
+        snap = snapshot()
+        res = fn()
+        if rdist.any_rank(self._giveups_since_ack()) == 0:
+            return res
+        logging.warning('a persistent kernel gave up on a peer workgroup during %s: repeated with the launch-per-step kernels', what)
+        self.guarded_repeats += 1
+        restore(snap)
+        self._acknowledge_aborts()
+        with stepwise_kernels():
+            res = fn()
+        if rdist.any_rank(self._giveups_since_ack()):
+            raise lib.Re2eError('%s gave up with the launch-per-step kernels as well' % what)
+        return res
+
     def _d_real(self, clean_feat, enhance_cmvn, hold=None):
         """Real half of the discriminator update on the CURRENT stream, ahead of the G-step: forward of D(clean) with the
         BatchNorm running-statistics update deferred (upstream applies it AFTER the G-step's D(fake) pass; ``_d_step``
@@ -530,7 +585,15 @@ class JointTrainer(object):
             from .data.prefetch import DevicePrefetcher, collate_device_pinned
             return DevicePrefetcher(train_loader, next(self.enhance_model.parameters()).device,
                                     collate=prefetch if callable(prefetch) else collate_device_pinned)
-        enhance_cmvn = compute_cmvn_epoch(opt, loader(), self.enhance_model, self.feat_model)
+        fm = self.feat_model
+        cmvn_keys = ('sum', 'sum_sq', 'frame_count', 'cmvn_processed_num')
+
+        def cmvn_estimate():
+            # (compute_cmvn's host-side accumulators are never reset upstream: a repeated pass starts from the values this one found)
+            return self.run_guarded(lambda: compute_cmvn_epoch(opt, loader(), self.enhance_model, fm),
+                                    lambda: {k: copy.deepcopy(getattr(fm, k)) for k in cmvn_keys if hasattr(fm, k)},
+                                    lambda snap: [setattr(fm, k, v) for k, v in snap.items()], 'the CMVN estimate')
+        enhance_cmvn = cmvn_estimate()
         rampup = utils.ScheSampleRampup(opt.sche_samp_start_iter, opt.sche_samp_final_iter, opt.sche_samp_final_rate)
         sche_samp_rate = rampup.update(iters)
         acc_report = loss_report = None
@@ -564,8 +627,9 @@ class JointTrainer(object):
 
         def check_recurrences():
             # a persistent kernel that gave up on a peer workgroup poisons its outputs with NaN and the step gate refuses the update;
-            # flush() repeats such a step.  What is left to check here is a give-up that the gate counted in a step whose norm was finite
-            # all the same (collective: all replicas fail together).
+            # flush() repeats such a step; the validation pass and the CMVN estimate, which have no gate, check the device counter themselves
+            # (run_guarded).  What is left to check here is a give-up that the gate counted in a step whose norm was finite all the same
+            # (collective: all replicas fail together).
             n = rdist.any_rank(self.unexplained_aborts)
             if n != 0:
                 raise lib.Re2eError('%d recurrent sequences were aborted by a persistent kernel (a peer workgroup never arrived) in a step whose '
@@ -599,19 +663,31 @@ class JointTrainer(object):
                 if iters % opt.validate_freq == 0:
                     flush()
                     sche_samp_rate = rampup.update(iters)
+                    def validation_pass():
+                        got, saved = [], 0
+                        for vdata in val_loader:
+                            want = opt.num_save_attention > 0 and opt.mtlalpha != 1.0 and saved < opt.num_save_attention
+                            verr = self.validate(vdata, enhance_cmvn, want_attention=want)
+                            got.append((vdata, self.to_floats(verr), verr.get('att_ws') if want else None))
+                            if want:
+                                saved += len(vdata[0]) if vdata[0] is not None else verr['att_ws'].shape[0]
+                        return got
+                    # (the meters and plots reach the visualizer only when no persistent kernel gave up in the pass on any replica: NaN validation
+                    #  scores would otherwise enter best_loss / best_acc and the model selection below.  D's BatchNorm buffers move in validation,
+                    #  as upstream: a repeated pass starts from their values before the first one.)
+                    results = self.run_guarded(validation_pass, self._bn_snapshot,
+                                               lambda snap: [b.copy_(s_) for b, s_ in zip(self.gan_model.buffers(), snap)] if self.isGAN else None,
+                                               'the validation pass')
                     saved = 0
-                    for vdata in val_loader:
-                        want = opt.num_save_attention > 0 and opt.mtlalpha != 1.0 and saved < opt.num_save_attention
-                        verr = self.validate(vdata, enhance_cmvn, want_attention=want)
-                        visualizer.set_current_errors(self.to_floats(verr))
-                        if want:
-                            for x in range(len(vdata[0]) if vdata[0] is not None else verr['att_ws'].shape[0]):
-                                name = vdata[0][x] if vdata[0] is not None else 'utt%d' % x
-                                visualizer.plot_attention(verr['att_ws'][x], int(vdata[9][x]), int(vdata[8][x]),
-                                                          '{}_ep{}_it{}.png'.format(name, epoch, iters))
-                                saved += 1
+                    for vdata, vfloats, att_ws in results:
+                        visualizer.set_current_errors(vfloats)
+                        if att_ws is not None:
+                            for x in range(len(vdata[0]) if vdata[0] is not None else att_ws.shape[0]):
                                 if saved >= opt.num_save_attention:
                                     break
+                                name = vdata[0][x] if vdata[0] is not None else 'utt%d' % x
+                                visualizer.plot_attention(att_ws[x], int(vdata[9][x]), int(vdata[8][x]), '{}_ep{}_it{}.png'.format(name, epoch, iters))
+                                saved += 1
                     visualizer.print_epoch_errors(epoch, iters)
                     acc_report = visualizer.plot_epoch_errors(epoch, iters, 'acc.png')
                     loss_report = visualizer.plot_epoch_errors(epoch, iters, 'loss.png')
@@ -637,7 +713,7 @@ class JointTrainer(object):
                         st.update(acc_report=acc_report, loss_report=loss_report)
                         utils.save_checkpoint(st, opt.exp_path, filename=filename)
                     visualizer.reset()
-                    enhance_cmvn = compute_cmvn_epoch(opt, loader(), self.enhance_model, self.feat_model)
+                    enhance_cmvn = cmvn_estimate()
                 if max_iters is not None and iters >= max_iters:
                     flush()
                     return iters, best_loss, best_acc
@@ -688,18 +764,8 @@ class JointTrainer(object):
                 b.copy_(s)
         self._uncount_step()
         self._acknowledge_aborts()
-        saved = {k: os.environ.get(k) for k in ('RE2E_LSTM_PERSIST', 'RE2E_LSTM_PERSIST_BWD')}
-        os.environ['RE2E_LSTM_PERSIST'] = os.environ['RE2E_LSTM_PERSIST_BWD'] = '0'
-        dec_persist, ops.DECODER_PERSIST = ops.DECODER_PERSIST, False        # ... and the launch-per-token decoder loop (csrc/decloop.hip counts with them)
-        try:
+        with stepwise_kernels():
             vals = self.to_floats({k: v for k, v in self.step(data, rate, cmvn).items() if k.startswith('train/') or k in ('grad_norm', 'aborts')})
-        finally:
-            ops.DECODER_PERSIST = dec_persist
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
         gn, again = vals.pop('grad_norm', 0.0), int(vals.pop('aborts', 0.0))
         if rdist.any_rank(1 if (again or not math.isfinite(gn)) else 0):
             raise lib.Re2eError('a step that a persistent kernel had aborted is not finite with the launch-per-step kernels either (grad norm %r)' % gn)

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
-ABI_VERSION = 317      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
+ABI_VERSION = 318      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
@@ -34,7 +34,7 @@ SIGNATURES = {
     're2e_gemm': (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, I, F, P, P, P, I, P, Z, P]),
     're2e_gemm_nt_rows': (I, [I, I, I, P, L, P, L, P, L, P, P, I, F, P, I, I, P, Z, P]),
     're2e_gemm_tn_rows': (I, [I, I, I, P, L, P, L, P, L, F, P, I, I, P, Z, P]),
-    're2e_fill_rows': (I, [P, L, I, P, I, F, P]),
+    're2e_fill_rows': (I, [P, L, I, P, I, F, P, I, P]),
     're2e_conv_igemm': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, I, F, P]),
     're2e_conv3x3_relu_pool': (I, [P, I, I, I, I, P, I, P, P, P, P]),
     're2e_conv_igemm_masked': (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, P, I, I, I, I, I, I, P, P]),
@@ -190,12 +190,18 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+FLOP_METER = None        # a dict while robust_e2e_gan_amd.flops.meter() is active: executed matrix-core FLOPs per entry point (bench.py)
+
+
 def call(name, *args):
     """Invoke ``name`` on the current torch stream; raises Re2eError(re2e_last_error()) on failure."""
     lib = load()
     rc = getattr(lib, name)(*args, stream())
     if rc != 0:
         raise Re2eError('%s failed (%d): %s' % (name, rc, lib.re2e_last_error().decode()))
+    if FLOP_METER is not None:
+        from . import flops
+        flops.count(name, args)
 
 
 def call_supported(name, *args):
@@ -206,6 +212,9 @@ def call_supported(name, *args):
         return False
     if rc != 0:
         raise Re2eError('%s failed (%d): %s' % (name, rc, lib.re2e_last_error().decode()))
+    if FLOP_METER is not None:
+        from . import flops
+        flops.count(name, args)
     return True
 
 

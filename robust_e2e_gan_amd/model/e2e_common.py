@@ -1,4 +1,5 @@
 """Helpers that fix padding / init / freezing semantics (mirror of model/e2e_common.py)."""
+import collections
 import math
 import weakref
 
@@ -70,7 +71,8 @@ def host_to_dev(values, device, dtype=torch.int32):
     return t.pin_memory().to(device, non_blocking=True)
 
 
-_LENS_CACHE = {}
+_LENS_CACHE = collections.OrderedDict()     # least recently used first: a step touches ~25 entries, so nothing a step in flight uses is ever evicted
+_LENS_CACHE_MAX = 256
 LENS_HOST = {}        # data_ptr of a cached length tensor -> the host tuple it was made from (ops.row_maps: the valid rows of a ragged batch)
 
 
@@ -82,9 +84,14 @@ def dev_cached(key, make, device):
     ent = _LENS_CACHE.get(key)
     cuda = torch.device(device).type == 'cuda'
     if ent is None:
-        if len(_LENS_CACHE) >= 256:
-            _LENS_CACHE.clear()
-            LENS_HOST.clear()
+        if len(_LENS_CACHE) >= _LENS_CACHE_MAX:
+            # evict the least recently used quarter (never everything: the length tensors of the step being enqueued must keep their host
+            # tuples -- ops.row_maps would silently fall back to all rows for the rest of the step -- and the tensors of steps still in flight
+            # stay referenced by their autograd graphs; users on other streams have told the allocator, ``record_stream`` below / ops._touch)
+            for _ in range(_LENS_CACHE_MAX // 4):
+                _LENS_CACHE.popitem(last=False)
+            for k_ in [k_ for k_, (_, ref) in LENS_HOST.items() if ref() is None]:
+                del LENS_HOST[k_]
         t = host_to_dev(np.asarray(make(), np.int32), device)
         if cuda:
             ev = torch.cuda.Event()
@@ -94,6 +101,7 @@ def dev_cached(key, make, device):
             ent = (t, None, None, set())
         _LENS_CACHE[key] = ent
         return t
+    _LENS_CACHE.move_to_end(key)
     t, ev, sid, seen = ent
     if cuda:
         cur = torch.cuda.current_stream()

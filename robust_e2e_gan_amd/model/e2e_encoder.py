@@ -38,8 +38,8 @@ class BLSTM(torch.nn.Module):
             # tensor is the same arithmetic on the valid frames.
             if self.dropout and self.training and l + 1 < self.elayers:
                 x_tm = ops.dropout(x_tm, self.dropout)
-        # (upstream applies it to the padded rows too, :173-176: tanh(bias) there, which nothing downstream reads -- the mask layer and the
-        #  attention select by length -- here the product runs over the valid rows and the padded ones are 0)
+        # (upstream applies it to the padded rows too, :173-176: tanh(bias) there -- here the product runs over the valid rows and the padded
+        #  ones get tanh(bias) written, ops.gemm_rows fill)
         return ops.linear(x_tm, self.l_last.weight, self.l_last.bias, 'tanh', maps=ops.row_maps(lens_d, x_tm.shape[0], x_tm.shape[1]))
 
     def forward(self, xpad, ilens):
@@ -88,7 +88,7 @@ class BLSTMP(torch.nn.Module):
                 cur = [i // sub for i in cur]
                 lens_d = lens_dev(cur, y.device)
             bt = getattr(self, 'bt%d' % l)
-            # (upstream applies it to the padded rows too, :145-147: tanh(bias) there, which nothing downstream reads -- here those rows are 0)
+            # (upstream applies it to the padded rows too, :145-147: tanh(bias) there -- the mapped product writes the same, ops.gemm_rows fill)
             x_tm = ops.linear(y, bt.weight, bt.bias, 'tanh', maps=ops.row_maps(lens_d, y.shape[0], y.shape[1]))
         return (x_tm, cur) if lens is not None else x_tm
 

@@ -112,8 +112,8 @@ def row_maps(lens_d, T, B):
         v_ = idx[ok]
         neq = np.nonzero(v_ != idx[:v_.size])[0]
         hit = (v_, idx[~ok], int(neq[0]) if neq.size else int(v_.size))
-        if len(_ROW_MAPS) >= 64:
-            _ROW_MAPS.clear()
+        while len(_ROW_MAPS) >= 64:
+            _ROW_MAPS.pop(next(iter(_ROW_MAPS)))          # oldest first (dicts keep insertion order)
         _ROW_MAPS[key] = hit
     v, iv, ident = hit
     if v.size < 256 or iv.size < ROW_MAPS_MIN_PAD * T * B:
@@ -124,8 +124,12 @@ def row_maps(lens_d, T, B):
 
 
 def gemm_rows(A, B, C, N, K, maps, lda=None, ldb=None, ldc=None, bias=None, bias2=None, act=lib.ACT_NONE, beta=0.0, fill=False):
-    """C[r] = act(A[r] B^T + bias + bias2) + beta C[r] over the rows r of ``maps.valid`` (B stored (N, K): x W^T); ``fill``: zeros in the other
-    rows of C (only with beta = 0).  Falls back to the product over all rows when the pipeline declines the shape."""
+    """C[r] = act(A[r] B^T + bias + bias2) + beta C[r] over the rows r of ``maps.valid`` (B stored (N, K): x W^T); ``fill``: the other rows of C
+    get what the product over a zero row of A leaves there -- act(bias), zeros without a bias (only with beta = 0, at most one bias): upstream's
+    Linear + tanh over the zero-padded frames (e2e_encoder.py:145-147,173-176).  Falls back to the product over all rows when the pipeline
+    declines the shape."""
+    if fill and bias2 is not None:
+        raise lib.Re2eError('gemm_rows(fill=True) takes one bias')
     lda = lda if lda is not None else K
     ldb = ldb if ldb is not None else K
     ldc = ldc if ldc is not None else N
@@ -139,7 +143,7 @@ def gemm_rows(A, B, C, N, K, maps, lda=None, ldb=None, ldc=None, bias=None, bias
     if lib.call_supported('re2e_gemm_nt_rows', maps.nv, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, ptr(bias), ptr(bias2), act, float(beta),
                           maps.valid.data_ptr(), maps.ident, maps.rows, ptr(ws), wsb):
         if fill and N % 4 == 0 and ldc % 4 == 0:
-            call('re2e_fill_rows', _p(C), ldc, N, maps.invalid.data_ptr(), maps.ni, 0.0)
+            call('re2e_fill_rows', _p(C), ldc, N, maps.invalid.data_ptr(), maps.ni, 0.0, ptr(bias), act if bias is not None else lib.ACT_NONE)
         return C
     return gemm(A, B, C, maps.rows, N, K, transb=True, lda=lda, ldb=ldb, ldc=ldc, bias=bias, bias2=bias2, act=act, beta=beta)
 
@@ -239,8 +243,15 @@ class param_grads(object):
         ev.record(cur)
         ws.wait_event(ev)
         for t in self.ts:
-            if t is not None:
+            if isinstance(t, torch.Tensor):
                 t.record_stream(ws)
+            elif t is not None:
+                # RowMaps / RowLims: small cached index tensors (model.e2e_common.dev_cached) that the weight-gradient kernels read on THIS
+                # stream -- the cache may evict them while such a kernel is still queued
+                for name in t.__slots__:
+                    v = getattr(t, name)
+                    if isinstance(v, torch.Tensor):
+                        v.record_stream(ws)
         self.ctx = torch.cuda.stream(ws)
         self.ctx.__enter__()
         return self
@@ -347,8 +358,8 @@ class LinearFn(torch.autograd.Function):
         N = W.shape[0]
         y = empty((M, N), x)
         if maps is not None and maps.rows == M and W.is_contiguous() and N % 4 == 0:
-            # ragged time-major rows: the valid (t, b) only, zeros in the padded rows (upstream they hold act(b), which nothing reads:
-            # the next recurrence packs them away, attention and CTC mask them)
+            # ragged time-major rows: the product over the valid (t, b) only; the padded rows get act(b) written -- what upstream's Linear over
+            # the zero-padded frames leaves there (nothing downstream reads them: the next recurrence packs them away, attention and CTC mask them)
             gemm_rows(x2, W, y, N, K, maps, bias=b, act=act, fill=True)
         else:
             maps = None
@@ -382,7 +393,7 @@ class LinearFn(torch.autograd.Function):
             else:
                 gemm_input_grad(dz, W, dx, M, K, N)            # dx = dz[M,N] * W[N,K]
             dx = dx.view(ctx.xshape)
-        with param_grads(dz, x2):
+        with param_grads(dz, x2, ctx.maps):
             if need_w:
                 with accumulate(W) as (gw, beta):
                     if ctx.maps is not None:
@@ -671,6 +682,16 @@ def fill_image_rows(t, lim, div, max_tail):
         call('re2e_fill_image_rows', t.data_ptr(), N, H, t.shape[2] * t.shape[3], lim.data_ptr(), div, int(max_tail), 0.0)
 
 
+def _note_row_limits(row_lim):
+    """bench.py's executed-FLOP meter (flops.py) counts a row-limited launch with the rows below its limits: the host copy of the limits."""
+    if row_lim is not None and lib.FLOP_METER is not None:
+        from . import flops
+        from .model import e2e_common as ec
+        host = ec.host_lens_of(row_lim)
+        if host is not None:
+            flops.note_rows(row_lim.data_ptr(), host)
+
+
 def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool=False, row_lim=None):
     """re2e_conv3x3_wino on NHWC ``x`` with the layer's weight ``W`` in PyTorch layout: forward (dgrad=False: bias / ReLU / fused
     2x2 max pool -> (pooled, index bytes)) or data gradient (dgrad=True: ``x`` is dy; ``mask``: the ReLU output in front).  Tensors of
@@ -679,6 +700,7 @@ def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool
     wsb = query('re2e_conv3x3_wino_workspace_bytes', C, Cout)
     ws = workspace(wsb, x.device, 'wino')
     nb = _wino_images(N, H, Wd, C, Cout)
+    _note_row_limits(row_lim)
     if pool:
         yp = empty((N, (H + 1) // 2, (Wd + 1) // 2, Cout), x)
         idx = torch.empty(yp.shape, dtype=torch.uint8, device=x.device)
@@ -804,13 +826,14 @@ class Conv2dFn(torch.autograd.Function):
             dx = conv_dgrad(dz, W, (N, H, Wd, Cin), stride, pad, relu_out=x if ctx.x_is_relu_out else None, row_lim=lims.inp if lims is not None else None)
             if lims is not None and lims.inp is not None:
                 fill_image_rows(dx, lims.inp, 1, lims.inp_tail)         # the gradient is zero there: written, not computed
-        with param_grads(dz, x):
+        with param_grads(dz, x, lims):
             if need_w and WINO_WGRAD and _wino_ok(N, H, Wd, Cin, Cout, (KH, KW), stride, pad) and Cin % 64 == 0 and x.is_contiguous() \
                     and dz.is_contiguous():
                 # 3x3 / stride-1 VGG layers: the sum over pixels in the Winograd domain (re2e_conv3x3_wino_wgrad), 2.25x fewer matrix FLOPs
                 nb = _wino_images(N, H, Wd, Cin, Cout)                # tensors of 2 GiB or more: slices of the image axis, accumulated
                 wsb = query('re2e_conv3x3_wino_wgrad_workspace_bytes', nb, H, Wd, Cin, Cout)
                 ws = workspace(wsb, x.device, 'winow')
+                _note_row_limits(lims.out if lims is not None else None)
                 with accumulate(W) as (gw, beta):
                     for i in range(0, N, nb):
                         n = min(nb, N - i)
@@ -1326,7 +1349,7 @@ class BiLstmFn(torch.autograd.Function):
         needs = ctx.needs_input_grad
 
         def weight_grads(inline):
-            with param_grads(g_f, g_r, x2, ybuf, inline=inline):
+            with param_grads(g_f, g_r, x2, ybuf, ctx.maps, inline=inline):
                 for d in range(2):
                     w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
                     n_ih, n_hh, n_bi, n_bh = needs[2 + 4 * d:6 + 4 * d]

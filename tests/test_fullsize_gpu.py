@@ -2,6 +2,7 @@
 small batch, (b) size-independent properties at BASELINE.json's full config-4 size, (c) the long-utterance
 shape of config 5."""
 import math
+import os
 
 import pytest
 import torch
@@ -127,6 +128,9 @@ def test_config4_full_size_properties():
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), 'updated parameters must be bitwise reproducible'
 
 
+WORST_GRADS = []      # (ratio, tensor) of every gradient comparison of this file: printed with RE2E_PRINT_WORST=1 (margins of the 1.5e-3 bar)
+
+
 def _grad_report(named_params, ref_grads, tol, floor=1e-8):
     bad = []
     for k, p in named_params:
@@ -134,8 +138,11 @@ def _grad_report(named_params, ref_grads, tol, floor=1e-8):
             continue
         want = ref_grads[k]
         err, scale = float((p.grad.cpu() - want).abs().max()), float(want.abs().max())
+        WORST_GRADS.append((err / max(scale, 1e-30), k))
         if err > tol * scale + floor:
             bad.append((k, err / max(scale, 1e-30)))
+    if os.environ.get('RE2E_PRINT_WORST'):
+        print('WORST full-size gradient ratios:', sorted(WORST_GRADS, reverse=True)[:6])
     return bad
 
 
@@ -144,8 +151,8 @@ def test_config4_full_size_vs_oracle():
     against oracle.joint.joint_step on the same batch, weights and cmvn (~80 s of host time).  800-step fp32
     recurrences, the 2B=64 shared BLSTMP and the 41-step decoder are where accumulation error grows; north_star's bar is
     1e-3 on losses and masks.  Gradients: every parameter tensor of the three nets, relative to the tensor's max, within
-    2e-3 (two independent fp32 roundings of the same quantity, each up to ~1e-3 from the exact value at this depth: see
-    test_fp32_sides_within_1e3_of_fp64 for the arbitration at a size where float64 is affordable)."""
+    1.5e-3 (round 6: down from 2e-3, the bar of every other gradient comparison in tests/; two independent fp32 roundings of the
+    same quantity: see test_config4_architecture_fp64_arbitration for the arbitration at a size where float64 is affordable)."""
     from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
     from oracle import joint as oj
     opt = config4_opt()
@@ -172,8 +179,8 @@ def test_config4_full_size_vs_oracle():
     eo, ef = tr.last['enhance_out'].cpu(), tr.last['enhance_feat'].cpu()
     assert (eo - ref['enhance_out']).abs().max() <= 1e-3 * ref['enhance_out'].abs().max()      # the masks (x mix)
     assert (ef - ref['enhance_feat']).abs().max() <= 1e-3 * ref['enhance_feat'].abs().max()
-    bad = _grad_report(asr.named_parameters(), ref['g_asr'], 2e-3) + _grad_report(enh.named_parameters(), ref['g_enh'], 2e-3) + \
-        _grad_report(gan.named_parameters(), ref['g_gan'], 2e-3)
+    bad = _grad_report(asr.named_parameters(), ref['g_asr'], 1.5e-3) + _grad_report(enh.named_parameters(), ref['g_enh'], 1.5e-3) + \
+        _grad_report(gan.named_parameters(), ref['g_gan'], 1.5e-3)
     assert not bad, sorted(bad, key=lambda r: -r[1])[:8]
 
 
@@ -206,7 +213,7 @@ def test_config5_full_step_vs_oracle():
     """NUMERICAL parity of the WHOLE step at config 5's per-GPU shape (B=8, T=3000, L=150, V=4233, full-width networks): the
     3000-step enhancer BPTT, the T'=750 BLSTMP and the 151-step decoder against oracle.joint.joint_step on the same batch,
     weights and cmvn (minutes of host time).  Same bars as test_config4_full_size_vs_oracle: losses, accuracy, ASR grad norm,
-    masks and features at 1e-3; every gradient tensor of the three nets at 2e-3 of its max."""
+    masks and features at 1e-3; every gradient tensor of the three nets at 1.5e-3 of its max."""
     from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
     from oracle import joint as oj
     opt = config4_opt()
@@ -235,8 +242,8 @@ def test_config5_full_step_vs_oracle():
     eo, ef = tr.last['enhance_out'].cpu(), tr.last['enhance_feat'].cpu()
     assert (eo - ref['enhance_out']).abs().max() <= 1e-3 * ref['enhance_out'].abs().max()
     assert (ef - ref['enhance_feat']).abs().max() <= 1e-3 * ref['enhance_feat'].abs().max()
-    bad = _grad_report(asr.named_parameters(), ref['g_asr'], 2e-3) + _grad_report(enh.named_parameters(), ref['g_enh'], 2e-3) + \
-        _grad_report(gan.named_parameters(), ref['g_gan'], 2e-3)
+    bad = _grad_report(asr.named_parameters(), ref['g_asr'], 1.5e-3) + _grad_report(enh.named_parameters(), ref['g_enh'], 1.5e-3) + \
+        _grad_report(gan.named_parameters(), ref['g_gan'], 1.5e-3)
     assert not bad, sorted(bad, key=lambda r: -r[1])[:8]
 
 

@@ -116,6 +116,63 @@ def test_e2e(golden_dir):
         rel('g.' + k, p.grad, fx['g.' + k], tol=1.5e-3)
 
 
+def test_encoder_padded_rows_at_production_width():
+    """Encoder.forward at eunits = 512 / eprojs = 512 on a ragged batch: the BLSTMP products run over the valid (t, b) rows (row maps: K = 1024 >= 384,
+    > 256 valid rows) and the WHOLE ``hpad`` -- padded frames included, where upstream's tanh(Linear) over zero-padded frames leaves tanh(bias)
+    (model/e2e_encoder.py:145-147) -- equals oracle.nets.encoder_forward; so do the gradients of a loss that reads every row."""
+    from robust_e2e_gan_amd import ops
+    from robust_e2e_gan_amd.model.e2e_encoder import Encoder
+    from robust_e2e_gan_amd.model.e2e_common import lens_dev
+    from oracle import nets
+    torch.manual_seed(11)
+    B, T, idim, elayers, eunits, eprojs = 8, 240, 40, 2, 512, 512
+    lens = [240, 228, 200, 170, 150, 120, 100, 80]
+    enc = Encoder('vggblstmp', idim, elayers, eunits, eprojs, [1] * (elayers + 1), 'skip', 0.0)
+    for n_, p_ in enc.named_parameters():
+        p_.data.uniform_(-0.08, 0.08) if p_.dim() > 1 else p_.data.uniform_(-0.3, 0.3)       # biases large enough that tanh(bias) is not ~0
+    x = torch.randn(B, T, idim) * 0.7
+    for b, l in enumerate(lens):
+        x[b, l:] = 0
+    p32 = {'enc.' + k: v.detach().clone() for k, v in enc.state_dict().items()}
+    with torch.no_grad():
+        href, hl_ref = nets.encoder_forward(p32, x, lens, elayers)
+    go = torch.randn(href.shape, generator=torch.Generator().manual_seed(5)) * 0.1
+    # gradients: the same oracle function in float64 arbitrates (two fp32 runs of a gradient through a VGG + 2 x BLSTMP-512 stack differ by more
+    # than 1.5e-3 of its largest entry by themselves; DESIGN.md section 2, "Arbitration in float64")
+    p = {k: v.double().requires_grad_(True) for k, v in p32.items()}
+    h64, _ = nets.encoder_forward(p, x.double(), lens, elayers)
+    (h64 * go.double()).sum().backward()
+    assert float((h64.detach().float() - href).abs().max()) <= 1e-4
+    enc = enc.to(DEV).train()
+    # the products around the recurrences must take the valid-rows path at this width (that is the path whose padded rows this test pins)
+    nl = enc.enc1.pooled_lens(lens)
+    maps = ops.row_maps(lens_dev(nl, torch.device(DEV)), max(nl), B)
+    assert maps is not None and maps.nv >= 256 and 2 * eunits >= ops.ROW_MAPS_MIN_K
+    seen = []
+    orig = ops.lib.call_supported
+
+    def spy(name, *a):
+        ok = orig(name, *a)
+        if ok:
+            seen.append(name)
+        return ok
+    ops.lib.call_supported = spy
+    try:
+        hpad, hl = enc(x.to(DEV), lens)
+        (hpad * go.to(DEV)).sum().backward()
+    finally:
+        ops.lib.call_supported = orig
+    assert seen.count('re2e_gemm_nt_rows') >= 2 * elayers and 're2e_gemm_tn_rows' in seen, seen
+    assert list(hl) == list(hl_ref)
+    rel('hpad, every row', hpad, href.numpy(), tol=1e-3)
+    pad = torch.arange(href.shape[1])[None, :] >= torch.tensor(hl_ref)[:, None]
+    assert pad.any()
+    bias = p32['enc.enc2.bt%d.bias' % (elayers - 1)]
+    assert float((hpad.detach().cpu()[pad] - torch.tanh(bias)[None, :]).abs().max()) <= 1e-6, 'padded frames hold tanh(bias), as upstream'
+    for k, v in enc.named_parameters():
+        rel('d ' + k, v.grad, p['enc.' + k].grad.float().numpy(), tol=1.5e-3)
+
+
 @pytest.mark.parametrize('tag', ['a.', 'b.'])
 def test_persistent_decoder_loop_vs_reference(golden_dir, tag):
     """The ONE-launch decoder loop (csrc/decloop.hip, forward and backward) against vectors from the reference's own Decoder + AttLoc

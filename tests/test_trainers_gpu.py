@@ -576,6 +576,85 @@ def test_fit_repeats_a_step_whose_recurrence_was_aborted(tmp_path):
         lib.query('re2e_debug_force_abort', 0)
 
 
+def test_fit_repeats_a_validation_pass_or_cmvn_estimate_that_was_aborted(tmp_path):
+    """The validation pass and the CMVN estimate run the persistent recurrences behind no step gate: a give-up there must not reach the model
+    selection as NaN scores, nor sit in the device counter until the next training step's gate refuses that step on one replica only.
+    JointTrainer.run_guarded reads the counter after the pass, repeats the pass with the launch-per-step kernels on the state it first ran on
+    (D's BatchNorm buffers, the CMVN accumulators) and acknowledges: scores, CMVN and final weights equal an undisturbed run's."""
+    from robust_e2e_gan_amd import lib
+    from robust_e2e_gan_amd.data.synthetic import make_batch
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.e2e_model import ShareE2E
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    import __graft_entry__ as g
+
+    class Rec(object):
+        def __init__(self):
+            self.vals = []
+
+        def set_current_errors(self, e):
+            self.vals.append(dict(e))
+
+        def __getattr__(self, name):
+            return lambda *a, **k: 0.0
+
+    def run(abort_validate_call, abort_enhancer_call):
+        opt = g._tiny_opt()
+        for k, v in dict(exp_path=str(tmp_path), print_freq=100, validate_freq=2, epochs=1, shuffle_epoch=100, criterion='acc', eps_decay=0.01,
+                         sche_samp_start_iter=300, sche_samp_final_iter=600, sche_samp_final_rate=0.0, train_dataset_len=3, num_utt_cmvn=3,
+                         num_save_attention=0).items():
+            setattr(opt, k, v)
+        torch.manual_seed(11)
+        enh, fb, asr, gan = (m.to(DEV).train() for m in (EnhanceModel(opt), FbankModel(opt), ShareE2E(opt), GANModel(opt)))
+        batches = []
+        for i in range(5):
+            clean, mix, mix_log, targets, il, tl = make_batch(3, 40, 4, opt.odim, seed=5 + i)
+            batches.append((['u%d' % j for j in range(3)], None, clean, None, mix, mix_log, None, targets, il, tl))
+        tr = JointTrainer(opt, enh, fb, asr, gan)
+        nv, orig_v = [0], tr.validate
+
+        def validate(data, cmvn, want_attention=False):
+            nv[0] += 1
+            if nv[0] == abort_validate_call:
+                lib.query('re2e_debug_force_abort', 1)
+            return orig_v(data, cmvn, want_attention=want_attention)
+        tr.validate = validate
+        ne, orig_e = [0], enh.forward
+
+        def enh_forward(*a, **k):
+            ne[0] += 1
+            if ne[0] == abort_enhancer_call:
+                lib.query('re2e_debug_force_abort', 1)
+            return orig_e(*a, **k)
+        enh.forward = enh_forward
+        vis = Rec()
+        iters, _, best_acc = tr.fit(batches[:4], batches[4:], vis)
+        torch.cuda.synchronize()
+        assert iters == 4 and tr.recovered_steps == 0 and tr.unexplained_aborts == 0
+        state = {k: v.detach().clone() for m in (enh, asr, gan) for k, v in m.state_dict().items()}
+        vals = [v for v in vis.vals if any(k.startswith('val/') for k in v)]
+        return tr, state, vals, fb.fbank_cmvn.copy()
+    try:
+        _, ref, vref, cref = run(0, 0)
+        assert len(vref) == 2 and all(np.isfinite(list(v.values())).all() for v in vref)
+        # (a) the first validation pass (its enhancer recurrence) gives up; (b) the very first CMVN estimate does (enhancer call 1, before any step)
+        for av, ae in ((1, 0), (0, 1)):
+            tr, got, vgot, cgot = run(av, ae)
+            assert tr.guarded_repeats == 1, (av, ae, tr.guarded_repeats)
+            assert len(vgot) == len(vref)
+            for a, b in zip(vgot, vref):
+                for k in b:
+                    assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= 2e-4 * max(1.0, abs(b[k])), (av, ae, k, a[k], b[k])
+            assert np.isfinite(cgot).all() and np.abs(cgot - cref).max() <= 2e-4 * np.abs(cref).max()
+            for k in ref:
+                assert torch.isfinite(got[k].float()).all(), k
+                rel('%r %s' % ((av, ae), k), got[k].float(), ref[k].float().cpu().numpy(), tol=2e-4, atol=1e-6)
+    finally:
+        lib.query('re2e_debug_force_abort', 0)
+
+
 # ---- InstanceNorm variants against vectors from the reference import (tests/golden/make_fixtures_n4c.py, round 4) ----
 def test_instance_norm_discriminator_vs_reference(golden_dir):
     """--norm_D instance (gan_model.py:42-46,57): InstanceNorm2d(affine=False) between biased convolutions, against the reference's own run:
