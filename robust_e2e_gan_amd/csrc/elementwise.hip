@@ -110,8 +110,27 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
   const int col = blockIdx.x * ct + c4 * 4;
   const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int r = r0 + rl;
+  if (!FUSED) {
+    // the plain column sum (bias gradients of the recurrent layers: 105 MB per direction and layer) with EIGHT 16-byte loads in flight per lane
+    // and four independent partial sums: at one row per pass (N >= 1024) the two-deep loop below kept 32 bytes per lane in flight and the
+    // launches ran at 2.4 TB/s (profiles/r05_bench_nooverlap_kernel_stats.csv: 44 us per 105 MB).  The summation order changes with it
+    // (rows r, r + 4 rpb, ... per partial): still a fixed order, bitwise reproducible run to run.
+    f32x4 s1 = s, s2 = s, s3 = s;
+    const long st = (long)rpb * N;
+    for (; r + 7 * rpb < r1; r += 8 * rpb) {
+      const float* q = dy + (long)r * N + col;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(q), g1 = *reinterpret_cast<const f32x4*>(q + st);
+      const f32x4 g2 = *reinterpret_cast<const f32x4*>(q + 2 * st), g3 = *reinterpret_cast<const f32x4*>(q + 3 * st);
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(q + 4 * st), g5 = *reinterpret_cast<const f32x4*>(q + 5 * st);
+      const f32x4 g6 = *reinterpret_cast<const f32x4*>(q + 6 * st), g7 = *reinterpret_cast<const f32x4*>(q + 7 * st);
+      s += g0; s1 += g1; s2 += g2; s3 += g3;
+      s += g4; s1 += g5; s2 += g6; s3 += g7;
+    }
+    s = (s + s1) + (s2 + s3);
+  }
 #pragma unroll 2
-  for (int r = r0 + rl; r < r1; r += rpb) {
+  for (; r < r1; r += rpb) {
     const long off = (long)r * N + col;
     f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
     if (FUSED) {

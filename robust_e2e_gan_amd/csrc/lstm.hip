@@ -361,17 +361,22 @@ __device__ __forceinline__ bool tags_are(const u32x4& v, unsigned want) {
   return (((v[0] & v[1] & v[2] & v[3]) ^ want) & kTagBit) == 0u && (((v[0] | v[1] | v[2] | v[3]) ^ want) & kTagBit) == 0u;
 }
 
-template <int TILES, int NJ, bool PERSIST>
+// TT (round 6): utterance tiles per workgroup.  TT = 2: ONE workgroup carries TWO independent 16-utterance tiles (same units, same W_hh registers,
+// own tags / parity buffers / cell state per tile) and alternates between them inside a step: publish tile A's h(t) -> poll, MFMA and cell of
+// tile B -> poll A, meant to fill the ~1-1.5 us a workgroup waits for its peers' h(t) (profiles/r04_chain_budget.md section 2) with the other
+// tile's ~0.8 us of work.  Per tile the instruction sequence is the TT = 1 one: bitwise-equal results.  Measured slower and not selected
+// (fwd2_config: why); experiments build only, RE2E_LSTM_FWD2_TT=2.
+template <int TILES, int NJ, bool PERSIST, int TT = 1>
 __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const float* __restrict__ whh_f, const float* __restrict__ whh_r,
                                                  float* ybuf, float* cbuf, unsigned* hx_, unsigned* err, const int* __restrict__ lens, int T,
                                                  int B, int H, int s_arg, int mode) {
+  static_assert(TT == 1 || PERSIST, "two tiles per workgroup: the persistent form only");
   constexpr int KS = 4;                                         // K quarters = waves
-  extern __shared__ __attribute__((aligned(16))) float lds2[];  // part[2][TILES][KS][64] f32x4 | abort word
-  f32x4* part = reinterpret_cast<f32x4*>(lds2);
-  int* abortw = reinterpret_cast<int*>(lds2 + 2 * TILES * KS * 64 * 4);
-  const int dir = blockIdx.z, mt = blockIdx.y, MT = gridDim.y, x = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float lds2[];  // TT x part[2][TILES][KS][64] f32x4 | abort word
+  f32x4* part_all = reinterpret_cast<f32x4*>(lds2);
+  int* abortw = reinterpret_cast<int*>(lds2 + TT * 2 * TILES * KS * 64 * 4);
+  const int dir = blockIdx.z, MT = gridDim.y * TT, x = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6, n = lane & 15, kk = lane >> 4;
-  const int b = 16 * mt + n;
   const int ft = ks < TILES ? ks : -1;                           // the tile this wave finishes (gates, cell, publish), if any
   float* xg = dir ? xg_r : xg_f;
   const float* whh = dir ? whh_r : whh_f;
@@ -388,36 +393,55 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
   }
   // exchange buffer (words): [parity][dir][mt][k / 4][16 utterances][4]
   const int par_w = 2 * MT * H * 16;
-  const int grp = (dir * MT + mt) * H * 16;
   const __amdgpu_buffer_rsrc_t hx_rs = __builtin_amdgcn_make_buffer_rsrc(hx_, 0, (int)(2 * par_w * 4), 0x00020000);
-  const unsigned rd_w = (unsigned)(grp + ((4 * ks * NJ + kk) * 16 + n) * 4);          // + jj * 256 words
-  const unsigned poll_w = (unsigned)(grp + ((4 * ks * NJ + (lane < 4 * NJ ? lane : 0)) * 16) * 4);     // utterance 0 of piece lane of this quarter
   const bool fin = ft >= 0;
   const int j = 4 * TILES * x + 4 * (fin ? ft : 0) + kk;                               // the unit whose cell this lane owns
-  const bool ok = fin && b < B;
-  const int ln = ok ? lens[b] : 0;
-  const unsigned wr_w = (unsigned)(grp + ((TILES * x + (fin ? ft : 0)) * 16 + n) * 4);
-  float c = 0.f, pre[4] = {0.f, 0.f, 0.f, 0.f};
   const int s0 = PERSIST ? 0 : s_arg, s1 = PERSIST ? T : s_arg + 1;
-  if (ok) {
-    const int t0 = dir ? T - 1 - s0 : s0;
-    const float* gp = xg + ((long)t0 * B + b) * 4 * H + j;
+  // ---- per utterance tile u of this workgroup ----
+  int b_[TT], ln_[TT];
+  bool ok_[TT];
+  unsigned rd_w_[TT], poll_w_[TT], wr_w_[TT];
+  float c_[TT], pre_[TT][4];
+  u32x4 ld_[TT][NJ];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = gp[g * H];
-    if (!PERSIST) c = cbuf[((long)(dir ? t0 + 2 : t0) * B + b) * H2 + dir * H + j];
-  }
-  u32x4 ld[NJ];
+  for (int u = 0; u < TT; ++u) {
+    const int mt = blockIdx.y * TT + u;
+    const int grp = (dir * MT + mt) * H * 16;
+    b_[u] = 16 * mt + n;
+    rd_w_[u] = (unsigned)(grp + ((4 * ks * NJ + kk) * 16 + n) * 4);          // + jj * 256 words
+    poll_w_[u] = (unsigned)(grp + ((4 * ks * NJ + (lane < 4 * NJ ? lane : 0)) * 16) * 4);     // utterance 0 of piece lane of this quarter
+    ok_[u] = fin && b_[u] < B;
+    ln_[u] = ok_[u] ? lens[b_[u]] : 0;
+    wr_w_[u] = (unsigned)(grp + ((TILES * x + (fin ? ft : 0)) * 16 + n) * 4);
+    c_[u] = 0.f;
 #pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) ld[jj] = u32x4{0u, 0u, 0u, 0u};
-  if (!PERSIST && s0 > 0) {                       // plain loads: the previous launch wrote them
-    const u32x4* src = reinterpret_cast<const u32x4*>(hx_ + ((s0 & 1) ^ 1) * par_w) + rd_w / 4;
+    for (int g = 0; g < 4; ++g) pre_[u][g] = 0.f;
+    if (ok_[u]) {
+      const int t0 = dir ? T - 1 - s0 : s0;
+      const float* gp = xg + ((long)t0 * B + b_[u]) * 4 * H + j;
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) ld[jj] = src[jj * 64];
+      for (int g = 0; g < 4; ++g) pre_[u][g] = gp[g * H];
+      if (!PERSIST) c_[u] = cbuf[((long)(dir ? t0 + 2 : t0) * B + b_[u]) * H2 + dir * H + j];
+    }
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) ld_[u][jj] = u32x4{0u, 0u, 0u, 0u};
+    if (!PERSIST && s0 > 0) {                       // plain loads: the previous launch wrote them
+      const u32x4* src = reinterpret_cast<const u32x4*>(hx_ + ((s0 & 1) ^ 1) * par_w) + rd_w_[u] / 4;
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) ld_[u][jj] = src[jj * 64];
+    }
   }
   LSTM_STAMP_DECL;
   if (PERSIST) __syncthreads();
-  for (int s = s0; s < s1; ++s) {
+  bool aborted = false;
+  for (int s = s0; s < s1 && !aborted; ++s) {
     const int t = dir ? T - 1 - s : s;
+#pragma unroll
+   for (int u = 0; u < TT; ++u) {
+    const int b = b_[u], ln = ln_[u];
+    const bool ok = ok_[u];
+    const unsigned rd_w = rd_w_[u], poll_w = poll_w_[u], wr_w = wr_w_[u];
+    f32x4* part = part_all + u * (2 * TILES * KS * 64);
     LSTM_STAMP(0); LSTM_STAMP(10);
     constexpr int NACC = TILES == 1 ? 2 : TILES;            // one tile: two chains (even / odd k) hide the 40-cycle dependent latency
     f32x4 acc[NACC];
@@ -441,21 +465,21 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
         if (mode & 1) {                         // poll first, sweep once
           wait_producers();
 #pragma unroll
-          for (int jj = 0; jj < NJ; ++jj) ld[jj] = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)jj * 1024u, 0, 16);
+          for (int jj = 0; jj < NJ; ++jj) ld_[u][jj] = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)jj * 1024u, 0, 16);
         }
         LSTM_STAMP(7);
       }
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
-        u32x4 v = ld[jj];
+        u32x4 v = ld_[u][jj];
         if (PERSIST) {
           if (!__all(tags_are(v, want))) {
             // the sweep came before this chunk's producer had published: wait for all producers (cheap poll), read this and the
             // later chunks again; should the chunk still be stale (the poll looks at one piece per producer), poll it alone
             wait_producers();
 #pragma unroll
-            for (int j2 = jj; j2 < NJ; ++j2) ld[j2] = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)j2 * 1024u, 0, 16);
-            v = ld[jj];
+            for (int j2 = jj; j2 < NJ; ++j2) ld_[u][j2] = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)j2 * 1024u, 0, 16);
+            v = ld_[u][jj];
             for (unsigned spins = 0; !__all(tags_are(v, want)); ++spins) {
               asm volatile("" ::: "memory");
               v = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_b + (unsigned)jj * 1024u, 0, 16);
@@ -466,9 +490,9 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
         float hv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          unsigned u = PERSIST ? (v[i] & ~kTagBit) : v[i];
-          if (PERSIST) u = u == kNanPub ? 0x7fc00000u : u;
-          hv[i] = __uint_as_float(u);
+          unsigned uu = PERSIST ? (v[i] & ~kTagBit) : v[i];
+          if (PERSIST) uu = uu == kNanPub ? 0x7fc00000u : uu;
+          hv[i] = __uint_as_float(uu);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -489,7 +513,7 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
     LSTM_STAMP(2);
     __syncthreads();
     LSTM_STAMP(3);
-    if (PERSIST && *abortw) break;
+    if (PERSIST && *abortw) { aborted = true; break; }
     float og[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // activated gates, c, h of this lane's cell: written after the next sweep is on its way
     if (fin) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -501,20 +525,20 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
       float gi, gf, gg, go, cn, h;
 #ifdef RE2E_EXPERIMENTS
       if (mode & 16) {                           // v_rcp_f32 (1 ulp) instead of the IEEE division: experiment
-        auto sg = [](float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); };
-        auto th = [](float x) { float e = __expf(-2.0f * fabsf(x)); return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x); };
-        gi = sg(v[0] + pre[0]); gf = sg(v[1] + pre[1]); gg = th(v[2] + pre[2]); go = sg(v[3] + pre[3]);
-        cn = gf * c + gi * gg;
+        auto sg = [](float x_) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x_)); };
+        auto th = [](float x_) { float e = __expf(-2.0f * fabsf(x_)); return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x_); };
+        gi = sg(v[0] + pre_[u][0]); gf = sg(v[1] + pre_[u][1]); gg = th(v[2] + pre_[u][2]); go = sg(v[3] + pre_[u][3]);
+        cn = gf * c_[u] + gi * gg;
         h = go * th(cn);
       } else
 #endif
       {
-        gi = sigmoidf_(v[0] + pre[0]); gf = sigmoidf_(v[1] + pre[1]); gg = tanhf_(v[2] + pre[2]); go = sigmoidf_(v[3] + pre[3]);
-        cn = __builtin_fmaf(gf, c, gi * gg);     // spelled out: the persistent kernel and its launch-per-step twin must not contract differently
+        gi = sigmoidf_(v[0] + pre_[u][0]); gf = sigmoidf_(v[1] + pre_[u][1]); gg = tanhf_(v[2] + pre_[u][2]); go = sigmoidf_(v[3] + pre_[u][3]);
+        cn = __builtin_fmaf(gf, c_[u], gi * gg);     // spelled out: the persistent kernel and its launch-per-step twin must not contract differently
         h = go * tanhf_(cn);
       }
       if (t >= ln) { cn = 0.f; h = 0.f; }        // packed semantics (also rows b >= B: ln = 0)
-      c = cn;
+      c_[u] = cn;
       // The next step's pre-activations are loaded HERE: a whole step before the cell needs them, and in front of the publish.  The
       // compiler guards a load into registers it cannot prove idle with s_waitcnt vmcnt(0) (the poll loops have exits it cannot count
       // across): behind the publish that wait is the write-through latency of the sc1 store (0.7 us per step at H = 512), just in front
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
       if (PERSIST && ok && s + 1 < T) {
         const float* gp = xg + ((long)(dir ? t - 1 : t + 1) * B + b) * 4 * H + j;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = gp[g * H];
+        for (int g = 0; g < 4; ++g) pre_[u][g] = gp[g * H];
       }
       if (!PERSIST || s + 1 < T) {
         // the four units of a 16-byte piece sit in lanes n, n + 16, n + 32, n + 48: gather them into lane n, one store per piece
@@ -550,7 +574,7 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
       const unsigned rd_n = (unsigned)(((s & 1) * par_w) * 4) + rd_w * 4u;
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) ld[jj] = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_n + (unsigned)jj * 1024u, 0, 16);
+      for (int jj = 0; jj < NJ; ++jj) ld_[u][jj] = __builtin_amdgcn_raw_buffer_load_b128(hx_rs, rd_n + (unsigned)jj * 1024u, 0, 16);
     };
     if (PERSIST && (mode & 1) == 0 && s + 1 < T) next_sweep();
     LSTM_STAMP(5);
@@ -561,9 +585,13 @@ __global__ __launch_bounds__(256) void lstm_fwd2(float* xg_f, float* xg_r, const
       ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = og[5];
     }
     LSTM_STAMP(6);
+   }
   }
-  if (PERSIST && *abortw && ok) {                           // a peer never published: make the failure visible downstream
-    for (int t = 0; t < T; ++t) ybuf[((long)(t + 1) * B + b) * H2 + dir * H + j] = __uint_as_float(0x7fc00000u);
+  if (PERSIST && *abortw) {                           // a peer never published: make the failure visible downstream
+#pragma unroll
+    for (int u = 0; u < TT; ++u)
+      if (ok_[u])
+        for (int t = 0; t < T; ++t) ybuf[((long)(t + 1) * B + b_[u]) * H2 + dir * H + j] = __uint_as_float(0x7fc00000u);
   }
 }
 
@@ -1206,8 +1234,8 @@ bool launch_bwd_persist(hipStream_t st, float* g_f, float* g_r, const float* wb,
 }
 
 // ---- round-4 forward (lstm_fwd2): configuration, launch of the persistent kernel and of its launch-per-step twin ----------
-struct Fwd2Cfg { int tiles, nj; };
-template <int TILES, int NJ, bool P> LdsLimit& fwd2_lim() { static LdsLimit l; return l; }
+struct Fwd2Cfg { int tiles, nj, tt; };      // tt: utterance tiles per workgroup (2: the interleaved form, persistent launches only)
+template <int TILES, int NJ, bool P, int TT = 1> LdsLimit& fwd2_lim() { static LdsLimit l; return l; }
 
 // RE2E_LSTM_FWD2=0 keeps the round-1..3 forward kernels (also used for widths this form is not instantiated for: H % 64 != 0)
 bool fwd2_config(int B, int H, const float* whh_f, const float* whh_r, Fwd2Cfg& c) {
@@ -1222,9 +1250,27 @@ bool fwd2_config(int B, int H, const float* whh_f, const float* whh_r, Fwd2Cfg& 
   // (128 against 64) and the step loses 1.7 ms with it (57.4 against 55.7, two A/B rounds); on as many CUs (64: 16 units per workgroup)
   // it is slower than the round-1..3 kernel (3.7).  It is the better kernel where that one wastes its tile or is bound by its matrix
   // work: <= 16 utterances (half of a 32-row tile empty: 2.5 against 3.2 us, same CUs) and wide layers (H = 512, B = 64: 5.2 against 6.2).
-  if (!exp_env("RE2E_LSTM_FWD2_MINH") && !exp_env("RE2E_LSTM_FWD2_MAXH") && B > 16 && H < 384) return false;
+  // Round 6, built and measured, NOT selected (RE2E_LSTM_FWD2_TT=2 in the experiments build turns it on): TWO utterance tiles per workgroup
+  // (lstm_fwd2<.., TT = 2>), a workgroup working on one tile while the other's h(t) is on its way, so that B = 32 / H = 256 would keep this form's
+  // 2.9 us per step on the round-1..3 kernel's 64 CUs.  Bitwise equal to the one-tile form -- and 5.14 us per step against 3.22 (the step 51.4
+  // against 47.7 ms, profiles/r06_chain_two_tiles.txt): vmcnt retires in order and counts stores, so the finishing waves' poll of tile B cannot
+  // return before the write-through (sc1) publish of tile A and its output stores are acknowledged by the memory side (~0.7 us) -- the hand-off
+  // latency the interleave was to hide is paid once per TILE instead of once per step.
   c.nj = H / 64;
+  c.tt = 1;
+  static const int tt_env = exp_env("RE2E_LSTM_FWD2_TT") ? atoi(exp_env("RE2E_LSTM_FWD2_TT")) : 1;
+  const bool two = tt_env == 2 && B > 16 && H < 384 && cdiv(B, 16) % 2 == 0 && (c.nj == 2 || c.nj == 4 || c.nj == 5);
+  if (!exp_env("RE2E_LSTM_FWD2_MINH") && !exp_env("RE2E_LSTM_FWD2_MAXH") && B > 16 && H < 384 && !two) return false;
   if (!(c.nj == 1 || c.nj == 2 || c.nj == 4 || c.nj == 5 || c.nj == 8)) return false;
+  if (two) {
+    // units per workgroup = 4 x tiles: the smallest that keeps the grid within a quarter of the chip (the chains own their CUs)
+    const long groups = (long)(cdiv(B, 16) / 2) * 2;
+    c.tiles = 0;
+    for (int tl = 1; tl <= 4; tl *= 2)
+      if (H % (4 * tl) == 0 && (long)(H / (4 * tl)) * groups <= cu_count() / 4) { c.tiles = tl; break; }
+    if (c.tiles) { c.tt = 2; return true; }
+    if (!exp_env("RE2E_LSTM_FWD2_MINH") && !exp_env("RE2E_LSTM_FWD2_MAXH")) return false;
+  }
   // units per workgroup = 4 x tiles: the smallest that keeps the grid within half of the chip (the rest stays with the filler
   // streams), else within the chip
   const long per = (long)cdiv(B, 16) * 2;
@@ -1238,11 +1284,12 @@ bool fwd2_config(int B, int H, const float* whh_f, const float* whh_r, Fwd2Cfg& 
   return true;
 }
 
-template <int TILES, int NJ>
+template <int TILES, int NJ, int TT = 1>
 bool launch_fwd2(bool persist, hipStream_t st, float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf, void* hxmem,
                  size_t hxbytes, const int* lens, int T, int B, int H) {
-  size_t lds = (size_t)TILES * 8192 + 16;
-  dim3 grid(H / (4 * TILES), cdiv(B, 16), 2);
+  if (TT > 1 && !persist) return launch_fwd2<TILES, NJ, 1>(false, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
+  size_t lds = (size_t)TT * TILES * 8192 + 16;
+  dim3 grid(H / (4 * TILES), cdiv(B, 16) / TT, 2);
   unsigned* err = (unsigned*)hxmem;
   unsigned* hx = (unsigned*)((char*)hxmem + 16);
   if (!persist) {
@@ -1260,10 +1307,10 @@ bool launch_fwd2(bool persist, hipStream_t st, float* xg_f, float* xg_r, const f
   static const int mode_env = exp_env("RE2E_LSTM_FWD2_MODE") ? atoi(exp_env("RE2E_LSTM_FWD2_MODE")) : -1;
   const int mode = mode_env >= 0 ? mode_env : 1;
   if (hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac) lds = (size_t)hog * 1024;
-  fwd2_lim<TILES, NJ, true>().ensure(reinterpret_cast<const void*>(&lstm_fwd2<TILES, NJ, true>), lds);
+  fwd2_lim<TILES, NJ, true, TT>().ensure(reinterpret_cast<const void*>(&lstm_fwd2<TILES, NJ, true, TT>), lds);
   lstm_stamps_arm();
   (void)hipMemsetAsync(hxmem, 0, hxbytes, st);                             // tags and the error word start at zero, every call
-  hipLaunchKernelGGL((lstm_fwd2<TILES, NJ, true>), grid, dim3(256), lds, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hx, err, lens, T, B, H, 0, mode);
+  hipLaunchKernelGGL((lstm_fwd2<TILES, NJ, true, TT>), grid, dim3(256), lds, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hx, err, lens, T, B, H, 0, mode);
   return true;
 }
 
@@ -1273,6 +1320,13 @@ bool launch_fwd2(bool persist, hipStream_t st, float* xg_f, float* xg_r, const f
 
 bool try_fwd2(const Fwd2Cfg& c, bool persist, hipStream_t st, float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
               void* hxmem, size_t hxbytes, const int* lens, int T, int B, int H) {
+  if (c.tt == 2) {        // the interleaved form: instantiated for the widths it is selected for (fwd2_config: H in 128 / 256 / 320)
+#define RE2E_F2T(TL, NJV) \
+    if (c.tiles == TL && c.nj == NJV) return launch_fwd2<TL, NJV, 2>(persist, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
+    RE2E_F2T(1, 2) RE2E_F2T(2, 2) RE2E_F2T(4, 2) RE2E_F2T(1, 4) RE2E_F2T(2, 4) RE2E_F2T(4, 4) RE2E_F2T(1, 5) RE2E_F2T(2, 5) RE2E_F2T(4, 5)
+#undef RE2E_F2T
+    return false;
+  }
 #define RE2E_F2(TL, NJV) \
   if (c.tiles == TL && c.nj == NJV) return launch_fwd2<TL, NJV>(persist, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
   RE2E_FWD2_ALL(RE2E_F2)

@@ -32,6 +32,8 @@
 // autograd data gradients.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -91,10 +93,23 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, int Cout, int C
 #define WSTAMP(k) do { } while (0)
 #endif
 
-template <int TXW>      // tiles per patch row: 8 (16 x 8 pixel patch) or 4 (8 x 16)
+// LDSIN (round 6, C % 64 == 0): the input patch travels global -> LDS by LDS-DMA, 32 channels at a time, and the lanes read their tile's pixels out of
+// LDS.  Before, every lane loaded its own 16 bytes of 8 pixels per chunk straight from memory: 64 separate cache lines per load instruction, every
+// pixel fetched by all four wavefronts and by both tiles that share it -- 0.88 vector-L1 accesses per cycle and CU, the L1's limit: the kernel was bound
+// by the ACCESS RATE of the L1, not by issue or latency (TCP_TOTAL_CACHE_ACCESSES, and the diagnostic that read 1 KB contiguous per instruction instead:
+// conv1_2 1.47 -> 1.26 ms with the same bytes and instructions; profiles/r06_wino_attribution.md).  Staged, a (PH + 2) x (PW + 2) patch of 32 channels
+// is 24 load instructions per workgroup instead of 128, and each pixel is fetched once.
+//   LDS image of a half (32 channels): [8 granule planes g = channel / 4][192 slots][16 bytes], slot(py, px) = py * IPW + (px & 1) * IPW / 2 + px / 2
+//   (even columns first): the 8 tiles of a patch row read consecutive slots -- conflict-free ds_read_b128 -- and a chunk's position inside the half
+//   is an instruction immediate: no address arithmetic in the loop.  Two halves are resident (2 x 24 KB, aliased with the epilogue's exchange
+//   buffer); half h + 2 is requested when the last chunk of half h has left LDS (one workgroup barrier per half).
+template <int TXW, bool LDSIN>      // TXW = tiles per patch row: 8 (16 x 8 pixel patch) or 4 (8 x 16)
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
   constexpr int TYH = 32 / TXW;
   constexpr int PW = 2 * TXW, PH = 2 * TYH;
+  constexpr int IPW = PW + 2, IPH = PH + 2, NPIX = IPW * IPH;        // the input patch: 18 x 10 or 10 x 18 pixels
+  constexpr int NSLOT = 192, PLANE = NSLOT * 16, HALFB = 8 * PLANE;  // bytes; 8 planes x 192 slots = 24 LDS-DMA instructions of 64 lanes
+  static_assert(NPIX <= NSLOT && IPW % 2 == 0, "patch geometry");
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 rows i][2 b][32 tiles][LDR]
 
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
@@ -159,7 +174,52 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
     }
   };
 
+  // ---- LDSIN: per-lane constants of the staging requests (6 per wavefront and half) and of the fragment reads (8 pixels)
+  unsigned st_off[6];       // byte offset of the lane's 16 bytes inside the image (channel half 0), or out of range
+  unsigned rd_off[8];       // LDS byte offset of pixel k's granule (plane lh) in a half at chunk position 0
+  const char* const sbytes = reinterpret_cast<const char*>(smem);
+  auto set_item_lds = [&](const Geo& g) {
+    u_s0 = (unsigned)(((g.nblk * nch) * 16 + 4 * wid) * 2) * 1024u;
+    const bool interior = g.y0 >= 1 && g.x0 >= 1 && g.y0 + PH + 1 <= p.H && g.x0 + PW + 1 <= p.W;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int q = wid + 4 * i;                                   // instruction q of 24: granules [64 q, 64 q + 64)
+      const int gq = q / 3, slot = (q - 3 * gq) * 64 + lane;        // plane (wave-uniform), slot
+      const int py = slot / IPW, rem = slot - py * IPW;
+      const int px = rem < IPW / 2 ? 2 * rem : 2 * (rem - IPW / 2) + 1;
+      const int iy = g.y0 - 1 + py, ix = g.x0 - 1 + px;
+      const bool ok = slot < NPIX && (interior || ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W));
+      st_off[i] = ok ? (unsigned)(iy * rowb + ix * colb + gq * 16) : WOOB;
+    }
+  };
+  auto stage = [&](int half, int buf) {                            // half `half` of the channels -> LDS buffer `buf`
+#ifdef RE2E_EXPERIMENTS
+    if (p.dbg & 64) return;                                        // diagnostic (timing only): no pixel traffic at all
+#endif
+    const unsigned so = a_s + (unsigned)half * 128u;
+    float* base = smem + buf * (HALFB / 4) + wid * 256;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, st_off[i], so, 0, 0);
+  };
+  if constexpr (LDSIN) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int py = 2 * tyi + (k < 4 ? ra : rb), px = 2 * txi + (k & 3);
+      rd_off[k] = (unsigned)((py * IPW + (px & 1) * (IPW / 2) + (px >> 1)) * 16 + lh * PLANE);
+    }
+  }
   f32x4 raw[8], uf[4][2];
+  auto read_raw = [&](int buf, int cc) {                           // chunk position cc (8 channels = planes 2 cc, 2 cc + 1) of the half in `buf`
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = *reinterpret_cast<const f32x4*>(sbytes + rd_off[k] + (buf * HALFB + cc * 2 * PLANE));
+  };
+#ifdef RE2E_EXPERIMENTS
+  // diagnostic (RE2E_WINO_DBG bit 16): the eight pixel loads of a chunk read 1 KB CONTIGUOUS each (lane-linear, wrong pixels) instead of 64 separate
+  // 16-byte pieces 512 bytes apart: same instruction stream, same bytes, 1/4 .. 1/8 of the vector-L1 accesses -- is the kernel bound by the L1's
+  // access rate (TCP_TOTAL_CACHE_ACCESSES: 0.88 per cycle and CU, profiles/r06_wino_attribution.md)?
+  const bool coalesced_dbg = (p.dbg & 16) != 0;
+#endif
   auto fetch_raw = [&](int chunk) {
     unsigned cb = a_s + (unsigned)(chunk * WCK * 4);
 #ifdef RE2E_EXPERIMENTS
@@ -194,16 +254,42 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
   Geo cur = geo_of(item);
   // ragged image batches (re2e_conv3x3_wino_rows): rows the caller never reads (beyond an utterance's end + the stack's reach) are left alone
   if (p.row_lim && cur.y0 >= p.row_lim[n]) return;
-  set_item(cur);
-  // (same issue order as in the loop -- pixels first, then the weights position by position -- or the wait at the loop's head
-  // has to cover the prologue's order as well and degenerates to vmcnt(0))
-  __builtin_amdgcn_sched_barrier(0);
-  fetch_raw(0);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    fetch_u(0, j);
+  if constexpr (LDSIN) {
+    // half 0 is requested first, the first weights behind it; "at most the 8 weight loads outstanding" = half 0 has landed (vmcnt retires in order)
+    set_item_lds(cur);
     __builtin_amdgcn_sched_barrier(0);
+    stage(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fetch_u(0, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage(1, 1);                                                    // (C % 64 == 0: there is a half 1)
+    __builtin_amdgcn_sched_barrier(0);
+    read_raw(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+    set_item(cur);
+#ifdef RE2E_EXPERIMENTS
+    if (coalesced_dbg) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a_off[k] = (unsigned)(lane * 16 + k * 1024 + (cur.y0 * rowb + cur.x0 * colb));
+    }
+#endif
+    // (same issue order as in the loop -- pixels first, then the weights position by position -- or the wait at the loop's head
+    // has to cover the prologue's order as well and degenerates to vmcnt(0))
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_raw(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fetch_u(0, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   WSTAMP(1);
@@ -229,31 +315,88 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
     if (p.dbg & 4) __builtin_amdgcn_s_setprio(0);
     if (p.dbg & 8) __builtin_amdgcn_s_setprio(3);
 #endif
-    do {
-      f32x4 T[4], V[4];
+    if constexpr (LDSIN) {
+      // Eight chunks (two 32-channel halves: LDS buffers 0 and 1) per pass, unrolled, so that buffer and chunk position are instruction
+      // immediates.  At the last chunk of a half every wavefront holds that chunk in registers: behind ONE workgroup barrier the half's buffer is free
+      // for half h + 2, and the barrier also publishes half h + 1 (each wavefront has waited for its own requests: at most the 8 weight loads of the
+      // chunk may still be in flight -- they are younger).  The LAST pass is a copy of the body without requests (there is no half to ask for, and an
+      // out-of-range LDS-DMA request would write zeros into space the epilogue's exchange buffer is about to use): the load counts the compiler waits
+      // with are exact in both copies.
+      auto pass_body = [&](auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) T[b] = raw[b] + tsign * raw[4 + b];
-      V[0] = T[0] + m1 * T[2];                        // subtractions as packed fused multiply-adds (there is no packed subtract)
-      V[1] = T[1] + T[2];
-      V[2] = T[2] + m1 * T[1];
-      V[3] = T[1] + m1 * T[3];
-      const int nxt = chunk + 1 < nch ? chunk + 1 : chunk;
-      // (sched_barrier: the scheduler otherwise sinks every load to the end of the body, right in front of the wait that needs it)
-      __builtin_amdgcn_sched_barrier(0);
-      fetch_raw(nxt);                                 // the raw registers are free: next chunk's pixels fly under this chunk's MFMAs
-      __builtin_amdgcn_sched_barrier(0);
+        for (int c8 = 0; c8 < 8; ++c8) {
+          const int cc = c8 & 3, bf = c8 >> 2;
+          f32x4 T[4], V[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+          for (int b = 0; b < 4; ++b) T[b] = raw[b] + tsign * raw[4 + b];
+          V[0] = T[0] + m1 * T[2];
+          V[1] = T[1] + T[2];
+          V[2] = T[2] + m1 * T[1];
+          V[3] = T[1] + m1 * T[3];
+          const int nxt = chunk + 1 < nch ? chunk + 1 : chunk;
+          __builtin_amdgcn_sched_barrier(0);
+          if (cc == 3) {
+#ifdef RE2E_EXPERIMENTS
+            if (!(p.dbg & 32))       // diagnostic (timing only, results may be wrong): no wait / barrier per half -- what do they cost?
+#endif
+            {
+              asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+              asm volatile("" ::: "memory");
+            }
+            if (!LAST) {
+              stage((chunk >> 2) + 2, bf);                         // the half after next: it exists in every pass but the last
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if (!(LAST && c8 == 7)) read_raw(((c8 + 1) >> 2) & 1, (c8 + 1) & 3);     // next chunk's pixels out of LDS
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+          for (int j = 0; j < 4; ++j) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j][jj], uf[j][nt][jj], acc[j][nt], 0, 0, 0);
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+                acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j][jj], uf[j][nt][jj], acc[j][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(LAST && c8 == 7)) {
+              fetch_u(nxt, j);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          ++chunk;
+        }
+      };
+      for (int pass = 8; pass < nch; pass += 8) pass_body(std::false_type{});
+      pass_body(std::true_type{});
+    } else {
+      do {
+        f32x4 T[4], V[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) T[b] = raw[b] + tsign * raw[4 + b];
+        V[0] = T[0] + m1 * T[2];                        // subtractions as packed fused multiply-adds (there is no packed subtract)
+        V[1] = T[1] + T[2];
+        V[2] = T[2] + m1 * T[1];
+        V[3] = T[1] + m1 * T[3];
+        const int nxt = chunk + 1 < nch ? chunk + 1 : chunk;
+        // (sched_barrier: the scheduler otherwise sinks every load to the end of the body, right in front of the wait that needs it)
         __builtin_amdgcn_sched_barrier(0);
-        fetch_u(nxt, j);                              // ... and position j's weights of the next chunk behind its last use
+        fetch_raw(nxt);                                 // the raw registers are free: next chunk's pixels fly under this chunk's MFMAs
         __builtin_amdgcn_sched_barrier(0);
-      }
-    } while (++chunk < nch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j][jj], uf[j][nt][jj], acc[j][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          fetch_u(nxt, j);                              // ... and position j's weights of the next chunk behind its last use
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } while (++chunk < nch);
+    }
 
     WSTAMP(2);
 #ifdef RE2E_EXPERIMENTS
@@ -372,14 +515,14 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
 #include "experiments/wino_pipe.hip"      // the rejected pipelined form (RE2E_WINO_PIPE=1): experiments build only
 #endif
 
-template <int TXW>
+template <int TXW, bool LDSIN>
 void launch_wino(const WinoArgs& a, hipStream_t st) {
-  size_t lds = (size_t)8 * 32 * LDR * sizeof(float);
+  size_t lds = (size_t)8 * 32 * LDR * sizeof(float);      // the exchange buffer (LDSIN: aliases the two staged halves, 2 x 24 KB)
   static const char* lds_env = exp_env("RE2E_WINO_LDS_KB");       // experiments: a larger request = one workgroup per CU (one wavefront per SIMD)
   if (lds_env && (size_t)atoi(lds_env) * 1024 > lds) lds = (size_t)atoi(lds_env) * 1024;
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&wino_conv3x3_kernel<TXW>), lds);
-  hipLaunchKernelGGL((wino_conv3x3_kernel<TXW>), dim3((unsigned)a.per_image, (unsigned)a.NI), dim3(256), lds, st, a);
+  lim.ensure(reinterpret_cast<const void*>(&wino_conv3x3_kernel<TXW, LDSIN>), lds);
+  hipLaunchKernelGGL((wino_conv3x3_kernel<TXW, LDSIN>), dim3((unsigned)a.per_image, (unsigned)a.NI), dim3(256), lds, st, a);
 }
 
 }  // namespace
@@ -436,7 +579,12 @@ static int wino_impl(const float* in, int NI, int H, int W, int C, const float* 
 #ifdef RE2E_EXPERIMENTS
   if (wino_pipe_try(a, per_image, NI, C, wide, stream)) { RE2E_LAUNCH_CHECK(); return RE2E_OK; }
 #endif
-  if (wide) launch_wino<8>(a, stream); else launch_wino<4>(a, stream);
+  // the input patch through LDS (round 6) wherever the channel count allows it (whole pairs of 32-channel halves); RE2E_WINO_LDSIN=0 (experiments
+  // build): the per-lane loads of rounds 3-5
+  static const bool ldsin_env = !(exp_env("RE2E_WINO_LDSIN") && atoi(exp_env("RE2E_WINO_LDSIN")) == 0);
+  const bool ldsin = ldsin_env && C % 64 == 0 && !a.stamps && !(a.dbg & ~(1 | 32 | 64));
+  if (ldsin) { if (wide) launch_wino<8, true>(a, stream); else launch_wino<4, true>(a, stream); }
+  else { if (wide) launch_wino<8, false>(a, stream); else launch_wino<4, false>(a, stream); }
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }
