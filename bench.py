@@ -129,8 +129,9 @@ def engine_average():
 def conv_roofline(dev, iters=20):
     """Average launch duration of the dominant convolution, measured with HIP events on the stream the kernel is launched on: the 3x3
     convolution at the VGG conv1_2 shape of this workload (2B=64 images, 800x80, 64->64) AS THE TRAINING STEP LAUNCHES IT:
-    ``re2e_conv3x3_wino`` with the fused ReLU + 2x2 max pool epilogue (csrc/winograd.hip: fused Winograd F(2x2,3x3); only the pooled
-    tensor and the index bytes are written).
+    ``re2e_conv3x3_wino`` with the fused ReLU + 2x2 max pool epilogue (csrc/winograd.hip: fused Winograd F(2x2,3x3), the input patch staged
+    through LDS by LDS-DMA since round 6; only the pooled tensor and the index bytes are written).  Timed at the full height of the 64 images; the
+    step launches it row-limited (``re2e_conv3x3_wino_rows``).
 
     ``achieved`` = the FLOPs the matrix cores EXECUTE per launch (the Winograd form: 16 instead of 36 multiply-adds per 2x2 outputs, i.e. the
     direct form's 2*9*Cin*Cout per output pixel / 2.25) / launch time, so ``frac`` <= 1 is a utilisation of the 157.3 TFLOP/s fp32-MFMA peak;
@@ -161,8 +162,9 @@ def conv_roofline(dev, iters=20):
     pj2, tsrc2 = _profile_json(['r03_conv1_2_pmc_traffic.json', 'r02_conv1_2_pmc_traffic.json'])
     eng, eng_exe, esrc = engine_average()
     pk = PEAK_FP32_MFMA_TFLOPS
-    return {'bound': 'mfma', 'kernel': 'wino_conv3x3_kernel (VGG conv1_2 fwd as the step launches it: fused Winograd F(2x2,3x3) + bias + ReLU + 2x2 max '
-                                       'pool in one launch, 64x800x80, 64->64, 3x3)',
+    return {'bound': 'mfma', 'kernel': 'wino_conv3x3_kernel<8, LDSIN> (VGG conv1_2 forward: fused Winograd F(2x2,3x3) + bias + ReLU + 2x2 max pool in one launch, '
+                                       '64x800x80, 64->64, 3x3, at its FULL height; the step launches the same kernel through re2e_conv3x3_wino_rows, '
+                                       'which skips the 12-14 % of the rows beyond the utterances)',
             'achieved': round(ach, 2), 'peak': pk, 'unit': 'TFLOP/s', 'frac': round(ach / pk, 4),
             'note': 'achieved = EXECUTED matrix-core FLOPs (the Winograd form: direct FLOPs / 2.25) / launch time, so frac <= 1 is a utilisation of the '
                     'fp32-MFMA peak; the direct-form figure is direct_equivalent_tflops',
@@ -281,7 +283,7 @@ def chain_roofline(dev):
                      lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
             ev[1].record()
             lib.call('re2e_lstm_seq_bwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
-                     cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+                     cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, None, ws.data_ptr(), wsb)
             ev[2].record()
             torch.cuda.synchronize()
             if rep:

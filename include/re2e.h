@@ -48,7 +48,7 @@ typedef struct ihipStream_t* re2e_stream_t; /* == hipStream_t */
 /* ABI version of this header: bumped whenever an entry point is added or a signature changes (positional arguments carry no
  * names across the boundary).  re2e_version() returns the value the library was built with; a binding written for another value
  * must refuse to call (robust_e2e_gan_amd/lib.py load()). */
-#define RE2E_ABI_VERSION 318
+#define RE2E_ABI_VERSION 319
 int re2e_version(void);
 const char* re2e_last_error(void);
 /* 1 when device 0 is gfx950, 0 when another arch, <0 on HIP error. */
@@ -340,10 +340,13 @@ int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, const float*
                       re2e_stream_t stream);
 /* g_f/g_r: activated gates in, d(pre-activation gates) out (in place).  dy [T*B,2H].
  * whh_*: W_hh [4H,H] as stored by nn.LSTM.  dc_state [B,2H] scratch (zeroed by the call).
+ * dbias (optional, [2][4H]): the column sums of d(gates) over all T*B rows, forward direction then reverse = the gradient of
+ * bias_ih and of bias_hh (autograd of nn.LSTM, e2e_encoder.py:128-132) -- accumulated beside the recurrence where the kernel
+ * form allows it, so that the caller needs no pass of its own over the (T*B, 4H) tensors.
  * workspace (re2e_lstm_workspace_bytes) holds the MFMA-fragment-ordered weight / state copies. */
 int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, const float* whh_r, const float* dy,
                       const float* ybuf, const float* cbuf, float* dc_state, const int* lens_dev, int T, int B, int H,
-                      void* workspace, size_t workspace_bytes, re2e_stream_t stream);
+                      float* dbias, void* workspace, size_t workspace_bytes, re2e_stream_t stream);
 
 /* ---- K8 LSTMCell pointwise (decoder, e2e_decoder.py:131), embedding, cross-entropy -------- */
 /* gates [B,4H] pre-activation in -> activated out; c_prev [B,H] -> c_out, h_out */

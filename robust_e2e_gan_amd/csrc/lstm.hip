@@ -948,7 +948,7 @@ __global__ void pack_w_bwd3_kernel(const float* __restrict__ whh, float* __restr
 template <int UN, int TPW>       // UN: hidden units per workgroup (8 | 16); TPW: 16-unit output tiles per wave (H = 64 TPW)
 __global__ __launch_bounds__(256) void lstm_bwd3(float* g_f, float* g_r, const float* __restrict__ wb, const float* __restrict__ dy,
                                                  const float* __restrict__ cbuf, float* dc_state, float* xbuf, unsigned* flags_, unsigned* err,
-                                                 const int* __restrict__ lens, int T, int B, int H) {
+                                                 const int* __restrict__ lens, int T, int B, int H, float* __restrict__ dbp) {
   constexpr int KG = 4 * UN;              // gate rows per workgroup = K of the partial product
   constexpr int LDG = KG + 4;             // padded row of the d(gates) tile
   constexpr int BLK = 16 * UN;            // floats per (consumer, producer) block: [16 b][UN units]
@@ -986,6 +986,9 @@ __global__ __launch_bounds__(256) void lstm_bwd3(float* g_f, float* g_r, const f
   const long bb = ok ? b : 0;
   const int ln = lens[bb];
   float dcr = 0.f;                                              // d(cell state) carried across steps
+  // the bias gradient rides along (round 6): sum over the steps of this thread's four d(gates) -- the column sums of d(gates) the caller used to
+  // take in a pass of its own over the (T B, 4H) tensor (105 MB per direction and layer at config 4); summed over the tile's utterances at the end
+  float sbi = 0.f, sbf = 0.f, sbg = 0.f, sbo = 0.f;
   float n_dy, n_g[4], n_c, n_cp;
   {
     const int t = dir ? 0 : T - 1;
@@ -1081,6 +1084,7 @@ __global__ __launch_bounds__(256) void lstm_bwd3(float* g_f, float* g_r, const f
         dcp = dct * gf;
       }
       dcr = dcp;
+      sbi += di; sbf += df; sbg += dg; sbo += dout;
       if (ok) {
         float* gp = G + ((long)t * B + b) * K4 + j;
         gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dout;
@@ -1130,9 +1134,46 @@ __global__ __launch_bounds__(256) void lstm_bwd3(float* g_f, float* g_r, const f
       __hip_atomic_store(flags + (s & 1) * f_par + f_grp + (long)x * 32 + wid * 8, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (ok) dc_state[(long)b * H2 + dir * H + j] = dcr;
+  if (dbp) {
+    // dbp[dir][mt][gate * H + unit] = sum over this tile's 16 utterances (fixed order) of the per-thread sums over time
+    __syncthreads();
+    if (cell) {
+      float* dq = dgs + bm * LDG + jj;
+      dq[0] = sbi; dq[UN] = sbf; dq[2 * UN] = sbg; dq[3 * UN] = sbo;
+    }
+    __syncthreads();
+    if (tid < KG) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += dgs[r * LDG + tid];
+      dbp[(grp * 4 + tid / UN) * H + j0 + tid % UN] = v;
+    }
+  }
   if (aborted && ok) {                              // a peer never published: make the failure visible downstream
     for (int t = 0; t < T; ++t) G[((long)t * B + b) * K4 + j] = __uint_as_float(0x7fc00000u);
   }
+}
+
+// out[dir][c] = sum over the utterance tiles (fixed order) of lstm_bwd3's partial bias sums dbp[dir][mt][c], c < 4H
+__global__ void lstm_dbias_reduce_kernel(const float* __restrict__ dbp, int MT, int H4, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, dir = blockIdx.y;
+  if (c >= H4) return;
+  float v = 0.f;
+  for (int mt = 0; mt < MT; ++mt) v += dbp[((long)dir * MT + mt) * H4 + c];
+  out[(long)dir * H4 + c] = v;
+}
+// the same sums for the paths without the fused form (launch-per-step kernels, the round-1..3 persistent backward): column sums of d(gates) over
+// all T B rows, one workgroup per 64 columns and direction, rows in a fixed order (deterministic; these paths are not the training step's)
+__global__ __launch_bounds__(256) void gates_colsum_kernel(const float* __restrict__ g_f, const float* __restrict__ g_r, long M, int H4, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int dir = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const float* G = dir ? g_r : g_f;
+  float v = 0.f;
+  if (c < H4)
+    for (long r = rl; r < M; r += 4) v += G[r * H4 + c];
+  red[rl][threadIdx.x & 63] = v;
+  __syncthreads();
+  if (rl == 0 && c < H4) out[(long)dir * H4 + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void zero_kernel(float* p, long n) {
@@ -1353,7 +1394,7 @@ int bwd3_units(int T, int B, int H) {
 template <int UN, int TPW> LdsLimit& bwd3_lim() { static LdsLimit l; return l; }
 template <int UN, int TPW>
 bool launch_bwd3(hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs, void* flagmem,
-                 size_t flagbytes, const int* lens, int T, int B, int H) {
+                 size_t flagbytes, const int* lens, int T, int B, int H, float* dbp) {
   dim3 grid(H / UN, cdiv(B, 16), 2);
   lstm_stamps_arm();
   (void)hipMemsetAsync(flagmem, 0, flagbytes, st);
@@ -1363,13 +1404,13 @@ bool launch_bwd3(hipStream_t st, float* g_f, float* g_r, const float* wb, const 
   static const int frac = exp_env("RE2E_LSTM_OWN_CU_FRAC") ? atoi(exp_env("RE2E_LSTM_OWN_CU_FRAC")) : 2;
   size_t lds = hog && (long)grid.x * grid.y * grid.z <= cu_count() / frac ? (size_t)(hog - 16) * 1024 : 0;     // + ~9 KB static
   bwd3_lim<UN, TPW>().ensure(reinterpret_cast<const void*>(&lstm_bwd3<UN, TPW>), lds);
-  hipLaunchKernelGGL((lstm_bwd3<UN, TPW>), grid, dim3(256), lds, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H);
+  hipLaunchKernelGGL((lstm_bwd3<UN, TPW>), grid, dim3(256), lds, st, g_f, g_r, wb, dy, cbuf, dc, slabs, flags, err, lens, T, B, H, dbp);
   return true;
 }
 #define RE2E_BWD3_ALL(M) M(8, 1) M(8, 2) M(8, 3) M(8, 4) M(8, 5) M(8, 6) M(8, 7) M(8, 8) M(16, 1) M(16, 2) M(16, 3) M(16, 4) M(16, 5) M(16, 6) M(16, 7) M(16, 8)
 bool try_bwd3(int un, hipStream_t st, float* g_f, float* g_r, const float* wb, const float* dy, const float* cbuf, float* dc, float* slabs, void* flagmem,
-              size_t flagbytes, const int* lens, int T, int B, int H) {
-#define RE2E_B3(U, TP) if (un == U && H == 64 * TP) return launch_bwd3<U, TP>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H);
+              size_t flagbytes, const int* lens, int T, int B, int H, float* dbp) {
+#define RE2E_B3(U, TP) if (un == U && H == 64 * TP) return launch_bwd3<U, TP>(st, g_f, g_r, wb, dy, cbuf, dc, slabs, flagmem, flagbytes, lens, T, B, H, dbp);
   RE2E_BWD3_ALL(RE2E_B3)
 #undef RE2E_B3
   return false;
@@ -1504,8 +1545,10 @@ extern "C" int re2e_warmup(void) {
   return RE2E_OK;
 }
 
+// the backward's partial bias sums [2][cdiv(B, 16)][4H] floats, behind its flag lines
+size_t bwd_dbp_bytes(int B, int H) { return (size_t)2 * ((B + 15) / 16) * 4 * H * sizeof(float); }
 extern "C" size_t re2e_lstm_workspace_bytes(int B, int H) {
-  size_t a = fwd_ws_floats(B, H) * sizeof(float) + fwd_hx_bytes(B, H), b = bwd_ws_floats(B, H) * sizeof(float) + bwd_flag_bytes(B, H);
+  size_t a = fwd_ws_floats(B, H) * sizeof(float) + fwd_hx_bytes(B, H), b = bwd_ws_floats(B, H) * sizeof(float) + bwd_flag_bytes(B, H) + bwd_dbp_bytes(B, H);
   return a > b ? a : b;
 }
 
@@ -1603,13 +1646,20 @@ extern "C" int re2e_lstm_seq_fwd(float* xg_f, float* xg_r, const float* whh_f, c
 }
 
 extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, const float* whh_r, const float* dy, const float* ybuf,
-                                 const float* cbuf, float* dc_state, const int* lens_dev, int T, int B, int H, void* workspace,
+                                 const float* cbuf, float* dc_state, const int* lens_dev, int T, int B, int H, float* dbias, void* workspace,
                                  size_t workspace_bytes, hipStream_t stream) {
   (void)ybuf;
   RE2E_CHECK_ARG(g_f && g_r && whh_f && whh_r && dy && cbuf && dc_state && lens_dev && workspace, "null arg");
   RE2E_CHECK_ARG(T > 0 && B > 0 && H > 0, "bad shape");
   if (H % 8 != 0) { re2e_set_error("re2e_lstm_seq_bwd: hidden size must be a multiple of 8 (got %d)", H); return RE2E_EUNSUPPORTED; }
-  RE2E_CHECK_ARG(workspace_bytes >= bwd_ws_floats(B, H) * sizeof(float) + bwd_flag_bytes(B, H), "workspace too small");
+  RE2E_CHECK_ARG(workspace_bytes >= bwd_ws_floats(B, H) * sizeof(float) + bwd_flag_bytes(B, H) + (dbias ? bwd_dbp_bytes(B, H) : 0), "workspace too small");
+  // dbias (optional, [2][4H]): the column sums of d(gates) per direction = the gradient of b_ih and of b_hh.  The 16-utterance-tile kernel
+  // accumulates them beside the recurrence (per-tile partials behind the flag lines, summed here); the other paths take them in a pass over
+  // d(gates) behind the recurrence.
+  const long M_rows = (long)T * B;
+  auto dbias_fallback = [&]() {
+    if (dbias) hipLaunchKernelGGL(gates_colsum_kernel, dim3(cdiv(4 * H, 64), 2), dim3(256), 0, stream, g_f, g_r, M_rows, 4 * H, dbias);
+  };
   long wn = (long)(H / 8) * ((H + 31) / 32) * 1024;
   float* wb = (float*)workspace;
   float* slabs = wb + 2 * wn;
@@ -1620,7 +1670,9 @@ extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, con
     long nz3 = (long)B * 2 * H;
     hipLaunchKernelGGL(zero_kernel, dim3(cdiv(nz3, 256)), dim3(256), 0, stream, dc_state, nz3);
     void* flagmem3 = (char*)workspace + bwd_ws_floats(B, H) * sizeof(float);
-    if (try_bwd3(un, stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, flagmem3, bwd_flag_bytes(B, H), lens_dev, T, B, H)) {
+    float* dbp = dbias ? (float*)((char*)flagmem3 + bwd_flag_bytes(B, H)) : nullptr;
+    if (try_bwd3(un, stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, flagmem3, bwd_flag_bytes(B, H), lens_dev, T, B, H, dbp)) {
+      if (dbias) hipLaunchKernelGGL(lstm_dbias_reduce_kernel, dim3(cdiv(4 * H, 256), 2), dim3(256), 0, stream, dbp, cdiv(B, 16), 4 * H, dbias);
       RE2E_LAUNCH_CHECK();
       return RE2E_OK;
     }
@@ -1632,11 +1684,13 @@ extern "C" int re2e_lstm_seq_bwd(float* g_f, float* g_r, const float* whh_f, con
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(nz, 256)), dim3(256), 0, stream, dc_state, nz);
   void* flagmem = (char*)workspace + bwd_ws_floats(B, H) * sizeof(float);
   if (uw && try_bwd_persist(uw, stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, flagmem, bwd_flag_bytes(B, H), lens_dev, T, B, H)) {
+    dbias_fallback();
     RE2E_LAUNCH_CHECK();
     return RE2E_OK;
   }
   if (H / 32 >= 8) launch_bwd<2>(stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, lens_dev, T, B, H);
   else launch_bwd<1>(stream, g_f, g_r, wb, dy, cbuf, dc_state, slabs, lens_dev, T, B, H);
+  dbias_fallback();
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
 }

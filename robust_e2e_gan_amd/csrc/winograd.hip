@@ -99,16 +99,20 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, int Cout, int C
 // by the ACCESS RATE of the L1, not by issue or latency (TCP_TOTAL_CACHE_ACCESSES, and the diagnostic that read 1 KB contiguous per instruction instead:
 // conv1_2 1.47 -> 1.26 ms with the same bytes and instructions; profiles/r06_wino_attribution.md).  Staged, a (PH + 2) x (PW + 2) patch of 32 channels
 // is 24 load instructions per workgroup instead of 128, and each pixel is fetched once.
-//   LDS image of a half (32 channels): [8 granule planes g = channel / 4][192 slots][16 bytes], slot(py, px) = py * IPW + (px & 1) * IPW / 2 + px / 2
-//   (even columns first): the 8 tiles of a patch row read consecutive slots -- conflict-free ds_read_b128 -- and a chunk's position inside the half
-//   is an instruction immediate: no address arithmetic in the loop.  Two halves are resident (2 x 24 KB, aliased with the epilogue's exchange
-//   buffer); half h + 2 is requested when the last chunk of half h has left LDS (one workgroup barrier per half).
+//   LDS image of a half (32 channels): [2 planes of 16 channels][192 slots][64 bytes], slot(py, px) = py * IPW + (px & 1) * IPW / 2 + px / 2 (even
+//   columns first: the 8 tiles of a patch row read consecutive slots), the four 16-byte granules of a slot ROTATED by slot / 2 -- so that
+//   (a) a request instruction covers 16 pixels x 64 contiguous bytes (4 lanes per pixel: 16 cache lines per instruction; the first form,
+//   16-byte granule planes, asked 64 lines per instruction and cost 5 % of the six launches: profiles/r06_wino_attribution.md), and (b) the
+//   eight lanes a ds_read_b128 serves together hit eight different 16-byte bank groups (conflict-free).  The rotation makes a granule's position
+//   lane-dependent, so a lane keeps TWO read addresses per pixel (the two chunks of a plane); plane and buffer are instruction immediates:
+//   no address arithmetic in the loop.  Two halves are resident (2 x 24 KB, aliased with the epilogue's exchange buffer); half h + 2 is
+//   requested when the last chunk of half h has left LDS (one workgroup barrier per half).
 template <int TXW, bool LDSIN>      // TXW = tiles per patch row: 8 (16 x 8 pixel patch) or 4 (8 x 16)
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
   constexpr int TYH = 32 / TXW;
   constexpr int PW = 2 * TXW, PH = 2 * TYH;
   constexpr int IPW = PW + 2, IPH = PH + 2, NPIX = IPW * IPH;        // the input patch: 18 x 10 or 10 x 18 pixels
-  constexpr int NSLOT = 192, PLANE = NSLOT * 16, HALFB = 8 * PLANE;  // bytes; 8 planes x 192 slots = 24 LDS-DMA instructions of 64 lanes
+  constexpr int NSLOT = 192, PLANE = NSLOT * 64, HALFB = 2 * PLANE;  // bytes; 2 planes x 192 slots x 64 bytes = 24 LDS-DMA instructions of 64 lanes
   static_assert(NPIX <= NSLOT && IPW % 2 == 0, "patch geometry");
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 rows i][2 b][32 tiles][LDR]
 
@@ -176,20 +180,25 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
 
   // ---- LDSIN: per-lane constants of the staging requests (6 per wavefront and half) and of the fragment reads (8 pixels)
   unsigned st_off[6];       // byte offset of the lane's 16 bytes inside the image (channel half 0), or out of range
-  unsigned rd_off[8];       // LDS byte offset of pixel k's granule (plane lh) in a half at chunk position 0
+  unsigned rd_off[8][2];    // LDS byte offset of pixel k's granule (this lane's k-half) for the first / second chunk of a 16-channel plane
   const char* const sbytes = reinterpret_cast<const char*>(smem);
   auto set_item_lds = [&](const Geo& g) {
     u_s0 = (unsigned)(((g.nblk * nch) * 16 + 4 * wid) * 2) * 1024u;
     const bool interior = g.y0 >= 1 && g.x0 >= 1 && g.y0 + PH + 1 <= p.H && g.x0 + PW + 1 <= p.W;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const int q = wid + 4 * i;                                   // instruction q of 24: granules [64 q, 64 q + 64)
-      const int gq = q / 3, slot = (q - 3 * gq) * 64 + lane;        // plane (wave-uniform), slot
+      const int q = wid + 4 * i;                                   // instruction q of 24: plane q / 12, slots [16 (q % 12), + 16), 4 lanes per slot
+      const int pl = q / 12, slot = (q - 12 * pl) * 16 + (lane >> 2);
+      const int gr = ((lane & 3) - (slot >> 1)) & 3;               // LDS position lane & 3 of the slot holds granule (position - slot / 2) mod 4
       const int py = slot / IPW, rem = slot - py * IPW;
       const int px = rem < IPW / 2 ? 2 * rem : 2 * (rem - IPW / 2) + 1;
       const int iy = g.y0 - 1 + py, ix = g.x0 - 1 + px;
       const bool ok = slot < NPIX && (interior || ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W));
-      st_off[i] = ok ? (unsigned)(iy * rowb + ix * colb + gq * 16) : WOOB;
+      st_off[i] = ok ? (unsigned)(iy * rowb + ix * colb + pl * 64 + gr * 16) : WOOB;
+#ifdef RE2E_EXPERIMENTS
+      // diagnostic (RE2E_WINO_DBG bit 128, timing only): every request instruction reads 1 KB CONTIGUOUS (wrong pixels)
+      if (p.dbg & 128) st_off[i] = (unsigned)((g.y0 * rowb + g.x0 * colb) + q * 1024 + lane * 16);
+#endif
     }
   };
   auto stage = [&](int half, int buf) {                            // half `half` of the channels -> LDS buffer `buf`
@@ -206,13 +215,15 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int py = 2 * tyi + (k < 4 ? ra : rb), px = 2 * txi + (k & 3);
-      rd_off[k] = (unsigned)((py * IPW + (px & 1) * (IPW / 2) + (px >> 1)) * 16 + lh * PLANE);
+      const int slot = py * IPW + (px & 1) * (IPW / 2) + (px >> 1);
+      rd_off[k][0] = (unsigned)(slot * 64 + ((lh + (slot >> 1)) & 3) * 16);            // granule lh (chunk 0 of the plane) ...
+      rd_off[k][1] = (unsigned)(slot * 64 + ((2 + lh + (slot >> 1)) & 3) * 16);        // ... and granule 2 + lh (chunk 1)
     }
   }
   f32x4 raw[8], uf[4][2];
-  auto read_raw = [&](int buf, int cc) {                           // chunk position cc (8 channels = planes 2 cc, 2 cc + 1) of the half in `buf`
+  auto read_raw = [&](int buf, int cc) {                           // chunk position cc (8 channels: plane cc / 2, its first or second chunk) of the half in `buf`
 #pragma unroll
-    for (int k = 0; k < 8; ++k) raw[k] = *reinterpret_cast<const f32x4*>(sbytes + rd_off[k] + (buf * HALFB + cc * 2 * PLANE));
+    for (int k = 0; k < 8; ++k) raw[k] = *reinterpret_cast<const f32x4*>(sbytes + rd_off[k][cc & 1] + (buf * HALFB + (cc >> 1) * PLANE));
   };
 #ifdef RE2E_EXPERIMENTS
   // diagnostic (RE2E_WINO_DBG bit 16): the eight pixel loads of a chunk read 1 KB CONTIGUOUS each (lane-linear, wrong pixels) instead of 64 separate
@@ -582,7 +593,7 @@ static int wino_impl(const float* in, int NI, int H, int W, int C, const float* 
   // the input patch through LDS (round 6) wherever the channel count allows it (whole pairs of 32-channel halves); RE2E_WINO_LDSIN=0 (experiments
   // build): the per-lane loads of rounds 3-5
   static const bool ldsin_env = !(exp_env("RE2E_WINO_LDSIN") && atoi(exp_env("RE2E_WINO_LDSIN")) == 0);
-  const bool ldsin = ldsin_env && C % 64 == 0 && !a.stamps && !(a.dbg & ~(1 | 32 | 64));
+  const bool ldsin = ldsin_env && C % 64 == 0 && !a.stamps && !(a.dbg & ~(1 | 32 | 64 | 128));
   if (ldsin) { if (wide) launch_wino<8, true>(a, stream); else launch_wino<4, true>(a, stream); }
   else { if (wide) launch_wino<8, false>(a, stream); else launch_wino<4, false>(a, stream); }
   RE2E_LAUNCH_CHECK();

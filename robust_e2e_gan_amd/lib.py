@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RE2E_LIB selects another build of the same C ABI (A/B measurements of kernel changes inside one GPU session)
 LIB_PATH = os.environ.get('RE2E_LIB') or os.path.join(_HERE, 'libre2e_hip.so')
-ABI_VERSION = 318      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
+ABI_VERSION = 319      # include/re2e.h RE2E_ABI_VERSION this table was written for (checked against the library in load())
 
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_SIGMOID_MASK_MUL = range(6)
 LOSS_L2, LOSS_L1, LOSS_SMOOTH_L1, LOSS_BCE = range(4)
@@ -97,7 +97,7 @@ SIGNATURES = {
     're2e_debug_occupy': (I, [I, I, I, P]),
     're2e_step_gate': (I, [P, I, P, P, P, P, P, P, P]),
     're2e_lstm_seq_fwd': (I, [P, P, P, P, P, P, P, I, I, I, P, Z, P]),
-    're2e_lstm_seq_bwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, Z, P]),
+    're2e_lstm_seq_bwd': (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P, Z, P]),
     're2e_lstm_cell_fwd': (I, [P, P, P, P, I, I, P]),
     're2e_lstm_cell_bwd': (I, [P, P, P, P, P, P, P, I, I, P]),
     're2e_dec_gates_cell_fwd': (I, [P, P, P, L, P, P, P, P, P, I, I, I, P]),

@@ -54,6 +54,7 @@ def gemm(A, B, C, M, N, K, transa=False, transb=False, lda=None, ldb=None, ldc=N
 
 NT_INPUT_GRAD = lib.exp_env('RE2E_NO_NT_INPUT_GRAD') is None
 INLINE_LAST_WGRAD = lib.exp_env('RE2E_NO_INLINE_LAST_WGRAD') is None
+FUSED_DBIAS = lib.exp_env('RE2E_NO_FUSED_DBIAS') is None
 
 
 def gemm_input_grad(dz, W, dx, M, K, N, beta=0.0):
@@ -682,14 +683,25 @@ def fill_image_rows(t, lim, div, max_tail):
         call('re2e_fill_image_rows', t.data_ptr(), N, H, t.shape[2] * t.shape[3], lim.data_ptr(), div, int(max_tail), 0.0)
 
 
-def _note_row_limits(row_lim):
-    """bench.py's executed-FLOP meter (flops.py) counts a row-limited launch with the rows below its limits: the host copy of the limits."""
-    if row_lim is not None and lib.FLOP_METER is not None:
+_LOG_CALLS = os.environ.get('RE2E_IGEMM_LOG') is not None
+
+
+def _note_row_limits(row_lim, H=0, W=0):
+    """bench.py's executed-FLOP meter (flops.py) counts a row-limited launch with the rows below its limits: the host copy of the limits.  With
+    RE2E_IGEMM_LOG (tools/igemm_table.py) the pixels the next Winograd launch really computes go to the engine's call log."""
+    if row_lim is None or (lib.FLOP_METER is None and not _LOG_CALLS):
+        return
+    from .model import e2e_common as ec
+    host = ec.host_lens_of(row_lim)
+    if host is None:
+        return
+    if lib.FLOP_METER is not None:
         from . import flops
-        from .model import e2e_common as ec
-        host = ec.host_lens_of(row_lim)
-        if host is not None:
-            flops.note_rows(row_lim.data_ptr(), host)
+        flops.note_rows(row_lim.data_ptr(), host)
+    if _LOG_CALLS and H:
+        import sys
+        sys.stderr.write('[igemm-rows] M=%d\n' % (sum(min(H, (min(int(l), H) + 7) // 8 * 8) for l in host) * W))
+        sys.stderr.flush()
 
 
 def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool=False, row_lim=None):
@@ -700,7 +712,7 @@ def conv3x3_wino(x, W, Cout, dgrad=False, bias=None, relu=False, mask=None, pool
     wsb = query('re2e_conv3x3_wino_workspace_bytes', C, Cout)
     ws = workspace(wsb, x.device, 'wino')
     nb = _wino_images(N, H, Wd, C, Cout)
-    _note_row_limits(row_lim)
+    _note_row_limits(row_lim, H, Wd)
     if pool:
         yp = empty((N, (H + 1) // 2, (Wd + 1) // 2, Cout), x)
         idx = torch.empty(yp.shape, dtype=torch.uint8, device=x.device)
@@ -833,7 +845,7 @@ class Conv2dFn(torch.autograd.Function):
                 nb = _wino_images(N, H, Wd, Cin, Cout)                # tensors of 2 GiB or more: slices of the image axis, accumulated
                 wsb = query('re2e_conv3x3_wino_wgrad_workspace_bytes', nb, H, Wd, Cin, Cout)
                 ws = workspace(wsb, x.device, 'winow')
-                _note_row_limits(lims.out if lims is not None else None)
+                _note_row_limits(lims.out if lims is not None else None, H, Wd)
                 with accumulate(W) as (gw, beta):
                     for i in range(0, N, nb):
                         n = min(nb, N - i)
@@ -1323,8 +1335,13 @@ class BiLstmFn(torch.autograd.Function):
         dc = empty((B, 2 * H), dy)
         wsb = query('re2e_lstm_workspace_bytes', B, H)
         ws = workspace(wsb, dy.device, 'lstm')
+        # dbias (2, 4H): the column sums of d(gates) = the gradient of b_ih and of b_hh per direction, accumulated beside the recurrence
+        # (csrc/lstm.hip lstm_bwd3: no pass of its own over the (T B, 4H) tensors, 105 MB per direction and layer at config 4)
+        dbias = empty((2, 4 * H), dy) if any(ctx.needs_input_grad[4 + 4 * d] or ctx.needs_input_grad[5 + 4 * d] for d in range(2)) else None
+        if dbias is not None and not FUSED_DBIAS:      # (experiments: the column sums as a pass of their own on the weight-gradient stream, rounds 1-5)
+            dbias = None
         call('re2e_lstm_seq_bwd', g_f.data_ptr(), g_r.data_ptr(), w[1].data_ptr(), w[5].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
-             cbuf.data_ptr(), dc.data_ptr(), ctx.lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+             cbuf.data_ptr(), dc.data_ptr(), ctx.lens.data_ptr(), T, B, H, ptr(dbias), ws.data_ptr(), wsb)
         dG = (g_f, g_r)
         M = T * B
         dx = None
@@ -1349,7 +1366,7 @@ class BiLstmFn(torch.autograd.Function):
         needs = ctx.needs_input_grad
 
         def weight_grads(inline):
-            with param_grads(g_f, g_r, x2, ybuf, ctx.maps, inline=inline):
+            with param_grads(g_f, g_r, x2, ybuf, dbias, ctx.maps, inline=inline):
                 for d in range(2):
                     w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
                     n_ih, n_hh, n_bi, n_bh = needs[2 + 4 * d:6 + 4 * d]
@@ -1379,18 +1396,17 @@ class BiLstmFn(torch.autograd.Function):
                                 gemm_tn_rows(dG[d], hprev.data_ptr(), gw, 4 * H, H, mp, beta=beta, lda=4 * H, ldb=2 * H)
                             else:
                                 call_gemm_strided(dG[d], hprev, gw, 4 * H, H, M, lda=4 * H, ldb=2 * H, beta=beta)
-                    if n_bi and n_bh:                         # the same column sums: ONE pass over d(gates) (105 MB per direction and layer)
+                    csum = dbias[d] if dbias is not None else None
+                    if csum is None and (n_bi or n_bh):
                         csum = empty((4 * H,), dy)
                         colsum_into(dG[d], M, 4 * H, csum, 0.0)
-                        for b_ in (b_ih, b_hh):
+                    for b_, need in ((b_ih, n_bi), (b_hh, n_bh)):    # both biases get the column sums of d(gates): the recurrence left them in dbias
+                        if need:
                             with accumulate(b_) as (gb, beta):
                                 if beta == 0.0:
                                     gb.copy_(csum)
                                 else:
                                     gb.add_(csum)
-                    elif n_bi or n_bh:
-                        with accumulate(b_ih if n_bi else b_hh) as (gb, beta):
-                            colsum_into(dG[d], M, 4 * H, gb, beta)
 
         weight_grads(last)
         return (dx, None) + (None,) * len(w)

@@ -770,7 +770,7 @@ def test_lstm_persistent_vs_stepwise(B, T, H, uw, fwd2, monkeypatch):
             G = [gf.clone(), gr.clone()]
             dc = torch.full((B, 2 * H), float('nan'), device=DEV)
             lib.call('re2e_lstm_seq_bwd', G[0].data_ptr(), G[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
-                     cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+                     cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, None, ws.data_ptr(), wsb)
         torch.cuda.synchronize()
         bouts[mode] = (G[0], G[1])
     for name, a, b in zip(('dgates_f', 'dgates_r'), bouts['0'], bouts['1']):

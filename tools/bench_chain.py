@@ -33,7 +33,7 @@ def run(T, B, H, reps=5):
              lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
         e[1].record()
         call('re2e_lstm_seq_bwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
-             cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+             cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, None, ws.data_ptr(), wsb)
         e[2].record()
         torch.cuda.synchronize()
         if rep:

@@ -37,7 +37,7 @@ def main(filler='conv', which='fwd'):
                  lens.data_ptr(), T, B, Hh, ws.data_ptr(), wsb)
         else:
             call('re2e_lstm_seq_bwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
-                 cbuf.data_ptr(), dcs.data_ptr(), lens.data_ptr(), T, B, Hh, ws.data_ptr(), wsb)
+                 cbuf.data_ptr(), dcs.data_ptr(), lens.data_ptr(), T, B, Hh, None, ws.data_ptr(), wsb)
 
     from robust_e2e_gan_amd import ops
     vx = torch.randn(32, 800, 80, 1, device=DEV)

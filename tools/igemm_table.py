@@ -16,11 +16,23 @@ from collections import defaultdict
 
 def main(log_path, trace_path):
     calls = []
+    rows_m = None          # "[igemm-rows] M=<pixels>" (ops._note_row_limits): the pixels the NEXT Winograd launch computes (per-image row limits)
     for line in open(log_path, errors="replace"):
+        mr = re.search(r"\[igemm-rows\] M=(\d+)", line)
+        if mr:
+            rows_m = int(mr.group(1))
+            continue
         m = re.search(r"\[igemm\] A=(\w+) B=(\w+) tile=(\d+)x(\d+)x(\d+) vec=(\d) M=(\d+) N=(\d+) K=(\d+) splits=(-?\d+)", line)
         if m:
             a, b = m.group(1), m.group(2)
-            calls.append((a, b) + tuple(int(x) for x in m.groups()[2:]))
+            vals = [int(x) for x in m.groups()[2:]]
+            if a.startswith("Wino") and rows_m is not None:
+                if a == "WinoW":
+                    vals[6] = min(vals[6], rows_m)       # weight gradient: the pixels are the contraction (K)
+                else:
+                    vals[4] = min(vals[4], rows_m)       # forward / data gradient: the pixels are M
+                rows_m = None
+            calls.append((a, b) + tuple(vals))
     kern = []
     for r in csv.DictReader(open(trace_path)):
         if "igemm_kernel" in r["Kernel_Name"] or "gemm_nt2_kernel" in r["Kernel_Name"] or "conv3x3_halo_kernel" in r["Kernel_Name"] or "conv3x3_wgrad_kernel" in r["Kernel_Name"] or "wino_conv3x3_kernel" in r["Kernel_Name"] or "wino_wgrad_kernel" in r["Kernel_Name"]:

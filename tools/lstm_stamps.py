@@ -91,7 +91,7 @@ def run(T, B, H):
     for rep in range(2):
         stamps.zero_()
         call('re2e_lstm_seq_bwd', xg[0].data_ptr(), xg[1].data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dy.data_ptr(), ybuf.data_ptr(),
-             cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, ws.data_ptr(), wsb)
+             cbuf.data_ptr(), dc.data_ptr(), lens.data_ptr(), T, B, H, None, ws.data_ptr(), wsb)
         torch.cuda.synchronize()
     if un3:
         analyse('backward (bwd3, %d units x 16 utterances per workgroup) T=%d B=%d H=%d' % (un3, T, B, H), (H // un3) * ((B + 15) // 16) * 2, 4, BWD, 8)

@@ -5,7 +5,7 @@ O=$R/gpurun_out/r6_diag4
 rm -rf $O; mkdir -p $O
 cd $R
 export RE2E_EXPERIMENTS=1 RE2E_LIB=$R/robust_e2e_gan_amd/libre2e_hip_exp.so
-for D in 0 32 64 96 97; do
+for D in 0 128 64 0 128; do
   RE2E_WINO_DBG=$D timeout 300 python tools/bench_wino_ab.py dbg$D 2>/dev/null | grep -v wgrad >> $O/wino_lds_dbg.txt
 done
 cat $O/wino_lds_dbg.txt
