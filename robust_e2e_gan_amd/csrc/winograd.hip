@@ -179,26 +179,31 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
   };
 
   // ---- LDSIN: per-lane constants of the staging requests (6 per wavefront and half) and of the fragment reads (8 pixels)
-  unsigned st_off[6];       // byte offset of the lane's 16 bytes inside the image (channel half 0), or out of range
+  unsigned st_off[3];       // byte offset of the lane's 16 bytes inside the image (channel half 0, plane 0) for its three slots, or out of range
   unsigned rd_off[8][2];    // LDS byte offset of pixel k's granule (this lane's k-half) for the first / second chunk of a 16-channel plane
   const char* const sbytes = reinterpret_cast<const char*>(smem);
+  // Request instruction q = wid + 4 i (i < 6) of a half covers plane q / 12, slots [16 (q % 12), + 16), four lanes per slot.  q % 12 = wid, wid + 4,
+  // wid + 8 for i = 0, 1, 2 and AGAIN for i = 3, 4, 5 (the second plane: + 64 bytes, through the instruction's scalar offset): a lane has three
+  // slots, 64 apart, and since 64 / 2 is a multiple of 4 the same granule rotation in all of them -- one division per work item, the rest are adds
+  // (the first form of this set-up cost 0.85 vector instructions per MFMA: profiles/r06_conv1_2_wino_pmc_sq.json against r05).
   auto set_item_lds = [&](const Geo& g) {
     u_s0 = (unsigned)(((g.nblk * nch) * 16 + 4 * wid) * 2) * 1024u;
     const bool interior = g.y0 >= 1 && g.x0 >= 1 && g.y0 + PH + 1 <= p.H && g.x0 + PW + 1 <= p.W;
+    int slot = wid * 16 + (lane >> 2);                              // < 64
+    int py = slot / IPW, rem = slot - py * IPW;
+    const int gr16 = (((lane & 3) - (slot >> 1)) & 3) * 16;         // LDS position lane & 3 of a slot holds granule (position - slot / 2) mod 4
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int q = wid + 4 * i;                                   // instruction q of 24: plane q / 12, slots [16 (q % 12), + 16), 4 lanes per slot
-      const int pl = q / 12, slot = (q - 12 * pl) * 16 + (lane >> 2);
-      const int gr = ((lane & 3) - (slot >> 1)) & 3;               // LDS position lane & 3 of the slot holds granule (position - slot / 2) mod 4
-      const int py = slot / IPW, rem = slot - py * IPW;
+    for (int i = 0; i < 3; ++i) {
       const int px = rem < IPW / 2 ? 2 * rem : 2 * (rem - IPW / 2) + 1;
       const int iy = g.y0 - 1 + py, ix = g.x0 - 1 + px;
       const bool ok = slot < NPIX && (interior || ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W));
-      st_off[i] = ok ? (unsigned)(iy * rowb + ix * colb + pl * 64 + gr * 16) : WOOB;
+      st_off[i] = ok ? (unsigned)(iy * rowb + ix * colb + gr16) : WOOB;
 #ifdef RE2E_EXPERIMENTS
       // diagnostic (RE2E_WINO_DBG bit 128, timing only): every request instruction reads 1 KB CONTIGUOUS (wrong pixels)
-      if (p.dbg & 128) st_off[i] = (unsigned)((g.y0 * rowb + g.x0 * colb) + q * 1024 + lane * 16);
+      if (p.dbg & 128) st_off[i] = (unsigned)((g.y0 * rowb + g.x0 * colb) + (wid + 4 * i) * 1024 + lane * 16);
 #endif
+      slot += 64; py += 64 / IPW; rem += 64 % IPW;
+      if (rem >= IPW) { rem -= IPW; ++py; }
     }
   };
   auto stage = [&](int half, int buf) {                            // half `half` of the channels -> LDS buffer `buf`
@@ -209,15 +214,16 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
     float* base = smem + buf * (HALFB / 4) + wid * 256;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, st_off[i], so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, st_off[i % 3], so + (unsigned)(i / 3) * 64u, 0, 0);
   };
   if constexpr (LDSIN) {
+    const int base_lane = 2 * tyi * IPW + txi;                    // slot of the tile's pixel (0, 0); pixel (r, c) adds a wave-uniform constant
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int py = 2 * tyi + (k < 4 ? ra : rb), px = 2 * txi + (k & 3);
-      const int slot = py * IPW + (px & 1) * (IPW / 2) + (px >> 1);
+      const int r = k < 4 ? ra : rb, c = k & 3;
+      const int slot = base_lane + (r * IPW + (c & 1) * (IPW / 2) + (c >> 1));
       rd_off[k][0] = (unsigned)(slot * 64 + ((lh + (slot >> 1)) & 3) * 16);            // granule lh (chunk 0 of the plane) ...
-      rd_off[k][1] = (unsigned)(slot * 64 + ((2 + lh + (slot >> 1)) & 3) * 16);        // ... and granule 2 + lh (chunk 1)
+      rd_off[k][1] = rd_off[k][0] ^ 32u;                                               // ... and granule 2 + lh (chunk 1): the position + 2 mod 4
     }
   }
   f32x4 raw[8], uf[4][2];
@@ -307,6 +313,8 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
   {
     const int y0 = cur.y0, x0 = cur.x0, n0 = cur.nblk * WNT;
     f32x16 acc[4][2];
+    // (Measured and rejected again in round 6, now that the kernel is issue-bound: the first MFMA of every accumulator with the constant 0 as C instead
+    // of these 128 clears needs a third and fourth copy of the unrolled pass below, and the register allocation of that function spills.)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll

@@ -1331,7 +1331,10 @@ def test_conv_relu_propagates_nan_like_torch(C, K):
 
 
 @pytest.mark.parametrize('N,H,W,C,K', [(2, 16, 32, 8, 64), (1, 35, 80, 64, 64), (2, 33, 40, 16, 128), (1, 19, 7, 24, 64), (3, 8, 16, 128, 128),
-                                       (1, 100, 40, 128, 64)])
+                                       (1, 100, 40, 128, 64),
+                                       # the LDS-staged input path (C % 64 == 0) at a width below one patch, with two and four passes of the
+                                       # chunk loop, and with a single row
+                                       (1, 19, 7, 64, 64), (1, 21, 24, 256, 64), (2, 16, 17, 128, 128), (1, 1, 40, 64, 64)])
 def test_conv3x3_wino(N, H, W, C, K):
     """re2e_conv3x3_wino (fused Winograd F(2x2,3x3), csrc/winograd.hip) against F.conv2d: forward with bias + ReLU, forward fused with
     the 2x2 ceil-mode max pool (values and index bytes = re2e_maxpool2_fwd with relu_in), data gradient plain and through the ReLU
