@@ -107,8 +107,9 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, int Cout, int C
 //   lane-dependent, so a lane keeps TWO read addresses per pixel (the two chunks of a plane); plane and buffer are instruction immediates:
 //   no address arithmetic in the loop.  Two halves are resident (2 x 24 KB, aliased with the epilogue's exchange buffer); half h + 2 is
 //   requested when the last chunk of half h has left LDS (one workgroup barrier per half).
-template <int TXW, bool LDSIN>      // TXW = tiles per patch row: 8 (16 x 8 pixel patch) or 4 (8 x 16)
+template <int TXW, bool LDSIN, bool C64 = false>      // TXW = tiles per patch row: 8 (16 x 8 pixel patch) or 4 (8 x 16); C64: LDSIN with exactly 64 input channels
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
+  static_assert(LDSIN || !C64, "C64 is a variant of the LDS-staged kernel");
   constexpr int TYH = 32 / TXW;
   constexpr int PW = 2 * TXW, PH = 2 * TYH;
   constexpr int IPW = PW + 2, IPH = PH + 2, NPIX = IPW * IPH;        // the input patch: 18 x 10 or 10 x 18 pixels
@@ -313,14 +314,17 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
   {
     const int y0 = cur.y0, x0 = cur.x0, n0 = cur.nblk * WNT;
     f32x16 acc[4][2];
-    // (Measured and rejected again in round 6, now that the kernel is issue-bound: the first MFMA of every accumulator with the constant 0 as C instead
-    // of these 128 clears needs a third and fourth copy of the unrolled pass below, and the register allocation of that function spills.)
+    // 64-channel layers on the LDS-staged path (their own instantiation: ONE pass of eight chunks): no clears -- the first MFMA of every accumulator
+    // takes the constant 0 as C (128 vector moves fewer per work item of 256 MFMAs).  For the other channel counts the same needs more copies of the
+    // unrolled pass in one function, and its register allocation spills.
+    if constexpr (!C64) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+    }
 
     // The chunk loop has no branch -- the very last chunk of the workgroup re-fetches itself instead of fetching nothing -- so the
     // compiler's s_waitcnt counts stay exact: a wait only covers the loads it needs, never the ones issued a few instructions
@@ -341,8 +345,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
       // chunk may still be in flight -- they are younger).  The LAST pass is a copy of the body without requests (there is no half to ask for, and an
       // out-of-range LDS-DMA request would write zeros into space the epilogue's exchange buffer is about to use): the load counts the compiler waits
       // with are exact in both copies.
-      auto pass_body = [&](auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      auto pass_body = [&](auto only_tag, auto last_tag) {
+        constexpr bool ONLY = decltype(only_tag)::value, LAST = decltype(last_tag)::value;     // ONLY: the single pass of a 64-channel layer
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
           const int cc = c8 & 3, bf = c8 >> 2;
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
               for (int nt = 0; nt < 2; ++nt)
-                acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j][jj], uf[j][nt][jj], acc[j][nt], 0, 0, 0);
+                acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j][jj], uf[j][nt][jj], (ONLY && c8 == 0 && jj == 0) ? zero16 : acc[j][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (!(LAST && c8 == 7)) {
               fetch_u(nxt, j);
@@ -387,8 +392,12 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
           ++chunk;
         }
       };
-      for (int pass = 8; pass < nch; pass += 8) pass_body(std::false_type{});
-      pass_body(std::true_type{});
+      if constexpr (C64) {
+        pass_body(std::true_type{}, std::true_type{});
+      } else {
+        for (int pass = 8; pass < nch; pass += 8) pass_body(std::false_type{}, std::false_type{});
+        pass_body(std::false_type{}, std::true_type{});
+      }
     } else {
       do {
         f32x4 T[4], V[4];
@@ -534,14 +543,14 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs p) {
 #include "experiments/wino_pipe.hip"      // the rejected pipelined form (RE2E_WINO_PIPE=1): experiments build only
 #endif
 
-template <int TXW, bool LDSIN>
+template <int TXW, bool LDSIN, bool C64 = false>
 void launch_wino(const WinoArgs& a, hipStream_t st) {
   size_t lds = (size_t)8 * 32 * LDR * sizeof(float);      // the exchange buffer (LDSIN: aliases the two staged halves, 2 x 24 KB)
   static const char* lds_env = exp_env("RE2E_WINO_LDS_KB");       // experiments: a larger request = one workgroup per CU (one wavefront per SIMD)
   if (lds_env && (size_t)atoi(lds_env) * 1024 > lds) lds = (size_t)atoi(lds_env) * 1024;
   static LdsLimit lim;
-  lim.ensure(reinterpret_cast<const void*>(&wino_conv3x3_kernel<TXW, LDSIN>), lds);
-  hipLaunchKernelGGL((wino_conv3x3_kernel<TXW, LDSIN>), dim3((unsigned)a.per_image, (unsigned)a.NI), dim3(256), lds, st, a);
+  lim.ensure(reinterpret_cast<const void*>(&wino_conv3x3_kernel<TXW, LDSIN, C64>), lds);
+  hipLaunchKernelGGL((wino_conv3x3_kernel<TXW, LDSIN, C64>), dim3((unsigned)a.per_image, (unsigned)a.NI), dim3(256), lds, st, a);
 }
 
 }  // namespace
@@ -602,7 +611,8 @@ static int wino_impl(const float* in, int NI, int H, int W, int C, const float* 
   // build): the per-lane loads of rounds 3-5
   static const bool ldsin_env = !(exp_env("RE2E_WINO_LDSIN") && atoi(exp_env("RE2E_WINO_LDSIN")) == 0);
   const bool ldsin = ldsin_env && C % 64 == 0 && !a.stamps && !(a.dbg & ~(1 | 32 | 64 | 128));
-  if (ldsin) { if (wide) launch_wino<8, true>(a, stream); else launch_wino<4, true>(a, stream); }
+  if (ldsin && C == 64) { if (wide) launch_wino<8, true, true>(a, stream); else launch_wino<4, true, true>(a, stream); }
+  else if (ldsin) { if (wide) launch_wino<8, true>(a, stream); else launch_wino<4, true>(a, stream); }
   else { if (wide) launch_wino<8, false>(a, stream); else launch_wino<4, false>(a, stream); }
   RE2E_LAUNCH_CHECK();
   return RE2E_OK;
