@@ -337,6 +337,8 @@ def chain_roofline(dev):
     return out
 
 
+GRAD_TOL = 1.5e-3          # the tests' bar for a gradient tensor against the oracle's (relative to the tensor's largest entry): REPORTED here, not gated --
+#                            on the bench's batch + estimated CMVN both fp32 sides sit 2-3e-3 from the float64 result (profiles/r06_grad_arbitration_fp64.txt)
 PARITY_TOL = 1e-3
 PARITY_KEYS = ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'gan_loss', 'loss_D')
 
@@ -375,7 +377,26 @@ def cpu_baseline_and_parity(opt, sd0, fbank_W, batch, cmvn, gpu_first, sample_b=
     eo = gpu_first['enhance_out']
     par['enhance_out_max'] = float((eo - ref['enhance_out']).abs().max() / ref['enhance_out'].abs().max())
     par = {k: float('%.3e' % v) for k, v in par.items()}
-    parity = {'tolerance': PARITY_TOL, 'rel_err': par, 'max_rel_err': max(par.values()), 'ok': all(v <= PARITY_TOL for v in par.values()),
+    # every gradient tensor of the three networks: max |gpu - oracle| over the tensor's largest oracle entry (the bar of tests/test_fullsize_gpu.py;
+    # a tensor whose gradient is exactly zero -- att.gvec.bias in front of the softmax -- is held to an absolute floor)
+    gworst = []
+    for pre, key in (('enh', 'g_enh'), ('asr', 'g_asr'), ('gan', 'g_gan')):
+        for k, g in gpu_first.get('grads', {}).get(pre, {}).items():
+            if k in ref.get(key, {}):
+                want = ref[key][k]
+                err, scale = float((g - want).abs().max()), float(want.abs().max())
+                gworst.append((max(err - 1e-8, 0.0) / max(scale, 1e-30), pre + '.' + k))
+    gworst.sort(reverse=True)
+    gmax = gworst[0][0] if gworst else None
+    nz = [(e, n) for e, n in gworst if e < 1.0]          # (a ratio >= 1 is a tensor whose reference gradient is exactly zero: noise over ~0)
+    grads = {'gated': False, 'tests_bar': GRAD_TOL, 'tensors': len(gworst), 'within_tests_bar': sum(1 for e, _ in nz if e <= GRAD_TOL),
+             'max_rel_err': float('%.3e' % nz[0][0]) if nz else None, 'worst': [[n, float('%.3e' % e)] for e, n in nz[:3]],
+             'note': 'every gradient tensor of the three networks after GPU step 1 against the fp32 oracle (max |d| / max |ref| per tensor); on this batch with '
+                     'the estimated CMVN the enhancer gradients of BOTH fp32 sides are 2-3e-3 from the float64 result (profiles/r06_grad_arbitration_fp64.txt), '
+                     'so this is reported and the gate stays on the scalars, the masks and the gradient norm; tests/test_fullsize_gpu.py holds every tensor to '
+                     '1e-3 at this size with a fixed CMVN'}
+    parity = {'tolerance': PARITY_TOL, 'rel_err': par, 'max_rel_err': max(par.values()),
+              'ok': all(v <= PARITY_TOL for v in par.values()), 'gradients': grads,
               'what': 'GPU step 1 vs oracle/joint.py joint_step on the same B=%d batch, initial weights and cmvn; |a-b|/|b| for the losses and '
                       'the ASR grad norm, max|d|/max|ref| for enhance_out' % B,
               'gpu': {k: gpu_first['train/' + k] for k in PARITY_KEYS}, 'oracle': {k: float(ref[k]) for k in PARITY_KEYS}}
@@ -649,6 +670,10 @@ def main():
         if i == 0 and want_cpu:                          # the step the parity gate compares: first update from the initial weights
             gpu_first = JointTrainer.to_floats(out)
             gpu_first['enhance_out'] = tr.last['enhance_out'].detach().cpu()
+            # ... and every gradient tensor of the three networks (the kernels leave them unclipped in p.grad: the clip coefficient is applied
+            # inside the fused optimizer step)
+            gpu_first['grads'] = {pre: {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+                                  for pre, m in (('enh', enh), ('asr', asr), ('gan', gan))}
         log('warm-up step %d done (host enqueue %.1f ms)' % (i, host_ms))
     if world > 1:
         torch.distributed.barrier()
