@@ -1361,13 +1361,17 @@ bool launch_fwd2(bool persist, hipStream_t st, float* xg_f, float* xg_r, const f
 
 bool try_fwd2(const Fwd2Cfg& c, bool persist, hipStream_t st, float* xg_f, float* xg_r, const float* whh_f, const float* whh_r, float* ybuf, float* cbuf,
               void* hxmem, size_t hxbytes, const int* lens, int T, int B, int H) {
-  if (c.tt == 2) {        // the interleaved form: instantiated for the widths it is selected for (fwd2_config: H in 128 / 256 / 320)
+#ifdef RE2E_EXPERIMENTS
+  if (c.tt == 2) {        // the interleaved form (not selected, experiments build only): instantiated for H in 128 / 256 / 320
 #define RE2E_F2T(TL, NJV) \
     if (c.tiles == TL && c.nj == NJV) return launch_fwd2<TL, NJV, 2>(persist, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
     RE2E_F2T(1, 2) RE2E_F2T(2, 2) RE2E_F2T(4, 2) RE2E_F2T(1, 4) RE2E_F2T(2, 4) RE2E_F2T(4, 4) RE2E_F2T(1, 5) RE2E_F2T(2, 5) RE2E_F2T(4, 5)
 #undef RE2E_F2T
     return false;
   }
+#else
+  if (c.tt == 2) return false;
+#endif
 #define RE2E_F2(TL, NJV) \
   if (c.tiles == TL && c.nj == NJV) return launch_fwd2<TL, NJV>(persist, st, xg_f, xg_r, whh_f, whh_r, ybuf, cbuf, hxmem, hxbytes, lens, T, B, H);
   RE2E_FWD2_ALL(RE2E_F2)

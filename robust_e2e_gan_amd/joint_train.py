@@ -639,13 +639,13 @@ class JointTrainer(object):
             if train_sampler is not None and epoch > opt.shuffle_epoch:
                 train_sampler.shuffle(epoch)
             for data in loader():
-                entry = (data, sche_samp_rate, enhance_cmvn, self._bn_snapshot())
+                entry = (data, sche_samp_rate, enhance_cmvn, self._bn_snapshot(), self._rng_snapshot())
                 errors = self.step(data, sche_samp_rate, enhance_cmvn)
                 if flush():                               # previous step's meters, now that this step is queued
                     # the previous step was repeated: THIS one ran behind the give-up and was held (it applied nothing; what it did to D's
                     # running statistics was put back with the previous step's snapshot): run it again, on the repaired state
                     self._uncount_step()
-                    entry = (data, sche_samp_rate, enhance_cmvn, self._bn_snapshot())
+                    entry = (data, sche_samp_rate, enhance_cmvn, self._bn_snapshot(), self._rng_snapshot())
                     errors = self.step(data, sche_samp_rate, enhance_cmvn)
                 pending = {k: v for k, v in errors.items() if k.startswith('train/') or k in ('grad_norm', 'aborts')}
                 pending['_entry'] = entry
@@ -740,6 +740,21 @@ class JointTrainer(object):
         """D's BatchNorm buffers (a few KB) before a step: what ``recover_aborted_step`` puts back before it repeats the step."""
         return [b.detach().clone() for b in self.gan_model.buffers()] if self.isGAN else []
 
+    @staticmethod
+    def _rng_snapshot():
+        """What a step draws from besides its batch: the dropout mask stream (seed, next mask index) and Python's RNG (one draw per output token for
+        scheduled sampling, e2e_decoder.py:123).  Put back in front of the repeat of an aborted step: the repeat then draws what the aborted
+        attempt drew, and the held step behind it -- run again afterwards -- what it would have drawn in an undisturbed run."""
+        import random
+        return ops.dropout_state(), random.getstate()
+
+    @staticmethod
+    def _rng_restore(snap):
+        import random
+        (seed, call), pystate = snap
+        ops.dropout_seed(seed, call)
+        random.setstate(pystate)
+
     def _uncount_step(self):
         """A step whose update the gate refused because of a give-up is run again: it must not count twice (Adam's bias correction)."""
         for o in (self.enhance_optimizer, self.asr_optimizer, self.gan_optimizer):
@@ -752,9 +767,11 @@ class JointTrainer(object):
         collective all of them reach), the step is repeated with the launch-per-step recurrences -- same arithmetic, no in-launch hand-off that
         can time out -- on the state it first ran on.  Returns the repeated step's meters, or None if nothing gave up (the NaN was the
         model's own).  Raises if the repeated step is not finite either."""
-        data, rate, cmvn, bn = entry
+        data, rate, cmvn, bn = entry[:4]
         if rdist.any_rank(max(0, int(mine))) == 0:
             return None
+        if len(entry) > 4:
+            self._rng_restore(entry[4])
         if self.recovered_steps == 0:
             logging.warning('a persistent kernel gave up on a peer workgroup (%d sequence(s) on this rank): the step is repeated with the '
                             'launch-per-step kernels.  Further repeats are counted in JointTrainer.recovered_steps', mine)
