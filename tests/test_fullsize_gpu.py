@@ -393,6 +393,118 @@ def test_config2_asr_full_size():
     assert 150.0 < first['train/loss_att'] < 260.0             # ~ L * ln(V) = 25 * 8.35 for a random-initialised model
 
 
+# ---- ... and NUMERICAL parity of configurations 1-3 at their full sizes against the oracle's restatement of each trainer (oracle/trainers.py, pinned
+# by tests/golden/trainers_tiny.npz): losses, gradient norm, masks and every gradient tensor (after the clip both sides apply) ----
+_N1_CFG = dict(enhance_layers=2, elayers=3, mtlalpha=0.5, enhance_loss_lambda=1.0, coral_loss_lambda=0.0, gan_loss_lambda=1.0, grad_clip=5.0, eps=1e-8,
+               isGAN=True, enhance_loss_type='L2')
+
+
+def _scalars_close(out, ref, keys, tol=1e-3):
+    for k in keys:
+        a, b = out['train/' + k], float(ref[k])
+        assert abs(a - b) <= tol * abs(b), (k, a, b)
+
+
+def _oracle_grads(params, norm, clip=5.0):
+    """The oracle's gradients as they were BEFORE its clip (oracle.joint.clip_grad_norm scales them in place by clip / (norm + 1e-6); the HIP trainers
+    apply that factor inside the fused Adadelta update and leave ``p.grad`` as computed)."""
+    c = clip / (norm + 1e-6)
+    return {k: (v.grad / c if c < 1 else v.grad) for k, v in params.items() if v.grad is not None}
+
+
+def test_config1_enhance_base_vs_oracle():
+    """BASELINE config 1 (enhance_base_train.py:85-95, B=4, T=200) against oracle.trainers.enhance_base_step on the same weights and batch."""
+    from oracle import joint as oj, trainers as ot
+    from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.trainers import EnhanceBaseTrainer
+    opt = config4_opt()
+    clean, mix, mix_log, targets, il, tl = _data(4, 200, 10, opt.odim)
+    cos = torch.cos(torch.linspace(-1.0, 1.0, clean.numel()).view_as(clean))
+    torch.manual_seed(11)
+    enh = EnhanceModel(opt).train()
+    p = ot.leaf({k: v.clone() for k, v in enh.state_dict().items()})
+    ref = ot.enhance_base_step(p, oj.Adadelta(p, eps=1e-8), (clean, mix, mix_log, cos, il.tolist()), _N1_CFG)
+    enh = enh.to(DEV)
+    tr = EnhanceBaseTrainer(opt, enh)
+    out = JointTrainer.to_floats(tr.step((None, None, clean, None, mix, mix_log, cos, targets, il, tl)))
+    _scalars_close(out, ref, ('loss',))
+    assert abs(out['grad_norm'] - ref['grad_norm']) <= 1e-3 * ref['grad_norm']
+    eo = tr.last['enhance_out'].detach().cpu()
+    assert (eo - ref['enhance_out']).abs().max() <= 1e-3 * ref['enhance_out'].abs().max()
+    bad = _grad_report(enh.named_parameters(), _oracle_grads(p, ref['grad_norm']), 1e-3)
+    assert not bad, sorted(bad, key=lambda r: -r[1])[:8]
+
+
+def test_config2_asr_vs_oracle():
+    """BASELINE config 2 (asr_train.py:118-131: VGG + 3 x BLSTMP-512, CTC + location-attention decoder, B=16, T=500, L=25) against
+    oracle.trainers.asr_step on the same weights and batch (~20 s of host time): the E2E trainer's own path (one encoder pass, no shared branch)."""
+    from oracle import joint as oj, trainers as ot
+    from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
+    from robust_e2e_gan_amd.model.e2e_model import E2E
+    from robust_e2e_gan_amd.trainers import AsrTrainer
+    from conftest import host_threads
+    opt = config4_opt()
+    g = torch.Generator().manual_seed(3)
+    lens = sorted([500 - 11 * i for i in range(16)], reverse=True)
+    feats = torch.randn(16, 500, 80, generator=g)
+    for b, l in enumerate(lens):
+        feats[b, l:] = 0
+    targets = torch.randint(1, opt.odim - 1, (16 * 25,), generator=g)
+    tls = [25] * 16
+    torch.manual_seed(13)
+    asr = E2E(opt).train()
+    p = ot.leaf({k: v.clone() for k, v in asr.state_dict().items() if not k.startswith('dec.att.')})
+    asr = asr.to(DEV)
+    out = JointTrainer.to_floats(AsrTrainer(opt, asr).step((None, None, feats.to(DEV), targets, torch.IntTensor(lens), torch.IntTensor(tls)), 0.0))
+    torch.cuda.synchronize()
+    torch.set_num_threads(host_threads())
+    ref = ot.asr_step(p, oj.Adadelta(p, eps=1e-8), feats, targets, lens, tls, _N1_CFG)
+    _scalars_close(out, ref, ('loss', 'loss_ctc', 'loss_att'))
+    assert abs(out['train/acc'] - ref['acc']) < 1e-9
+    assert abs(out['grad_norm'] - ref['grad_norm']) <= 1e-3 * ref['grad_norm']
+    bad = _grad_report(asr.named_parameters(), _oracle_grads(p, ref['grad_norm']), 1e-3)
+    assert not bad, sorted(bad, key=lambda r: -r[1])[:8]
+
+
+def test_config3_enhance_gan_vs_oracle():
+    """BASELINE config 3 (enhance_gan_train.py:123-150: G-step through the frozen discriminator, then the D-step; B=32, T=800) against
+    oracle.trainers.enhance_gan_step on the same weights, batch and cmvn (~30 s of host time): the four losses, both gradient norms, every gradient
+    tensor of the enhancer (G-step) and of the discriminator (D-step), and D's BatchNorm running statistics after its three passes."""
+    from oracle import joint as oj, trainers as ot
+    from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.feat_model import FbankModel
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    from robust_e2e_gan_amd.trainers import EnhanceGanTrainer
+    from conftest import host_threads
+    opt = config4_opt()
+    clean, mix, mix_log, targets, il, tl = _data(32, 800, 40, opt.odim, seed=31)
+    cos = torch.ones_like(clean)
+    cm = torch.stack([torch.linspace(-10.0, -7.0, 80), torch.linspace(0.3, 0.5, 80)])
+    torch.manual_seed(12)
+    enh, fb, gan = EnhanceModel(opt).train(), FbankModel(opt).train(), GANModel(opt).train()
+    sd_e, sd_g = [{k: v.clone() for k, v in m.state_dict().items()} for m in (enh, gan)]
+    W = fb.state_dict()['fc'].clone()
+    enh, fb, gan = enh.to(DEV), fb.to(DEV), gan.to(DEV)
+    tr = EnhanceGanTrainer(opt, enh, fb, gan)
+    out = JointTrainer.to_floats(tr.step((None, None, clean.to(DEV), None, mix.to(DEV), mix_log.to(DEV), cos.to(DEV), targets, il, tl), cm.to(DEV)))
+    torch.cuda.synchronize()
+    torch.set_num_threads(host_threads())
+    pe, pg, buf = ot.leaf(sd_e), ot.leaf(sd_g), ot.buffers(sd_g)
+    ref = ot.enhance_gan_step(pe, pg, buf, oj.Adadelta(pe, eps=1e-8), oj.Adadelta(pg, eps=1e-8), W, (clean, mix, mix_log, cos, il.tolist()), cm, _N1_CFG)
+    _scalars_close(out, ref, ('loss', 'gan_loss', 'enhance_loss', 'loss_D'))
+    assert abs(out['grad_norm'] - ref['grad_norm']) <= 1e-3 * ref['grad_norm']
+    assert abs(out['grad_norm_D'] - ref['grad_norm_D']) <= 1e-3 * ref['grad_norm_D']
+    bad = _grad_report(enh.named_parameters(), _oracle_grads(pe, ref['grad_norm']), 1e-3) + \
+        _grad_report(gan.named_parameters(), _oracle_grads(pg, ref['grad_norm_D']), 1e-3)
+    assert not bad, sorted(bad, key=lambda r: -r[1])[:8]
+    got = gan.state_dict()
+    for k, v in buf.items():
+        if v.dtype.is_floating_point:
+            assert (got[k].cpu() - v).abs().max() <= 1e-4 * v.abs().max() + 1e-6, k
+
+
 @pytest.mark.parametrize('ctc_weight', [0.3, 1.0])
 def test_recognize_full_width_device_ctc_vs_host_ctc(ctc_weight):
     """Joint CTC/attention beam search at the config-4 width (V = 4233, T' = 200, beam 10): the device prefix scorers -- 15 candidates
