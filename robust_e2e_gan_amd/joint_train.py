@@ -612,7 +612,7 @@ class JointTrainer(object):
             nonlocal pending
             repeated = False
             if pending is not None:
-                vals = self.to_floats(pending)
+                vals = self.finish_read(pending['_read'])
                 gn, mine = vals.pop('grad_norm', 0.0), int(vals.pop('aborts', 0.0))
                 if not math.isfinite(gn):             # joint_train.py:189-193: the update was skipped on the device
                     # ... either by non-finite numbers of the model's own (upstream: warn and go on), or because a persistent kernel gave up
@@ -651,6 +651,7 @@ class JointTrainer(object):
                     entry = (data, sche_samp_rate, enhance_cmvn, self._bn_snapshot(), self._rng_snapshot())
                     errors = self.step(data, sche_samp_rate, enhance_cmvn)
                 pending = {k: v for k, v in errors.items() if k.startswith('train/') or k in ('grad_norm', 'aborts')}
+                pending['_read'] = self.start_read(pending)        # the copy is enqueued NOW, behind this step; read after the next one is enqueued
                 pending['_entry'] = entry
                 iters += 1
                 if iters % opt.print_freq == 0:
@@ -792,17 +793,42 @@ class JointTrainer(object):
         return vals
 
     @staticmethod
-    def to_floats(errors):
-        """The meters as host floats: ONE device-to-host copy -- the only host synchronisation of a step.  The ragged-shard counters of
-        synchronised BatchNorm (ops._sync_rows_poison) ride along and raise here, on every rank in the same step."""
+    def start_read(errors):
+        """First half of ``to_floats``: ONE device-to-host copy of the meters into pinned memory, enqueued on the current stream behind what is
+        already there, and an event behind it.  ``finish_read`` waits for THAT event only -- ``fit`` enqueues the next step in between, and reading
+        the meters of step k must not drain step k + 1 (a ``.cpu()`` at that point waits for everything the stream has been given since: the host
+        would start enqueueing step k + 2 only when step k + 1 has ended, 1.5 ms of idle GPU per step, profiles/r06_soak.txt)."""
         keys = [k for k, v in errors.items() if isinstance(v, torch.Tensor)]      # (att_ws is a numpy array)
         if not keys:
-            return {}
+            return (keys, None, None, 0, None)
         flags = [f for f in ops.sync_bn_flags() if f.device == errors[keys[0]].device]
-        vals = torch.stack([errors[k].detach().double().reshape(()) for k in keys] + flags).cpu().tolist()
-        if flags:
+        dev = torch.stack([errors[k].detach().double().reshape(()) for k in keys] + flags)
+        if not dev.is_cuda:
+            return (keys, dev, None, len(flags), None)
+        host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+        host.copy_(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return (keys, host, ev, len(flags), dev)          # (``dev`` rides along: it must outlive the copy)
+
+    @staticmethod
+    def finish_read(handle):
+        """Second half of ``to_floats``: the meters as host floats.  The ragged-shard counters of synchronised BatchNorm (ops._sync_rows_poison)
+        ride along and raise here, on every rank in the same step."""
+        keys, host, ev, nflags, _ = handle
+        if host is None:
+            return {}
+        if ev is not None:
+            ev.synchronize()
+        vals = host.tolist()
+        if nflags:
             ops.check_sync_bn(vals[len(keys):])
         return dict(zip(keys, vals[:len(keys)]))
+
+    @staticmethod
+    def to_floats(errors):
+        """The meters as host floats: ONE device-to-host copy -- the only host synchronisation of a step (``start_read`` + ``finish_read``)."""
+        return JointTrainer.finish_read(JointTrainer.start_read(errors))
 
     def state(self, epoch, iters, best_loss=float('inf'), best_acc=0.0):
         """checkpoint dict with the reference's keys (joint_train.py:225-233)."""

@@ -58,7 +58,7 @@ def main():
         import cProfile
         prof = cProfile.Profile()
     t_up = t_step = 0.0
-    prev = None
+    prev = prev_out = None
     t0 = time.time()
     for i in range(steps):
         d = pool[i % len(pool)]
@@ -73,8 +73,8 @@ def main():
         # (without it the host gets ~10 steps ahead in this loop and every tensor another stream has been told about -- record_stream -- stays
         # reserved until the GPU catches up: 100 GiB reserved for an 8 GiB live set)
         if prev is not None and not os.environ.get('SOAK_NO_LATE_READ'):
-            JointTrainer.to_floats(prev)
-        prev = out
+            JointTrainer.finish_read(prev) if not os.environ.get('SOAK_DRAINING_READ') else JointTrainer.to_floats(prev_out)
+        prev, prev_out = JointTrainer.start_read({k: v for k, v in out.items() if k.startswith('train/') or k in ('grad_norm', 'aborts')}), out
         t_up, t_step = t_up + tb - ta, t_step + time.time() - tb
         if (i + 1) % 50 == 0 or i + 1 == steps:
             f = JointTrainer.to_floats(out)
