@@ -83,11 +83,25 @@ class E2E(ModelBase):
         ilens = lens_list(input_sizes)
         ys = self._split_targets(targets, target_sizes)
         h_tm, hlens = self.enc.forward_tm(xpad, ilens)
-        loss_ctc = self.ctc.forward_tm(h_tm, hlens, ys) if self.mtlalpha != 0 else None
+        # CTC and the attention decoder only share the encoder output: with a filler stream available (trainers.StepStreams, JointTrainer) the
+        # CTC head -- ctc_lo product, softmax, alpha / beta; autograd runs its backward on the same stream -- goes beside the decoder's
+        # latency-bound token loop instead of in front of it (ShareE2E.forward does the same with its two heads)
+        aux = ops.AUX_STREAM if (ops.MULTI_STREAM and self.mtlalpha not in (0, 1)) else None
+        if aux is not None:
+            cur = torch.cuda.current_stream()
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                h_tm.record_stream(aux)
+                loss_ctc = self.ctc.forward_tm(h_tm, hlens, ys)
+        else:
+            loss_ctc = self.ctc.forward_tm(h_tm, hlens, ys) if self.mtlalpha != 0 else None
         if self.mtlalpha == 1:
             loss_att, acc = None, None
         else:
             loss_att, acc = self.dec(ops.transpose01(h_tm), hlens, ys, scheduled_sampling_rate)
+        if aux is not None:
+            cur.wait_stream(aux)
+            loss_ctc.record_stream(cur)
         return loss_ctc, loss_att, acc
 
     def calculate_all_attentions(self, inputs, targets, input_sizes, target_sizes):

@@ -95,6 +95,50 @@ def test_asr_trainer(golden_dir):
     _after(asr, fx, 'asr.after.')
 
 
+@pytest.mark.parametrize('which', ['base', 'fbank', 'gan', 'asr'])
+def test_n1_trainers_streams_equal_single_stream(golden_dir, which):
+    """Round 6: the four N1 trainers run their step on a stream of their own with the weight gradients (and EnhanceGanTrainer's whole D-step) on
+    filler streams (trainers.StepStreams).  Same kernels in the same per-tensor order: the meters, every gradient and every updated parameter /
+    buffer of the multi-stream step must equal the single-stream step's, and the routing must not leak out of the step."""
+    from robust_e2e_gan_amd import ops
+    from robust_e2e_gan_amd.joint_train import JointTrainer
+    from robust_e2e_gan_amd.model.e2e_model import E2E
+    from robust_e2e_gan_amd.model.enhance_model import EnhanceModel
+    from robust_e2e_gan_amd.model.gan_model import GANModel
+    from robust_e2e_gan_amd import trainers as T
+    fx = _fx(golden_dir, 'trainers_tiny.npz')
+    opt = _opt()
+    res = {}
+    for on in (True, False):
+        if which == 'base':
+            nets = [_load(EnhanceModel(opt), fx, 'base.p.')]
+            tr, run = T.EnhanceBaseTrainer(opt, nets[0]), (lambda tr: tr.step(_data(fx)))
+        elif which == 'fbank':
+            nets = [_load(EnhanceModel(opt), fx, 'fbank.p.')]
+            tr, run = T.EnhanceFbankTrainer(opt, nets[0], _fbank(fx)), (lambda tr: tr.step(_data(fx)))
+        elif which == 'gan':
+            nets = [_load(EnhanceModel(opt), fx, 'gan.enh.p.'), _load(GANModel(opt), fx, 'gan.d.p.')]
+            tr, run = T.EnhanceGanTrainer(opt, nets[0], _fbank(fx), nets[1]), (lambda tr: tr.step(_data(fx), torch.from_numpy(fx['cmvn'])))
+        else:
+            nets = [_load(E2E(opt), fx, 'asr.p.')]
+            data = (None, None, torch.from_numpy(fx['asr.feats']), torch.from_numpy(fx['targets']), torch.IntTensor(fx['lens']), torch.IntTensor(fx['tlens']))
+            tr, run = T.AsrTrainer(opt, nets[0]), (lambda tr: tr.step(data, 0.0))
+        assert tr.streams.on                       # the schedule is what runs by default on a GPU
+        tr.streams.on = on
+        outs = [JointTrainer.to_floats(run(tr)) for _ in range(2)]          # two steps: the second starts from the first one's update
+        torch.cuda.synchronize()
+        assert ops.MULTI_STREAM is False and ops.WGRAD_STREAM is None and ops.AUX_STREAM is None
+        res[on] = (outs, {'%d.%s' % (i, k): v.detach().clone() for i, m in enumerate(nets) for k, v in m.state_dict().items()},
+                   {'%d.%s' % (i, k): p.grad.detach().clone() for i, m in enumerate(nets) for k, p in m.named_parameters() if p.grad is not None})
+    for a, b in zip(res[True][0], res[False][0]):
+        for k in b:
+            assert abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    for part in (1, 2):
+        for k, ref in res[False][part].items():
+            if ref.dtype.is_floating_point:
+                rel(k, res[True][part][k], ref.cpu().numpy(), tol=2e-5, atol=1e-9)
+
+
 def test_scheduled_sampling(golden_dir):
     """Rate 1.0: every step i > 0 feeds back the arg-max of its own previous output (e2e_decoder.py:123-127)."""
     from robust_e2e_gan_amd.model.e2e_model import E2E
