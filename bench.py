@@ -21,7 +21,7 @@ Extra objects on the line:
                   weighted by its calls per step: executed TFLOP/s, fraction of the 157.3 peak, ms per step
   roofline_chain -- the latency-bound recurrent chains: us per step of the persistent bi-LSTM kernels alone on the chip, measured
                   live, next to the bare hand-off floor (tools/micro/handoff_probe.hip) and the MFMA floor
-  other_configs -- configurations 2, 3 and 5 of BASELINE.json, 5 timed steps each in this same process (N = 1, --config 4)
+  other_configs -- configurations 2, 3 and 5 of BASELINE.json, 10 timed steps each in this same process (N = 1, --config 4)
   cpu_baseline -- the CPU oracle (oracle/joint.py, "port") timed on this box's host cores on the metric's own configuration
                   (rank 0, N=1 only): B=32, 1 warm-up (the parity step) + 3 timed steps, median; a B=8 sample next to it
   parity       -- the FIRST GPU step against the oracle's step on the SAME full batch, initial weights and cmvn
@@ -537,7 +537,7 @@ def make_stepper(cfg_id, opt, nets, batch, cmvn_d, dev):
     raise SystemExit('bench: --config must be 2, 3, 4 or 5 (config 1 is the CPU plumbing case of the tests)')
 
 
-def time_other_config(cfg_id, dev, steps=5, warmup=2):
+def time_other_config(cfg_id, dev, steps=10, warmup=3):
     """One of the other BASELINE configurations (2: asr_train, 3: enhance_gan_train, 5: joint_train on long utterances) in THIS process:
     fresh networks, its own synthetic batch and CMVN, ``warmup`` untimed + ``steps`` timed steps.  N = 1 only."""
     from robust_e2e_gan_amd.data.synthetic import make_batch
