@@ -123,13 +123,13 @@ class JointTrainer(object):
             if 0 < ncu < 256:
                 self.side_stream = lib.cu_masked_stream(ncu, 256, dev)
                 self.wgrad_stream = lib.cu_masked_stream(ncu, 256, dev)
+            shared = lib.step_streams(dev, int(lib.exp_env('RE2E_MAIN_PRIORITY', '-1')))       # ONE set per process: see lib.step_streams
             if self.side_stream is None:
-                self.side_stream = torch.cuda.Stream()
-            if self.wgrad_stream is None:
-                self.wgrad_stream = torch.cuda.Stream()
-            # both run beside the resident recurrences of the main stream: 4-wave engine tiles there (re2e_stream_role)
-            lib.set_stream_role(self.side_stream, True)
-            lib.set_stream_role(self.wgrad_stream, True)
+                self.side_stream, self.wgrad_stream = shared[1], shared[2]
+            else:
+                # both run beside the resident recurrences of the main stream: 4-wave engine tiles there (re2e_stream_role)
+                lib.set_stream_role(self.side_stream, True)
+                lib.set_stream_role(self.wgrad_stream, True)
             # NB: no further streams.  A process gets 4 hardware queues by default; a fifth stream (default + main + side
             # + wgrad + one more) is multiplexed onto an occupied queue and serialises against it (measured with a
             # dedicated D-step stream: 91 -> 155 ms/step).  Measured and rejected as well: running the D-step's
@@ -149,7 +149,7 @@ class JointTrainer(object):
             # the persistent sequences (GPU_MAX_HW_QUEUES=8) changed nothing: what slows a resident chain beside the
             # fillers is two of its workgroups sharing a CU (tools/bench_fill_under_chain.py), not the queue it came from.
             try:
-                self.main_stream = torch.cuda.Stream(priority=int(lib.exp_env('RE2E_MAIN_PRIORITY', '-1')))
+                self.main_stream = lib.step_streams(next(enhance_model.parameters()).device, int(lib.exp_env('RE2E_MAIN_PRIORITY', '-1')))[0]
             except Exception:
                 self.main_stream = None
 

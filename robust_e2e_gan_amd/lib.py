@@ -239,6 +239,29 @@ def query(name, *args):
     return getattr(load(), name)(*args)
 
 
+_STEP_STREAMS = {}
+
+
+def step_streams(device=None, main_priority=-1):
+    """(main, side, wgrad): ONE set of step streams per device and process, shared by every trainer (only one steps at a time).  main: the
+    critical stream (high priority); side / wgrad: filler streams (re2e_stream_role).  Shared because a HIP stream is bound to one of the process's
+    hardware queues when it is created (4 by default, 8 with GPU_MAX_HW_QUEUES=8), round-robin: the streams of the FIRST trainer of a process sit on
+    three different queues, those of the fourth may not -- two of a step's streams on one queue serialise against each other (bench.py's
+    other_configs leg, which builds four trainers in one process: configuration 3 at 24.0 instead of 21.7 ms per step, configuration 5 at 90.0
+    instead of 85.1)."""
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+    key = (idx, int(main_priority))
+    got = _STEP_STREAMS.get(key)
+    if got is None:
+        with torch.cuda.device(idx):
+            main = torch.cuda.Stream(priority=int(main_priority))
+            side, wgrad = torch.cuda.Stream(), torch.cuda.Stream()
+        set_stream_role(side, True)          # both run beside the resident recurrences of the main stream: 4-wave engine tiles there
+        set_stream_role(wgrad, True)
+        got = _STEP_STREAMS[key] = (main, side, wgrad)
+    return got
+
+
 _ws_cache = {}
 
 

@@ -50,10 +50,7 @@ class StepStreams(object):
         self.on = torch.cuda.is_available() and os.environ.get('RE2E_NO_OVERLAP', '0') != '1'
         self.main = self.side = self.wgrad = None
         if self.on:
-            self.main = torch.cuda.Stream(priority=-1)
-            self.side, self.wgrad = torch.cuda.Stream(), torch.cuda.Stream()
-            lib.set_stream_role(self.side, True)          # beside resident recurrences: 4-wave engine tiles there (re2e_stream_role)
-            lib.set_stream_role(self.wgrad, True)
+            self.main, self.side, self.wgrad = lib.step_streams()      # the process's ONE set of step streams (shared with JointTrainer)
 
     @contextlib.contextmanager
     def step(self):
