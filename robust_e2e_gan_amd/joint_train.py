@@ -213,8 +213,7 @@ class JointTrainer(object):
                     clean_feat = self.feat_model(clean_inputs)
                 ev_cf = torch.cuda.Event()
                 ev_cf.record()
-                # (the branch split needs the two-phase backward below: its side-stream half is run from there)
-                clean_branch = self.asr_model.encode_clean(clean_feat, enhance_cmvn, input_sizes, split=bool(self.isGAN))
+                clean_branch = self.asr_model.encode_clean(clean_feat, enhance_cmvn, input_sizes)
             self._mark('clean branch enqueued (side)')
             enhance_out = self.enhance_model(mix_inputs, mix_log_inputs, input_sizes)
             self._mark('enhancer fwd')
@@ -326,10 +325,8 @@ class JointTrainer(object):
                 side = self.side_stream
                 side.wait_event(ev_cut if cut_fired else ev_bwd1)
                 with torch.cuda.stream(side):
-                    ops.run_split_deferred()           # (ops.BranchSplit) the clean rows of the first recurrent layer's dx and their un-packing
                     gs[1].record_stream(side)
                     torch.autograd.backward([cut[0]], [gs[1]])
-            ops._SPLIT_DEFERRED.clear()
             ev_side_bwd = torch.cuda.Event()          # clean-branch conv backward (ASR gradients) enqueued on the side stream
             ev_side_bwd.record(self.side_stream)
             if self.marks is not None:

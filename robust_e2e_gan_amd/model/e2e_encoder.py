@@ -172,8 +172,7 @@ class VGG2L(torch.nn.Module):
         lens_d = [lens_dev(nl, hs[0].device) for nl in nls]
         out = ops.vgg_pack_multi(hs, lens_d)
         nl = sum(nls, [])
-        # (a collated batch is as long as its longest utterance: no slice then -- a slice's backward is a zero-fill + copy of the whole gradient on
-        # the stream of the backward, which would read the rows ops.BranchSplit produces on the side stream)
+        # (a collated batch is as long as its longest utterance: no slice then -- a slice's backward is a zero-fill + copy of the whole gradient)
         return (out if max(nl) == out.shape[0] else out[:max(nl)]), nl
 
     def forward_tm(self, xs, ilens):

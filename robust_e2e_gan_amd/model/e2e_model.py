@@ -117,7 +117,7 @@ class ShareE2E(E2E):
     one 2B batch, losses come from the enhanced branch exactly as E2E.forward, contexts are the
     encoder states of the valid frames of each branch."""
 
-    def encode_clean(self, clean_feat, cmvn, input_sizes=None, split=False):
+    def encode_clean(self, clean_feat, cmvn, input_sizes=None):
         """Clean-branch CMVN + VGG conv stack, to be enqueued on a SIDE stream while the enhancer's recurrent chain
         occupies the main stream (the clean branch does not depend on the enhancer).  Returns a handle for
         ``forward(..., clean_branch=handle)``."""
@@ -125,16 +125,6 @@ class ShareE2E(E2E):
         if cmvn is not None:
             cln = ops.cmvn_pair(cln, None, to_cuda(self, cmvn).float().contiguous())
         h = self.enc.enc1.conv_stack(cln, input_sizes)
-        # (round 6) the clean branch's rows of the shared recurrent stack's input -- the packed tensor and the first layer's x W_ih^T -- are
-        # produced HERE, on this (side) stream, so that the critical stream packs and projects the enhanced rows only (ops.BranchSplit).
-        # ``split``: the caller runs ops.run_split_deferred() on this stream in front of this stack's backward (JointTrainer's two-phase backward)
-        self.branch_split = None
-        if (split and ops.BRANCH_SPLIT and ops.MULTI_STREAM and input_sizes is not None and self.etype == 'vggblstmp'
-                and not self.enc.enc2.subsampling and torch.cuda.current_stream() != torch.cuda.default_stream()):
-            il = lens_list(input_sizes)
-            nl = self.enc.enc1.pooled_lens(il)
-            self.branch_split = ops.branch_split_prepare(h.detach(), lens_dev(nl, h.device), lens_dev(nl + nl, h.device), len(il),
-                                                         self.enc.enc2.bilstm0.layer_weights(0), torch.cuda.current_stream())
         ev = torch.cuda.Event()
         ev.record()
         return h, ev
@@ -163,17 +153,9 @@ class ShareE2E(E2E):
                 h_cln = leaf
             ops.mark_grad(h_enh, 'h_enh (BLSTMP bwd done, main)')
             ops.mark_grad(h_cln, 'h_cln (side: clean conv bwd starts)')
-            sp, self.branch_split = getattr(self, 'branch_split', None), None
-            if sp is not None and (h_cln.shape[0] != B or h_enh.shape[0] != B):
-                sp = None
             ops.mark('  conv stack (enhanced branch) fwd done')
-            del ops._SPLIT_DEFERRED[:]
-            ops._PENDING_SPLIT[0] = sp        # consumed by the pack and by the first recurrent layer (ops.VggPackFn / ops.BiLstmFn)
-            try:
-                h_in, hl2 = self.enc.enc1.pack_tm([h_enh, h_cln], [ilens, ilens])
-                h_tm2 = self.enc.enc2.forward_tm(h_in, lens_dev(hl2, enh.device))
-            finally:
-                ops._PENDING_SPLIT[0] = None
+            h_in, hl2 = self.enc.enc1.pack_tm([h_enh, h_cln], [ilens, ilens])
+            h_tm2 = self.enc.enc2.forward_tm(h_in, lens_dev(hl2, enh.device))
             ops.mark('  shared BLSTMP fwd done')
         else:
             x2 = ops.cmvn_pair(enh, cln, cm) if cm is not None else torch.cat([enh, cln], 0)

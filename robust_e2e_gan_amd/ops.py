@@ -1053,125 +1053,21 @@ def maxpool2(x, relu_in=False):
     return MaxPool2Fn.apply(x, relu_in)
 
 
-# ---- Round 6 experiment (OFF: neutral, see below): the clean branch's share of the shared recurrent stack's FIRST layer off the critical stream ----
-# ShareE2E runs both ASR branches through one (T', 2B, .) recurrent stack.  The two widest products of that stack -- the first BLSTMP layer's
-# x W_ih^T (K = 2560) and its input gradient (2 x 100 GFLOP at config 4) -- are row-wise independent, and the clean branch's rows are known long
-# before the enhanced ones (its conv stack runs on the side stream under the enhancer's forward chain) and are consumed only by side-stream work
-# in the backward (its conv-stack backward).  With ``BRANCH_SPLIT`` the clean rows of the packed tensor and of x W_ih^T are produced on the SIDE
-# stream right behind the clean conv stack, the clean rows of dx (and the clean branch's un-packing) on the side stream in the backward; the
-# critical stream computes the enhanced rows only.  Same kernels, same per-row arithmetic (re2e_gemm_nt_rows over two disjoint row lists);
-# tests/test_fullsize_gpu.py::test_branch_split_equals_unsplit_step holds it to the unsplit step.
-# Measured (profiles/r06_ab_branch_split.txt): the critical stream's recurrent phases do get shorter (BLSTMP forward -0.8 ms, backward -1.3 ms),
-# and the step does not: 46.65 against 46.57 ms.  The three streams end within 1 ms of each other and the chip is full -- the moved work comes
-# back as contention under the enhancer's forward chain (+0.45 ms) and beside the conv stack's backward (+1.5 ms).  A timing-only run with the
-# clean rows left out altogether gains 1.6 ms: it is the WORK that costs, not where it sits.  Default off (RE2E_BRANCH_SPLIT=1 in the experiments
-# build, or ops.BRANCH_SPLIT = True).
-BRANCH_SPLIT = lib.exp_env('RE2E_BRANCH_SPLIT') == '1'
-BRANCH_SPLIT_STATS = {'prepared': 0, 'forward': 0, 'backward': 0}        # how often each leg ran (tests)
-_SPLIT_DEFERRED = []            # the backward's side-stream half: closures the trainer runs on the side stream (run_split_deferred)
-_PENDING_SPLIT = [None]         # set by ShareE2E in front of the pack + first recurrent layer, consumed by VggPackFn / BiLstmFn.forward
-
-
-def run_split_deferred():
-    """The clean branch's half of the first recurrent layer's backward (its rows of dx, their un-packing), on the CURRENT stream.  The trainer
-    calls it on the side stream in front of the clean conv stack's backward, behind an event of the critical stream -- NOT from inside the
-    autograd nodes: the side stream is in order, and a wait enqueued there while the recurrent backward is still running would hold back the
-    discriminator's backward, which autograd enqueues on that stream a little later and which belongs UNDER the recurrent chains (measured:
-    it started at 31.3 ms instead of 20.6 ms of the step and ran beside the conv stack's backward instead)."""
-    fs, _SPLIT_DEFERRED[:] = list(_SPLIT_DEFERRED), []
-    for f in fs:
-        f()
-
-
-class BranchSplit(object):
-    """y: the packed (T, 2B, F) buffer whose branches ``packed`` (indices into the pack's inputs) are already written -- on ``side``;
-    xg: the two (T' 2B, 4H) gate pre-activation buffers of the first layer with the rows of ``maps_side`` already projected; ``ev``: recorded on
-    ``side`` behind all of that.  maps_main / maps_side: RowMaps of the rows the critical stream / the side stream own."""
-    __slots__ = ('y', 'packed', 'xg', 'maps_main', 'maps_side', 'ev_maps', 'ev', 'side', 'Tq')
-
-    def __init__(self, y, packed, xg, maps_main, maps_side, ev_maps, ev, side, Tq):
-        self.y, self.packed, self.xg, self.maps_main, self.maps_side, self.ev_maps, self.ev, self.side, self.Tq = \
-            y, packed, xg, maps_main, maps_side, ev_maps, ev, side, Tq
-
-
-def split_row_maps(maps, lens_d, T, B2, first_side):
-    """RowMaps of a (T, B2, .) batch -> (rows with b < first_side, rows with b >= first_side).  The first keeps ALL padded rows as its
-    ``invalid`` list (whoever fills padded rows fills them all), the second has none.  From the HOST copy of the map (no device read-back)."""
-    import numpy as np
-    from .model import e2e_common as ec
-    dev = lens_d.device
-    key = (ec.host_lens_of(lens_d), T, B2, str(dev))
-    hit = _ROW_MAPS.get(key)
-    if hit is None:
-        return None
-    v = hit[0]
-    side = (v % B2) >= first_side
-    vm, vs = v[~side], v[side]
-    if vm.size < 256 or vs.size < 256:
-        return None
-    none = ec.dev_cached(('rows_none', str(dev)), lambda: np.zeros(0, np.int32), dev)
-    return (RowMaps(ec.dev_cached(('rows_vm', first_side) + key, lambda: vm, dev), maps.invalid, int(vm.size), maps.ni, maps.rows, 0),
-            RowMaps(ec.dev_cached(('rows_vs', first_side) + key, lambda: vs, dev), none, int(vs.size), 0, maps.rows, 0))
-
-
-def branch_split_prepare(h_side, lens_side_d, lens_all_d, n_main, w, side):
-    """Called on ``side`` behind the clean branch's conv stack: packs ``h_side`` (N, T, Fq, C) into utterances [n_main, n_main + N) of a new
-    (T, n_main + N, C Fq) buffer and projects those rows onto the first layer's gates (``w``: its 8 weight tensors).  Returns a BranchSplit, or
-    None when the batch has no row maps (then nothing was done)."""
-    N, T, Fq, C = h_side.shape
-    B2 = n_main + N
-    from .model import e2e_common as ec
-    lens = ec.host_lens_of(lens_all_d)
-    if lens is None:
-        return None
-    Tq = max(lens)
-    if Tq != T:            # (the packed tensor would be sliced: its backward copies the whole gradient on the backward's stream)
-        return None
-    maps = row_maps(lens_all_d, Tq, B2)
-    if maps is None:
-        return None
-    pair = split_row_maps(maps, lens_all_d, Tq, B2, n_main)
-    H, I = w[1].shape[1], C * Fq
-    if pair is None or I < ROW_MAPS_MIN_K or I % 4 or not (w[0].is_contiguous() and w[4].is_contiguous()):
-        return None
-    ev_maps = torch.cuda.Event()          # behind the upload of the two row lists (the critical stream reads one of them)
-    ev_maps.record()
-    y = empty((T, B2, I), h_side)
-    call('re2e_vgg_pack_fwd', h_side.data_ptr(), lens_side_d.data_ptr(), N, T, Fq, C, y.data_ptr(), B2, n_main)
-    y2 = y.view(T * B2, I)
-    xg = [empty((Tq * B2, 4 * H), h_side), empty((Tq * B2, 4 * H), h_side)]
-    for d in range(2):
-        gemm_rows(y2, w[4 * d].detach(), xg[d], 4 * H, I, pair[1], bias=w[4 * d + 2].detach(), bias2=w[4 * d + 3].detach())
-    ev = torch.cuda.Event()
-    ev.record()
-    mark('  side stream: clean rows packed + projected (branch split)')
-    BRANCH_SPLIT_STATS['prepared'] += 1
-    return BranchSplit(y, (1,), xg, pair[0], pair[1], ev_maps, ev, side, Tq)
-
-
 class VggPackFn(torch.autograd.Function):
     """NHWC branches [(N_k,T,Fq,C)] -> ONE time-major (T, sum N_k, C*Fq) tensor, frames >= lens zeroed
-    (e2e_encoder.py:272-278).  ``lens_list`` holds one int32 device tensor per branch.  With a pending BranchSplit the branches it names are
-    already in its buffer (written on the side stream) and their gradients are un-packed on the side stream."""
+    (e2e_encoder.py:272-278).  ``lens_list`` holds one int32 device tensor per branch."""
 
     @staticmethod
     def forward(ctx, lens_list, *xs):
         xs = [_f32(x) for x in xs]
         _, T, Fq, C = xs[0].shape
         Ntot = sum(x.shape[0] for x in xs)
-        sp = _PENDING_SPLIT[0]
-        if sp is not None and tuple(sp.y.shape) == (T, Ntot, C * Fq):
-            y = sp.y
-            y.record_stream(torch.cuda.current_stream())
-        else:
-            sp, y = None, empty((T, Ntot, C * Fq), xs[0])
+        y = empty((T, Ntot, C * Fq), xs[0])
         off = 0
-        for k, (x, ld) in enumerate(zip(xs, lens_list)):
-            if sp is None or k not in sp.packed:
-                call('re2e_vgg_pack_fwd', x.data_ptr(), ld.data_ptr(), x.shape[0], T, Fq, C, y.data_ptr(), Ntot, off)
+        for x, ld in zip(xs, lens_list):
+            call('re2e_vgg_pack_fwd', x.data_ptr(), ld.data_ptr(), x.shape[0], T, Fq, C, y.data_ptr(), Ntot, off)
             off += x.shape[0]
         ctx.lens, ctx.shapes, ctx.Ntot = lens_list, [x.shape for x in xs], Ntot
-        ctx.side = (sp.side, sp.packed) if sp is not None else None
         return y
 
     @staticmethod
@@ -1181,20 +1077,8 @@ class VggPackFn(torch.autograd.Function):
         for k, (shp, ld) in enumerate(zip(ctx.shapes, ctx.lens)):
             N, T, Fq, C = shp
             if ctx.needs_input_grad[1 + k]:
-                if ctx.side is not None and k in ctx.side[1]:
-                    # this branch's rows of dy are produced later, on the side stream (BiLstmFn.backward's deferred half), and its gradient is
-                    # consumed there: the un-packing joins that queue; the tensor handed to autograd is filled by then
-                    dx = empty(shp, dy)
-
-                    def unpack(dx=dx, ld=ld, shp=shp, off=off):
-                        st = torch.cuda.current_stream()
-                        dy.record_stream(st)
-                        dx.record_stream(st)
-                        call('re2e_vgg_pack_bwd', dy.data_ptr(), ld.data_ptr(), shp[0], shp[1], shp[2], shp[3], dx.data_ptr(), ctx.Ntot, off)
-                    _SPLIT_DEFERRED.append(unpack)
-                else:
-                    dx = empty(shp, dy)
-                    call('re2e_vgg_pack_bwd', dy.data_ptr(), ld.data_ptr(), N, T, Fq, C, dx.data_ptr(), ctx.Ntot, off)
+                dx = empty(shp, dy)
+                call('re2e_vgg_pack_bwd', dy.data_ptr(), ld.data_ptr(), N, T, Fq, C, dx.data_ptr(), ctx.Ntot, off)
                 outs.append(dx)
             else:
                 outs.append(None)
@@ -1404,28 +1288,9 @@ class BiLstmFn(torch.autograd.Function):
         # there), so those rows of xg stay unwritten
         maps = row_maps(lens_dev, T, B)
         ctx.maps = maps
-        sp, _PENDING_SPLIT[0] = _PENDING_SPLIT[0], None
-        if sp is not None and not (maps is not None and sp.Tq == T and tuple(sp.xg[0].shape) == (T * B, 4 * H) and sp.maps_main.rows == T * B):
-            sp = None
-        ctx.split = sp is not None and (sp.maps_main, sp.maps_side, sp.side)
-        if sp is not None:
-            # the rows of ``sp.maps_side`` (the clean branch) are in xg already, projected on the side stream: this stream does the others, then waits
-            xg = sp.xg
-            cur = torch.cuda.current_stream()
-            cur.wait_event(sp.ev_maps)
-            sp.maps_main.valid.record_stream(cur)
-            BRANCH_SPLIT_STATS['forward'] += 1
-            for d in range(2):
-                xg[d].record_stream(cur)
-                gemm_rows(x2, w[4 * d], xg[d], 4 * H, I, sp.maps_main, bias=w[4 * d + 2], bias2=w[4 * d + 3])
-            mark('  branch split: main rows projected')
-            cur.wait_event(sp.ev)
-        else:
-            xg = [empty((T * B, 4 * H), x), empty((T * B, 4 * H), x)]
+        xg = [empty((T * B, 4 * H), x), empty((T * B, 4 * H), x)]
         Ip = (I + 3) & ~3
-        if sp is not None:
-            pass
-        elif Ip != I and T * B >= 1024 and lib.exp_env('RE2E_NO_PAD_INPUT') != '1':
+        if Ip != I and T * B >= 1024 and lib.exp_env('RE2E_NO_PAD_INPUT') != '1':
             # an input width that is not a multiple of 4 (the enhancer's 257 bins) would send three large GEMMs of this layer down
             # the scalar-load path of the engine: work on zero-padded copies of x and W_ih instead (exact: the extra products are 0)
             x2p = zeros((T * B, Ip), x)
@@ -1482,25 +1347,7 @@ class BiLstmFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = empty((M, I), dy)
-            if ctx.split:
-                # (BranchSplit) this stream: the rows of the branch it consumes itself (and the zeros of every padded row); the side stream: the
-                # clean branch's rows, behind the recurrence -- they are read there only (VggPackFn.backward, the clean conv stack's backward)
-                maps_main, maps_side, side = ctx.split
-                BRANCH_SPLIT_STATS['backward'] += 1
-                gemm_input_grad_rows(dG[0], w[0], dx, I, 4 * H, maps_main, fill=True)
-                gemm_input_grad_rows(dG[1], w[4], dx, I, 4 * H, maps_main, beta=1.0)
-                mark('  branch split: dx of the main rows done')
-                w0, w4 = w[0], w[4]
-
-                def clean_rows():         # run by the trainer on the side stream, behind an event of this stream (run_split_deferred)
-                    st = torch.cuda.current_stream()
-                    for t_ in (dx, g_f, g_r):
-                        t_.record_stream(st)
-                    gemm_input_grad_rows(g_f, w0, dx, I, 4 * H, maps_side)
-                    gemm_input_grad_rows(g_r, w4, dx, I, 4 * H, maps_side, beta=1.0)
-                    mark('  side stream: dx of the clean rows done (branch split)')
-                _SPLIT_DEFERRED.append(clean_rows)
-            elif ctx.maps is not None and I % 4 == 0:
+            if ctx.maps is not None and I % 4 == 0:
                 # d(gates) is zero in the padded rows (the recurrence wrote them): so is dx there -- written as zeros, not computed
                 gemm_input_grad_rows(dG[0], w[0], dx, I, 4 * H, ctx.maps, fill=True)
                 gemm_input_grad_rows(dG[1], w[4], dx, I, 4 * H, ctx.maps, beta=1.0)

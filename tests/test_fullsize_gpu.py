@@ -185,46 +185,6 @@ def test_config4_full_size_vs_oracle():
     assert not bad, sorted(bad, key=lambda r: -r[1])[:8]
 
 
-def test_branch_split_equals_unsplit_step():
-    """Round 6: the clean branch's rows of the shared recurrent stack's first layer (the packed input, x W_ih^T, dx and the un-packing of dx) are
-    produced on the side stream (ops.BranchSplit).  Same kernels over two disjoint row lists: the step with the split must give the losses and
-    every gradient tensor of the step without it (to the summation order of the x W^T tail split), and the split must actually have run."""
-    from robust_e2e_gan_amd import ops
-    from robust_e2e_gan_amd.joint_train import JointTrainer, config4_opt
-    opt = config4_opt(coral_loss_lambda=0.5)
-    clean, mix, mix_log, targets, il, tl = _data(8, 320, 12, opt.odim, seed=99)
-    assert int(il.min()) < int(il.max())
-    cm = torch.stack([torch.full((80,), -9.0), torch.full((80,), 0.4)])
-    data = (None, None, clean, None, mix, mix_log, None, targets, il, tl)
-    runs, was = {}, ops.BRANCH_SPLIT
-    try:
-        for split in (True, False):
-            ops.BRANCH_SPLIT = split
-            before = dict(ops.BRANCH_SPLIT_STATS)
-            enh, fb, asr, gan = [m.to(DEV) for m in _build(opt)]
-            tr = JointTrainer(opt, enh, fb, asr, gan)
-            out = JointTrainer.to_floats(tr.step(data, 0.0, cm))
-            torch.cuda.synchronize()
-            ran = {k: ops.BRANCH_SPLIT_STATS[k] - before[k] for k in before}
-            assert ran == ({'prepared': 1, 'forward': 1, 'backward': 1} if split else {'prepared': 0, 'forward': 0, 'backward': 0}), (split, ran)
-            runs[split] = (out, {n + '.' + k: p.grad.clone() for n, m in (('enh', enh), ('asr', asr), ('gan', gan)) for k, p in m.named_parameters()})
-    finally:
-        ops.BRANCH_SPLIT = was
-    for k in ('loss', 'loss_ctc', 'loss_att', 'enhance_loss', 'coral_loss', 'gan_loss', 'loss_D'):
-        a, b = runs[True][0]['train/' + k], runs[False][0]['train/' + k]
-        assert abs(a - b) <= 1e-5 * abs(b), (k, a, b)
-    worst = (0.0, None)
-    for k, ref in runs[False][1].items():
-        scale = float(ref.abs().max())
-        err = float((runs[True][1][k] - ref).abs().max())
-        assert torch.isfinite(runs[True][1][k]).all(), k
-        if k == 'asr.att.gvec.bias':       # true gradient 0 (a shift in front of the softmax): rounding noise on both sides
-            assert err < 1e-6, (k, err)
-            continue
-        worst = max(worst, (err / max(scale, 1e-12), k))
-    assert worst[0] < 5e-5, worst
-
-
 def test_config5_forward_vs_oracle():
     """Config 5's shape (B=8, T=3000): the enhancer's mask product and the fbank features after a 3000-step bidirectional
     recurrence, against oracle.nets (forward only: ~15 s of host time)."""

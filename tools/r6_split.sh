@@ -1,4 +1,4 @@
-# round 6: the branch split -- parity first, then a same-session A/B against the switch that turns it on, then the two timelines
+# round 6: the branch split (apply profiles/r06_branch_split.patch first: the experiment is not in the product) -- parity first, then a same-session A/B against the switch that turns it on, then the two timelines
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r6_split
