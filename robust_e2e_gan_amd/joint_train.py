@@ -326,6 +326,8 @@ class JointTrainer(object):
                 side.wait_event(ev_cut if cut_fired else ev_bwd1)
                 with torch.cuda.stream(side):
                     gs[1].record_stream(side)
+                    # (its weight gradients stay on the weight-gradient stream: inline here, like the D-step's, 46.0 -> 46.7 ms per step,
+                    #  profiles/r06_ab_dstep_inline_wgrad.txt)
                     torch.autograd.backward([cut[0]], [gs[1]])
             ev_side_bwd = torch.cuda.Event()          # clean-branch conv backward (ASR gradients) enqueued on the side stream
             ev_side_bwd.record(self.side_stream)
@@ -494,6 +496,10 @@ class JointTrainer(object):
         loss_D_real = self.criterionGAN(d_real, True)
         gan_params = [p for p in self.gan_model.parameters() if p.requires_grad]
         torch.autograd.grad(loss_D_real * 0.5 if hold is None else loss_D_real * 0.5 * hold, gan_params, allow_unused=True)
+        self._ev_dreal_wgrad = None
+        if ops.WGRAD_STREAM is not None:
+            self._ev_dreal_wgrad = torch.cuda.Event()          # behind this half's weight gradients on the weight-gradient stream
+            self._ev_dreal_wgrad.record(ops.WGRAD_STREAM)
         return loss_D_real.detach(), stats
 
     def _d_step(self, clean_feat, enhance_feat, enhance_cmvn, d_fake=None, fake_stats=None, fake_bn=None, real_part=None, hold=None):
@@ -504,6 +510,13 @@ class JointTrainer(object):
         have applied (``fake_stats``), in upstream's order (after the D(real) pass)."""
         opt = self.opt
         set_requires_grad([self.gan_model], True)
+        # D's weight gradients of THIS pass run inline, on the stream of the D-step (the side stream), not behind the weight-gradient stream's
+        # backlog (round 6): that stream was the last of the three to finish (46.6 ms of the step against 45.7 / 45.6), and the D-step's update
+        # waited for all of it.  46.47 -> 45.99 ms per step (five interleaved rounds, profiles/r06_ab_dstep_inline_wgrad.txt).
+        # RE2E_DSTEP_WGRAD_STREAM=1 (experiments build): as before.
+        wg_keep = ops.WGRAD_STREAM
+        if lib.exp_env('RE2E_DSTEP_WGRAD_STREAM') != '1':
+            ops.WGRAD_STREAM = None
         if real_part is not None:
             loss_D_real, real_stats = real_part
             replay_running_stats(real_stats)
@@ -522,7 +535,11 @@ class JointTrainer(object):
             loss_D_fake = self.criterionGAN(self.gan_model(enhance_feat.detach(), enhance_cmvn), False)
             loss_D = (loss_D_real + loss_D_fake) * 0.5
             (loss_D if hold is None else loss_D * hold).backward()
-        if ops.WGRAD_STREAM is not None:
+        inline = ops.WGRAD_STREAM is None and wg_keep is not None
+        ops.WGRAD_STREAM = wg_keep
+        if inline and real_part is not None and getattr(self, '_ev_dreal_wgrad', None) is not None:
+            torch.cuda.current_stream().wait_event(self._ev_dreal_wgrad)      # only the early real half went through the weight-gradient stream
+        elif ops.WGRAD_STREAM is not None:
             torch.cuda.current_stream().wait_stream(ops.WGRAD_STREAM)
         GradSync().finish([self.gan_optimizer])
         self.gan_optimizer.clip_grad_norm(opt.grad_clip)

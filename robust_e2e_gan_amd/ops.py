@@ -1360,7 +1360,7 @@ class BiLstmFn(torch.autograd.Function):
         # gradients here, while on the weight-gradient stream they would queue behind everything deferred so far: they stay on this
         # stream and run beside that backlog: step 72.26 -> 71.71 ms (3 + 3 runs, one GPU session; RE2E_NO_INLINE_LAST_WGRAD=1:
         # deferred like the others).  Handing the weight gradients of the layers ABOVE it to the trainer to run behind the chain as
-        # well was measured and changes nothing (71.63 against 71.55).
+        # well was measured and changes nothing (71.63 against 71.55; again in round 6, with the filler streams the last to finish: 46.21 against 46.13).
         yflat = ybuf.view((T + 2) * B, 2 * H)
         last = INLINE_LAST_WGRAD and not ctx.needs_input_grad[0]
         needs = ctx.needs_input_grad
